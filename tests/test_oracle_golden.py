@@ -1,0 +1,141 @@
+"""The oracle (oracle/*.py) against the golden vectors produced by the
+reference's own modules (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN, golden_files
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize('fname', golden_files('a1_'))
+def test_a1_pair_loss_literal(fname):
+    z = _load(fname)
+    I = torch.from_numpy(z['I']).requires_grad_(True)
+    T = torch.from_numpy(z['T']).requires_grad_(True)
+    a = torch.tensor([float(z['a'])], requires_grad=True)
+    b = torch.tensor([float(z['b'])], requires_grad=True)
+    loss, ld = oracle.pair_loss_literal(I, T, a, b)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z['loss']), rtol=1e-6)
+    ref = dict(zip([str(k) for k in z['dict_keys']], z['dict_vals']))
+    assert list(ld.keys()) == list(ref.keys())
+    for k in ref:
+        np.testing.assert_allclose(ld[k], ref[k], rtol=2e-6, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(I.grad.numpy(), z['dI'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(T.grad.numpy(), z['dT'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a.grad.numpy(), z['da'], rtol=1e-5)
+    np.testing.assert_allclose(b.grad.numpy(), z['db'], rtol=1e-5)
+    mp = oracle.match_prob(I.detach(), T.detach(), a.detach(), b.detach())
+    np.testing.assert_allclose(mp.numpy(), z['match_prob'], rtol=1e-5, atol=1e-30)
+
+
+@pytest.mark.parametrize('fname', golden_files('a1_'))
+def test_a1_closed_form_matches_reference(fname):
+    """fp64 closed form vs. the reference's fp32 result: the north-star tolerance
+    (loss rel 1e-4), grads to fp32 round-off."""
+    z = _load(fname)
+    I, T = torch.from_numpy(z['I']), torch.from_numpy(z['T'])
+    a, b = float(z['a']), float(z['b'])
+    cf = oracle.pair_loss_closed_form(I, T, a, b)
+    # The reference evaluates NLL = logsumexp(s,-s) - m*s in fp32: when |s| ~ 15 the two
+    # terms cancel, leaving up to ~ulp(15)/2 = 5e-7 of noise PER PAIR (probemb.py:82-86).
+    # The fp64 closed form is the exact value; the reference agrees to rtol 1e-5 plus that
+    # per-pair round-off budget (which only matters when the total loss is tiny).
+    n = I.shape[0]
+    noise = n * n * 2.5e-7
+    np.testing.assert_allclose(cf['loss'].item(), float(z['loss']), rtol=1e-5, atol=2 * noise)
+    ref = dict(zip([str(k) for k in z['dict_keys']], z['dict_vals']))
+    np.testing.assert_allclose(cf['pos'].item(), ref['i2t_pos_loss'], rtol=1e-5, atol=n * 5e-7)
+    np.testing.assert_allclose(cf['neg'].item(), ref['i2t_neg_loss'], rtol=1e-5, atol=noise)
+    g = oracle.pair_loss_grads_closed_form(I, T, a, b)
+    # Reference autograd evaluates d/ds[logsumexp(s,-s) + s] = (p0 - p1) + 1 in fp32, which
+    # cancels to ~6e-8 absolute per negative pair; gradients therefore agree with the exact
+    # closed form only to ~1e-3 of their scale ("grads rel 1e-3").
+    # Budget per row: n pairs x ulp(1) x a (|I-T|/d <= 1).
+    scale = np.abs(z['dI']).max()
+    atol = max(1e-3 * scale, n * a * 1.2e-7)
+    np.testing.assert_allclose(g['dI'].numpy(), z['dI'], rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(g['dT'].numpy(), z['dT'], rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(g['da'].item(), float(z['da'][0]), rtol=1e-3, atol=n * n * 2.4e-7)
+    np.testing.assert_allclose(g['db'].item(), float(z['db'][0]), rtol=1e-3, atol=n * n * 2.4e-7)
+
+
+@pytest.mark.parametrize('fname', golden_files('a2_'))
+def test_a2_pie_head(fname):
+    z = _load(fname)
+    x = torch.from_numpy(z['x']).requires_grad_(True)
+    out = torch.from_numpy(z['out']).requires_grad_(True)
+    mask = torch.from_numpy(z['mask']) if z['mask'].size else None
+    names = ['attention__w_1__weight', 'attention__w_2__weight', 'fc__weight', 'fc__bias',
+             'layer_norm__weight', 'layer_norm__bias']
+    w1, w2, fcw, fcb, lnw, lnb = [torch.from_numpy(z['p_' + n]).requires_grad_(True) for n in names]
+    o, attn, res = oracle.pie_head(out, x, w1, w2, fcw, fcb, lnw, lnb, pad_mask=mask)
+    y = oracle.l2_normalize(o)
+    (y * torch.from_numpy(z['gy'])).sum().backward()
+    np.testing.assert_allclose(o.detach().numpy(), z['o'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(attn.detach().numpy(), z['attn'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(res.detach().numpy(), z['res'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(y.detach().numpy(), z['y'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), z['dx'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(out.grad.numpy(), z['dout'], rtol=1e-4, atol=1e-7)
+    for n, p in zip(names, [w1, w2, fcw, fcb, lnw, lnb]):
+        np.testing.assert_allclose(p.grad.numpy(), z['g_' + n], rtol=1e-4, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.parametrize('fname', golden_files('a34_'))
+def test_a34_client_contrast(fname):
+    z = _load(fname)
+    f = torch.from_numpy(z['f']).requires_grad_(True)
+    args = (torch.from_numpy(z['g_same']), torch.from_numpy(z['g_other']),
+            tuple(int(v) for v in z['d_idx']), torch.from_numpy(z['f_old']))
+    loss, li, lm = oracle.client_contrast_loss(f, *args, interintra_weight=float(z['weight']),
+                                               loss_scale=bool(z['loss_scale']))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z['loss']), rtol=1e-6)
+    np.testing.assert_allclose(li.item(), float(z['loss_inter']), rtol=1e-6)
+    np.testing.assert_allclose(lm.item(), float(z['loss_moon']), rtol=1e-6)
+    np.testing.assert_allclose(f.grad.numpy(), z['df'], rtol=1e-5, atol=1e-8)
+    f2 = torch.from_numpy(z['f']).requires_grad_(True)
+    oracle.client_contrast_loss(f2, *args, use_intra=False)[0].backward()
+    np.testing.assert_allclose(f2.grad.numpy(), z['df_inter_only'], rtol=1e-5, atol=1e-8)
+    f3 = torch.from_numpy(z['f']).requires_grad_(True)
+    oracle.client_contrast_loss(f3, *args, use_inter=False)[0].backward()
+    np.testing.assert_allclose(f3.grad.numpy(), z['df_intra_only'], rtol=1e-5, atol=1e-8)
+    # closed forms (fp64) agree with the reference's fp32 numbers
+    cf = oracle.client_contrast_grads_closed_form(torch.from_numpy(z['f']), *args)
+    np.testing.assert_allclose(cf['loss_inter'].item(), float(z['loss_inter']), rtol=1e-5)
+    np.testing.assert_allclose(cf['loss_moon'].item(), float(z['loss_moon']), rtol=1e-5)
+    np.testing.assert_allclose(cf['d_inter'].numpy(), z['df_inter_only'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(cf['d_moon'].numpy(), z['df_intra_only'], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('fname', golden_files('a5_'))
+@pytest.mark.parametrize('literal', [True, False])
+def test_a5_conw(fname, literal):
+    z = _load(fname)
+    vecs = [torch.from_numpy(v) for v in z['vecs']]
+    agg, w, lp = oracle.conw_aggregate(vecs, torch.from_numpy(z['g_other']), literal=literal)
+    tol = 1e-6 if literal else 1e-5
+    np.testing.assert_allclose(lp.numpy(), z['logprob'], rtol=tol, atol=tol)
+    np.testing.assert_allclose(w.numpy(), z['weights'], rtol=10 * tol, atol=tol)
+    np.testing.assert_allclose(agg.numpy(), z['agg'], rtol=10 * tol, atol=tol)
+
+
+@pytest.mark.parametrize('fname', golden_files('a6_'))
+def test_a6_recall(fname):
+    z = _load(fname)
+    keys = [str(k) for k in z['keys']]
+    for (q, g, ql, gl, want) in [(z['img'], z['cap'], z['img_cls'], z['cap_cls'], z['i2t']),
+                                 (z['cap'], z['img'], z['cap_cls'], z['img_cls'], z['t2i'])]:
+        lit = oracle.recall_ranks_literal(q, g, ql, gl, n_embeddings=7, batch_size=64)
+        cnt = oracle.recall_ranks_count(q, g, ql, gl)
+        assert np.array_equal(lit, cnt)
+        sc = oracle.recall_scores(cnt)
+        np.testing.assert_array_equal(np.array([sc[k] for k in keys]), want)
