@@ -1,0 +1,100 @@
+"""ctypes binding of libcreamfl_hip.so (C ABI declared in include/creamfl_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+returns non-zero, this module raises.  Build the library with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C creamfl_amd/csrc``.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcreamfl_hip.so')
+
+_P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/creamfl_hip.h one to one
+SIGNATURES = {
+    'cfl_version': (c_int, []),
+    'cfl_arch': (c_char_p, []),
+    'cfl_num_kernels': (c_int, []),
+    'cfl_kernel_name': (c_char_p, [c_int]),
+    'cfl_prof_enable': (c_int, [c_int]),
+    'cfl_prof_reset': (c_int, []),
+    'cfl_prof_query': (c_int, [c_int, POINTER(c_longlong), POINTER(c_double)]),
+    'cfl_pair_loss_ws_bytes': (c_size_t, [c_int, c_int]),
+    'cfl_pair_loss_fwd': (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P]),
+    'cfl_pair_loss_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    'cfl_bank_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cfl_bank_lse_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
+    'cfl_bank_lse_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'cfl_intra_ws_bytes': (c_size_t, [c_int]),
+    'cfl_intra_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'cfl_conw_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cfl_conw_logprob': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'cfl_conw_combine': (c_int, [POINTER(c_void_p), _P, c_int, c_int, c_int, _P, _P, _P]),
+    'cfl_pie_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'cfl_pie_pool_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    'cfl_pie_pool_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    'cfl_pie_epilogue_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
+    'cfl_pie_epilogue_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'cfl_l2norm_fwd': (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    'cfl_l2norm_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    'cfl_rank_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cfl_rank_count': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class CreamflHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CreamflHipError(
+            f'{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; '
+            'run `make -C creamfl_amd/csrc` (hipcc --offload-arch=gfx950) first.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: 'CFL_EINVAL (bad size / null pointer)', -2: 'CFL_EALIGN', -3: 'CFL_ELIMIT (size out of range)'}
+        raise CreamflHipError(f'{what} failed: {kind.get(rc, "hipError_t " + str(rc))}')
+
+
+def kernel_names():
+    lib = load()
+    return [lib.cfl_kernel_name(i).decode() for i in range(lib.cfl_num_kernels())]
+
+
+def prof_enable(on=True):
+    check(load().cfl_prof_enable(1 if on else 0), 'cfl_prof_enable')
+
+
+def prof_reset():
+    check(load().cfl_prof_reset(), 'cfl_prof_reset')
+
+
+def prof_query():
+    """{kernel_name: (launches, total_ms)} for every kernel launched since the last reset."""
+    lib = load()
+    out = {}
+    for i, name in enumerate(kernel_names()):
+        n, ms = c_longlong(0), c_double(0.0)
+        check(lib.cfl_prof_query(i, ctypes.byref(n), ctypes.byref(ms)), 'cfl_prof_query')
+        if n.value:
+            out[name] = (n.value, ms.value)
+    return out

@@ -1,0 +1,254 @@
+// pair_loss.hip -- row A1: PCME soft-contrastive loss over all N^2 image/caption pairs.
+//
+// Reference: src/criterions/probemb.py:7-86,150-256 (MCSoftContrastiveLoss).  The reference
+// gathers N^2 x D operands and evaluates (a-b)^2 element-wise; here the pair-similarity matrix
+// S = I T^T is ONE fp32 MFMA GEMM (exact fp32 FMA chains) and d^2 = |I_i|^2 + |T_j|^2 - 2 S_ij.
+// The N diagonal (positive) pairs dominate the loss and suffer the cancellation of the GEMM
+// form when matched pairs are close, so their distances are recomputed exactly as
+// sum (I_ik - T_ik)^2 by cfl_pair_prep_kernel.
+//
+// HBM layout: I, T [N, D] row-major fp32; coef [N, N] row-major fp32; ws (floats):
+//   ni[N] nt[N] dd[N] rowsum[N] colsum[N] rowpart[NT*N] colpart[NT*N] part[NT*NT*4]
+// with NT = ceil(N / 64) (sized for the smallest tile).
+#include "common.h"
+
+namespace {
+
+struct PairWs {
+    float *ni, *nt, *dd, *rowsum, *colsum, *rowpart, *colpart, *part;
+};
+static PairWs pair_ws(void* ws, int N) {
+    const int NT = cfl_cdiv(N, 64);
+    float* p = (float*)ws;
+    PairWs w;
+    w.ni = p; p += N; w.nt = p; p += N; w.dd = p; p += N;
+    w.rowsum = p; p += N; w.colsum = p; p += N;
+    w.rowpart = p; p += (size_t)NT * N; w.colpart = p; p += (size_t)NT * N;
+    w.part = p;
+    return w;
+}
+
+// one wave per row: |I_i|^2, |T_i|^2 and the exact diagonal squared distance.
+__global__ __launch_bounds__(256) void cfl_pair_prep_kernel(const float* __restrict__ I, const float* __restrict__ T,
+                                                            int N, int D, float* ni, float* nt, float* dd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* a = I + (long long)row * D;
+    const float* b = T + (long long)row * D;
+    float sa = 0.f, sb = 0.f, sd = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float x = a[k], y = b[k], e = x - y;
+        sa = fmaf(x, x, sa); sb = fmaf(y, y, sb); sd = fmaf(e, e, sd);
+    }
+    sa = wave_sum(sa); sb = wave_sum(sb); sd = wave_sum(sd);
+    if (lane == 0) { ni[row] = sa; nt[row] = sb; dd[row] = sd; }
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N, const float* __restrict__ a_dev, const float* __restrict__ b_dev, float eps,
+                                                           const float* __restrict__ ni, const float* __restrict__ nt,
+                                                           const float* __restrict__ dd, float* coef,
+                                                           float* rowpart, float* colpart, float* part) {
+    using C = TileCfg<TM, TN, true, true>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ntc = (N + C::BN - 1) / C::BN;                  // tile columns
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ti = tile / ntc, tj = tile % ntc;
+    const int row0 = ti * C::BM, col0 = tj * C::BN;
+    f32x16 acc[TM][TN];
+    tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
+
+    const float a = a_dev[0], b = b_dev[0];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
+    constexpr int CLD = C::BN + 1;
+    float* cs = lds;                                          // [BM][BN+1] coefficient tile
+    float pos = 0.f, neg = 0.f, da = 0.f, db = 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int lc = acc_col<TN>(wc, n, lane);
+            const int j = col0 + lc;
+            const float ntj = j < N ? nt[j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = acc_row<TM>(wr, m, r, lane);
+                const int i = row0 + lr;
+                float c = 0.f;
+                if (i < N && j < N) {
+                    const bool diag = (i == j);
+                    const float d2 = diag ? dd[i] : fmaxf(ni[i] + ntj - 2.f * acc[m][n][r], 0.f);
+                    const float d = sqrtf(d2 + eps);
+                    const float s = fmaf(-a, d, b);
+                    const float mm = diag ? 1.f : -1.f;
+                    const float x = -2.f * mm * s;
+                    const float nll = softplusf(x);
+                    const float g = 4.f * mm * sigmoidf(x);     // dL/dd / a   (both directions)
+                    c = a * g / d;
+                    if (diag) pos += nll; else neg += nll;
+                    da = fmaf(g, d, da);
+                    db -= g;
+                }
+                cs[lr * CLD + lc] = c;
+            }
+        }
+    __shared__ float red[4];
+    pos = block_sum_256(pos, red);
+    neg = block_sum_256(neg, red);
+    da = block_sum_256(da, red);
+    db = block_sum_256(db, red);          // (each call starts with a barrier: cs is complete here)
+    if (threadIdx.x == 0) {
+        float* p = part + (size_t)tile * 4;
+        p[0] = pos; p[1] = neg; p[2] = da; p[3] = db;
+    }
+    const int t = threadIdx.x;
+    if (t < C::BM) {
+        float s = 0.f;
+        for (int j = 0; j < C::BN; ++j) s += cs[t * CLD + j];
+        if (row0 + t < N) rowpart[(size_t)tj * N + row0 + t] = s;
+    } else if (t < C::BM + C::BN) {
+        const int cj = t - C::BM;
+        float s = 0.f;
+        for (int i = 0; i < C::BM; ++i) s += cs[i * CLD + cj];
+        if (col0 + cj < N) colpart[(size_t)ti * N + col0 + cj] = s;
+    }
+    if (coef) {
+        for (int e = t; e < C::BM * C::BN; e += 256) {
+            const int lr = e / C::BN, lc = e % C::BN;
+            if (row0 + lr < N && col0 + lc < N) coef[(long long)(row0 + lr) * N + col0 + lc] = cs[lr * CLD + lc];
+        }
+    }
+}
+
+// deterministic reductions: out8 from per-tile partials; rowsum/colsum from per-tile-column partials
+__global__ __launch_bounds__(256) void cfl_pair_final_kernel(const float* part, int ntiles, const float* rowpart,
+                                                             const float* colpart, int ntr, int ntc, int N,
+                                                             float* rowsum, float* colsum, float* out8) {
+    __shared__ float red[4];
+    if (blockIdx.x == 0) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = threadIdx.x; t < ntiles; t += 256)
+            for (int e = 0; e < 4; ++e) v[e] += part[(size_t)t * 4 + e];
+        for (int e = 0; e < 4; ++e) v[e] = block_sum_256(v[e], red);
+        if (threadIdx.x == 0) {
+            out8[0] = 2.f * (v[0] + v[1]); out8[1] = v[0]; out8[2] = v[1]; out8[3] = v[2]; out8[4] = v[3];
+            out8[5] = 0.f; out8[6] = 0.f; out8[7] = 0.f;
+        }
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) {
+        float s = 0.f;
+        for (int t = 0; t < ntc; ++t) s += rowpart[(size_t)t * N + i];
+        rowsum[i] = s;
+        s = 0.f;
+        for (int t = 0; t < ntr; ++t) s += colpart[(size_t)t * N + i];
+        colsum[i] = s;
+    }
+}
+
+// z = 0: dI = gout * (I * rowsum - coef   @ T)   A = coef (K contiguous), B = T (K strided)
+// z = 1: dT = gout * (T * colsum - coef^T @ I)   A = coef^T (K strided),  B = I (K strided)
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void cfl_pair_bwd_kernel(const float* __restrict__ I, const float* __restrict__ T,
+                                                           const float* __restrict__ coef, int N, int D, int vecN, int vecD,
+                                                           const float* __restrict__ rowsum, const float* __restrict__ colsum,
+                                                           const float* __restrict__ gout, float* dI, float* dT) {
+    using C = TileCfg<TM, TN, true, false>;                   // (KS,KS) needs no more LDS than (KC,KS)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ntc = (D + C::BN - 1) / C::BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (tile / ntc) * C::BM, col0 = (tile % ntc) * C::BN;
+    const bool second = blockIdx.z != 0;
+    f32x16 acc[TM][TN];
+    const float* X = second ? T : I;        // the tensor whose gradient this block produces
+    const float* Y = second ? I : T;
+    Opnd Bo{Y, D, D, N, vecD};
+    if (!second) {
+        Opnd Ao{coef, N, N, N, vecN};
+        tile_gemm<TM, TN, true, false>(Ao, Bo, row0, col0, 0, N, lds, acc, XfIdentity());
+    } else {
+        Opnd Ao{coef, N, N, N, vecN};
+        tile_gemm<TM, TN, false, false>(Ao, Bo, row0, col0, 0, N, lds, acc, XfIdentity());
+    }
+    const float* sums = second ? colsum : rowsum;
+    float* out = second ? dT : dI;
+    const float g = gout[0];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int j = col0 + acc_col<TN>(wc, n, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = row0 + acc_row<TM>(wr, m, r, lane);
+                if (i < N && j < D) {
+                    const long long o = (long long)i * D + j;
+                    out[o] = g * (sums[i] * X[o] - acc[m][n][r]);
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cfl_pair_loss_ws_bytes(int N, int D) {
+    (void)D;
+    if (N <= 0) return 256;
+    const size_t NT = (size_t)cfl_cdiv(N, 64);
+    return cfl_align256((5 * (size_t)N + 2 * NT * N + 4 * NT * NT) * sizeof(float));
+}
+
+int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float* a_dev, const float* b_dev, float eps,
+                      float* out8, float* coef, void* ws, void* stream_) {
+    if (!I || !T || !a_dev || !b_dev || !out8 || !ws || N <= 0 || D <= 0) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    PairWs w = pair_ws(ws, N);
+    CFL_LAUNCH(K_PAIR_PREP, cfl_pair_prep_kernel, dim3(cfl_cdiv(N, 4)), dim3(256), 0, stream, I, T, N, D, w.ni, w.nt, w.dd);
+    Opnd A{I, D, N, D, cfl_vec_ok(I, D)};
+    Opnd B{T, D, N, D, cfl_vec_ok(T, D)};
+    // 128x128 tiles once they fill the chip, 64x64 tiles below that (latency-bound regime)
+    const bool big = (long long)cfl_cdiv(N, 128) * cfl_cdiv(N, 128) >= 256;
+    int ntr, ntc;
+    if (big) {
+        using C = TileCfg<2, 2, true, true>;
+        ntr = cfl_cdiv(N, C::BM); ntc = cfl_cdiv(N, C::BN);
+        CFL_SET_LDS((cfl_pair_fwd_kernel<2, 2>), C::LDS_BYTES);
+        CFL_LAUNCH(K_PAIR_FWD, (cfl_pair_fwd_kernel<2, 2>), dim3(ntr * ntc), dim3(256), C::LDS_BYTES, stream,
+                   A, B, N, a_dev, b_dev, eps, w.ni, w.nt, w.dd, coef, w.rowpart, w.colpart, w.part);
+    } else {
+        using C = TileCfg<1, 1, true, true>;
+        ntr = cfl_cdiv(N, C::BM); ntc = cfl_cdiv(N, C::BN);
+        CFL_LAUNCH(K_PAIR_FWD, (cfl_pair_fwd_kernel<1, 1>), dim3(ntr * ntc), dim3(256), C::LDS_BYTES, stream,
+                   A, B, N, a_dev, b_dev, eps, w.ni, w.nt, w.dd, coef, w.rowpart, w.colpart, w.part);
+    }
+    CFL_LAUNCH(K_PAIR_FINAL, cfl_pair_final_kernel, dim3(cfl_cdiv(N, 256)), dim3(256), 0, stream,
+               w.part, ntr * ntc, w.rowpart, w.colpart, ntr, ntc, N, w.rowsum, w.colsum, out8);
+    return 0;
+}
+
+int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, int D,
+                      const float* gout_dev, float* dI, float* dT, void* ws, void* stream_) {
+    if (!I || !T || !coef || !gout_dev || !dI || !dT || !ws || N <= 0 || D <= 0) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    PairWs w = pair_ws(ws, N);
+    const int vecN = cfl_vec_ok(coef, N);
+    const int vecD = (cfl_vec_ok(I, D) && cfl_vec_ok(T, D)) ? 1 : 0;
+    const bool big = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 128) * 2 >= 256;
+    if (big) {
+        using C = TileCfg<2, 2, true, false>;
+        CFL_SET_LDS((cfl_pair_bwd_kernel<2, 2>), C::LDS_BYTES);
+        CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<2, 2>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
+                   C::LDS_BYTES, stream, I, T, coef, N, D, vecN, vecD, w.rowsum, w.colsum, gout_dev, dI, dT);
+    } else {
+        using C = TileCfg<1, 1, true, false>;
+        CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<1, 1>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
+                   C::LDS_BYTES, stream, I, T, coef, N, D, vecN, vecD, w.rowsum, w.colsum, gout_dev, dI, dT);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// runtime.hip -- library identity + per-kernel HIP-event profiler behind the C ABI.
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+static const char* const g_kernel_names[K_NUM] = {
+    "cfl_pair_prep_kernel", "cfl_pair_fwd_kernel", "cfl_pair_final_kernel", "cfl_pair_bwd_kernel",
+    "cfl_bank_fwd_kernel", "cfl_lse_final_kernel", "cfl_bank_loss_kernel", "cfl_bank_bwd_kernel",
+    "cfl_bank_bwd_reduce_kernel", "cfl_intra_kernel", "cfl_conw_combine_kernel",
+    "cfl_pie_scores_kernel", "cfl_pie_pool_kernel", "cfl_pie_bwd_ds_kernel", "cfl_pie_bwd_dx_kernel",
+    "cfl_pie_bwd_dh_kernel", "cfl_pie_bwd_dw2_kernel", "cfl_pie_epi_fwd_kernel",
+    "cfl_pie_epi_bwd_kernel", "cfl_pie_epi_bwd_ln_kernel", "cfl_l2norm_fwd_kernel",
+    "cfl_l2norm_bwd_kernel", "cfl_rank_posmax_kernel", "cfl_rank_count_kernel",
+};
+
+namespace {
+struct Pending { int id; hipEvent_t e0, e1; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_pool;
+long long g_launches[K_NUM];
+double g_ms[K_NUM];
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void drain_locked() {
+    for (auto& p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            g_launches[p.id] += 1;
+            g_ms[p.id] += (double)ms;
+        }
+        g_pool.push_back(p.e0);
+        g_pool.push_back(p.e1);
+    }
+    g_pending.clear();
+}
+}  // namespace
+
+CflProfScope::CflProfScope(int id_, hipStream_t s_) : id(id_), s(s_), e0(nullptr), e1(nullptr), on(false) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    e0 = get_event();
+    e1 = get_event();
+    on = (e0 && e1 && hipEventRecord(e0, s) == hipSuccess);
+}
+CflProfScope::~CflProfScope() {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (hipEventRecord(e1, s) == hipSuccess) g_pending.push_back({id, e0, e1});
+}
+
+extern "C" {
+int cfl_version(void) { return 100; }
+const char* cfl_arch(void) { return "gfx950"; }
+int cfl_num_kernels(void) { return K_NUM; }
+const char* cfl_kernel_name(int id) { return (id >= 0 && id < K_NUM) ? g_kernel_names[id] : ""; }
+
+int cfl_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return 0;
+}
+int cfl_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain_locked();
+    for (int i = 0; i < K_NUM; ++i) { g_launches[i] = 0; g_ms[i] = 0.0; }
+    return 0;
+}
+int cfl_prof_query(int id, long long* launches, double* total_ms) {
+    if (id < 0 || id >= K_NUM) return CFL_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain_locked();
+    if (launches) *launches = g_launches[id];
+    if (total_ms) *total_ms = g_ms[id];
+    return 0;
+}
+}

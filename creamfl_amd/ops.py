@@ -1,0 +1,379 @@
+"""torch.autograd wrappers over the C ABI (include/creamfl_hip.h).
+
+Every function here runs on the current HIP stream of the tensors' device, takes and returns
+ordinary torch tensors, and raises if the HIP library is missing or an argument is not a
+contiguous fp32 device tensor -- there is no CPU fallback (the CPU oracle lives in oracle/ and is
+test infrastructure only).
+"""
+import ctypes
+from collections.abc import Mapping
+
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _f32(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise _lib.CreamflHipError(f'{name}: expected a CUDA/HIP tensor (no CPU fallback in creamfl_amd)')
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------- A1: pair loss
+class LazyLossDict(Mapping):
+    """The reference returns 11 python floats (11 device syncs, probemb.py:245-255).  This mapping
+    has the same keys and values but copies the 8-float statistics block to the host only when a
+    value is first read."""
+    KEYS = ('i2t_loss', 't2i_loss', 'i2t_pos_loss', 'i2t_neg_loss', 't2i_pos_loss', 't2i_neg_loss',
+            'uniform_loss', 'vib_loss', 'shift', 'negative_scale', 'loss')
+
+    def __init__(self, out8, shift, negative_scale):
+        self._dev = (out8, shift, negative_scale)
+        self._host = None
+
+    def _materialise(self):
+        if self._host is None:
+            out8, shift, ns = self._dev
+            v = torch.cat([out8.detach(), shift.detach().reshape(1), ns.detach().reshape(1)]).cpu().tolist()
+            loss, pos, neg = v[0], v[1], v[2]
+            self._host = {'i2t_loss': pos + neg, 't2i_loss': pos + neg, 'i2t_pos_loss': pos, 'i2t_neg_loss': neg,
+                          't2i_pos_loss': pos, 't2i_neg_loss': neg, 'uniform_loss': 0, 'vib_loss': 0,
+                          'shift': v[8], 'negative_scale': v[9], 'loss': loss}
+        return self._host
+
+    def __getitem__(self, k):
+        return self._materialise()[k]
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def __len__(self):
+        return len(self.KEYS)
+
+
+class _PairLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, I, T, a, b, eps):
+        lib = _lib.load()
+        N, D = I.shape
+        need_grad = any(ctx.needs_input_grad[:4])
+        out8 = torch.empty(8, dtype=torch.float32, device=I.device)
+        coef = torch.empty(N, N, dtype=torch.float32, device=I.device) if need_grad else None
+        ws = _ws(lib.cfl_pair_loss_ws_bytes(N, D), I.device)
+        _lib.check(lib.cfl_pair_loss_fwd(_ptr(I), _ptr(T), N, D, _ptr(a), _ptr(b), eps, _ptr(out8), _ptr(coef),
+                                         _ptr(ws), _stream(I)), 'cfl_pair_loss_fwd')
+        ctx.save_for_backward(I, T, coef if coef is not None else out8, out8, ws)
+        ctx.has_coef = need_grad
+        ctx.mark_non_differentiable(out8)
+        return out8[0].clone(), out8
+
+    @staticmethod
+    def backward(ctx, gloss, _gstats):
+        lib = _lib.load()
+        I, T, coef, out8, ws = ctx.saved_tensors
+        if not ctx.has_coef:
+            raise _lib.CreamflHipError('pair_loss backward without saved coefficients')
+        N, D = I.shape
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        dI = torch.empty_like(I)
+        dT = torch.empty_like(T)
+        _lib.check(lib.cfl_pair_loss_bwd(_ptr(I), _ptr(T), _ptr(coef), N, D, _ptr(g), _ptr(dI), _ptr(dT), _ptr(ws),
+                                         _stream(I)), 'cfl_pair_loss_bwd')
+        da = (out8[3] * g[0]).reshape(1)
+        db = (out8[4] * g[0]).reshape(1)
+        return dI, dT, da, db, None
+
+
+def pair_loss(image_features, caption_features, negative_scale, shift, eps=1e-6):
+    """A1 (src/criterions/probemb.py:221-256).  Returns (loss 0-d tensor with grad, stats[8] tensor =
+    {loss, pos, neg, dL/da, dL/db, 0, 0, 0})."""
+    I = _f32(image_features, 'image_features')
+    T = _f32(caption_features, 'caption_features')
+    if I.dim() != 2 or I.shape != T.shape:
+        raise RuntimeError('# anchors ({}) != # candidates ({})'.format(tuple(I.shape), tuple(T.shape)))
+    a = _f32(negative_scale, 'negative_scale').reshape(1)
+    b = _f32(shift, 'shift').reshape(1)
+    return _PairLossFn.apply(I, T, a, b, float(eps))
+
+
+# --------------------------------------------------------------------------- A3/A4: client contrast
+class _BankInterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, F, G, idx, inv_tau):
+        lib = _lib.load()
+        B, D = F.shape
+        M = G.shape[0]
+        dev = F.device
+        lse = torch.empty(B, dtype=torch.float32, device=dev)
+        pos = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0]
+        logits_t = torch.empty(M, B, dtype=torch.float32, device=dev) if need else None
+        ws = _ws(lib.cfl_bank_ws_bytes(B, M, D), dev)
+        _lib.check(lib.cfl_bank_lse_fwd(_ptr(F), _ptr(G), _ptr(idx), B, M, D, inv_tau, _ptr(lse), _ptr(pos), _ptr(loss),
+                                        _ptr(logits_t), _ptr(ws), _stream(F)), 'cfl_bank_lse_fwd')
+        ctx.save_for_backward(G, idx, lse, logits_t if need else lse, ws)
+        ctx.inv_tau = inv_tau
+        ctx.shape = (B, M, D)
+        ctx.mark_non_differentiable(lse, pos)
+        return loss[0].clone(), lse, pos
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g2):
+        lib = _lib.load()
+        G, idx, lse, logits_t, ws = ctx.saved_tensors
+        B, M, D = ctx.shape
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        dF = torch.empty(B, D, dtype=torch.float32, device=G.device)
+        _lib.check(lib.cfl_bank_lse_bwd(_ptr(logits_t), _ptr(G), _ptr(idx), _ptr(lse), B, M, D, ctx.inv_tau, _ptr(g),
+                                        _ptr(dF), _ptr(ws), _stream(G)), 'cfl_bank_lse_bwd')
+        return dF, None, None, None
+
+
+def _idx(d_idx, device):
+    if torch.is_tensor(d_idx):
+        return d_idx.to(device=device, dtype=torch.int64).contiguous()
+    return torch.as_tensor(list(d_idx) if not isinstance(d_idx, (list, tuple)) else d_idx,
+                           dtype=torch.int64, device=device)
+
+
+def inter_contrast(feature, global_other, d_idx, temperature=0.5):
+    """A3: CrossEntropy(feature @ global_other.T / temperature, d_idx)  (ClientTrainer.py:388,400-401).
+    Returns (loss, lse[B], pos[B])."""
+    F = _f32(feature, 'feature')
+    G = _f32(global_other.detach(), 'global_other')
+    if F.dim() != 2 or G.dim() != 2 or F.shape[1] != G.shape[1]:
+        raise RuntimeError(f'shape mismatch {tuple(F.shape)} vs {tuple(G.shape)}')
+    return _BankInterFn.apply(F, G, _idx(d_idx, F.device), 1.0 / float(temperature))
+
+
+class _IntraFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, F, Gs, idx, Fo, inv_tau, b_div):
+        lib = _lib.load()
+        B, D = F.shape
+        loss = torch.empty(1, dtype=torch.float32, device=F.device)
+        need = ctx.needs_input_grad[0]
+        dF = torch.empty_like(F) if need else None
+        ws = _ws(lib.cfl_intra_ws_bytes(B), F.device)
+        _lib.check(lib.cfl_intra_fwd(_ptr(F), _ptr(Gs), _ptr(idx), _ptr(Fo), B, D, b_div, inv_tau, _ptr(loss), _ptr(dF),
+                                     _ptr(ws), _stream(F)), 'cfl_intra_fwd')
+        ctx.save_for_backward(dF if need else loss)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (dF,) = ctx.saved_tensors
+        return dF * gloss, None, None, None, None, None
+
+
+def intra_contrast(feature, global_same, d_idx, old_feature, temperature=0.5, mean_divisor=None):
+    """A4: CE([<f, G_same[idx]>, <f, f_old>] / temperature, 0)  (ClientTrainer.py:404-414).
+    `mean_divisor` overrides the CE mean divisor (2B when two modalities are stacked,
+    MMClientTrainer.py:184-188)."""
+    F = _f32(feature, 'feature')
+    Gs = _f32(global_same.detach(), 'global_same')
+    Fo = _f32(old_feature.detach(), 'old_feature')
+    if F.shape != Fo.shape:
+        raise RuntimeError(f'shape mismatch {tuple(F.shape)} vs {tuple(Fo.shape)}')
+    return _IntraFn.apply(F, Gs, _idx(d_idx, F.device), Fo, 1.0 / float(temperature),
+                          int(mean_divisor) if mean_divisor else F.shape[0])
+
+
+# --------------------------------------------------------------------------- A5: con_w
+@torch.no_grad()
+def conw_logprob(vec, global_other, row0=0, rows=None):
+    """A5 (MMFL.py:304-307) for rows [row0, row0+rows) of one client representation [M, D]."""
+    lib = _lib.load()
+    V = _f32(vec, 'vec')
+    G = _f32(global_other, 'global_other')
+    M, D = V.shape
+    if G.shape != V.shape:
+        raise RuntimeError(f'shape mismatch {tuple(V.shape)} vs {tuple(G.shape)}')
+    rows = M - row0 if rows is None else rows
+    out = torch.empty(rows, dtype=torch.float32, device=V.device)
+    ws = _ws(lib.cfl_conw_ws_bytes(rows, M, D), V.device)
+    _lib.check(lib.cfl_conw_logprob(_ptr(V), _ptr(G), M, D, row0, rows, _ptr(out), _ptr(ws), _stream(V)),
+               'cfl_conw_logprob')
+    return out
+
+
+@torch.no_grad()
+def conw_combine(vecs, logprobs, return_weights=False):
+    """A5 (MMFL.py:311-314): softmax over clients of logprobs [C, M], weighted sum of vecs."""
+    lib = _lib.load()
+    vecs = [_f32(v, 'vec') for v in vecs]
+    L = _f32(logprobs, 'logprobs')
+    C = len(vecs)
+    M, D = vecs[0].shape
+    if L.shape != (C, M):
+        raise RuntimeError(f'logprobs shape {tuple(L.shape)} != ({C}, {M})')
+    out = torch.empty(M, D, dtype=torch.float32, device=L.device)
+    W = torch.empty(C, M, dtype=torch.float32, device=L.device) if return_weights else None
+    arr = (ctypes.c_void_p * C)(*[v.data_ptr() for v in vecs])
+    _lib.check(lib.cfl_conw_combine(arr, _ptr(L), C, M, D, _ptr(out), _ptr(W), _stream(L)), 'cfl_conw_combine')
+    return (out, W) if return_weights else out
+
+
+# --------------------------------------------------------------------------- A2-head: PIE
+class _PiePoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, H, w2, mask, want_mean):
+        lib = _lib.load()
+        N, P, Cd = X.shape
+        dh = H.shape[2]
+        dev = X.device
+        attn = torch.empty(N, P, dtype=torch.float32, device=dev)
+        pooled = torch.empty(N, Cd, dtype=torch.float32, device=dev)
+        xmean = torch.empty(N, Cd, dtype=torch.float32, device=dev) if want_mean else None
+        ws = _ws(lib.cfl_pie_ws_bytes(N, P, Cd, dh), dev)
+        _lib.check(lib.cfl_pie_pool_fwd(_ptr(X), _ptr(H), _ptr(w2), _ptr(mask), N, P, Cd, dh, _ptr(attn), _ptr(pooled),
+                                        _ptr(xmean), _ptr(ws), _stream(X)), 'cfl_pie_pool_fwd')
+        ctx.save_for_backward(X, H, w2, attn)
+        ctx.mask = mask
+        ctx.want_mean = want_mean
+        ctx.mark_non_differentiable(attn)
+        if want_mean:
+            return pooled, attn, xmean
+        return pooled, attn, pooled.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, dpooled, _dattn, dxmean):
+        lib = _lib.load()
+        X, H, w2, attn = ctx.saved_tensors
+        N, P, Cd = X.shape
+        dh = H.shape[2]
+        dpooled = dpooled.contiguous().float()
+        dxm = dxmean.contiguous().float() if ctx.want_mean else None
+        dX = torch.empty_like(X)
+        dH = torch.empty_like(H)
+        dw2 = torch.empty_like(w2)
+        ws = _ws(lib.cfl_pie_ws_bytes(N, P, Cd, dh), X.device)
+        _lib.check(lib.cfl_pie_pool_bwd(_ptr(X), _ptr(H), _ptr(w2), _ptr(ctx.mask), _ptr(attn), _ptr(dpooled), _ptr(dxm),
+                                        N, P, Cd, dh, _ptr(dX), _ptr(dH), _ptr(dw2), _ptr(ws), _stream(X)),
+                   'cfl_pie_pool_bwd')
+        return dX, dH, dw2, None, None
+
+
+def pie_pool(x, h, w2, pad_mask=None, want_mean=False):
+    """softmax_P(w2 . tanh(h)) attention pooling of x (pie_model.py:28-40, n_head = 1).
+    x [N,P,Cd], h = w_1(x) [N,P,dh], w2 [dh] or [1,dh], pad_mask [N,P] bool (True = padded).
+    Returns (pooled [N,Cd], attn [N,P], xmean [N,Cd] or empty)."""
+    X = _f32(x, 'x')
+    H = _f32(h, 'h')
+    W2 = _f32(w2, 'w2').reshape(-1)
+    if X.dim() != 3 or H.dim() != 3 or X.shape[:2] != H.shape[:2] or W2.numel() != H.shape[2]:
+        raise RuntimeError(f'pie_pool shape mismatch x{tuple(X.shape)} h{tuple(H.shape)} w2{tuple(W2.shape)}')
+    m = None
+    if pad_mask is not None:
+        m = pad_mask.to(device=X.device, dtype=torch.uint8).contiguous()
+    return _PiePoolFn.apply(X, H, W2, m, bool(want_mean))
+
+
+class _PieEpilogueFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, res_pre, ln_w, ln_b, eps, flags):
+        lib = _lib.load()
+        N, D = out.shape
+        dev = out.device
+        y = torch.empty_like(out)
+        o = torch.empty_like(out)
+        r = torch.empty_like(out)
+        stats = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.cfl_pie_epilogue_fwd(_ptr(out), _ptr(res_pre), _ptr(ln_w), _ptr(ln_b), N, D, eps, flags, _ptr(y),
+                                            _ptr(o), _ptr(r), _ptr(stats), _stream(out)), 'cfl_pie_epilogue_fwd')
+        ctx.save_for_backward(out, r, ln_w, ln_b, stats)
+        ctx.flags = flags
+        ctx.set_materialize_grads(False)
+        return y, o, r
+
+    @staticmethod
+    def backward(ctx, dy, do_, dres):
+        lib = _lib.load()
+        out, r, ln_w, ln_b, stats = ctx.saved_tensors
+        N, D = out.shape
+        dy = dy.contiguous().float() if dy is not None else torch.zeros_like(out)
+        do_ = do_.contiguous().float() if do_ is not None else None
+        dres = dres.contiguous().float() if dres is not None else None
+        d_out = torch.empty_like(out)
+        d_res = torch.empty_like(out)
+        d_w = torch.empty_like(ln_w)
+        d_b = torch.empty_like(ln_b)
+        ws = _ws(lib.cfl_pie_ws_bytes(N, 1, D, 1), out.device)
+        _lib.check(lib.cfl_pie_epilogue_bwd(_ptr(dy), _ptr(do_), _ptr(dres), _ptr(out), _ptr(r), _ptr(ln_w), _ptr(ln_b),
+                                            _ptr(stats), N, D, ctx.flags, _ptr(d_out), _ptr(d_res), _ptr(d_w), _ptr(d_b),
+                                            _ptr(ws), _stream(out)), 'cfl_pie_epilogue_bwd')
+        return d_out, d_res, d_w, d_b, None, None
+
+
+def pie_epilogue(out, res_pre, ln_w, ln_b, eps=1e-5, l2norm=True):
+    """r = sigmoid(res_pre); o = LayerNorm(out + r); y = l2_normalize(o) (pie_model.py:63-66 +
+    tensor_utils.py:25-27).  Returns (y, o, r); with l2norm=False, y == o."""
+    return _PieEpilogueFn.apply(_f32(out, 'out'), _f32(res_pre, 'res_pre'), _f32(ln_w, 'ln_w'), _f32(ln_b, 'ln_b'),
+                                float(eps), 0 if l2norm else 1)
+
+
+class _L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        N, D = x.shape
+        y = torch.empty_like(x)
+        inv = torch.empty(N, dtype=torch.float32, device=x.device)
+        _lib.check(lib.cfl_l2norm_fwd(_ptr(x), N, D, _ptr(y), _ptr(inv), _stream(x)), 'cfl_l2norm_fwd')
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, inv = ctx.saved_tensors
+        N, D = y.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(y)
+        _lib.check(lib.cfl_l2norm_bwd(_ptr(dy), _ptr(y), _ptr(inv), N, D, _ptr(dx), _stream(y)), 'cfl_l2norm_bwd')
+        return dx
+
+
+def l2_normalize(tensor, axis=-1):
+    """src/utils/tensor_utils.py:25-27 for 2-D [N, D] tensors normalised along the last axis."""
+    x = _f32(tensor, 'tensor')
+    if x.dim() != 2 or axis not in (-1, 1):
+        raise RuntimeError('creamfl_amd.ops.l2_normalize handles [N, D] tensors along the last axis')
+    return _L2NormFn.apply(x)
+
+
+# --------------------------------------------------------------------------- A6: retrieval ranks
+@torch.no_grad()
+def rank_count(q_features, g_features, q_labels, g_labels):
+    """A6 (eval_coco.py:37-51,296-317): int32 rank of the best positive for every query."""
+    lib = _lib.load()
+    Q = _f32(q_features, 'q_features')
+    G = _f32(g_features, 'g_features')
+    ql = torch.as_tensor(q_labels).to(device=Q.device, dtype=torch.int64).contiguous()
+    gl = torch.as_tensor(g_labels).to(device=Q.device, dtype=torch.int64).contiguous()
+    if len(Q) != len(ql):
+        raise RuntimeError('length mismatch {}, {}'.format(tuple(Q.shape), tuple(ql.shape)))
+    if len(G) != len(gl):
+        raise RuntimeError('length mismatch {}, {}'.format(tuple(G.shape), tuple(gl.shape)))
+    Nq, D = Q.shape
+    Ng = G.shape[0]
+    ranks = torch.empty(Nq, dtype=torch.int32, device=Q.device)
+    ws = _ws(lib.cfl_rank_ws_bytes(Nq, Ng, D), Q.device)
+    _lib.check(lib.cfl_rank_count(_ptr(Q), _ptr(G), _ptr(ql), _ptr(gl), Nq, Ng, D, _ptr(ranks), _ptr(ws), _stream(Q)),
+               'cfl_rank_count')
+    return ranks

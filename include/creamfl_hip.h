@@ -1,0 +1,160 @@
+/*
+ * creamfl_hip.h -- C ABI of libcreamfl_hip.so, the MI355X (gfx950) implementation of the
+ * CreamFL contrastive hot path.
+ *
+ * The reference (FLAIR-THU/CreamFL) is pure Python on PyTorch and has no FFI; the boundary
+ * it would bind for this path is therefore designed here and each entry
+ * point cites the reference code it replaces (paths relative to the reference checkout).
+ * INTEGRATION.md shows the ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; tensors are dense
+ *     row-major fp32 unless stated; int64 index arrays are `const long long*`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued asynchronously on it; nothing synchronises, allocates or frees.
+ *   - scratch memory is provided by the caller: cfl_*_ws_bytes() returns the size needed.
+ *   - return value: 0 on success, a hipError_t (> 0) for a HIP failure, or a negative
+ *     CFL_E* code for an argument error.  Nothing throws across the boundary.
+ */
+#ifndef CREAMFL_HIP_H
+#define CREAMFL_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFL_EINVAL   (-1)   /* bad size / null pointer */
+#define CFL_EALIGN   (-2)   /* pointer not 4-byte aligned */
+#define CFL_ELIMIT   (-3)   /* size outside the supported range (documented per call) */
+
+/* ---- library / profiling ------------------------------------------------------------- */
+int         cfl_version(void);                 /* 100*major + minor */
+const char* cfl_arch(void);                    /* "gfx950" */
+int         cfl_num_kernels(void);
+const char* cfl_kernel_name(int kernel_id);    /* name as it appears in rocprofv3 traces */
+/* When enabled every kernel launch is bracketed by hipEvents recorded on the launch
+ * stream; cfl_prof_query drains finished events (it synchronises on them). */
+int cfl_prof_enable(int on);
+int cfl_prof_reset(void);
+int cfl_prof_query(int kernel_id, long long* launches, double* total_ms);
+
+/* ---- A1: all-pairs soft-contrastive loss ------------------------------------------------
+ * Replaces MCSoftContrastiveLoss.forward / _compute_loss / pairwise_sampling / full_sampling /
+ * batchwise_cdist / soft_contrastive_nll  (src/criterions/probemb.py:7-86,150-256) for 2-D
+ * features, uniform_lambda = vib_beta = 0.
+ *
+ * fwd: I, T [N, D]; a_dev/b_dev: device scalars negative_scale / shift (the criterion's learnable
+ *      parameters stay on the device: no host sync per step).  d_ij = sqrt(|I_i - T_j|^2 + eps), s = -a d + b, m = +1 (i == j) / -1,
+ *      NLL = softplus(-2 m s).  out[8] = { loss (= 2*(pos+neg)), pos, neg, dL/da, dL/db, 0,0,0 }
+ *      (pos/neg are the one-direction sums: i2t_pos_loss == t2i_pos_loss == pos).
+ *      If coef != NULL it also writes coef[N, N] = (dL/dd_ij) / d_ij  (both directions, not
+ *      scaled by any upstream gradient) and leaves row/column sums of coef in ws for bwd.
+ * bwd: dI = gout * (I * rowsum(coef) - coef @ T),  dT = gout * (T * colsum(coef) - coef^T @ I).
+ *      gout_dev is a device scalar (the upstream gradient of the loss).
+ * ws must be the same buffer for fwd and the following bwd.
+ */
+size_t cfl_pair_loss_ws_bytes(int N, int D);
+int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float* a_dev,
+                      const float* b_dev, float eps,
+                      float* out8, float* coef, void* ws, void* stream);
+int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, int D,
+                      const float* gout_dev, float* dI, float* dT, void* ws, void* stream);
+
+/* ---- A3: inter-modal contrast against the frozen global bank ------------------------------
+ * Replaces  logits = matmul(f, G.T)/0.5 ; CrossEntropyLoss()(logits, d_idx)
+ * (src/algorithms/ClientTrainer.py:388,400-401,493-502; MMClientTrainer.py:194-201,301-308).
+ *
+ * fwd: F [B, D], G [M, D], idx [B] (int64, 0 <= idx < M).  lse[b] = logsumexp_m(inv_tau F_b.G_m),
+ *      pos[b] = inv_tau F_b.G_idx[b] (exact fp32 dot), loss[0] = mean_b(lse - pos).
+ *      If logits_t != NULL the scaled logits are stored TRANSPOSED, logits_t[M, B], for bwd.
+ * bwd: dF[b,:] = coef * (sum_m softmax_bm G_m - G_idx[b]),  coef = inv_tau / B * gout.
+ */
+size_t cfl_bank_ws_bytes(int B, int M, int D);
+int cfl_bank_lse_fwd(const float* F, const float* G, const long long* idx, int B, int M, int D,
+                     float inv_tau, float* lse, float* pos, float* loss, float* logits_t,
+                     void* ws, void* stream);
+int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx, const float* lse,
+                     int B, int M, int D, float inv_tau, const float* gout_dev, float* dF,
+                     void* ws, void* stream);
+
+/* ---- A4: intra-modal (MOON style) contrast ------------------------------------------------
+ * Replaces pos = sum(f*G_same[d_idx]), neg = sum(f*f_old), CE([pos,neg]/0.5, 0)
+ * (ClientTrainer.py:404-414,458-468; MMClientTrainer.py:173-191,246-264).
+ * loss[0] = mean_b softplus((neg-pos)*inv_tau);  dF_unit[b,:] = sigmoid(z_b)*inv_tau/B *
+ * (Fold_b - G_same[idx_b])  (gradient for an upstream gradient of 1; may be NULL).
+ * `B_div` is the CE mean divisor (B, or 2B when two modalities are stacked, MMClientTrainer.py:188).
+ */
+size_t cfl_intra_ws_bytes(int B);
+int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, const float* Fold,
+                  int B, int D, int B_div, float inv_tau, float* loss, float* dF_unit, void* ws,
+                  void* stream);
+
+/* ---- A5: con_w aggregation ----------------------------------------------------------------
+ * Replaces the closure `aggregation` in MMFL.distill (src/algorithms/MMFL.py:298-335).
+ * logprob: out_l[n - row0] = V_n.G_n - log sum_m exp(V_n.G_m)  for n in [row0, row0+rows)
+ *          (rows are independent => row-shardable across GPUs).
+ * combine: W = softmax over the C clients of L[C, M]; out[n,:] = sum_c W[c,n] V_c[n,:].
+ *          Vptrs_host: HOST array of C device pointers, C <= 64.  W_out [C, M] may be NULL.
+ */
+size_t cfl_conw_ws_bytes(int rows, int M, int D);
+int cfl_conw_logprob(const float* V, const float* G, int M, int D, int row0, int rows,
+                     float* out_l, void* ws, void* stream);
+int cfl_conw_combine(const float* const* Vptrs_host, const float* L, int C, int M, int D,
+                     float* out, float* W_out, void* stream);
+
+/* ---- A2-head: PIE attention pooling + epilogue --------------------------------------------
+ * Replaces MultiHeadSelfAttention.forward (n_head = 1) and the tail of PIENet.forward
+ * (src/networks/models/pie_model.py:28-40,61-67), the avgpool of EncoderImage.forward
+ * (image_encoder.py:55) and l2_normalize (src/utils/tensor_utils.py:25-27).
+ * The two dense projections (w_1: Cd -> dh and fc: Cd -> D) stay library GEMMs on the host side.
+ *
+ * pool fwd: X [N,P,Cd], H = w_1(X) [N,P,dh] (pre-tanh), w2 [dh], mask [N,P] uint8 (1 = padded,
+ *           may be NULL).  attn = softmax_P(w2 . tanh(H)), pooled = attn^T X [N,Cd],
+ *           xmean = mean_P X [N,Cd] (may be NULL).
+ * pool bwd: given d_pooled [N,Cd] and d_xmean [N,Cd] (may be NULL):
+ *           dX = attn (x) d_pooled + d_xmean/P ; dH = ds (x) w2 * (1 - tanh^2 H) ; dw2 = sum ds tanh(H)
+ *           with ds = softmax-backward of <d_pooled, X_p>.
+ * epilogue fwd: r = sigmoid(res_pre); o = LayerNorm(out + r) * ln_w + ln_b; y = o / max(|o|, 1e-12)
+ *           (flags & CFL_EPI_NO_L2NORM: y = o).  Saves stats[N,4] = {mean, rstd, 1/norm, 0}.
+ * epilogue bwd: given dy (and optional direct gradients do_, dres on the o / r outputs), the
+ *           forward inputs `out`, the saved r and stats -> d_out [N,D], d_res_pre [N,D], d_ln_w [D],
+ *           d_ln_b [D].  ws: cfl_pie_ws_bytes(N, 1, D, 1).
+ * l2norm: y = x / max(|x|_2, 1e-12) row-wise; inv_norm [N] saved for bwd.
+ * Limits: P <= 1024, D <= 4096.
+ */
+#define CFL_EPI_NO_L2NORM 1
+size_t cfl_pie_ws_bytes(int N, int P, int Cd, int dh);
+int cfl_pie_pool_fwd(const float* X, const float* H, const float* w2, const unsigned char* mask,
+                     int N, int P, int Cd, int dh, float* attn, float* pooled, float* xmean,
+                     void* ws, void* stream);
+int cfl_pie_pool_bwd(const float* X, const float* H, const float* w2, const unsigned char* mask,
+                     const float* attn, const float* d_pooled, const float* d_xmean,
+                     int N, int P, int Cd, int dh, float* dX, float* dH, float* dw2,
+                     void* ws, void* stream);
+int cfl_pie_epilogue_fwd(const float* out, const float* res_pre, const float* ln_w, const float* ln_b,
+                         int N, int D, float ln_eps, int flags, float* y, float* o, float* r,
+                         float* stats, void* stream);
+int cfl_pie_epilogue_bwd(const float* dy, const float* do_, const float* dres, const float* out,
+                         const float* r, const float* ln_w, const float* ln_b, const float* stats,
+                         int N, int D, int flags, float* d_out, float* d_res_pre, float* d_ln_w,
+                         float* d_ln_b, void* ws, void* stream);
+int cfl_l2norm_fwd(const float* x, int N, int D, float* y, float* inv_norm, void* stream);
+int cfl_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int N, int D,
+                   float* dx, void* stream);
+
+/* ---- A6: retrieval rank of the best positive ----------------------------------------------
+ * Replaces ParallelMatMulModule.forward + the positive-rank loop of evaluate_recall
+ * (src/algorithms/eval_coco.py:37-51,296-317): ranks[q] = #{g : <Q_q,G_g> > max_{lab_g == lab_q}
+ * <Q_q,G_g>} with products and sums in fp64 on the fp32-valued inputs, like the reference's
+ * float64 numpy buffers.  ranks [Nq] int32.  Queries with no positive get rank Ng.
+ */
+size_t cfl_rank_ws_bytes(int Nq, int Ng, int D);
+int cfl_rank_count(const float* Q, const float* G, const long long* qlab, const long long* glab,
+                   int Nq, int Ng, int D, int* ranks, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CREAMFL_HIP_H */

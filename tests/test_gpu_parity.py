@@ -1,0 +1,345 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden vectors.  Run on an MI355X with `pytest -m gpu`.
+
+Tolerances (north star: loss within 1e-4 fp32, retrieval indices exact):
+  * vs. the fp64 closed forms of the oracle: rtol 2e-5 on losses, 1e-4 (of the tensor's scale) on grads
+  * vs. the reference's own fp32 numbers (golden): rtol 1e-4 on losses plus the reference's
+    documented fp32 cancellation budget (tests/test_oracle_golden.py), 1e-3 of scale on grads
+  * ranks / R@K: exact
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN, golden_files
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import _lib
+    _lib.load()                       # fail loudly if the extension is missing
+    return torch.device('cuda:0')
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def _unit(gen, *shape):
+    return torch.nn.functional.normalize(torch.randn(*shape, generator=gen), dim=-1)
+
+
+def _close(got, want, rtol, atol, msg=''):
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64),
+                               rtol=rtol, atol=atol, err_msg=msg)
+
+
+# ------------------------------------------------------------------------------------------ A1
+def _run_pair(dev, I, T, a, b):
+    from creamfl_amd import ops
+    Ig = I.to(dev).requires_grad_(True)
+    Tg = T.to(dev).requires_grad_(True)
+    ag = torch.tensor([a], device=dev, requires_grad=True)
+    bg = torch.tensor([b], device=dev, requires_grad=True)
+    loss, stats = ops.pair_loss(Ig, Tg, ag, bg)
+    loss.backward()
+    return (loss.item(), stats.cpu().numpy(), Ig.grad.cpu().numpy(), Tg.grad.cpu().numpy(),
+            ag.grad.item(), bg.grad.item())
+
+
+@pytest.mark.parametrize('fname', golden_files('a1_'))
+def test_a1_pair_loss_golden(dev, fname):
+    z = _load(fname)
+    I, T = torch.from_numpy(z['I']), torch.from_numpy(z['T'])
+    a, b = float(z['a']), float(z['b'])
+    n = I.shape[0]
+    loss, stats, dI, dT, da, db = _run_pair(dev, I, T, a, b)
+    cf = oracle.pair_loss_closed_form(I, T, a, b)
+    g = oracle.pair_loss_grads_closed_form(I, T, a, b)
+    # exact (fp64) oracle
+    _close(loss, cf['loss'].item(), 2e-5, 1e-6)
+    _close(stats[1], cf['pos'].item(), 2e-5, 1e-6)
+    _close(stats[2], cf['neg'].item(), 2e-5, 1e-6)
+    scale = max(np.abs(g['dI'].numpy()).max(), 1e-12)
+    _close(dI, g['dI'].numpy(), 1e-4, 1e-4 * scale, 'dI')
+    _close(dT, g['dT'].numpy(), 1e-4, 1e-4 * scale, 'dT')
+    _close(da, g['da'].item(), 1e-4, 1e-5)
+    _close(db, g['db'].item(), 1e-4, 1e-5)
+    # the reference's own fp32 result
+    noise = n * n * 2.5e-7
+    _close(loss, float(z['loss']), 1e-4, 2 * noise)
+    gat = max(1e-3 * np.abs(z['dI']).max(), n * a * 1.2e-7)
+    _close(dI, z['dI'], 1e-3, gat, 'dI vs reference')
+    _close(dT, z['dT'], 1e-3, gat, 'dT vs reference')
+
+
+@pytest.mark.parametrize('n,d,matched', [(1, 8, False), (7, 5, False), (64, 64, True), (65, 130, False),
+                                         (129, 257, True), (256, 512, True), (300, 768, False),
+                                         (2048, 512, True), (2049, 96, False)])
+def test_a1_pair_loss_shapes(dev, n, d, matched):
+    """ragged / odd sizes, both tile variants (64x64 below 2048 rows, 128x128 from 2048), unaligned D."""
+    gen = torch.Generator().manual_seed(n * 1000 + d)
+    I = _unit(gen, n, d)
+    T = torch.nn.functional.normalize(I + 0.5 * _unit(gen, n, d), dim=-1) if matched else _unit(gen, n, d)
+    a, b = 15.0, 15.0
+    loss, stats, dI, dT, da, db = _run_pair(dev, I, T, a, b)
+    if n <= 512:
+        cf = oracle.pair_loss_closed_form(I, T, a, b)
+        g = oracle.pair_loss_grads_closed_form(I, T, a, b)
+    else:   # the O(N^2 D) oracle is too slow: chunked fp64 closed form on the GPU-free path
+        cf, g = _closed_form_big(I, T, a, b)
+    _close(loss, float(cf['loss']), 3e-5, 1e-6)
+    scale = max(float(np.abs(np.asarray(g['dI'])).max()), 1e-12)
+    _close(dI, np.asarray(g['dI']), 1e-4, 2e-4 * scale, 'dI')
+    _close(dT, np.asarray(g['dT']), 1e-4, 2e-4 * scale, 'dT')
+    _close(da, float(g['da']), 2e-4, 1e-5)
+    _close(db, float(g['db']), 2e-4, 1e-5)
+
+
+def _closed_form_big(I, T, a, b, eps=1e-6):
+    """fp64 closed form via the GEMM identity on CPU (used only where the O(N^2 D) broadcast oracle
+    would take minutes); diagonal handled exactly."""
+    I64, T64 = I.double(), T.double()
+    n = I.shape[0]
+    d2 = (I64 * I64).sum(1)[:, None] + (T64 * T64).sum(1)[None, :] - 2.0 * I64 @ T64.T
+    d2[torch.arange(n), torch.arange(n)] = ((I64 - T64) ** 2).sum(1)
+    d = torch.sqrt(d2.clamp_min(0) + eps)
+    s = -a * d + b
+    m = -torch.ones(n, n, dtype=torch.float64)
+    m.fill_diagonal_(1.0)
+    nll = torch.nn.functional.softplus(-2.0 * m * s)
+    gg = 4.0 * m * torch.sigmoid(-2.0 * m * s)
+    c = a * gg / d
+    return ({'loss': 2.0 * nll.sum()},
+            {'dI': (I64 * c.sum(1, keepdim=True) - c @ T64).numpy(),
+             'dT': (T64 * c.sum(0)[:, None] - c.t() @ I64).numpy(),
+             'da': (gg * d).sum(), 'db': -gg.sum()})
+
+
+def test_a1_linearity_in_upstream_gradient(dev):
+    """size-independent property at the bench size: grads scale linearly with the upstream gradient and
+    the loss is symmetric under swapping the two modalities."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    I = _unit(gen, 256, 512).to(dev)
+    T = torch.nn.functional.normalize(I.cpu() + 0.5 * _unit(gen, 256, 512), dim=-1).to(dev)
+    a = torch.tensor([15.0], device=dev)
+    b = torch.tensor([15.0], device=dev)
+    Ig = I.clone().requires_grad_(True)
+    l1, _ = ops.pair_loss(Ig, T, a, b)
+    (3.0 * l1).backward()
+    g3 = Ig.grad.clone()
+    Ig2 = I.clone().requires_grad_(True)
+    l2, _ = ops.pair_loss(Ig2, T, a, b)
+    l2.backward()
+    torch.testing.assert_close(g3, 3.0 * Ig2.grad, rtol=1e-6, atol=1e-9)
+    Tg = T.clone().requires_grad_(True)
+    l3, _ = ops.pair_loss(Tg, I, a, b)          # swapped roles
+    l3.backward()
+    torch.testing.assert_close(l3, l2, rtol=1e-5, atol=1e-6)
+    Tg2 = T.clone().requires_grad_(True)
+    l4, _ = ops.pair_loss(I, Tg2, a, b)
+    l4.backward()
+    torch.testing.assert_close(Tg.grad, Tg2.grad, rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ A3 / A4
+def _run_contrast(dev, f, g_same, g_other, d_idx, f_old, w, scale, use_inter=True, use_intra=True):
+    from creamfl_amd.algorithms.contrast import client_contrast_loss
+    fg = f.to(dev).requires_grad_(True)
+    loss, li, lm = client_contrast_loss(fg, g_same.to(dev), g_other.to(dev), d_idx, f_old.to(dev),
+                                        interintra_weight=w, loss_scale=scale, use_inter=use_inter,
+                                        use_intra=use_intra)
+    loss.backward()
+    return (loss.item(), None if li is None else li.item(), None if lm is None else lm.item(),
+            fg.grad.cpu().numpy())
+
+
+@pytest.mark.parametrize('fname', golden_files('a34_'))
+def test_a34_client_contrast_golden(dev, fname):
+    z = _load(fname)
+    args = (torch.from_numpy(z['f']), torch.from_numpy(z['g_same']), torch.from_numpy(z['g_other']),
+            [int(v) for v in z['d_idx']], torch.from_numpy(z['f_old']))
+    loss, li, lm, df = _run_contrast(dev, *args, float(z['weight']), bool(z['loss_scale']))
+    _close(loss, float(z['loss']), 1e-4, 0)
+    _close(li, float(z['loss_inter']), 1e-4, 0)
+    _close(lm, float(z['loss_moon']), 1e-4, 0)
+    sc = np.abs(z['df']).max()
+    _close(df, z['df'], 1e-3, 1e-4 * sc)
+    _, _, _, df2 = _run_contrast(dev, *args, 1.0, False, use_intra=False)
+    _close(df2, z['df_inter_only'], 1e-3, 1e-4 * np.abs(z['df_inter_only']).max())
+    _, _, _, df3 = _run_contrast(dev, *args, 1.0, False, use_inter=False)
+    _close(df3, z['df_intra_only'], 1e-3, 1e-4 * np.abs(z['df_intra_only']).max())
+    # exact oracle
+    cf = oracle.client_contrast_grads_closed_form(*args)
+    _close(li, cf['loss_inter'].item(), 2e-5, 0)
+    _close(lm, cf['loss_moon'].item(), 2e-5, 0)
+    _close(df2, cf['d_inter'].numpy(), 1e-4, 2e-5 * np.abs(cf['d_inter'].numpy()).max())
+    _close(df3, cf['d_moon'].numpy(), 1e-4, 2e-5 * np.abs(cf['d_moon'].numpy()).max())
+
+
+@pytest.mark.parametrize('b,m,d', [(1, 1, 4), (3, 200, 17), (64, 4097, 256), (65, 5000, 100), (128, 50000, 256),
+                                   (256, 20000, 512), (130, 3000, 768)])
+def test_a3_inter_shapes(dev, b, m, d):
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(b * 7 + m)
+    G = _unit(gen, m, d)
+    idx = torch.randint(0, m, (b,), generator=gen)
+    f = torch.nn.functional.normalize(G[idx] + 0.7 * _unit(gen, b, d), dim=-1)
+    fg = f.to(dev).requires_grad_(True)
+    loss, lse, pos = ops.inter_contrast(fg, G.to(dev), idx.tolist(), 0.5)
+    loss.backward()
+    cf = oracle.client_contrast_grads_closed_form(f, G, G, idx.tolist(), f)
+    _close(loss.item(), cf['loss_inter'].item(), 2e-5, 0)
+    _close(lse.cpu().numpy(), cf['lse'].numpy(), 1e-5, 1e-5)
+    _close(pos.cpu().numpy(), cf['pos_inter'].numpy(), 1e-5, 1e-5)
+    dref = cf['d_inter'].numpy()
+    _close(fg.grad.cpu().numpy(), dref, 1e-4, 3e-5 * np.abs(dref).max())
+
+
+def test_a3_online_lse_rescale_branch(dev):
+    """force the running-max update: one bank row far above the rest, late in the stream, for some
+    feature rows only (cdna guide rule 26: a rare data-dependent branch needs its own test)."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    b, m, d = 96, 9000, 64
+    G = 0.1 * torch.randn(m, d, generator=gen)
+    f = torch.randn(b, d, generator=gen)
+    G[8000] = 6.0 * f[5] / f[5].norm()       # huge logit for row 5 in a late chunk
+    G[10] = 4.0 * f[70] / f[70].norm()       # and an early one for row 70
+    idx = torch.randint(0, m, (b,), generator=gen)
+    loss, lse, _ = ops.inter_contrast(f.to(dev), G.to(dev), idx.tolist(), 0.5)
+    want = torch.logsumexp((f.double() @ G.double().T) / 0.5, dim=1)
+    _close(lse.cpu().numpy(), want.numpy(), 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ A5
+@pytest.mark.parametrize('fname', golden_files('a5_'))
+def test_a5_conw_golden(dev, fname):
+    from creamfl_amd import ops
+    z = _load(fname)
+    vecs = [torch.from_numpy(v).to(dev) for v in z['vecs']]
+    G = torch.from_numpy(z['g_other']).to(dev)
+    lp = torch.stack([ops.conw_logprob(v, G) for v in vecs], 0)
+    agg, w = ops.conw_combine(vecs, lp, return_weights=True)
+    _close(lp.cpu().numpy(), z['logprob'], 1e-5, 1e-5)
+    _close(w.cpu().numpy(), z['weights'], 1e-4, 1e-6)
+    _close(agg.cpu().numpy(), z['agg'], 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize('m,d,row0,rows', [(1000, 64, 0, 1000), (1000, 64, 300, 333), (5000, 256, 4096, 904),
+                                           (2500, 100, 0, 2500)])
+def test_a5_conw_row_shards(dev, m, d, row0, rows):
+    """rows are independent: any [row0, row0+rows) shard equals the same slice of the full result."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(m + d)
+    G = _unit(gen, m, d)
+    V = torch.nn.functional.normalize(G + 0.5 * _unit(gen, m, d), dim=-1)
+    got = ops.conw_logprob(V.to(dev), G.to(dev), row0, rows).cpu()
+    want = oracle.conw_logprob(V.double(), G.double(), literal=False)[row0:row0 + rows]
+    _close(got.numpy(), want.numpy(), 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ A2-head
+NAMES = ['attention__w_1__weight', 'attention__w_2__weight', 'fc__weight', 'fc__bias',
+         'layer_norm__weight', 'layer_norm__bias']
+
+
+@pytest.mark.parametrize('fname', golden_files('a2_'))
+def test_a2_pie_head_golden(dev, fname):
+    from creamfl_amd.networks.models.pie_model import PIENet
+    from creamfl_amd import ops
+    z = _load(fname)
+    cd, d, dh = z['x'].shape[2], z['out'].shape[1], z['p_attention__w_1__weight'].shape[0]
+    net = PIENet(1, cd, d, dh).to(dev)
+    sd = {n.replace('__', '.'): torch.from_numpy(z['p_' + n]) for n in NAMES}
+    net.load_state_dict(sd)
+    x = torch.from_numpy(z['x']).to(dev).requires_grad_(True)
+    out = torch.from_numpy(z['out']).to(dev).requires_grad_(True)
+    mask = torch.from_numpy(z['mask']).to(dev) if z['mask'].size else None
+    o, attn, res = net(out, x, mask)
+    y = ops.l2_normalize(o)
+    (y * torch.from_numpy(z['gy']).to(dev)).sum().backward()
+    _close(o.detach().cpu().numpy(), z['o'], 1e-4, 1e-5)
+    _close(attn.detach().cpu().numpy(), z['attn'], 1e-4, 1e-6)
+    _close(res.detach().cpu().numpy(), z['res'], 1e-4, 1e-6)
+    _close(y.detach().cpu().numpy(), z['y'], 1e-4, 1e-6)
+    _close(x.grad.cpu().numpy(), z['dx'], 1e-3, 1e-4 * np.abs(z['dx']).max(), 'dx')
+    _close(out.grad.cpu().numpy(), z['dout'], 1e-3, 1e-4 * np.abs(z['dout']).max(), 'dout')
+    for n, p in zip(NAMES, [net.attention.w_1.weight, net.attention.w_2.weight, net.fc.weight, net.fc.bias,
+                            net.layer_norm.weight, net.layer_norm.bias]):
+        ref = z['g_' + n]
+        _close(p.grad.cpu().numpy(), ref, 2e-3, 2e-4 * max(np.abs(ref).max(), 1e-8), n)
+
+
+@pytest.mark.parametrize('n,p,cd,dh,d', [(2, 49, 2048, 1024, 256), (5, 49, 512, 256, 512), (3, 7, 300, 150, 256),
+                                         (4, 33, 130, 66, 100)])
+def test_a2_fused_image_head_vs_oracle(dev, n, p, cd, dh, d):
+    """the fused path used by EncoderImage (avgpool + pool + epilogue incl. l2norm) vs oracle.image_head_glue
+    semantics on a [N, P, Cd] map, forward and backward."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(cd + d)
+    X = torch.randn(n, p, cd, generator=gen)
+    w1 = torch.randn(dh, cd, generator=gen) / cd ** 0.5
+    w2 = torch.randn(1, dh, generator=gen) / dh ** 0.5
+    fcw = torch.randn(d, cd, generator=gen) / cd ** 0.5
+    fcb = 0.1 * torch.randn(d, generator=gen)
+    pfw = torch.randn(d, cd, generator=gen) / cd ** 0.5
+    pfb = 0.1 * torch.randn(d, generator=gen)
+    lnw = 1 + 0.1 * torch.randn(d, generator=gen)
+    lnb = 0.1 * torch.randn(d, generator=gen)
+    gy = torch.randn(n, d, generator=gen)
+
+    def run(dv, fused):
+        t = [v.to(dv).requires_grad_(True) for v in (X, w1, w2, fcw, fcb, pfw, pfb, lnw, lnb)]
+        Xd, w1d, w2d, fcwd, fcbd, pfwd, pfbd, lnwd, lnbd = t
+        if fused:
+            H = torch.nn.functional.linear(Xd, w1d)
+            pooled, attn, xmean = ops.pie_pool(Xd, H, w2d, None, want_mean=True)
+            out = torch.nn.functional.linear(xmean, fcwd, fcbd)
+            y, o, r = ops.pie_epilogue(out, torch.nn.functional.linear(pooled, pfwd, pfbd), lnwd, lnbd)
+        else:
+            out = torch.nn.functional.linear(Xd.mean(1), fcwd, fcbd)
+            o, attn, r = oracle.pie_head(out, Xd, w1d, w2d, pfwd, pfbd, lnwd, lnbd)
+            y = oracle.l2_normalize(o)
+        (y * gy.to(dv)).sum().backward()
+        return [y.detach().cpu().numpy()] + [v.grad.cpu().numpy() for v in t]
+
+    got = run(dev, True)
+    want = run(torch.device('cpu'), False)
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        _close(g_, w_, 2e-3, 2e-4 * max(np.abs(w_).max(), 1e-8), f'tensor {i}')
+
+
+# ------------------------------------------------------------------------------------------ A6
+@pytest.mark.parametrize('fname', golden_files('a6_'))
+def test_a6_recall_golden(dev, fname):
+    from creamfl_amd import ops
+    z = _load(fname)
+    keys = [str(k) for k in z['keys']]
+    for (q, g, ql, gl, want) in [(z['img'], z['cap'], z['img_cls'], z['cap_cls'], z['i2t']),
+                                 (z['cap'], z['img'], z['cap_cls'], z['img_cls'], z['t2i'])]:
+        ranks = ops.rank_count(torch.from_numpy(q).to(dev), torch.from_numpy(g).to(dev), ql, gl).cpu().numpy()
+        ref = oracle.recall_ranks_count(q, g, ql, gl)
+        assert np.array_equal(ranks.astype(np.float64), ref)           # indices exact
+        sc = oracle.recall_scores(ranks.astype(np.float64))
+        np.testing.assert_array_equal(np.array([sc[k] for k in keys]), want)   # == reference evaluator
+
+
+def test_a6_coco_1k_fold_size(dev):
+    """one 1K fold (1000 images x 5000 captions, D = 512): exact ranks vs the fp64 count oracle."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    img = _unit(gen, 1000, 512)
+    cap = torch.nn.functional.normalize(img.repeat_interleave(5, 0) + 1.8 * _unit(gen, 5000, 512), dim=-1)
+    icls, ccls = np.arange(1000), np.arange(5000) // 5
+    for (q, g, ql, gl) in [(img, cap, icls, ccls), (cap, img, ccls, icls)]:
+        ranks = ops.rank_count(q.to(dev), g.to(dev), ql, gl).cpu().numpy()
+        assert np.array_equal(ranks.astype(np.float64), oracle.recall_ranks_count(q.numpy(), g.numpy(), ql, gl))
