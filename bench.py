@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-text pairs/sec of the server contrastive step.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+Workload at N = 1 = BASELINE.json configs[1]: "Server-only MSCOCO contrastive training, ResNet101 +
+BERT-base, d=512, batch 256, 1 x MI355X" on MSCOCO-shaped synthetic batches resident in HBM.  One step =
+PCME forward (ResNet-101 + PIE head | BERT-base + linear) -> MCSoftContrastiveLoss (HIP) -> backward ->
+clip_grad_norm_(2) -> AdamP.step.  At N > 1 every rank runs the same per-GPU batch (weak scaling) as
+large-batch global contrast: RCCL all-gather of the per-rank features, full-batch pair loss, DDP bucketed
+all-reduce of the encoder gradients.
+
+Prints ONE JSON line (rank 0) with the contract keys plus
+  roofline      -- the dominant hand-written kernel of the step, timed with HIP events inside the timed region
+  cpu_baseline  -- the oracle port of the same step timed on the host cores (N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s achievable)
+F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
+
+
+def algorithmic_cost(kernel, N, P, Cd, dh, D):
+    """(bound, algorithmic bytes or flops per launch) for each hand-written kernel at this workload
+    (SURVEY section 8d)."""
+    f = 4
+    table = {
+        'cfl_pie_scores_kernel': ('hbm', N * P * dh * f + N * P * f),                       # read H, write scores
+        'cfl_pie_pool_kernel': ('hbm', N * P * Cd * f + 2 * N * Cd * f + N * P * f),        # read X, write pooled+mean
+        'cfl_pie_bwd_ds_kernel': ('hbm', N * P * Cd * f + N * Cd * f + N * P * f),          # read X, d_pooled
+        'cfl_pie_bwd_dx_kernel': ('hbm', N * P * Cd * f + 2 * N * Cd * f),                  # write dX
+        'cfl_pie_bwd_dh_kernel': ('hbm', 2 * N * P * dh * f),                               # read H, write dH
+        'cfl_pie_bwd_dw2_kernel': ('hbm', (N * P // 64 + 1) * dh * f),
+        'cfl_pie_epi_fwd_kernel': ('hbm', 5 * N * D * f),
+        'cfl_pie_epi_bwd_kernel': ('hbm', 6 * N * D * f),
+        'cfl_pie_epi_bwd_ln_kernel': ('hbm', 3 * N * D * f),
+        'cfl_l2norm_fwd_kernel': ('hbm', 2 * N * D * f),
+        'cfl_l2norm_bwd_kernel': ('hbm', 3 * N * D * f),
+        'cfl_pair_prep_kernel': ('hbm', 2 * N * D * f),
+        'cfl_pair_fwd_kernel': ('mfma', 2 * N * N * D),
+        'cfl_pair_final_kernel': ('hbm', 4 * N * f),
+        'cfl_pair_bwd_kernel': ('mfma', 4 * N * N * D),
+    }
+    return table.get(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (pairs)')
+    ap.add_argument('--dim', type=int, default=512)
+    ap.add_argument('--cnn', default='resnet101')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'],
+                    help='encoder trunk precision (reference: apex O2 fp16); head + loss are always fp32')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from creamfl_amd import _lib
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import coco_batch
+    _lib.load()
+
+    torch.manual_seed(1234)                       # identical initial weights on every rank
+    cfg = default_config(embed_dim=args.dim, cnn_type=args.cnn, not_bert=False)
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    if args.dtype == 'bf16':
+        eng.to_half()
+    if world > 1:
+        eng.enable_data_parallel()
+    eng.model.train()
+
+    batch = coco_batch(args.batch, dev, seed=1234 + rank, bert=True)
+    images, captions, words, lens = batch[0], batch[1], batch[2], batch[3]
+    if args.dtype == 'bf16':
+        images = images.contiguous(memory_format=torch.channels_last)
+
+    def step():
+        return eng.train_step(images, captions, words, lens)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    prof = _lib.prof_query()
+    loss_val = float(loss)
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    if rank == 0:
+        # roofline of the dominant hand-written kernel (by total time in the timed region)
+        Cd = eng.model.img_enc.cnn_dim
+        roof = None
+        cand = []
+        Nloss = args.batch * world
+        for name, (n, ms) in prof.items():
+            base = name
+            cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim)
+            if base.startswith('cfl_pair_'):
+                cost = algorithmic_cost(base, Nloss, 49, Cd, Cd // 2, args.dim)
+            if cost:
+                cand.append((ms, name, n, cost))
+        if cand:
+            ms, name, n, (bound, work) = max(cand)
+            us = ms / n * 1e3
+            if bound == 'hbm':
+                ach = work / (us * 1e-6) / 1e9
+                roof = {'kernel': name, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
+                        'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
+                        'avg_launch_us': round(us, 2), 'launches': n, 'algorithmic_bytes': work}
+            else:
+                ach = work / (us * 1e-6) / 1e12
+                roof = {'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                        'avg_launch_us': round(us, 2), 'launches': n, 'algorithmic_flops': work}
+        hip_us = {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(prof.items())}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, args)
+
+        out = {
+            'metric': 'image-text pairs/sec (contrastive step)', 'value': round(value, 2), 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'server contrastive step: ResNet101+BERT-base PCME, d=%d, per-GPU batch %d, '
+                                   'MCSoftContrastiveLoss + clip + AdamP (BASELINE.json configs[1])' % (args.dim, args.batch),
+                       'global_batch': args.batch * world, 'cnn': args.cnn, 'text': 'bert-base',
+                       'encoder_precision': args.dtype, 'head_loss_precision': 'f32',
+                       'parallelism': 'dp%d' % world, 'loss': round(loss_val, 4)},
+            'roofline': roof, 'cpu_baseline': cpu, 'hip_kernels_us': hip_us,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(cfg, args):
+    """The oracle port of the same step on the host cores, on a bounded sample (small batch, few steps)."""
+    import oracle.step as ostep
+    from creamfl_amd.algorithms.optimizers import get_optimizer
+    from creamfl_amd.networks.models import get_model
+    from creamfl_amd.utils.synthetic import coco_batch
+    from types import SimpleNamespace
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    model = get_model({'<pad>': 0}, cfg.model, False).train()
+    crit = SimpleNamespace(negative_scale=torch.nn.Parameter(torch.tensor([15.0])),
+                           shift=torch.nn.Parameter(torch.tensor([15.0])))
+    params = [p for p in model.parameters() if p.requires_grad] + [crit.negative_scale, crit.shift]
+    opt = get_optimizer('adamp', params, cfg.optimizer)
+    b = coco_batch(args.cpu_batch, 'cpu', seed=1234, bert=True)
+    ostep.contrastive_step_cpu(model, crit, opt, b, cfg.train.grad_clip)            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        ostep.contrastive_step_cpu(model, crit, opt, b, cfg.train.grad_clip)
+    dt = time.perf_counter() - t0
+    return {'value': round(args.cpu_batch * args.cpu_steps / dt, 3), 'unit': 'pairs/s', 'cores': cores,
+            'kind': 'port', 'threads': torch.get_num_threads(),
+            'sample': 'same step (ResNet101+BERT-base fp32, d=%d, oracle head+loss, clip, AdamP) at batch %d, '
+                      '1 warm-up + %d timed steps' % (args.dim, args.cpu_batch, args.cpu_steps)}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,205 @@
+"""Server engine (row S1: the contrastive step the headline metric counts).
+
+Mirrors src/algorithms/retrieval_trainer.py:37-237 (EngineBase / TrainerEngine): create,
+model_to_device, to_half, train, evaluate, save_models / load_models, report_scores, and the attributes
+main.py / MMFL.py read (.model .optimizer .criterion .lr_scheduler .device .metadata .logger .eval_prefix).
+
+MI355X specifics:
+  * `to_half()` replaces apex amp O2 (:107-111) by bf16 autocast of the encoder trunks + channels_last
+    convolutions; the contrastive head and loss stay fp32 (apex also hands fp32 outputs to the criterion).
+  * `train_step()` is the per-batch body of `train()` (:192-214): forward -> MCSoftContrastiveLoss (HIP) ->
+    zero_grad -> backward -> clip_grad_norm_(model.parameters(), grad_clip) -> AdamP.step, with no host
+    synchronisation inside the step.
+  * with torch.distributed initialised (one process per GPU, RCCL), `enable_data_parallel()` turns the step
+    into large-batch global contrast: per-rank features are all-gathered (creamfl_amd/dist.py) and the encoder
+    gradients are summed by bucketed all-reduce overlapped with backward.
+"""
+import hashlib
+import json
+
+import torch
+import torch.nn as nn
+
+from ..criterions import get_criterion
+from ..networks.models import get_model
+from ..utils.serialize_utils import flatten_dict
+from .optimizers import get_lr_scheduler, get_optimizer
+
+
+def get_lr(optimizer):
+    for param_group in optimizer.param_groups:
+        return param_group['lr']
+
+
+class EngineBase(object):
+    def __init__(self, device='cuda', partition_train_distill=-1.):
+        self.device = device
+        self.model = None
+        self.optimizer = None
+        self.criterion = None
+        self.lr_scheduler = None
+        self.evaluator = None
+        self.config = None
+        self.logger = None
+        self.metadata = {}
+        self.partition_train_distill = partition_train_distill
+        self.autocast_dtype = None
+        self.dp = None                       # creamfl_amd.dist.DataParallelContext when enabled
+
+    def create(self, config, word2idx, evaluator, mlp_local):
+        self.config = config
+        self.word2idx = word2idx
+        self.model = get_model(word2idx, config.model, mlp_local)
+        self.set_criterion(get_criterion(config.criterion.name, config.criterion))
+        params = [param for param in self.model.parameters() if param.requires_grad]
+        params += [param for param in self.criterion.parameters() if param.requires_grad]
+        self.set_optimizer(get_optimizer(config.optimizer.name, params, config.optimizer))
+        self.set_lr_scheduler(get_lr_scheduler(config.lr_scheduler.name, self.optimizer, config.lr_scheduler))
+        if evaluator is not None:
+            evaluator.set_model(self.model)
+            evaluator.set_criterion(self.criterion)
+            self.set_evaluator(evaluator)
+        if self.logger is not None:
+            self.logger.log('Engine is created.')
+            self.logger.update_tracker({'full_config': dict(config)}, keys=['full_config'])
+        self.prefix = 'train__'
+        self.eval_prefix = ''
+        if self.logger is not None:
+            self.logger.log('start train')
+        self.img_code, self.txt_code, self.mm_txt_code, self.mm_img_code = None, None, None, None
+
+    def model_to_device(self):
+        self.model.to(self.device)
+        if self.criterion:
+            self.criterion.to(self.device)
+
+    def set_optimizer(self, optimizer):
+        self.optimizer = optimizer
+
+    def set_criterion(self, criterion):
+        self.criterion = criterion
+
+    def set_lr_scheduler(self, lr_scheduler):
+        self.lr_scheduler = lr_scheduler
+
+    def set_evaluator(self, evaluator):
+        self.evaluator = evaluator
+        self.evaluator.set_logger(self.logger)
+
+    def set_logger(self, logger):
+        self.logger = logger
+
+    def to_half(self):
+        """Mixed precision without apex: bf16 autocast for the encoder trunks, channels_last convolutions."""
+        self.autocast_dtype = torch.bfloat16
+        self.model.to(memory_format=torch.channels_last)
+        if self.evaluator is not None:
+            self.evaluator.autocast_dtype = self.autocast_dtype
+
+    def enable_data_parallel(self, process_group=None, bucket_cap_mb=128):
+        from ..dist import DataParallelContext
+        self.dp = DataParallelContext(self.model, process_group, bucket_cap_mb=bucket_cap_mb)
+
+    @torch.no_grad()
+    def evaluate(self, val_loaders, n_crossfolds=None, **kwargs):
+        if self.evaluator is None:
+            if self.logger is not None:
+                self.logger.log('[Evaluate] Warning, no evaluator is defined. Skip evaluation')
+            return
+        self.model_to_device()
+        self.model.eval()
+        if not isinstance(val_loaders, dict):
+            val_loaders = {'te': val_loaders}
+        scores = {}
+        for key, data_loader in val_loaders.items():
+            if 'train' in key:
+                continue
+            if self.logger is not None:
+                self.logger.log('Evaluating {}...'.format(key))
+            _n_crossfolds = -1 if key == 'val' else n_crossfolds
+            scores[key] = self.evaluator.evaluate(data_loader, n_crossfolds=_n_crossfolds, key=key, **kwargs)
+        return scores
+
+    def save_models(self, save_to, metadata=None):
+        state_dict = {
+            'model': self.model.state_dict(), 'criterion': self.criterion.state_dict(),
+            'optimizer': self.optimizer.state_dict(), 'lr_scheduler': self.lr_scheduler.state_dict(),
+            'config': json.loads(json.dumps(self.config, default=str)), 'word2idx': self.word2idx, 'metadata': metadata,
+        }
+        torch.save(state_dict, save_to)
+        if self.logger is not None:
+            self.logger.log('state dict is saved to {}, metadata: {}'.format(save_to, json.dumps(metadata, indent=4)))
+
+    def load_models(self, state_dict_path, load_keys=None):
+        with open(state_dict_path, 'rb') as fin:
+            self.metadata['pretrain_hash'] = hashlib.sha1(fin.read()).hexdigest()
+        state_dict = torch.load(state_dict_path, map_location='cpu')
+        if 'model' not in state_dict:
+            self.model.load_state_dict(state_dict, strict=False)
+            return
+        for key in (load_keys or ['model', 'criterion', 'optimizer', 'lr_scheduler']):
+            try:
+                getattr(self, key).load_state_dict(state_dict[key])
+            except RuntimeError as e:
+                if self.logger is not None:
+                    self.logger.log('Unable to import state_dict, missing keys are found. {}'.format(e))
+                getattr(self, key).load_state_dict(state_dict[key], strict=False)
+
+
+class TrainerEngine(EngineBase):
+
+    def forward_loss(self, images, captions, captions_word, caption_lens):
+        model = self.dp.module if self.dp is not None else self.model
+        with torch.autocast('cuda', dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
+            output = model(images, captions, captions_word, caption_lens)
+        if self.dp is not None:
+            output = dict(output)
+            output['image_features'], output['caption_features'] = self.dp.gather_features(
+                output['image_features'], output['caption_features'])
+        loss, loss_dict = self.criterion(**output)
+        return loss, loss_dict
+
+    def train_step(self, images, captions, captions_word, caption_lens):
+        """One server contrastive step (retrieval_trainer.py:192-214)."""
+        if self.autocast_dtype is not None and images.dim() == 4:
+            images = images.contiguous(memory_format=torch.channels_last)
+        loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.dp is not None:
+            self.dp.finish_backward(list(self.criterion.parameters()))
+        if self.config.train.grad_clip > 0:
+            nn.utils.clip_grad.clip_grad_norm_(self.model.parameters(), self.config.train.grad_clip)
+        self.optimizer.step()
+        return loss, loss_dict
+
+    def train(self, tr_loader, pub_data_ratio=1.):
+        self.model.train()
+        if self.logger is not None:
+            self.logger.log("Global Training!")
+        for idx, (images, captions, captions_word, caption_lens, a_, b_, index) in enumerate(tr_loader):
+            images = images.to(self.device, non_blocking=True)
+            captions = captions.to(self.device, non_blocking=True)
+            caption_lens = caption_lens.to(self.device, non_blocking=True)
+            if idx == int(len(tr_loader) * pub_data_ratio):
+                break
+            self.train_step(images, captions, captions_word, caption_lens)
+
+    def report_scores(self, step, scores, metadata, prefix=''):
+        report_dict = {data_key: flatten_dict(_scores, sep='_') for data_key, _scores in scores.items()}
+        report_dict = flatten_dict(report_dict, sep='__')
+        tracker_data = report_dict.copy()
+        report_dict = {'{}{}'.format(prefix, key): val for key, val in report_dict.items()}
+        report_dict['step'] = step
+        if 'lr' in metadata:
+            report_dict['{}lr'.format(prefix)] = metadata['lr']
+        keys = ['n_fold_i2t_recall_1', 'n_fold_i2t_recall_5', 'n_fold_i2t_recall_10', 'n_fold_t2i_recall_1',
+                'n_fold_t2i_recall_5', 'n_fold_t2i_recall_10', 'i2t_recall_1', 'i2t_recall_5', 'i2t_recall_10',
+                't2i_recall_1', 't2i_recall_5', 't2i_recall_10']
+        report_dict['summary'] = ', '.join(str(report_dict.get(f'{prefix}test__{k}')) for k in keys)
+        if self.logger is not None:
+            self.logger.report(report_dict, prefix='[Eval] Report @step: ', pretty=True)
+        tracker_data['metadata'] = metadata
+        tracker_data['scores'] = scores
+        if self.logger is not None:
+            self.logger.update_tracker(tracker_data)

@@ -1,0 +1,248 @@
+"""Encoder trunks in plain torch.nn (convolutions and dense GEMMs run on MIOpen / hipBLASLt; they are
+below the hot path of SURVEY section 8 and are not hand-written).
+
+torchvision is not available offline, so the ResNet definitions live here; module and parameter
+names follow torchvision.models.resnet (conv1, bn1, layer{1-4}.{i}.conv{1-3}, downsample.{0,1}, fc)
+so that an ImageNet state_dict loads unchanged.  `BertModel` follows the Hugging Face parameter
+names (embeddings.*, encoder.layer.{i}.attention.self.{query,key,value}, ...) for the same reason,
+and uses F.scaled_dot_product_attention.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + residual)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # stride on the 3x3 (torchvision v1.5)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + residual)
+
+
+class ResNetTrunk(nn.Module):
+    """conv1 .. layer4 of a torchvision-style ResNet; `features(x)` returns the last feature map."""
+
+    def __init__(self, block, layers, relu_inplace=True):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=relu_inplace)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], 2)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2)
+        self.layer4 = self._make_layer(block, 512, layers[3], 2)
+        self.out_dim = 512 * block.expansion
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def features(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+    def forward(self, x):
+        return self.features(x)
+
+
+_RESNETS = {
+    'resnet10': (BasicBlock, [1, 1, 1, 1]), 'resnet18': (BasicBlock, [2, 2, 2, 2]),
+    'resnet34': (BasicBlock, [3, 4, 6, 3]), 'resnet50': (Bottleneck, [3, 4, 6, 3]),
+    'resnet101': (Bottleneck, [3, 4, 23, 3]), 'resnet152': (Bottleneck, [3, 8, 36, 3]),
+}
+
+
+def resnet_trunk(name):
+    if name not in _RESNETS:
+        raise ValueError(f'unknown cnn_type {name}')
+    block, layers = _RESNETS[name]
+    return ResNetTrunk(block, layers)
+
+
+# ----------------------------------------------------------------------------------------- BERT
+class BertConfig:
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 hidden_dropout_prob=0.1):
+        self.__dict__.update(locals())
+        del self.__dict__['self']
+
+
+BERT_CONFIGS = {
+    'bert-base-uncased': dict(),
+    'bert-large-uncased': dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096),
+    'bert-mini': dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024),
+}
+
+
+class _BertEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)
+
+    def forward(self, input_ids, token_type_ids=None):
+        L = input_ids.shape[1]
+        pos = torch.arange(L, device=input_ids.device)
+        x = self.word_embeddings(input_ids) + self.position_embeddings(pos)[None]
+        tt = self.token_type_embeddings.weight[0] if token_type_ids is None else self.token_type_embeddings(token_type_ids)
+        return self.dropout(self.LayerNorm(x + tt))
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.h = c.num_attention_heads
+        self.query = nn.Linear(c.hidden_size, c.hidden_size)
+        self.key = nn.Linear(c.hidden_size, c.hidden_size)
+        self.value = nn.Linear(c.hidden_size, c.hidden_size)
+
+    def forward(self, x, mask):
+        B, L, H = x.shape
+        def split(t):
+            return t.view(B, L, self.h, H // self.h).transpose(1, 2)
+        o = F.scaled_dot_product_attention(split(self.query(x)), split(self.key(x)), split(self.value(x)), attn_mask=mask)
+        return o.transpose(1, 2).reshape(B, L, H)
+
+
+class _SelfOutput(nn.Module):
+    def __init__(self, c, d_in):
+        super().__init__()
+        self.dense = nn.Linear(d_in, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)
+
+    def forward(self, h, residual):
+        return self.LayerNorm(self.dropout(self.dense(h)) + residual)
+
+
+class _Attention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self = _SelfAttention(c)
+        self.output = _SelfOutput(c, c.hidden_size)
+
+    def forward(self, x, mask):
+        return self.output(self.self(x, mask), x)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+
+    def forward(self, x):
+        return F.gelu(self.dense(x))
+
+
+class _BertLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = _Attention(c)
+        self.intermediate = _Intermediate(c)
+        self.output = _SelfOutput(c, c.intermediate_size)
+
+    def forward(self, x, mask):
+        x = self.attention(x, mask)
+        return self.output(self.intermediate(x), x)
+
+
+class _BertEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([_BertLayer(c) for _ in range(c.num_hidden_layers)])
+
+    def forward(self, x, mask):
+        for l in self.layer:
+            x = l(x, mask)
+        return x
+
+
+class BertModel(nn.Module):
+    """Minimal BERT encoder returning {'last_hidden_state': [B, L, H]} (all PCME reads is [:, 0, :],
+    src/networks/models/pcme.py:44).  Randomly initialised (no checkpoint download offline)."""
+
+    def __init__(self, name_or_config='bert-base-uncased'):
+        super().__init__()
+        c = name_or_config if isinstance(name_or_config, BertConfig) else BertConfig(**BERT_CONFIGS[name_or_config])
+        self.config = c
+        self.embeddings = _BertEmbeddings(c)
+        self.encoder = _BertEncoder(c)
+        self.apply(self._init)
+
+    @staticmethod
+    def _init(m):
+        if isinstance(m, (nn.Linear, nn.Embedding)):
+            m.weight.data.normal_(0.0, 0.02)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, nn.LayerNorm):
+            m.weight.data.fill_(1.0)
+            m.bias.data.zero_()
+
+    @classmethod
+    def from_pretrained(cls, name):
+        return cls(name)
+
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, **_):
+        mask = None
+        if attention_mask is not None:
+            mask = attention_mask[:, None, None, :].to(torch.bool)
+        x = self.embeddings(input_ids, token_type_ids)
+        return {'last_hidden_state': self.encoder(x, mask)}

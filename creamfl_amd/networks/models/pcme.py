@@ -1,0 +1,71 @@
+"""PCME two-tower wrapper.  Mirrors src/networks/models/pcme.py:15-63: same constructor, attributes
+(img_enc, txt_enc, tokenizer, linear, n_embeddings, embed_dim) and the same 10-key output dict.
+
+Text tower: `not_bert` -> GRU EncoderText; else BERT -> CLS -> Linear(768, D) -> l2-normalise (:40-44).
+The reference tokenises `captions_word` with a downloaded BertTokenizer on every step; offline there is
+no vocabulary, so when no tokenizer is attached the already-tokenised `sentences` ids (+ `lengths` for the
+attention mask) are fed to BERT directly.  Attach a tokenizer with `model.tokenizer = ...` to get the
+reference behaviour.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..backbones import BertModel
+from .caption_encoder import EncoderText
+from .image_encoder import EncoderImage
+
+
+class PCME(nn.Module):
+    """Probabilistic CrossModal Embedding (PCME) module"""
+
+    def __init__(self, word2idx, config, mlp_local):
+        super().__init__()
+        self.config = config
+        self.embed_dim = config.embed_dim
+        if config.get('n_samples_inference', 0):
+            self.n_embeddings = config.n_samples_inference
+        else:
+            self.n_embeddings = 1
+        self.img_enc = EncoderImage(config, mlp_local)
+        if config.not_bert:
+            self.txt_enc = EncoderText(word2idx, config, mlp_local)
+        else:
+            self.txt_enc = BertModel.from_pretrained(config.get('bert_name', 'bert-base-uncased'))
+            self.tokenizer = None
+            self.linear = nn.Linear(self.txt_enc.config.hidden_size, self.embed_dim)
+
+    def _bert_inputs(self, sentences, captions_word, lengths):
+        if getattr(self, 'tokenizer', None) is not None and captions_word is not None:
+            inputs = self.tokenizer(captions_word, padding=True, return_tensors='pt')
+            dev = self.linear.weight.device
+            return {k: v.to(dev) for k, v in inputs.items()}
+        L = sentences.shape[1]
+        mask = torch.arange(L, device=sentences.device)[None, :] < lengths.to(sentences.device)[:, None]
+        return {'input_ids': sentences, 'attention_mask': mask}
+
+    def forward(self, images, sentences, captions_word, lengths):
+        image_output = self.img_enc(images)
+        if self.config.not_bert:
+            caption_output = self.txt_enc(sentences, lengths)
+        else:
+            hidden = self.txt_enc(**self._bert_inputs(sentences, captions_word, lengths))['last_hidden_state']
+            caption_output = {'embedding': ops.l2_normalize(self.linear(hidden[:, 0, :]))}
+        return {
+            'image_features': image_output['embedding'],
+            'image_attentions': image_output.get('attention'),
+            'image_residuals': image_output.get('residual'),
+            'image_logsigma': image_output.get('logsigma'),
+            'image_logsigma_att': image_output.get('uncertainty_attention'),
+            'caption_features': caption_output['embedding'],
+            'caption_attentions': caption_output.get('attention'),
+            'caption_residuals': caption_output.get('residual'),
+            'caption_logsigma': caption_output.get('logsigma'),
+            'caption_logsigma_att': caption_output.get('uncertainty_attention'),
+        }
+
+    def image_forward(self, images):
+        return self.img_enc(images)
+
+    def text_forward(self, sentences, lengths):
+        return self.txt_enc(sentences, lengths)

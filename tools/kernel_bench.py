@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Kernel-level microbenchmarks of the hot-path ops at the SURVEY section 8(d) shapes.
+Prints one JSON line per case with per-kernel HIP-event times (library profiler) and the
+algorithmic FLOP/byte rates.  GPU only.   python tools/kernel_bench.py [--cases a1,a3,a5,a2,a6]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from creamfl_amd import _lib, ops  # noqa: E402
+
+
+def unit(*shape, gen=None, device='cuda'):
+    return torch.nn.functional.normalize(torch.randn(*shape, generator=gen, device=device), dim=-1)
+
+
+def timed(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    prof = {k: round(ms / n * 1e3, 2) for k, (n, ms) in _lib.prof_query().items()}   # us per launch
+    return e0.elapsed_time(e1) / iters * 1e3, prof
+
+
+def case_a1(N, D):
+    g = torch.Generator(device='cuda').manual_seed(0)
+    I = unit(N, D, gen=g).requires_grad_(True)
+    T = torch.nn.functional.normalize(I.detach() + 0.5 * unit(N, D, gen=g), dim=-1).requires_grad_(True)
+    a = torch.tensor([15.0], device='cuda', requires_grad=True)
+    b = torch.tensor([15.0], device='cuda', requires_grad=True)
+
+    def step():
+        loss, _ = ops.pair_loss(I, T, a, b)
+        loss.backward()
+    us, prof = timed(step)
+    flops = 3 * 2 * N * N * D
+    return {'case': f'a1_pair_loss N={N} D={D}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'algo_TFLOPs': round(flops / us / 1e6, 2), 'pairs_per_s': round(N / us * 1e6)}
+
+
+def case_a3(B, M, D):
+    g = torch.Generator(device='cuda').manual_seed(1)
+    G = unit(M, D, gen=g)
+    Gs = unit(M, D, gen=g)
+    idx = torch.randperm(M, device='cuda')[:B]
+    f = unit(B, D, gen=g).requires_grad_(True)
+    fo = unit(B, D, gen=g)
+    from creamfl_amd.algorithms.contrast import client_contrast_loss
+
+    def step():
+        loss, _, _ = client_contrast_loss(f, Gs, G, idx, fo)
+        loss.backward()
+    us, prof = timed(step)
+    flops = 4 * B * M * D
+    byts = 2 * M * D * 4
+    return {'case': f'a3a4_client_contrast B={B} M={M} D={D}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'algo_TFLOPs': round(flops / us / 1e6, 2), 'algo_GBps': round(byts / us / 1e3, 1),
+            'pairs_per_s': round(B / us * 1e6)}
+
+
+def case_a5(M, D, C=1):
+    g = torch.Generator(device='cuda').manual_seed(2)
+    G = unit(M, D, gen=g)
+    vecs = [torch.nn.functional.normalize(G + 0.5 * unit(M, D, gen=g), dim=-1) for _ in range(C)]
+
+    def step():
+        lp = torch.stack([ops.conw_logprob(v, G) for v in vecs], 0)
+        ops.conw_combine(vecs, lp)
+    us, prof = timed(step, iters=3, warm=1)
+    flops = 2 * M * M * D * C
+    return {'case': f'a5_conw M={M} D={D} C={C}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'algo_TFLOPs': round(flops / us / 1e6, 2)}
+
+
+def case_a2(N, P, Cd, dh, D):
+    g = torch.Generator(device='cuda').manual_seed(3)
+    X = torch.randn(N, P, Cd, generator=g, device='cuda', requires_grad=True)
+    H = torch.randn(N, P, dh, generator=g, device='cuda', requires_grad=True)
+    w2 = (torch.randn(dh, generator=g, device='cuda') / dh ** 0.5).requires_grad_(True)
+    out = torch.randn(N, D, generator=g, device='cuda', requires_grad=True)
+    rp = torch.randn(N, D, generator=g, device='cuda', requires_grad=True)
+    lw = torch.ones(D, device='cuda', requires_grad=True)
+    lb = torch.zeros(D, device='cuda', requires_grad=True)
+
+    def step():
+        pooled, attn, xm = ops.pie_pool(X, H, w2, None, want_mean=True)
+        y, o, r = ops.pie_epilogue(out, rp, lw, lb)
+        (pooled.sum() + xm.sum() + y.sum()).backward()
+    us, prof = timed(step)
+    fwd_bytes = N * P * (Cd + dh) * 4
+    return {'case': f'a2_pie_head N={N} P={P} Cd={Cd} dh={dh} D={D}', 'us_per_step': round(us, 1),
+            'kernels_us': prof, 'fwd_algo_MB': round(fwd_bytes / 1e6, 1)}
+
+
+def case_a6(Nq, Ng, D):
+    g = torch.Generator(device='cuda').manual_seed(4)
+    img = unit(Nq, D, gen=g)
+    cap = torch.nn.functional.normalize(img.repeat_interleave(Ng // Nq, 0) + 1.5 * unit(Ng, D, gen=g), dim=-1)
+    ql = torch.arange(Nq, device='cuda')
+    gl = torch.arange(Ng, device='cuda') // (Ng // Nq)
+    us, prof = timed(lambda: ops.rank_count(img, cap, ql, gl), iters=5, warm=1)
+    flops = 2 * 2 * Nq * Ng * D
+    return {'case': f'a6_rank Nq={Nq} Ng={Ng} D={D}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'fp64_TFLOPs_two_pass': round(flops / us / 1e6, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', default='a1,a3,a5,a2,a6')
+    ap.add_argument('--conw-m', type=int, default=50000)
+    args = ap.parse_args()
+    cases = args.cases.split(',')
+    out = []
+    if 'a1' in cases:
+        out += [case_a1(256, 512), case_a1(128, 256), case_a1(4096, 512)]
+    if 'a3' in cases:
+        out += [case_a3(128, 50000, 256), case_a3(256, 50000, 512), case_a3(128, 50000, 768), case_a3(32, 50000, 256)]
+    if 'a5' in cases:
+        out += [case_a5(args.conw_m, 256)]
+    if 'a2' in cases:
+        out += [case_a2(256, 49, 2048, 1024, 512), case_a2(128, 49, 512, 256, 256)]
+    if 'a6' in cases:
+        out += [case_a6(1000, 5000, 512), case_a6(5000, 25000, 512)]
+    for r in out:
+        print(json.dumps(r))
+
+
+if __name__ == '__main__':
+    main()
