@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# MIOpen: pick convolution algorithms by (fast) find with workspace instead of the immediate-mode fallback;
+# must be set before the first convolution.  FIND_MODE=2 keeps the one-off search to ~10 s on a fresh box.
+os.environ.setdefault('MIOPEN_FIND_MODE', '2')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -74,6 +78,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
     torch.cuda.set_device(local_rank)
+    torch.backends.cudnn.benchmark = True
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
@@ -180,21 +185,34 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def usable_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box
+    reports 256 logical CPUs but grants a 16-CPU quota; oversubscribing it stalls the baseline)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, args):
     """The oracle port of the same step on the host cores, on a bounded sample (small batch, few steps)."""
     import oracle.step as ostep
-    from creamfl_amd.algorithms.optimizers import get_optimizer
+    from oracle.adamp import AdamP as OracleAdamP
     from creamfl_amd.networks.models import get_model
     from creamfl_amd.utils.synthetic import coco_batch
     from types import SimpleNamespace
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     model = get_model({'<pad>': 0}, cfg.model, False).train()
     crit = SimpleNamespace(negative_scale=torch.nn.Parameter(torch.tensor([15.0])),
                            shift=torch.nn.Parameter(torch.tensor([15.0])))
     params = [p for p in model.parameters() if p.requires_grad] + [crit.negative_scale, crit.shift]
-    opt = get_optimizer('adamp', params, cfg.optimizer)
+    opt = OracleAdamP(params, lr=cfg.optimizer.learning_rate, weight_decay=cfg.optimizer.weight_decay)
     b = coco_batch(args.cpu_batch, 'cpu', seed=1234, bert=True)
     ostep.contrastive_step_cpu(model, crit, opt, b, cfg.train.grad_clip)            # warm-up
     t0 = time.perf_counter()

@@ -1,97 +1,148 @@
 """Mirror of src/algorithms/optimizers.py:7-58 (get_optimizer / get_lr_scheduler).
 
-`AdamP` restates the published algorithm of adamp==0.3.0 (Heo et al., "AdamP: Slowing Down the
-Slowdown for Momentum Optimizers on Scale-invariant Weights", ICLR 2021), which the reference
-imports as a third-party package that is not vendored and not installed here: PARITY UNPINNED
-(self-consistency tests only, tests/test_host_logic.py).  Differences in form, not in arithmetic: the
-projection test `cosine_sim.max() < delta / sqrt(dim)` is evaluated on the device and applied
-with torch.where, so a step issues no host synchronisation (the package syncs once or twice per
-parameter tensor).
+`AdamP` implements the published algorithm of adamp==0.3.0 (Heo et al., "AdamP: Slowing Down the
+Slowdown for Momentum Optimizers on Scale-invariant Weights", ICLR 2021), which the reference imports as
+a third-party package that is not vendored and not installed here: PARITY UNPINNED -- the HIP kernels are
+checked against the paper restatement in oracle/adamp.py (tests/test_gpu_optimizer.py), not against the
+package.  The projection test `cosine_sim.max() < delta / sqrt(dim)` is evaluated on the device, so a step
+issues no host synchronisation (the package syncs once or twice per parameter tensor).
 """
-import math
+import ctypes
 import warnings
 
+import numpy as np
 import torch
-import torch.nn.functional as F
 import torch.optim as optim
 from torch.optim.optimizer import Optimizer
 
+from .. import _lib
+
 
 class AdamP(Optimizer):
+    """AdamP on the HIP path: gradient clipping + the whole optimizer step as three multi-tensor kernels
+    (csrc/adamp.hip), no host synchronisation.  Same constructor and state_dict layout as adamp.AdamP
+    (`step`, `exp_avg`, `exp_avg_sq` per parameter).  Parameters must live on a HIP device when `step()` runs;
+    there is no CPU path (the paper restatement used as the test oracle is oracle/adamp.py)."""
+
+    ROWS_TARGET = 16384          # elements per work item
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, delta=0.1, wd_ratio=0.1,
                  nesterov=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, delta=delta, wd_ratio=wd_ratio,
                         nesterov=nesterov)
         super().__init__(params, defaults)
+        self._plans = {}
 
-    @staticmethod
-    def _projection(p, grad, perturb, delta, wd_ratio, eps):
-        """Channel-wise, then layer-wise scale-invariance test; returns (perturb, wd multiplier tensor)."""
-        n0 = p.shape[0]
-        expand = [-1] + [1] * (p.dim() - 1)
-        pc, gc = p.reshape(n0, -1), grad.reshape(n0, -1)
-        pl, gl = p.reshape(1, -1), grad.reshape(1, -1)
-        cos_c = F.cosine_similarity(gc, pc, dim=1, eps=eps).abs().max()
-        cos_l = F.cosine_similarity(gl, pl, dim=1, eps=eps).abs().max()
-        hit_c = cos_c < delta / math.sqrt(pc.shape[1])
-        hit_l = (~hit_c) & (cos_l < delta / math.sqrt(pl.shape[1]))
-        # channel view
-        pn_c = p / (pc.norm(dim=1).view(expand) + eps)
-        proj_c = perturb - pn_c * (pn_c * perturb).reshape(n0, -1).sum(dim=1).view(expand)
-        # layer view
-        pn_l = p / (pl.norm() + eps)
-        proj_l = perturb - pn_l * (pn_l * perturb).sum()
-        out = torch.where(hit_c, proj_c, torch.where(hit_l, proj_l, perturb))
-        wd = torch.where(hit_c | hit_l, torch.full_like(cos_c, wd_ratio), torch.ones_like(cos_c))
-        return out, wd
+    META_DTYPE = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64),
+                           ('numel', np.int64), ('inner', np.int64), ('row_base', np.int64),
+                           ('n0', np.int32), ('flags', np.int32)])
+
+    def _plan(self, gi, params, clip_ids):
+        key = (gi, tuple(p.data_ptr() for p in params), tuple(sorted(clip_ids)) if clip_ids else ())
+        plan = self._plans.get(gi)
+        if plan is not None and plan['key'] == key:
+            return plan
+        dev = params[0].device
+        meta = np.zeros(len(params), dtype=self.META_DTYPE)
+        items, matrix_ids = [], []
+        row_base = 0
+        for t, p in enumerate(params):
+            numel = p.numel()
+            if p.dim() > 1:
+                n0 = p.shape[0]
+                inner = numel // n0
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if not dense or p.stride(0) != inner:
+                    raise _lib.CreamflHipError(f'AdamP: parameter {tuple(p.shape)} is not dense with dim 0 outermost')
+                flags = 1
+                rows_per = max(1, self.ROWS_TARGET // max(inner, 1))
+                for r0 in range(0, n0, rows_per):
+                    items.append((t, r0, min(rows_per, n0 - r0)))
+                matrix_ids.append(t)
+                meta[t]['row_base'] = row_base
+                row_base += n0
+            else:
+                n0, inner, flags = 1, numel, 0
+                for e0 in range(0, numel, self.ROWS_TARGET):
+                    items.append((t, e0, min(self.ROWS_TARGET, numel - e0)))
+            if id(p) in clip_ids:
+                flags |= 2
+            st = self.state[p]
+            meta[t]['p'] = p.data_ptr(); meta[t]['m'] = st['exp_avg'].data_ptr(); meta[t]['v'] = st['exp_avg_sq'].data_ptr()
+            meta[t]['numel'] = numel; meta[t]['inner'] = inner; meta[t]['n0'] = n0; meta[t]['flags'] = flags
+        plan = {
+            'key': key, 'meta': meta,
+            'meta_dev': torch.empty(meta.nbytes, dtype=torch.uint8, device=dev),
+            'items': torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 3).contiguous(),
+            'matrix_ids': torch.tensor(matrix_ids or [0], dtype=torch.int32, device=dev),
+            'n_matrix': len(matrix_ids),
+            'rowstats': torch.empty(max(row_base, 1) * 4, dtype=torch.float32, device=dev),
+            'tstats': torch.ones(len(params), dtype=torch.float32, device=dev),
+            'partial': torch.empty(len(items), dtype=torch.float32, device=dev),
+            'clip': torch.ones(2, dtype=torch.float32, device=dev),
+            'gptrs': None,
+        }
+        self._plans[gi] = plan
+        return plan
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, clip=None):
+        """clip = (iterable of parameters, max_norm): fuse nn.utils.clip_grad_norm_ over those parameters into
+        the step (the reference clips model parameters only, retrieval_trainer.py:211-213).  Returns the loss
+        of `closure` (None by default)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
-            beta1, beta2 = group['betas']
-            params, grads, avgs, sqs = [], [], [], []
-            for p in group['params']:
-                if p.grad is None:
-                    continue
-                state = self.state[p]
-                if len(state) == 0:
-                    state['step'] = 0
-                    state['exp_avg'] = torch.zeros_like(p)
-                    state['exp_avg_sq'] = torch.zeros_like(p)
-                state['step'] += 1
-                params.append(p); grads.append(p.grad); avgs.append(state['exp_avg']); sqs.append(state['exp_avg_sq'])
+        lib = _lib.load()
+        clip_ids, max_norm = (set(), 0.0)
+        if clip is not None:
+            clip_ids, max_norm = {id(p) for p in clip[0]}, float(clip[1])
+        self.last_grad_norm = None
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group['params'] if p.grad is not None]
             if not params:
                 continue
-            step = self.state[params[0]]['step']          # all parameters of a group step together
-            bc1 = 1 - beta1 ** step
-            bc2 = 1 - beta2 ** step
-            torch._foreach_mul_(avgs, beta1)
-            torch._foreach_add_(avgs, grads, alpha=1 - beta1)
-            torch._foreach_mul_(sqs, beta2)
-            torch._foreach_addcmul_(sqs, grads, grads, value=1 - beta2)
-            denoms = torch._foreach_sqrt(sqs)
-            torch._foreach_div_(denoms, math.sqrt(bc2))
-            torch._foreach_add_(denoms, group['eps'])
-            step_size = group['lr'] / bc1
-            if group['nesterov']:
-                perturbs = torch._foreach_mul(avgs, beta1)
-                torch._foreach_add_(perturbs, grads, alpha=1 - beta1)
-                torch._foreach_div_(perturbs, denoms)
-            else:
-                perturbs = torch._foreach_div(avgs, denoms)
-            perturbs = list(perturbs)
-            for i, p in enumerate(params):
-                wd_mul = None
-                if p.dim() > 1:
-                    perturbs[i], wd_mul = self._projection(p, grads[i], perturbs[i], group['delta'], group['wd_ratio'],
-                                                           group['eps'])
-                if group['weight_decay'] > 0:
-                    p.mul_(1 - group['lr'] * group['weight_decay'] * (1 if wd_mul is None else wd_mul))
-            torch._foreach_add_(params, perturbs, alpha=-step_size)
+            if not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+                raise _lib.CreamflHipError('creamfl_amd AdamP needs fp32 parameters on a HIP device (no CPU path)')
+            for p in params:
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['step'] += 1
+            plan = self._plan(gi, params, clip_ids)
+            grads = []
+            for p in params:
+                g = p.grad
+                if g.dtype != torch.float32 or g.stride() != p.stride():
+                    g2 = torch.empty_like(p, memory_format=torch.preserve_format)
+                    g2.copy_(g)
+                    g = g2
+                grads.append(g)
+            gptrs = [g.data_ptr() for g in grads]
+            if gptrs != plan['gptrs']:
+                plan['meta']['g'] = np.asarray(gptrs, dtype=np.uint64)
+                plan['meta_dev'].copy_(torch.from_numpy(plan['meta'].view(np.uint8).reshape(-1)), non_blocking=False)
+                plan['gptrs'] = gptrs
+            stream = ctypes.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
+            n_items = plan['items'].shape[0]
+            clip_ptr = ctypes.c_void_p(0)
+            if clip_ids and max_norm > 0:
+                _lib.check(lib.cfl_grad_clip_coef(plan['meta_dev'].data_ptr(), plan['items'].data_ptr(), n_items, max_norm,
+                                                  plan['partial'].data_ptr(), plan['clip'].data_ptr(), stream),
+                           'cfl_grad_clip_coef')
+                clip_ptr = ctypes.c_void_p(plan['clip'].data_ptr())
+                self.last_grad_norm = plan['clip'][0]
+            beta1, beta2 = group['betas']
+            _lib.check(lib.cfl_adamp_step(plan['meta_dev'].data_ptr(), len(params), plan['items'].data_ptr(), n_items,
+                                          plan['matrix_ids'].data_ptr(), plan['n_matrix'], plan['rowstats'].data_ptr(),
+                                          plan['tstats'].data_ptr(), float(group['lr']), float(beta1), float(beta2),
+                                          float(group['eps']), float(group['weight_decay']), float(group['delta']),
+                                          float(group['wd_ratio']), int(bool(group['nesterov'])),
+                                          int(self.state[params[0]]['step']), clip_ptr, stream), 'cfl_adamp_step')
+            del grads
         return loss
 
 

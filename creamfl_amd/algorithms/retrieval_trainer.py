@@ -23,7 +23,7 @@ import torch.nn as nn
 from ..criterions import get_criterion
 from ..networks.models import get_model
 from ..utils.serialize_utils import flatten_dict
-from .optimizers import get_lr_scheduler, get_optimizer
+from .optimizers import AdamP, get_lr_scheduler, get_optimizer
 
 
 def get_lr(optimizer):
@@ -168,10 +168,19 @@ class TrainerEngine(EngineBase):
         loss.backward()
         if self.dp is not None:
             self.dp.finish_backward(list(self.criterion.parameters()))
-        if self.config.train.grad_clip > 0:
-            nn.utils.clip_grad.clip_grad_norm_(self.model.parameters(), self.config.train.grad_clip)
-        self.optimizer.step()
+        self.optimizer_step()
         return loss, loss_dict
+
+    def optimizer_step(self):
+        """clip_grad_norm_(model.parameters(), grad_clip) + optimizer.step() (:211-214); fused into the
+        multi-tensor HIP kernels when the optimizer is creamfl_amd's AdamP."""
+        clip = self.config.train.grad_clip
+        if isinstance(self.optimizer, AdamP):
+            self.optimizer.step(clip=(self.model.parameters(), clip) if clip > 0 else None)
+        else:
+            if clip > 0:
+                nn.utils.clip_grad.clip_grad_norm_(self.model.parameters(), clip)
+            self.optimizer.step()
 
     def train(self, tr_loader, pub_data_ratio=1.):
         self.model.train()

@@ -24,6 +24,7 @@ enum CflKernel {
     K_PIE_SCORES, K_PIE_POOL, K_PIE_BWD_DS, K_PIE_BWD_DX, K_PIE_BWD_DH, K_PIE_BWD_DW2,
     K_PIE_EPI_FWD, K_PIE_EPI_BWD, K_PIE_EPI_BWD_LN, K_L2NORM_FWD, K_L2NORM_BWD,
     K_RANK_POSMAX, K_RANK_COUNT,
+    K_GRADNORM, K_ADAMP_PASS1, K_ADAMP_DECIDE, K_ADAMP_PASS3,
     K_NUM
 };
 

@@ -11,6 +11,7 @@ static const char* const g_kernel_names[K_NUM] = {
     "cfl_pie_bwd_dh_kernel", "cfl_pie_bwd_dw2_kernel", "cfl_pie_epi_fwd_kernel",
     "cfl_pie_epi_bwd_kernel", "cfl_pie_epi_bwd_ln_kernel", "cfl_l2norm_fwd_kernel",
     "cfl_l2norm_bwd_kernel", "cfl_rank_posmax_kernel", "cfl_rank_count_kernel",
+    "cfl_gradnorm_kernel", "cfl_adamp_pass1_kernel", "cfl_adamp_decide_kernel", "cfl_adamp_pass3_kernel",
 };
 
 namespace {

@@ -154,6 +154,35 @@ size_t cfl_rank_ws_bytes(int Nq, int Ng, int D);
 int cfl_rank_count(const float* Q, const float* G, const long long* qlab, const long long* glab,
                    int Nq, int Ng, int D, int* ranks, void* ws, void* stream);
 
+/* ---- S1 tail: fused multi-tensor gradient clip + AdamP step ------
+ * Replaces nn.utils.clip_grad_norm_(model.parameters(), 2) + AdamP.step()
+ * (src/algorithms/retrieval_trainer.py:211-214; optimizer = adamp.AdamP 0.3.0, optimizers.py:24).
+ * Tensors are described by a device array of CflTensorMeta (p, g, m, v share one dense layout whose
+ * outermost dimension is dim 0: `n0` rows of `inner` contiguous elements); work is described by a device
+ * array of int triples {tensor, start, count} -- rows for CFL_OPT_MATRIX tensors (dim > 1: projection
+ * applies), elements otherwise.  matrix_ids lists the CFL_OPT_MATRIX tensors.
+ * cfl_grad_clip_coef: out2 = { ||g||_2 over CFL_OPT_CLIP tensors, min(1, max_norm / (norm + 1e-6)) };
+ *                     partial_ws >= n_items floats.
+ * cfl_adamp_step:     rowstats_ws >= 4 * (total rows of matrix tensors) floats, tstats_ws >= n_tensors floats;
+ *                     clip_dev = out2 of cfl_grad_clip_coef or NULL; `step` is the 1-based step count.
+ */
+#define CFL_OPT_MATRIX 1
+#define CFL_OPT_CLIP   2
+typedef struct CflTensorMeta {
+    void* p; void* g; void* m; void* v;
+    long long numel;
+    long long inner;
+    long long row_base;     /* first row of this tensor in rowstats_ws */
+    int n0;
+    int flags;
+} CflTensorMeta;
+int cfl_grad_clip_coef(const CflTensorMeta* meta_dev, const int* items_dev, int n_items, float max_norm,
+                       float* partial_ws, float* out2, void* stream);
+int cfl_adamp_step(const CflTensorMeta* meta_dev, int n_tensors, const int* items_dev, int n_items,
+                   const int* matrix_ids_dev, int n_matrix, float* rowstats_ws, float* tstats_ws,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float delta,
+                   float wd_ratio, int nesterov, int step, const float* clip_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

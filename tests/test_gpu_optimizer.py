@@ -1,0 +1,61 @@
+"""GPU: fused multi-tensor clip + AdamP (csrc/adamp.hip) against the paper restatement (oracle/adamp.py)
+driven by torch's clip_grad_norm_ on CPU.  PARITY UNPINNED w.r.t. the adamp package (not installed)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_params(gen):
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 1, 1), (128, 64, 3, 3), (300, 77), (5, 1030), (10,), (1,), (1,),
+              (2, 40000), (33, 7)]
+    return [torch.randn(*s, generator=gen) * 0.1 for s in shapes]
+
+
+@pytest.mark.parametrize('weight_decay,nesterov,channels_last', [(0.0, False, False), (0.01, False, True), (0.01, True, False)])
+def test_fused_adamp_matches_oracle(weight_decay, nesterov, channels_last):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from oracle.adamp import AdamP as OracleAdamP
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(0)
+    init = _make_params(gen)
+    cpu = [torch.nn.Parameter(t.clone()) for t in init]
+    gpu = []
+    for t in init:
+        q = t.clone().to(dev)
+        if channels_last and q.dim() == 4:
+            q = q.contiguous(memory_format=torch.channels_last)
+        gpu.append(torch.nn.Parameter(q))
+    n_clip = len(init) - 2                      # the last two tensors play the criterion's (unclipped) scalars
+    ocpu = OracleAdamP(cpu, lr=1e-2, weight_decay=weight_decay, nesterov=nesterov)
+    ogpu = AdamP(gpu, lr=1e-2, weight_decay=weight_decay, nesterov=nesterov)
+    for it in range(4):
+        grads = [torch.randn(t.shape, generator=gen) * (3.0 if it % 2 == 0 else 0.01) for t in init]
+        # make some tensors scale-invariant-looking: gradient orthogonal to the weight (projection fires)
+        for k in (0, 3, 4):
+            w = cpu[k].detach().reshape(cpu[k].shape[0], -1)
+            g = grads[k].reshape(w.shape)
+            g = g - w * (g * w).sum(1, keepdim=True) / (w * w).sum(1, keepdim=True)
+            grads[k] = g.reshape(grads[k].shape)
+        w = cpu[9].detach().reshape(1, -1)
+        g = grads[9].reshape(1, -1)
+        grads[9] = (g - w * (g * w).sum() / (w * w).sum()).reshape(grads[9].shape)       # layer-wise only
+        for p, q, g in zip(cpu, gpu, grads):
+            p.grad = g.clone()
+            gg = g.to(dev)
+            if channels_last and gg.dim() == 4:
+                gg = gg.contiguous(memory_format=torch.channels_last)
+            q.grad = gg
+        norm = torch.nn.utils.clip_grad_norm_(cpu[:n_clip], 2.0)
+        ocpu.step()
+        ogpu.step(clip=(gpu[:n_clip], 2.0))
+        np.testing.assert_allclose(ogpu.last_grad_norm.item(), norm.item(), rtol=1e-5)
+        for k, (p, q) in enumerate(zip(cpu, gpu)):
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().numpy(), rtol=2e-4, atol=2e-6,
+                                       err_msg=f'step {it} tensor {k} {tuple(p.shape)}')
+    # state_dict layout like adamp.AdamP
+    st = ogpu.state[gpu[0]]
+    assert set(st) == {'step', 'exp_avg', 'exp_avg_sq'} and st['step'] == 4
