@@ -24,6 +24,26 @@ import time
 # must be set before the first convolution.  FIND_MODE=2 keeps the one-off search to ~10 s on a fresh box.
 os.environ.setdefault('MIOPEN_FIND_MODE', '2')
 
+
+def _seed_miopen_user_db():
+    """A fresh box has no MIOpen find-db for gfx950, and searching ResNet-101's ~150 convolution problems costs
+    ~3.5 minutes.  creamfl_amd/miopen_db holds the (text, ~50 KB) user find-db recorded on an MI355X for this
+    exact workload; it is copied to a private writable directory that MIOpen is pointed at."""
+    import shutil
+    import tempfile
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'creamfl_amd', 'miopen_db')
+    if 'MIOPEN_USER_DB_PATH' in os.environ or not os.path.isdir(src):
+        return
+    dst = os.path.join(tempfile.gettempdir(), 'creamfl_miopen_db_%d' % os.getuid(), str(os.environ.get('LOCAL_RANK', '0')))
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src):
+        if not os.path.exists(os.path.join(dst, f)):
+            shutil.copy(os.path.join(src, f), dst)
+    os.environ['MIOPEN_USER_DB_PATH'] = dst
+
+
+_seed_miopen_user_db()
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
