@@ -53,11 +53,14 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s ac
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 
 
-def algorithmic_cost(kernel, N, P, Cd, dh, D):
+def algorithmic_cost(kernel, N, P, Cd, dh, D, n_params=0, n_clip=0):
     """(bound, algorithmic bytes or flops per launch) for each hand-written kernel at this workload
     (SURVEY section 8d)."""
     f = 4
     table = {
+        'cfl_adamp_pass1_kernel': ('hbm', 6 * n_params * f),     # read p,g,m,v; write m,v
+        'cfl_adamp_pass3_kernel': ('hbm', 4 * n_params * f),     # read p,m,v; write p
+        'cfl_gradnorm_kernel': ('hbm', n_clip * f // 2),          # two launches (partial + final) share the id
         'cfl_pie_scores_kernel': ('hbm', N * P * dh * f + N * P * f),                       # read H, write scores
         'cfl_pie_pool_kernel': ('hbm', N * P * Cd * f + 2 * N * Cd * f + N * P * f),        # read X, write pooled+mean
         'cfl_pie_bwd_ds_kernel': ('hbm', N * P * Cd * f + N * Cd * f + N * P * f),          # read X, d_pooled
@@ -147,7 +150,7 @@ def main():
     dt = time.perf_counter() - t0
     _lib.prof_enable(False)
     prof = _lib.prof_query()
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -162,9 +165,10 @@ def main():
         roof = None
         cand = []
         Nloss = args.batch * world
+        n_model = sum(p.numel() for p in eng.model.parameters())
         for name, (n, ms) in prof.items():
             base = name
-            cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim)
+            cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim, n_model + 2, n_model)
             if base.startswith('cfl_pair_'):
                 cost = algorithmic_cost(base, Nloss, 49, Cd, Cd // 2, args.dim)
             if cost:

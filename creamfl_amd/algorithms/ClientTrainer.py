@@ -1,0 +1,277 @@
+"""Uni-modal client (rows A2c + A3 + A4 in their caller).  Mirrors src/algorithms/ClientTrainer.py:136-674:
+same constructor signature, `.train_loader` assigned by the owner (MMFL.py:136), `.client_idx`, `.cur_epoch`,
+`run(global_img_feature, global_txt_feature, distill_index, global_train_loader)`, `generate_logits(dataloader)`.
+
+Out of scope here: the CIFAR-100 / AG_NEWS dataset classes and transforms -- loaders are
+supplied by the caller (`train_loader`, `global_test_set`); only their batch contracts are used:
+  image client  : (inputs [B,3,H,W] f32, labels [B] i64)
+  text client   : (token ids [B,L] i64, labels [B] i64, lengths [B] i64)
+Representations stay on the GPU between server and clients (the reference bounces them through host memory,
+MMFL.py:209-210, ClientTrainer.py:370,651); `generate_logits` therefore returns device tensors.
+"""
+import copy
+import operator
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .. import losses
+from ..networks.language_model import EncoderText
+from ..networks.resnet_client import resnet18_client
+from ..utils.Utils import to_one_hot
+from .contrast import client_contrast_loss
+
+is_test = False
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def accuracy(output, target, topk=(1,)):
+    """Computes the precision@k for the specified values of k (ClientTrainer.py:113-129)."""
+    maxk = max(topk)
+    batch_size = target.size(0)
+    _, pred = output.topk(maxk, 1, True, True)
+    pred = pred.t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred).to(pred.device))
+    return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / batch_size) for k in topk]
+
+
+IMAGE_SETS = ('Cifar100', 'Cifar10')
+TEXT_SETS = ('AG_NEWS', 'YelpReviewPolarity')
+CLASSES = {'Cifar100': 100, 'Cifar10': 10, 'AG_NEWS': 4, 'YelpReviewPolarity': 2}
+
+
+class ClientTrainer:
+    def __init__(self, args, dataset, dst, RGBmean, RGBstdv, data_dict, logger, global_test_set, inter_distance=4,
+                 loss='softmax', gpuid='cuda:0', num_epochs=30, init_lr=0.0001, decay=0.1, batch_size=512,
+                 imgsize=256, num_workers=4, print_freq=10, save_step=10, scale=128, pool_type='max_avg',
+                 client_id=-1, wandb=None):
+        torch.manual_seed(0)
+        self.args = args
+        if dataset == 'Flickr30k':
+            init_lr = 0.0002
+        self.client_id = client_id
+        self.dset_name = dataset
+        self.dst = dst
+        self.gpuid = gpuid
+        self.batch_size = batch_size
+        self.num_workers = num_workers
+        self.decay_time = [False, False]
+        self.init_lr = init_lr
+        self.decay_rate = decay
+        self.num_epochs = num_epochs
+        self.cur_epoch = -1
+        self.data_dict = data_dict
+        self.imgsize = imgsize
+        self.RGBmean, self.RGBstdv = RGBmean, RGBstdv
+        self.record = []
+        self.epoch = 0
+        self.print_freq = print_freq
+        self.save_step = save_step
+        self.loss = loss
+        self.losses = AverageMeter()
+        self.top1, self.test_top1 = AverageMeter(), AverageMeter()
+        self.top5, self.test_top5 = AverageMeter(), AverageMeter()
+        self.scale = scale
+        self.pool_type = pool_type
+        self.inter_distance = inter_distance
+        if dst and not os.path.exists(dst):
+            os.makedirs(dst, exist_ok=True)
+        self.logger = logger
+        self.wandb = wandb
+        self.loadData()
+        self.setModel()
+        self.old_model = None
+        self.local_epochs = args.local_epochs
+        self.local_epoch = 0
+        self.global_test_set = global_test_set
+        self.train_loader = None
+        self.client_idx = -1
+
+    def _log(self, msg):
+        if self.logger is not None:
+            self.logger.log(msg)
+
+    # -- step 1: data (class counts only; loaders are injected) ---------------------------------------------
+    def loadData(self):
+        if self.dset_name not in CLASSES:
+            assert False, 'Dataset Not Supported!'
+        self.classSize = CLASSES[self.dset_name]
+        self.class_label_coco = torch.Tensor(np.array(range(80)))
+        self.class_label = torch.Tensor(np.array(range(self.classSize)))
+
+    # -- step 2: model ------------------------------------------------------------------------------------------
+    def setModel(self):
+        self._log(f'Setting model {self.client_id}')
+        if self.dset_name in IMAGE_SETS:
+            self.model = resnet18_client(pretrained=True, num_class=self.classSize, pool_type=self.pool_type,
+                                         is_train=True, scale=self.scale, mlp_local=self.args.mlp_local,
+                                         embed_dim=self.args.feature_dim)
+        else:
+            self.model = EncoderText(embed_dim=self.args.feature_dim, num_class=self.classSize, scale=self.scale,
+                                     mlp_local=self.args.mlp_local)
+        self.criterion = losses.create(self.loss)
+        self.center_criterion = nn.MSELoss()
+        self.optimizer = optim.SGD(self.model.parameters(), lr=self.init_lr, momentum=0.9, weight_decay=0.00005)
+
+    def lr_scheduler(self, epoch):
+        if epoch >= 0.5 * self.num_epochs and not self.decay_time[0]:
+            self.decay_time[0] = True
+            for g in self.optimizer.param_groups:
+                g['lr'] = self.init_lr * self.decay_rate
+        if epoch >= 0.8 * self.num_epochs and not self.decay_time[1]:
+            self.decay_time[1] = True
+            for g in self.optimizer.param_groups:
+                g['lr'] = self.init_lr * self.decay_rate * self.decay_rate
+
+    def run(self, global_img_feature, global_txt_feature, distill_index, global_train_loader):
+        self.model.to(self.gpuid)
+        self.old_model = copy.deepcopy(self.model)
+        self.old_model.eval()
+        self.lr_scheduler(self.cur_epoch)
+        for i in range(self.local_epochs):
+            self.local_epoch += 1
+            self.tra(global_img_feature, global_txt_feature, distill_index, global_train_loader)
+        self.test()
+        if getattr(self.args, 'save_client', False):
+            os.makedirs(f'./saved_clients/{self.dset_name}', exist_ok=True)
+            torch.save(self.model.state_dict(),
+                       f'./saved_clients/{self.dset_name}/Client{self.client_id}-model_{self.local_epoch}.pth')
+        del self.old_model
+        self.old_model = None
+
+    # -- step 3: learning ----------------------------------------------------------------------------------------
+    def _features(self, model, images, captions, caption_lens):
+        if self.dset_name in IMAGE_SETS:
+            return model(images.to(self.gpuid))
+        out = model(captions.to(self.gpuid), caption_lens.to(self.gpuid))
+        return out.squeeze() if out.dim() > 2 else out
+
+    def _supervised_epoch(self):
+        """ClientTrainer.py:322-365: CE with the one-hot margin + centre loss on the class weights."""
+        self.model.train()
+        for i, data in enumerate(self.train_loader or []):
+            self.optimizer.zero_grad()
+            center_labels_var = self.class_label.to(torch.long).to(self.gpuid)
+            if self.dset_name in IMAGE_SETS:
+                inputs_bt, labels_bt = data
+                labels_var = labels_bt.to(self.gpuid)
+                fvec, _, class_weight, _ = self.model(inputs_bt.to(self.gpuid))
+            else:
+                inputs_bt, labels_bt, caplens = data
+                labels_var = labels_bt.to(self.gpuid)
+                fvec, _, class_weight, _ = self.model(inputs_bt.to(self.gpuid).contiguous(), caplens.to(self.gpuid))
+            labels_var_one_hot = to_one_hot(labels_var.cpu(), n_dims=self.classSize)
+            fvec = fvec - self.inter_distance * labels_var_one_hot.to(self.gpuid)
+            loss = self.criterion(fvec, labels_var)
+            center_loss = self.criterion(torch.mm(class_weight, torch.t(class_weight)), center_labels_var)
+            total_loss = 0.5 * center_loss + loss
+            k5 = {'Cifar100': 5, 'Cifar10': 5, 'AG_NEWS': 4, 'YelpReviewPolarity': 2}[self.dset_name]
+            prec1, prec5 = accuracy(fvec.data, labels_bt, topk=(1, k5))
+            self.top1.update(prec1[0], inputs_bt.size(0))
+            self.top5.update(prec5[0], inputs_bt.size(0))
+            self.losses.update(total_loss.detach(), inputs_bt.size(0))
+            total_loss.backward()
+            self.optimizer.step()
+            if is_test:
+                break
+
+    def tra(self, global_img_feature, global_txt_feature, distill_index, global_train_loader):
+        self._supervised_epoch()
+        use_intra = bool(self.args.contrast_local_intra)
+        use_inter = bool(self.args.contrast_local_inter)
+        if not (use_intra or use_inter):
+            return
+        g_img = global_img_feature.to(self.gpuid)
+        g_txt = global_txt_feature.to(self.gpuid)
+        is_img = self.dset_name in IMAGE_SETS
+        g_same, g_other = (g_img, g_txt) if is_img else (g_txt, g_img)
+        distill_dict = {b: a for a, b in enumerate(distill_index)}
+        for m in ([self.model, self.old_model] if use_intra else [self.model]):
+            m.phase = 'extract_conv_feature'
+            m.is_train = False
+        self._log('Start %s Contrasting!' % ('Intra & Inter' if use_intra and use_inter else
+                                             'Intra-modal' if use_intra else 'Inter-modal'))
+        self.last_contrast_loss = None
+        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):
+            self.optimizer.zero_grad()
+            d_idx = operator.itemgetter(*index)(distill_dict)
+            d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
+            im_feature = self._features(self.model, images, captions, caption_lens)
+            old_im_feature = None
+            if use_intra:
+                with torch.no_grad():
+                    old_im_feature = self._features(self.old_model, images, captions, caption_lens)
+            loss, _, _ = client_contrast_loss(im_feature, g_same, g_other, d_idx, old_im_feature,
+                                              interintra_weight=self.args.interintra_weight,
+                                              loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
+                                              use_intra=use_intra)
+            loss.backward()
+            self.optimizer.step()
+            self.last_contrast_loss = loss.detach()
+            if is_test:
+                break
+        for m in ([self.model, self.old_model] if use_intra else [self.model]):
+            m.phase = 'None'
+            m.is_train = True
+
+    def test(self):
+        if self.global_test_set is None:
+            return
+        self.model.eval()
+        with torch.no_grad():
+            for i, data in enumerate(self.global_test_set):
+                if self.dset_name in IMAGE_SETS:
+                    inputs_bt, labels_bt = data
+                    fvec, _, _, _ = self.model(inputs_bt.to(self.gpuid))
+                else:
+                    inputs_bt, labels_bt, caplens = data
+                    fvec, _, _, _ = self.model(inputs_bt.to(self.gpuid), caplens.to(self.gpuid))
+                k5 = {'Cifar100': 5, 'Cifar10': 5, 'AG_NEWS': 4, 'YelpReviewPolarity': 2}[self.dset_name]
+                prec1, prec5 = accuracy(fvec.data, labels_bt, topk=(1, k5))
+                self.test_top1.update(prec1[0], inputs_bt.size(0))
+                self.test_top5.update(prec5[0], inputs_bt.size(0))
+        self._log('TTTEST:  Epoch: [{0}] {1}\tPrec@1 {2:.3f}\tPrec@5 {3:.3f}'.format(
+            self.local_epoch, self.dset_name, float(self.test_top1.avg), float(self.test_top5.avg)))
+        self.test_top1, self.test_top5 = AverageMeter(), AverageMeter()
+        self.model.train()
+
+    def generate_logits(self, dataloader):
+        vec, idx = self.extract_pub_feature(dataloader)
+        if self.dset_name in IMAGE_SETS:
+            return {'img': vec, 'txt': None}, idx
+        elif self.dset_name in TEXT_SETS:
+            return {'img': None, 'txt': vec}, idx
+        assert False
+
+    def extract_pub_feature(self, dataloader):
+        """ClientTrainer.py:631-664, device-resident."""
+        self.model.to(self.gpuid)
+        self.model.phase = 'extract_conv_feature'
+        self.model.is_train = False
+        was_training = self.model.training
+        feature, distill_index = [], []
+        with torch.no_grad():
+            for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(dataloader):
+                feature.append(self._features(self.model, images, captions, caption_lens).detach().float())
+                distill_index.extend(index)
+        feature = torch.cat(feature, dim=0)
+        self.model.phase = 'None'
+        self.model.is_train = True
+        self.model.train(was_training)
+        return feature, distill_index

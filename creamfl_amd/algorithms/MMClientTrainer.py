@@ -1,0 +1,106 @@
+"""Multi-modal client.  Mirrors src/algorithms/MMClientTrainer.py:89-370: `run(...)`, `train_epoch(...)`,
+`generate_logits(dataloader)` -> ({'img': [M,D], 'txt': [M,D]}, index)."""
+import copy
+import operator
+import os
+
+import torch
+import torch.nn as nn
+
+from .base import EngineBase
+from .contrast import mm_client_contrast_loss
+from .optimizers import AdamP
+
+is_test = False
+
+
+class MMClientTrainer(EngineBase):
+
+    def run(self, global_img_feature, global_txt_feature, distill_index, global_train_loader, prefix=''):
+        self.model.to(self.device)
+        self.criterion.to(self.device)
+        self.old_model = copy.deepcopy(self.model)
+        self.old_model.eval()
+        if self.local_epoch == 0 and self.config.train.get('use_fp16'):
+            self.to_half()
+        self.model.train()
+        for i in range(self.local_epochs):
+            self.local_epoch += 1
+            if self.logger is not None:
+                self.logger.log(f"Epoch {self.local_epoch}")
+            self.train_epoch(global_img_feature, global_txt_feature, distill_index, global_train_loader, prefix='')
+        if getattr(self.args, 'save_client', False):
+            os.makedirs('./saved_clients/Flicker30K', exist_ok=True)
+            torch.save(self.model.state_dict(),
+                       f'./saved_clients/Flicker30K/Client{self.client}-model_{self.local_epoch}.pth')
+        del self.old_model
+        self.old_model = None
+
+    def _forward(self, model, images, captions, captions_word, caption_lens):
+        with torch.autocast('cuda', dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
+            return model(images, captions, captions_word, caption_lens)
+
+    def _step(self, loss):
+        self.optimizer.zero_grad()
+        loss.backward()
+        clip = self.config.train.grad_clip
+        if isinstance(self.optimizer, AdamP):
+            self.optimizer.step(clip=(self.model.parameters(), clip) if clip > 0 else None)
+        else:
+            if clip > 0:
+                nn.utils.clip_grad.clip_grad_norm_(self.model.parameters(), clip)
+            self.optimizer.step()
+
+    def train_epoch(self, global_img_feature, global_txt_feature, distill_index, global_train_loader, prefix=''):
+        # local PCME training on the client's own pairs (MMClientTrainer.py:118-143)
+        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(self.train_loader or []):
+            images, captions, caption_lens = images.to(self.device), captions.to(self.device), caption_lens.to(self.device)
+            output = self._forward(self.model, images, captions, captions_word, caption_lens)
+            loss, loss_dict = self.criterion(**output)
+            self._step(loss)
+            if is_test:
+                break
+        use_intra = bool(self.args.contrast_local_intra)
+        use_inter = bool(self.args.contrast_local_inter)
+        if not (use_intra or use_inter):
+            return
+        g_img, g_txt = global_img_feature.to(self.device), global_txt_feature.to(self.device)
+        distill_dict = {b: a for a, b in enumerate(distill_index)}
+        self.last_contrast_loss = None
+        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):
+            d_idx = operator.itemgetter(*index)(distill_dict)
+            d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
+            images, captions, caption_lens = images.to(self.device), captions.to(self.device), caption_lens.to(self.device)
+            output = self._forward(self.model, images, captions, captions_word, caption_lens)
+            out_img, out_txt = output['image_features'], output['caption_features']
+            old_img = old_txt = None
+            if use_intra:
+                with torch.no_grad():
+                    output_o = self._forward(self.old_model, images, captions, captions_word, caption_lens)
+                    old_img, old_txt = output_o['image_features'], output_o['caption_features']
+            loss, _, _ = mm_client_contrast_loss(out_img, out_txt, g_img, g_txt, d_idx, old_img, old_txt,
+                                                 interintra_weight=self.args.interintra_weight,
+                                                 loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
+                                                 use_intra=use_intra)
+            self._step(loss)
+            self.last_contrast_loss = loss.detach()
+            if is_test:
+                break
+
+    def generate_logits(self, dataloader):
+        self.model.to(self.device)
+        was_training = self.model.training
+        self.model.eval()
+        img_vec, txt_vec, distill_index = [], [], []
+        with torch.no_grad():
+            for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(dataloader):
+                output = self._forward(self.model, images.to(self.device), captions.to(self.device), captions_word,
+                                       caption_lens.to(self.device))
+                img_vec.append(output['image_features'].float())
+                txt_vec.append(output['caption_features'].float())
+                distill_index.extend(index)
+                if is_test and idx == 1:
+                    break
+        self.model.train(was_training)
+        D = self.args.feature_dim
+        return {'img': torch.cat(img_vec, dim=0).view(-1, D), 'txt': torch.cat(txt_vec, dim=0).view(-1, D)}, distill_index

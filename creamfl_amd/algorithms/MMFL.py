@@ -1,0 +1,307 @@
+"""Server orchestration of one CreamFL communication round.
+
+Mirrors src/algorithms/MMFL.py:39-391: `MMFL(args, wandb)`, `set_config`, `load_dataset`, `create_model`,
+`train(round_n)` (global train -> global representations -> per-client run + generate_logits -> distill ->
+evaluate -> checkpoint) and `distill` with the `con_w` aggregation (row A5) and the KD steps.
+
+What differs, by design:
+  * representations never leave the GPU: global features, client representations and the con_w aggregate
+    stay device tensors (the reference round-trips them through host memory and runs con_w as a
+    50 000 x 50 000 fp32 matmul ON THE CPU, ~53 s and ~30 GB per client, MMFL.py:304-307).
+  * with torch.distributed initialised (one process per GPU), the sampled clients of a round are sharded
+    one per rank, their [M, D] representations are exchanged with ONE all-gather per client slot, and con_w is
+    row-sharded (creamfl_amd/dist.py).  Without it everything runs on the single GPU, clients in sequence.
+  * datasets are out of scope: `load_dataset` / `create_model` take ready loaders (any iterable with the
+    reference's batch-tuple contract); by default MSCOCO-shaped synthetic loaders are built.
+  * public-set size is `args.pub_data_num` everywhere (the reference hard-codes 50000 inside `aggregation`,
+    MMFL.py:302,319, which only works for the default).
+Reference quirks kept on purpose: the KD image term is added twice when both image and multimodal clients
+exist (MMFL.py:361-378); `best_score` is never updated (MMFL.py:275-276), so "best" is every round.
+"""
+import gc
+import operator
+import os
+import random
+
+import torch
+import torch.nn as nn
+
+from .. import dist as cdist
+from .. import ops
+from ..utils.config import default_config, parse_config
+from ..utils.logger import PythonLogger
+from ..utils.synthetic import SyntheticCocoLoader
+from .ClientTrainer import ClientTrainer
+from .MMClientTrainer import MMClientTrainer
+from .eval_coco import COCOEvaluator
+from .optimizers import AdamP
+from .retrieval_trainer import TrainerEngine
+
+is_test = False
+
+
+class _NullWandb:
+    def log(self, *a, **k):
+        pass
+
+
+class MMFL(object):
+    def __init__(self, args, wandb=None):
+        self.args = args
+        self.wandb = wandb if wandb is not None else _NullWandb()
+        self.device = None
+        self.img_local_trainers = None
+        self.txt_local_trainers = None
+        self.mm_local_trainers = None
+        self.engine = None
+        self.best_score = 0
+        self.cur_epoch = 0
+        self.img_train_loaders, self.txt_train_loaders = None, None
+        self.dataloaders_global = None
+        self.test_loader = None
+        self.config = None
+        self.set_config()
+        self.logger = PythonLogger(output_file=None, quiet=bool(getattr(args, 'quiet', False)))
+        self.img_vec, self.txt_vec = None, None
+        self.global_img_feature = None
+        self.global_txt_feature = None
+        self.distill_index = None
+        self.best_scores, self.best_metadata = None, None
+        self.total_local_trainers = []
+
+    def set_config(self, img='cifa100', txt='AG_NEWS'):
+        """MMFL.py:70-88.  Reads ./src/coco.yaml when it exists (drop-in next to the reference tree), else
+        the same values from creamfl_amd.utils.config.default_config."""
+        if os.path.exists('./src/coco.yaml'):
+            self.config = parse_config('./src/coco.yaml', strict_cast=False)
+        else:
+            self.config = default_config()
+        self.config.train.model_save_path = 'model_last_no_prob.pth'
+        self.config.train.best_model_save_path = 'model_best_no_prob.pth'
+        self.config.train.output_file = 'model_noprob.log'
+        self.config.model.img_client = img
+        self.config.model.txt_client = txt
+        self.config.model.embed_dim = self.args.feature_dim
+        if self.args.not_bert:
+            self.config.model.not_bert = True
+            self.config.model.cnn_type = 'resnet50'
+        else:
+            self.config.model.not_bert = False
+            self.config.model.cnn_type = 'resnet101'
+        for k in ('cnn_type', 'bert_name'):               # build-defined encoder overrides (configs 1 and 5)
+            if getattr(self.args, k, None):
+                self.config.model[k] = getattr(self.args, k)
+        self.config.model.wemb_type = None
+
+    # -------------------------------------------------------------------------------------------------- data
+    def _pub_key(self, eval_=False):
+        return ('train_subset_eval' if eval_ else 'train_subset') + f'_{self.args.pub_data_num}'
+
+    def load_dataset(self, args, dataloaders=None, vocab=None):
+        """MMFL.py:90-114.  `dataloaders` = {'train_subset_<M>', 'train_subset_eval_<M>', 'test'}."""
+        M = args.pub_data_num
+        if dataloaders is None:
+            bert = not self.config.model.not_bert
+            bs = self.config.dataloader.batch_size
+            img = getattr(args, 'image_size', 224)
+            dataloaders = {
+                self._pub_key(False): SyntheticCocoLoader(M, bs, seed=1, bert=bert, img=img),
+                self._pub_key(True): SyntheticCocoLoader(M, 2 * bs, seed=1, bert=bert, img=img),
+                'test': SyntheticCocoLoader(getattr(args, 'test_pairs', 5000), 2 * bs, seed=2, bert=bert,
+                                            captions_per_image=5, img=img),
+            }
+        self.dataloaders_global = dataloaders
+        self.vocab = vocab
+        word2idx = vocab.word2idx if vocab is not None else {i: i for i in range(11755)}
+        self.engine = TrainerEngine(device=self.device or 'cuda')
+        self.engine.set_logger(self.logger)
+        self.config.optimizer.learning_rate = self.args.server_lr
+        self._dataloaders = dict(self.dataloaders_global)
+        self.evaluator = COCOEvaluator(eval_method='matmul', verbose=False, eval_device=self.device or 'cuda',
+                                       extract_device=self.device or 'cuda', n_crossfolds=5)
+        self.engine.create(self.config, word2idx, self.evaluator, self.args.mlp_local)
+        self.train_eval_dataloader = self._dataloaders.pop(self._pub_key(True), None)
+        self.engine.model_to_device()
+        if self.config.train.get('use_fp16'):
+            self.engine.logger.log('Train with bf16 autocast (apex O2 replacement)')
+            self.engine.to_half()
+
+    def create_model(self, args, client_loaders=None, client_test_sets=None, mm_config=None):
+        """MMFL.py:116-178.  client_loaders = {'img': [loader per client], 'txt': [...], 'mm': [...]}."""
+        self.logger.log('start creating model and partition datasets')
+        self.device = torch.device('cuda:%d' % args.device)
+        client_loaders = client_loaders or {}
+        client_test_sets = client_test_sets or {}
+        self.img_local_trainers, self.txt_local_trainers, self.mm_local_trainers = [], [], []
+        for kind, dataset, store, n in (('img', 'Cifar100', self.img_local_trainers, args.num_img_clients),
+                                        ('txt', 'AG_NEWS', self.txt_local_trainers, args.num_txt_clients)):
+            for i in range(n):
+                t = ClientTrainer(args, dataset, None, None, None, None, self.logger,
+                                  global_test_set=client_test_sets.get(kind), inter_distance=4, client_id=i,
+                                  wandb=self.wandb, gpuid=str(self.device))
+                loaders = client_loaders.get(kind)
+                t.train_loader = loaders[i] if loaders else None
+                store.append(t)
+                if is_test and i == 0:
+                    break
+        if args.num_mm_clients > 0:
+            config = mm_config
+            if config is None:
+                config = default_config(embed_dim=args.feature_dim, cnn_type='resnet18', not_bert=True)
+                config.train.use_fp16 = False
+            config.model.embed_dim = args.feature_dim
+            config.model.not_bert = True
+            for client_id in range(args.num_mm_clients):
+                loaders = client_loaders.get('mm')
+                self.mm_local_trainers.append(
+                    MMClientTrainer(args, config, self.logger, client=client_id, dset_name='flicker30k',
+                                    device=str(self.device), mlp_local=self.args.mlp_local,
+                                    train_loader=loaders[client_id] if loaders else None))
+                if is_test and client_id == 0:
+                    break
+        self.total_local_trainers = self.img_local_trainers + self.txt_local_trainers + self.mm_local_trainers
+        for i in range(len(self.total_local_trainers)):
+            self.total_local_trainers[i].client_idx = i + 1
+
+    # -------------------------------------------------------------------------------------------------- round
+    @torch.no_grad()
+    def extract_global_features(self):
+        """MMFL.py:194-221, device-resident: [M, D] image and caption representations of the public set."""
+        loader = self.dataloaders_global[self._pub_key(True)]
+        img_feature, txt_feature, distill_index = [], [], []
+        eng = self.engine
+        was_training = eng.model.training
+        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(loader):
+            images = images.to(eng.device)
+            if eng.autocast_dtype is not None:
+                images = images.contiguous(memory_format=torch.channels_last)
+            with torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
+                output = eng.model(images, captions.to(eng.device), captions_word, caption_lens.to(eng.device))
+            img_feature.append(output['image_features'].float())
+            txt_feature.append(output['caption_features'].float())
+            distill_index.extend(index)
+        eng.model.train(was_training)
+        self.global_img_feature = torch.cat(img_feature, dim=0)
+        self.global_txt_feature = torch.cat(txt_feature, dim=0)
+        self.distill_index = distill_index
+
+    def train(self, round_n):
+        self.cur_epoch = round_n
+        self.cur_trainers = self.total_local_trainers
+        # multi-rank: the server phases are replicated on every rank; re-synchronise the replicas each round
+        cdist.broadcast_module(self.engine.model)
+        cdist.broadcast_module(self.engine.criterion)
+        if not is_test:
+            self.logger.log(f"Round {round_n + 1}!")
+            self.engine.train(tr_loader=self._dataloaders[self._pub_key(False)])
+            if len(self.total_local_trainers) != 0:
+                # every rank must sample the same clients: the python RNG is seeded identically (main.py)
+                self.cur_trainers = random.sample(self.total_local_trainers, self.args.client_num_per_round)
+        if self.args.agg_method == "con_w" or self.args.contrast_local_intra or self.args.contrast_local_inter:
+            self.extract_global_features()
+
+        rank, world = cdist._world()
+        my_trainers = cdist.shard_clients(self.cur_trainers, rank, world)
+        slots = -(-len(self.cur_trainers) // world) if self.cur_trainers else 0
+        local_reps = []
+        for trainer in my_trainers:
+            self.logger.log(f"Training Client {trainer.client_idx}!")
+            trainer.cur_epoch = round_n
+            trainer.run(self.global_img_feature, self.global_txt_feature, self.distill_index,
+                        self._dataloaders[self._pub_key(False)])
+            self.logger.log("Generate Local Representations")
+            _vec, i = trainer.generate_logits(self.dataloaders_global[self._pub_key(True)])
+            if self.distill_index is None:
+                self.distill_index = i
+            else:
+                assert i == self.distill_index
+            local_reps.append(_vec)
+        if world > 1:
+            while len(local_reps) < slots:
+                local_reps.append({'img': None, 'txt': None})
+            M, D = self.args.pub_data_num, self.args.feature_dim
+            img_vec, txt_vec = cdist.allgather_client_reps(local_reps, M, D, self.engine.device)
+        else:
+            img_vec = [v['img'] for v in local_reps if v['img'] is not None]
+            txt_vec = [v['txt'] for v in local_reps if v['txt'] is not None]
+
+        if not self.args.disable_distill:
+            self.distill(round_n, img_vec, txt_vec, None, None, self.distill_index)
+
+        metadata = self.engine.metadata.copy()
+        metadata['cur_epoch'] = round_n + 1
+        metadata['lr'] = self.engine.optimizer.param_groups[0]['lr']
+        test_scores = self.engine.evaluate({'test': self._dataloaders['test']})
+        self.engine.report_scores(step=round_n + 1, scores=test_scores, metadata=metadata,
+                                  prefix=self.engine.eval_prefix)
+        t = test_scores['test']
+        rsum = t['i2t']['recall_1'] + t['t2i']['recall_1']
+        if 'n_fold' in t:
+            rsum += t['n_fold']['i2t']['recall_1'] + t['n_fold']['t2i']['recall_1']
+            self.wandb.log({"Server n_fold_i2t_r1": t['n_fold']['i2t']['recall_1']}, step=self.cur_epoch)
+            self.wandb.log({"Server n_fold_t2i_r1": t['n_fold']['t2i']['recall_1']}, step=self.cur_epoch)
+        self.wandb.log({"Server rsum_r1": rsum}, step=self.cur_epoch)
+        self.wandb.log({"Server i2t_r1": t['i2t']['recall_1']}, step=self.cur_epoch)
+        self.wandb.log({"Server t2i_r1": t['t2i']['recall_1']}, step=self.cur_epoch)
+        if self.best_score < rsum:
+            metadata['best_score'] = rsum                 # (the reference never stores it back: MMFL.py:275-276)
+            metadata['best_epoch'] = round_n + 1
+            self.best_metadata, self.best_scores = metadata, test_scores
+            if rank == 0 and getattr(self.args, 'save_checkpoints', True):
+                torch.save({'net': self.engine.model.state_dict()}, self.args.name + '-best_model.pt')
+        if round_n == self.args.comm_rounds - 1 and rank == 0 and getattr(self.args, 'save_checkpoints', True):
+            torch.save({'net': self.engine.model.state_dict()}, self.args.name + '-last_model.pt')
+        self.engine.lr_scheduler.step()
+        del img_vec, txt_vec
+        gc.collect()
+
+    # -------------------------------------------------------------------------------------------------- distill
+    def aggregation(self, i_vec, t_vec):
+        """MMFL.py:298-335 (`con_w`): log-prob of every client representation against the other modality's global
+        bank, softmax over clients, weighted sum -- on the GPU (csrc/bank.hip), row-sharded across ranks."""
+        if self.args.agg_method != "con_w":
+            raise NotImplementedError
+        if i_vec:
+            i_vec = cdist.conw_aggregate_sharded(i_vec, self.global_txt_feature)
+        if t_vec:
+            t_vec = cdist.conw_aggregate_sharded(t_vec, self.global_img_feature)
+        return i_vec, t_vec
+
+    def distill(self, round_n, img_vec, txt_vec, img_num, txt_num, distill_index):
+        self.engine.model.train()
+        client_loss_cri = nn.MSELoss()
+        img_vec, txt_vec = self.aggregation(img_vec, txt_vec)
+        self.img_vec, self.txt_vec = img_vec, txt_vec
+        distill_dict = {b: a for a, b in enumerate(distill_index)}
+        self.logger.log("start distilling")
+        eng = self.engine
+        model = eng.dp.module if eng.dp is not None else eng.model
+
+        def code_sim(output, target):
+            output = output.sum(axis=1) if len(output.shape) == 3 else output
+            return client_loss_cri(output, target.type_as(output))
+
+        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(
+                self.dataloaders_global[self._pub_key(False)]):
+            images = images.to(eng.device)
+            if eng.autocast_dtype is not None:
+                images = images.contiguous(memory_format=torch.channels_last)
+            with torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
+                output = model(images, captions.to(eng.device), captions_word, caption_lens.to(eng.device))
+            d_idx = operator.itemgetter(*index)(distill_dict)
+            d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
+            loss = 0
+            if self.args.num_img_clients > 0 and self.img_vec is not None and len(self.img_vec):
+                loss = loss + self.args.kd_weight * code_sim(output['image_features'], self.img_vec[d_idx, :])
+            if self.args.num_txt_clients > 0 and self.txt_vec is not None and len(self.txt_vec):
+                loss = loss + self.args.kd_weight * code_sim(output['caption_features'], self.txt_vec[d_idx, :])
+            if self.args.num_mm_clients > 0:
+                if self.img_vec is not None and len(self.img_vec):
+                    loss = loss + self.args.kd_weight * code_sim(output['image_features'], self.img_vec[d_idx, :])
+                if self.txt_vec is not None and len(self.txt_vec):
+                    loss = loss + self.args.kd_weight * code_sim(output['caption_features'], self.txt_vec[d_idx, :])
+            if not torch.is_tensor(loss):
+                continue
+            eng.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            eng.optimizer_step()

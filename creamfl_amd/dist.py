@@ -45,6 +45,16 @@ def all_gather_cat(t, group=None):
     return out
 
 
+def broadcast_module(module, src=0, group=None):
+    """Make every rank's copy of `module` (parameters and buffers) identical to rank `src`'s."""
+    rank, world = _world(group)
+    if world == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src, group=group)
+
+
 class _GatherWithGrad(torch.autograd.Function):
     """forward: all-gather rows; backward: this rank's slice of the upstream gradient times W.
     Every rank evaluates the SAME full-batch loss L on the gathered features, so dL/d(local rows) is the local

@@ -1,0 +1,126 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU layer in creamfl_amd/dist.py.  The collectives and the
+sharding logic are the product's; the compute kernels are injected from the oracle because the HIP ops need
+a GPU (the product itself never falls back to CPU)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from creamfl_amd import dist as cdist
+
+
+def _init(rank, world, path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    dist.init_process_group('gloo', init_method=f'file://{path}', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _unit(gen, *s):
+    return torch.nn.functional.normalize(torch.randn(*s, generator=gen), dim=-1)
+
+
+# ------------------------------------------------------------------------------ global contrast across ranks
+def _worker_global_contrast(rank, world, path, out):
+    _init(rank, world, path)
+    torch.manual_seed(0)
+    enc_i = torch.nn.Linear(12, 8)
+    enc_t = torch.nn.Linear(10, 8)
+    model = torch.nn.ModuleDict({'i': enc_i, 't': enc_t})
+    gen = torch.Generator().manual_seed(1)
+    X = torch.randn(world * 6, 12, generator=gen)
+    Y = torch.randn(world * 6, 10, generator=gen)
+    a = torch.tensor([5.0], requires_grad=True)
+    b = torch.tensor([3.0], requires_grad=True)
+
+    class Both(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, y):
+            return (torch.nn.functional.normalize(self.m['i'](x), dim=-1),
+                    torch.nn.functional.normalize(self.m['t'](y), dim=-1))
+
+    wrapped = Both(model)
+    dp = cdist.DataParallelContext(wrapped, bucket_cap_mb=1)
+    xs, ys = X[rank * 6:(rank + 1) * 6], Y[rank * 6:(rank + 1) * 6]
+    fi, ft = dp.module(xs, ys)
+    gi, gt = dp.gather_features(fi, ft)
+    loss, _ = oracle.pair_loss_literal(gi, gt, a, b)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in wrapped.named_parameters()}
+    if rank == 0:
+        # single-process large-batch reference
+        torch.manual_seed(0)
+        ri, rt = torch.nn.Linear(12, 8), torch.nn.Linear(10, 8)
+        a2 = torch.tensor([5.0], requires_grad=True)
+        b2 = torch.tensor([3.0], requires_grad=True)
+        l2, _ = oracle.pair_loss_literal(torch.nn.functional.normalize(ri(X), dim=-1),
+                                         torch.nn.functional.normalize(rt(Y), dim=-1), a2, b2)
+        l2.backward()
+        ok = abs(loss.item() - l2.item()) < 1e-4 * abs(l2.item())
+        ok &= torch.allclose(grads['m.i.weight'], ri.weight.grad, rtol=1e-4, atol=1e-6)
+        ok &= torch.allclose(grads['m.t.bias'], rt.bias.grad, rtol=1e-4, atol=1e-6)
+        ok &= torch.allclose(a.grad, a2.grad, rtol=1e-4) and torch.allclose(b.grad, b2.grad, rtol=1e-4)
+        out.put(bool(ok))
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ client reps + sharded con_w
+def _worker_clients_conw(rank, world, path, out):
+    _init(rank, world, path)
+    M, D = 300, 16
+    gen = torch.Generator().manual_seed(7)
+    G_img, G_txt = _unit(gen, M, D), _unit(gen, M, D)
+    # 3 clients this round: img, txt, mm  -> rank 0 gets clients 0 and 2, rank 1 gets client 1
+    reps_all = [{'img': _unit(gen, M, D), 'txt': None}, {'img': None, 'txt': _unit(gen, M, D)},
+                {'img': _unit(gen, M, D), 'txt': _unit(gen, M, D)}]
+    mine = cdist.shard_clients(reps_all)
+    while len(mine) < 2:
+        mine.append({'img': None, 'txt': None})
+    img_vecs, txt_vecs = cdist.allgather_client_reps(mine, M, D, torch.device('cpu'))
+    ok = len(img_vecs) == 2 and len(txt_vecs) == 2
+    ok &= torch.equal(img_vecs[0], reps_all[0]['img']) and torch.equal(img_vecs[1], reps_all[2]['img'])
+    ok &= torch.equal(txt_vecs[0], reps_all[1]['txt']) and torch.equal(txt_vecs[1], reps_all[2]['txt'])
+
+    def lp_fn(v, g, r0, rows):
+        return oracle.conw_logprob(v, g, literal=False)[r0:r0 + rows]
+
+    def comb_fn(vs, lp):
+        w = torch.softmax(lp, 0)
+        return sum(w[c][:, None] * vs[c] for c in range(len(vs)))
+
+    agg = cdist.conw_aggregate_sharded(img_vecs, G_txt, logprob_fn=lp_fn, combine_fn=comb_fn)
+    want, _, _ = oracle.conw_aggregate(img_vecs, G_txt, literal=False)
+    ok &= torch.allclose(agg, want, rtol=1e-5, atol=1e-6) and agg.shape == (M, D)
+    # replica resynchronisation
+    lin = torch.nn.Linear(4, 4)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 1))
+    cdist.broadcast_module(lin)
+    ok &= bool(torch.all(lin.weight == 1.0))
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(bool(flag.item() == 1.0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('worker', [_worker_global_contrast, _worker_clients_conw])
+def test_two_rank_gloo(worker):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'rdzv')
+        procs = [ctx.Process(target=worker, args=(r, 2, path, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0, f'worker exited with {p.exitcode}'
+        assert out.get(timeout=10) is True

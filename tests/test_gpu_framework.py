@@ -1,0 +1,146 @@
+"""GPU: the host mirror of the reference API end to end -- server step vs. the CPU oracle port, evaluator vs.
+the recall oracle, and one full communication round (BASELINE.json configs[0]-style plumbing) on tiny
+synthetic data."""
+import copy
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import oracle.step as ostep
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _small_cfg(dim=64, cnn='resnet18', not_bert=False):
+    from creamfl_amd.utils.config import default_config
+    cfg = default_config(embed_dim=dim, cnn_type=cnn, not_bert=not_bert)
+    cfg.model.bert_name = 'bert-mini'
+    return cfg
+
+
+def test_server_step_matches_cpu_port(dev):
+    """TrainerEngine.train_step (fp32 trunks, HIP head + loss + clip + AdamP) against oracle.step on identical
+    weights and batch: features, loss and the updated parameters."""
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.synthetic import coco_batch
+    from oracle.adamp import AdamP as OracleAdamP
+    torch.manual_seed(0)
+    cfg = _small_cfg()
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model.eval()                                   # dropout off / BN in eval mode: deterministic on both sides
+    cpu_model = copy.deepcopy(eng.model)
+    crit = SimpleNamespace(negative_scale=torch.nn.Parameter(torch.tensor([15.0])),
+                           shift=torch.nn.Parameter(torch.tensor([15.0])))
+    eng.model_to_device()
+    b = coco_batch(24, 'cpu', seed=5, bert=True, img=96)
+    # --- CPU oracle port
+    params = [p for p in cpu_model.parameters()] + [crit.negative_scale, crit.shift]
+    opt = OracleAdamP(params, lr=cfg.optimizer.learning_rate)
+    img_c, txt_c = ostep.pcme_forward_cpu(cpu_model, b[0], b[1], b[3])
+    loss_c, _ = ostep.contrastive_step_cpu(cpu_model, crit, opt, b, cfg.train.grad_clip)
+    # --- HIP path
+    out = eng.model(b[0].to(dev), b[1].to(dev), None, b[3].to(dev))
+    assert list(out.keys()) == ['image_features', 'image_attentions', 'image_residuals', 'image_logsigma',
+                                'image_logsigma_att', 'caption_features', 'caption_attentions', 'caption_residuals',
+                                'caption_logsigma', 'caption_logsigma_att']
+    np.testing.assert_allclose(out['image_features'].detach().cpu().numpy(), img_c.detach().numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(out['caption_features'].detach().cpu().numpy(), txt_c.detach().numpy(), rtol=2e-3, atol=2e-4)
+    loss_g, ld = eng.train_step(b[0].to(dev), b[1].to(dev), None, b[3].to(dev))
+    np.testing.assert_allclose(loss_g.item(), loss_c.item(), rtol=2e-3)
+    assert set(ld.keys()) >= {'i2t_loss', 't2i_loss', 'loss', 'shift', 'negative_scale'}
+    np.testing.assert_allclose(ld['loss'], loss_g.item(), rtol=1e-6)
+    # updated parameters: one AdamP step moves every weight by ~lr; compare the update direction on a few tensors
+    names = ['img_enc.fc.weight', 'img_enc.pie_net.attention.w_1.weight', 'linear.weight', 'img_enc.cnn.conv1.weight']
+    gp = dict(eng.model.named_parameters())
+    cp = dict(cpu_model.named_parameters())
+    torch.manual_seed(0)
+    ref0 = dict(TrainerEngineInit(cfg).named_parameters())
+    for n in names:
+        dg = gp[n].detach().cpu() - ref0[n]
+        dc = cp[n].detach() - ref0[n]
+        cos = torch.nn.functional.cosine_similarity(dg.flatten(), dc.flatten(), dim=0).item()
+        assert cos > 0.98, (n, cos)
+    np.testing.assert_allclose(eng.criterion.shift.item(), crit.shift.item(), rtol=1e-4)
+    np.testing.assert_allclose(eng.criterion.negative_scale.item(), crit.negative_scale.item(), rtol=1e-4)
+
+
+def TrainerEngineInit(cfg):
+    """the initial weights again (same seed, same construction order as TrainerEngine.create)"""
+    from creamfl_amd.networks.models import get_model
+    return get_model({'<pad>': 0}, cfg.model, False)
+
+
+def test_evaluator_scores_match_oracle(dev):
+    from creamfl_amd.algorithms.eval_coco import COCOEvaluator
+    from creamfl_amd.networks.models import get_model
+    from creamfl_amd.utils.synthetic import SyntheticCocoLoader
+    torch.manual_seed(1)
+    cfg = _small_cfg(dim=32)
+    model = get_model({'<pad>': 0}, cfg.model, False).to(dev).eval()
+    ev = COCOEvaluator(eval_method='matmul', verbose=False, eval_device=str(dev), extract_device=str(dev), n_crossfolds=5)
+    ev.set_model(model)
+    loader = SyntheticCocoLoader(250, 50, seed=3, bert=True, captions_per_image=5, device='cpu', img=64)
+    scores = ev.evaluate(loader, n_crossfolds=5, n_images_per_crossfold=10, n_captions_per_crossfold=50)
+    assert set(scores) == {'mean_log_image_sigma', 'mean_log_caption_sigma', 'n_fold', 'i2t', 't2i', 'rsum', 'medr', 'meanr'}
+    assert set(scores['i2t']) == {'recall_1', 'recall_5', 'recall_10', 'rsum', 'medr', 'meanr'}
+    ef = ev.extract_features(loader)
+    img, cap = ef['image_features'].cpu().numpy(), ef['caption_features'].cpu().numpy()
+    icls, ccls = ef['image_classes'].numpy(), ef['caption_classes'].numpy()
+    assert img.shape == (50, 32) and cap.shape == (250, 32)
+    want = oracle.recall_scores(oracle.recall_ranks_count(img, cap, icls, ccls))
+    for k, v in want.items():
+        assert scores['i2t'][k] == v, k
+    want = oracle.recall_scores(oracle.recall_ranks_count(cap, img, ccls, icls))
+    for k, v in want.items():
+        assert scores['t2i'][k] == v, k
+
+
+def test_one_communication_round(dev):
+    """config[0]-style plumbing: 1 image + 1 text + 1 multimodal client, inter + intra contrast, con_w, KD, eval."""
+    from creamfl_amd.algorithms.MMFL import MMFL
+    torch.manual_seed(2)
+    M = 96
+    args = SimpleNamespace(name='/tmp/creamfl_test', feature_dim=64, pub_data_num=M, not_bert=False, mlp_local=False,
+                           server_lr=2e-4, local_epochs=1, comm_rounds=1, num_img_clients=1, num_txt_clients=1,
+                           num_mm_clients=1, client_num_per_round=3, agg_method='con_w', contrast_local_intra=True,
+                           contrast_local_inter=True, interintra_weight=0.5, loss_scale=False, kd_weight=0.3,
+                           disable_distill=False, save_client=False, device=0, cnn_type='resnet18', bert_name='bert-mini',
+                           image_size=64, test_pairs=100, quiet=True, save_checkpoints=False)
+    algo = MMFL(args, None)
+    algo.config.dataloader.batch_size = 32
+    algo.config.train.use_fp16 = False
+    algo.create_model(args)
+    algo.load_dataset(args)
+    captured = {}
+    orig = algo.aggregation
+
+    def spy(i_vec, t_vec):
+        captured['i'] = [v.clone() for v in i_vec]
+        captured['t'] = [v.clone() for v in t_vec]
+        captured['g_txt'] = algo.global_txt_feature.clone()
+        out = orig(i_vec, t_vec)
+        captured['agg_i'] = out[0].clone()
+        return out
+
+    algo.aggregation = spy
+    algo.train(0)
+    assert algo.global_img_feature.shape == (M, 64) and algo.global_img_feature.is_cuda
+    assert len(captured['i']) == 2 and len(captured['t']) == 2            # img + mm, txt + mm
+    want, _, _ = oracle.conw_aggregate([v.cpu() for v in captured['i']], captured['g_txt'].cpu(), literal=False)
+    np.testing.assert_allclose(captured['agg_i'].cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-6)
+    sc = algo.best_scores['test']
+    assert 0.0 <= sc['i2t']['recall_1'] <= 100.0 and np.isfinite(sc['rsum'])
+    for t in algo.total_local_trainers:
+        assert t.last_contrast_loss is not None and torch.isfinite(t.last_contrast_loss)
+    assert all(torch.isfinite(p).all() for p in algo.engine.model.parameters())

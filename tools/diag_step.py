@@ -13,10 +13,22 @@ B = int(os.environ.get('B', 256)); cnn = os.environ.get('CNN', 'resnet101'); dt 
 cfg = default_config(embed_dim=512, cnn_type=cnn)
 eng = TrainerEngine(device=dev); eng.create(cfg, {'<pad>': 0}, None, False); eng.model_to_device()
 if dt == 'bf16': eng.to_half()
+if os.environ.get('NATIVE_BN'):
+    import torch.nn.functional as F
+    class NBN(torch.nn.BatchNorm2d):
+        def forward(self, x):
+            with torch.backends.cudnn.flags(enabled=False):
+                return super().forward(x)
+    def swap(m):
+        for n, c in m.named_children():
+            if isinstance(c, torch.nn.BatchNorm2d):
+                nb = NBN(c.num_features).to(dev); nb.load_state_dict(c.state_dict()); setattr(m, n, nb)
+            else: swap(c)
+    swap(eng.model)
 eng.model.train(); log('model ready')
 b = coco_batch(B, dev, 1234, True); log('batch ready')
 images = b[0].contiguous(memory_format=torch.channels_last) if dt == 'bf16' else b[0]
-for it in range(4):
+for it in range(6):
     torch.cuda.synchronize(); t = time.time()
     loss, _ = eng.forward_loss(images, b[1], None, b[3]); torch.cuda.synchronize(); t1 = time.time()
     eng.optimizer.zero_grad(set_to_none=True); loss.backward(); torch.cuda.synchronize(); t2 = time.time()
