@@ -231,7 +231,11 @@ class MMFL(object):
         metadata = self.engine.metadata.copy()
         metadata['cur_epoch'] = round_n + 1
         metadata['lr'] = self.engine.optimizer.param_groups[0]['lr']
-        test_scores = self.engine.evaluate({'test': self._dataloaders['test']})
+        test_ds = self._dataloaders['test'].dataset
+        fold_kw = {}
+        if test_ds.n_images < 5000:          # smaller-than-COCO-5K test sets: 5 equal folds of what there is
+            fold_kw = dict(n_images_per_crossfold=test_ds.n_images // 5, n_captions_per_crossfold=len(test_ds) // 5)
+        test_scores = self.engine.evaluate({'test': self._dataloaders['test']}, **fold_kw)
         self.engine.report_scores(step=round_n + 1, scores=test_scores, metadata=metadata,
                                   prefix=self.engine.eval_prefix)
         t = test_scores['test']

@@ -3,8 +3,8 @@
 
 Text tower: `not_bert` -> GRU EncoderText; else BERT -> CLS -> Linear(768, D) -> l2-normalise (:40-44).
 The reference tokenises `captions_word` with a downloaded BertTokenizer on every step; offline there is
-no vocabulary, so when no tokenizer is attached the already-tokenised `sentences` ids (+ `lengths` for the
-attention mask) are fed to BERT directly.  Attach a tokenizer with `model.tokenizer = ...` to get the
+no vocabulary, so when no tokenizer is attached the COCO-vocabulary `sentences` ids are mapped into BERT's id
+space (`_bert_inputs`) and `lengths` gives the attention mask.  Attach a tokenizer with `model.tokenizer = ...` to get the
 reference behaviour.
 """
 import torch
@@ -40,9 +40,15 @@ class PCME(nn.Module):
             inputs = self.tokenizer(captions_word, padding=True, return_tensors='pt')
             dev = self.linear.weight.device
             return {k: v.to(dev) for k, v in inputs.items()}
+        # offline stand-in for the tokenizer: COCO-vocabulary ids -> BERT id space
+        # (<pad> 0 -> [PAD] 0, <start> 1 -> [CLS] 101, <end> 2 -> [SEP] 102, word w -> 1000 + w)
         L = sentences.shape[1]
         mask = torch.arange(L, device=sentences.device)[None, :] < lengths.to(sentences.device)[:, None]
-        return {'input_ids': sentences, 'attention_mask': mask}
+        ids = torch.where(sentences == 0, sentences,
+                          torch.where(sentences == 1, torch.full_like(sentences, 101),
+                                      torch.where(sentences == 2, torch.full_like(sentences, 102), sentences + 1000)))
+        ids = ids.clamp_max(self.txt_enc.config.vocab_size - 1)
+        return {'input_ids': ids, 'attention_mask': mask}
 
     def forward(self, images, sentences, captions_word, lengths):
         image_output = self.img_enc(images)

@@ -13,9 +13,11 @@ def coco_batch(batch, device='cpu', seed=1234, bert=True, vocab=11755, min_len=8
     images = torch.randn(batch, 3, img, img, generator=g)
     lens = torch.randint(min_len, max_len + 1, (batch,), generator=g).sort(descending=True).values
     L = int(lens.max())
-    lo, hi = (1000, 30522) if bert else (4, vocab)
-    captions = torch.randint(lo, hi, (batch, L), generator=g)
-    start, end = (101, 102) if bert else (1, 2)
+    # `captions` always holds COCO-vocabulary ids (<pad>=0 <start>=1 <end>=2 <unk>=3, 11 755 words), as the
+    # reference's loaders do for both towers; PCME's BERT path maps them into BERT's id space when no
+    # tokenizer is attached (`bert` is kept for call-site readability only).
+    captions = torch.randint(4, vocab, (batch, L), generator=g)
+    start, end = 1, 2
     captions[:, 0] = start
     for i, l in enumerate(lens.tolist()):
         captions[i, l - 1] = end

@@ -30,9 +30,7 @@ def pcme_forward_cpu(model, images, sentences, lengths):
     img = l2_normalize(o)
     if model.config.not_bert:
         raise NotImplementedError('cpu port covers the BERT text tower (config 2)')
-    L = sentences.shape[1]
-    mask = torch.arange(L)[None, :] < lengths[:, None]
-    hidden = model.txt_enc(input_ids=sentences, attention_mask=mask)['last_hidden_state']
+    hidden = model.txt_enc(**model._bert_inputs(sentences, None, lengths))['last_hidden_state']
     txt = l2_normalize(model.linear(hidden[:, 0, :]))
     return img, txt
 
