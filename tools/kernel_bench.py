@@ -116,6 +116,25 @@ def case_a6(Nq, Ng, D):
             'fp64_TFLOPs_two_pass': round(flops / us / 1e6, 2)}
 
 
+def case_opt(cnn='resnet101'):
+    """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from creamfl_amd.networks.models import get_model
+    from creamfl_amd.utils.config import default_config
+    torch.manual_seed(0)
+    model = get_model({'<pad>': 0}, default_config(embed_dim=512, cnn_type=cnn).model, False).cuda()
+    model.to(memory_format=torch.channels_last)
+    params = [p for p in model.parameters()]
+    for p in params:
+        p.grad = torch.randn_like(p) * 1e-3
+    opt = AdamP(params, lr=2e-4)
+    n = sum(p.numel() for p in params)
+    us, prof = timed(lambda: opt.step(clip=(params, 2.0)), iters=10, warm=2)
+    return {'case': f'opt_clip_adamp {cnn}+bert-base n_params={n}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'pass1_GBps': round(24 * n / prof['cfl_adamp_pass1_kernel'] / 1e3, 1),
+            'pass3_GBps': round(16 * n / prof['cfl_adamp_pass3_kernel'] / 1e3, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', default='a1,a3,a5,a2,a6')
@@ -133,6 +152,8 @@ def main():
         out += [case_a2(256, 49, 2048, 1024, 512), case_a2(128, 49, 512, 256, 256)]
     if 'a6' in cases:
         out += [case_a6(1000, 5000, 512), case_a6(5000, 25000, 512)]
+    if 'opt' in cases:
+        out += [case_opt()]
     for r in out:
         print(json.dumps(r))
 
