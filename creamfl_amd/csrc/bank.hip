@@ -187,19 +187,28 @@ __global__ __launch_bounds__(256) void cfl_bank_bwd_kernel(Opnd P, Opnd G, const
         }
 }
 
-// dF[f][d] = coef * (sum_x slab[x][f][d] - G[idx[f]][d]),  coef = inv_tau / B * gout
+// dF[f][d] = coef * (sum_x slab[x][f][d] - G[idx[f]][d]),  coef = inv_tau / B * gout.
+// block = 64 consecutive elements x 4 slab groups (wave w sums slabs x = w, w+4, ...), fixed order => deterministic.
 __global__ __launch_bounds__(256) void cfl_bank_bwd_reduce_kernel(const float* __restrict__ slab, int KS,
                                                                   const float* __restrict__ G, const long long* __restrict__ idx,
                                                                   int B, int M, int D, float inv_tau,
                                                                   const float* __restrict__ gout, float* dF) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)B * D) return;
-    const int f = (int)(e / D), d = (int)(e % D);
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long tot = (long long)B * D;
+    const long long e = (long long)blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int x = 0; x < KS; ++x) s += slab[(size_t)x * B * D + e];
-    const long long tgt = idx[f];
-    const float gpos = (tgt >= 0 && tgt < M) ? G[tgt * D + d] : 0.f;
-    dF[e] = (inv_tau / (float)B) * gout[0] * (s - gpos);
+    if (e < tot)
+        for (int x = w; x < KS; x += 4) s += slab[(size_t)x * tot + e];
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < tot) {
+        s = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+        const int f = (int)(e / D), d = (int)(e % D);
+        const long long tgt = idx[f];
+        const float gpos = (tgt >= 0 && tgt < M) ? G[tgt * D + d] : 0.f;
+        dF[e] = (inv_tau / (float)B) * gout[0] * (s - gpos);
+    }
 }
 
 // A4: one wave per row
@@ -267,7 +276,7 @@ static int bwd_ksplits(int B, int M, int D, int BM, int BN, int* kper) {
     int ks = cfl_cdiv(512, tiles);
     const int kmax = cfl_cdiv(M, 32);
     if (ks > kmax) ks = kmax;
-    if (ks > 256) ks = 256;
+    if (ks > 128) ks = 128;
     if (ks < 1) ks = 1;
     int per = cfl_cdiv(cfl_cdiv(M, ks), 32) * 32;
     *kper = per;
@@ -343,7 +352,7 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
                    C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab);
     }
     const long long tot = (long long)B * D;
-    CFL_LAUNCH(K_BANK_BWD_REDUCE, cfl_bank_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+    CFL_LAUNCH(K_BANK_BWD_REDUCE, cfl_bank_bwd_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream,
                w.slab, ks, G, idx, B, M, D, inv_tau, gout_dev, dF);
     return 0;
 }

@@ -1,0 +1,368 @@
+// bnorm.hip -- fused training-mode BatchNorm (+ residual add) (+ ReLU) for NHWC bf16 activations.
+//
+// Where it sits: the ResNet trunk of the image tower (row A2 / A2c of SURVEY section 8; reference
+// src/networks/models/image_encoder.py:27,55 -> torchvision Bottleneck: bn -> relu, bn3 -> += identity -> relu;
+// src/networks/resnet_client.py:60-98).  Convolutions stay on MIOpen; the normalisation, the residual add and the
+// activation between them are pure HBM streaming and are fused here: the rocprofv3 trace of the bench step showed
+// 31 % of GPU time in MIOpen's BatchNorm kernels plus 12 % in separate bf16 add / clamp kernels.
+//
+// Layout: a channels_last activation [N, C, H, W] is the row-major matrix [R = N*H*W, C] in bf16.  A thread owns 8
+// consecutive channels (one 16-byte access) for all its rows, so per-channel scale/shift live in registers and every
+// wave access is lane-contiguous.  Statistics are accumulated in fp32.
+//   fwd : stats  (read x)                      -> per-block partial sum / sum-of-squares [blocks, C]
+//         final  mean, invstd, running stats
+//         apply  y = relu?( (x-mean)*invstd*gamma + beta (+ residual) )     (read x (+res), write y)
+//   bwd : reduce (read dy, x, y)               -> partial sum(dy'), sum(dy' * xhat),  dy' = dy * (y > 0) if relu
+//         final  dgamma, dbeta
+//         apply  dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat));  dres = dy'   (write dx (+ dres))
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32;
+struct __attribute__((aligned(16))) U4 { u32 x, y, z, w; };
+
+__device__ __forceinline__ void unpack8(const U4& u, float (&f)[8]) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ u32 bf16_rne(float f) {
+    u32 u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ U4 pack8(const float (&f)[8]) {
+    U4 u;
+    u.x = bf16_rne(f[0]) | (bf16_rne(f[1]) << 16); u.y = bf16_rne(f[2]) | (bf16_rne(f[3]) << 16);
+    u.z = bf16_rne(f[4]) | (bf16_rne(f[5]) << 16); u.w = bf16_rne(f[6]) | (bf16_rne(f[7]) << 16);
+    return u;
+}
+
+// thread -> (channel group, row phase) map shared by every kernel
+struct Map {
+    int tprb;     // threads per row inside this block (<= 256)
+    int rpp;      // rows per pass
+    int c0;       // first of this thread's 8 channels
+    int rsub;     // row phase
+    bool active;
+};
+__device__ __forceinline__ Map make_map(int C) {
+    Map m;
+    const int tpr = C >> 3;
+    m.tprb = tpr < 256 ? tpr : 256;
+    m.rpp = 256 / m.tprb;
+    const int t = threadIdx.x;
+    m.rsub = t / m.tprb;
+    m.c0 = (blockIdx.y * 256 + (t % m.tprb)) * 8;
+    m.active = (m.rsub < m.rpp) && (m.c0 < C);
+    return m;
+}
+
+// column reduction of two per-thread 8-vectors across the row phases of the block -> partial[blockIdx.x][c]
+__device__ __forceinline__ void block_col_reduce(const Map& m, const float (&a)[8], const float (&b)[8], int C,
+                                                 float* pa, float* pb, float* lds) {
+    float* la = lds;                 // [rpp][tprb*8]
+    float* lb = lds + 2048;
+    const int w = m.tprb * 8;
+    if (m.rsub < m.rpp) {
+        const int col = (threadIdx.x % m.tprb) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { la[m.rsub * w + col + k] = a[k]; lb[m.rsub * w + col + k] = b[k]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < w; c += 256) {
+        float sa = 0.f, sb = 0.f;
+        for (int r = 0; r < m.rpp; ++r) { sa += la[r * w + c]; sb += lb[r * w + c]; }
+        const int cg = blockIdx.y * 2048 + c;
+        if (cg < C) { pa[(long long)blockIdx.x * C + cg] = sa; pb[(long long)blockIdx.x * C + cg] = sb; }
+    }
+}
+
+__global__ __launch_bounds__(256) void cfl_bn_stats_kernel(const U4* __restrict__ x, long long R, int C, int rows_per_block,
+                                                           float* psum, float* psq) {
+    __shared__ float lds[4096];
+    const Map m = make_map(C);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    if (m.active) {
+        const long long stride = (long long)m.rpp * (C >> 3);
+        const U4* p = x + (rb + m.rsub) * (C >> 3) + (m.c0 >> 3);
+        long long r = rb + m.rsub;
+        for (; r + 3 * m.rpp < re; r += 4 * m.rpp, p += 4 * stride) {
+            const U4 u0 = p[0], u1 = p[stride], u2 = p[2 * stride], u3 = p[3 * stride];
+            float f[8];
+            unpack8(u0, f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+            unpack8(u1, f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+            unpack8(u2, f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+            unpack8(u3, f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+        }
+        for (; r < re; r += m.rpp, p += stride) {
+            float f[8];
+            unpack8(p[0], f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+        }
+    }
+    block_col_reduce(m, s, q, C, psum, psq, lds);
+}
+
+// mean / invstd (+ running statistics) from the partials; block = 64 channels x 4 partial groups
+__global__ __launch_bounds__(256) void cfl_bn_final_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                                           int nblk, int C, long long R, float eps, float momentum,
+                                                           float* mean, float* invstd, float* rmean, float* rvar) {
+    __shared__ float sa[4][64], sb[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int i = w; i < nblk; i += 4) { a += psum[(long long)i * C + c]; b += psq[(long long)i * C + c]; }
+    sa[w][lane] = a; sb[w][lane] = b;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        a = sa[0][lane] + sa[1][lane] + sa[2][lane] + sa[3][lane];
+        b = sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane];
+        const float mu = a / (float)R;
+        const float var = fmaxf(b / (float)R - mu * mu, 0.f);
+        mean[c] = mu;
+        invstd[c] = rsqrtf(var + eps);
+        if (rmean) {
+            const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        }
+    }
+}
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const U4* __restrict__ x, const U4* __restrict__ res,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           long long R, int C, int rows_per_block, U4* y) {
+    const Map m = make_map(C);
+    if (!m.active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float g = gamma[m.c0 + k] * invstd[m.c0 + k];
+        sc[k] = g;
+        sh[k] = beta[m.c0 + k] - mean[m.c0 + k] * g;
+    }
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    const long long stride = (long long)m.rpp * (C >> 3);
+    long long off = (rb + m.rsub) * (C >> 3) + (m.c0 >> 3);
+#pragma unroll 4
+    for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
+        float f[8], g[8];
+        unpack8(x[off], f);
+        if (RES) unpack8(res[off], g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = fmaf(f[k], sc[k], sh[k]);
+            if (RES) v += g[k];
+            if (RELU) v = fmaxf(v, 0.f);
+            f[k] = v;
+        }
+        y[off] = pack8(f);
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __restrict__ dy, const U4* __restrict__ x,
+                                                                const U4* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, long long R, int C,
+                                                                int rows_per_block, float* pdb, float* pdg) {
+    __shared__ float lds[4096];
+    const Map m = make_map(C);
+    float db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m.active) {
+        float mu[8], is[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mu[k] = mean[m.c0 + k]; is[k] = invstd[m.c0 + k]; }
+        const long long rb = (long long)blockIdx.x * rows_per_block;
+        const long long re = min(R, rb + rows_per_block);
+        const long long stride = (long long)m.rpp * (C >> 3);
+        long long off = (rb + m.rsub) * (C >> 3) + (m.c0 >> 3);
+#pragma unroll 2
+        for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
+            float d[8], f[8], o[8];
+            unpack8(dy[off], d);
+            unpack8(x[off], f);
+            if (RELU) unpack8(y[off], o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dd = (RELU && !(o[k] > 0.f)) ? 0.f : d[k];
+                db[k] += dd;
+                dg[k] = fmaf(dd, (f[k] - mu[k]) * is[k], dg[k]);
+            }
+        }
+    }
+    block_col_reduce(m, db, dg, C, pdb, pdg, lds);
+}
+
+__global__ __launch_bounds__(256) void cfl_bn_bwd_final_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
+                                                               int nblk, int C, float* dbeta, float* dgamma) {
+    __shared__ float sa[4][64], sb[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int i = w; i < nblk; i += 4) { a += pdb[(long long)i * C + c]; b += pdg[(long long)i * C + c]; }
+    sa[w][lane] = a; sb[w][lane] = b;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        dbeta[c] = sa[0][lane] + sa[1][lane] + sa[2][lane] + sa[3][lane];
+        dgamma[c] = sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane];
+    }
+}
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restrict__ dy, const U4* __restrict__ x,
+                                                               const U4* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                               long long R, int C, int rows_per_block, U4* dx, U4* dres) {
+    const Map m = make_map(C);
+    if (!m.active) return;
+    float mu[8], is[8], a[8], b[8], c[8];
+    const float invR = 1.f / (float)R;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[m.c0 + k]; is[k] = invstd[m.c0 + k];
+        a[k] = gamma[m.c0 + k] * is[k];                 // dx = a * (dy' - b - xhat * c)
+        b[k] = dbeta[m.c0 + k] * invR;
+        c[k] = dgamma[m.c0 + k] * invR;
+    }
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    const long long stride = (long long)m.rpp * (C >> 3);
+    long long off = (rb + m.rsub) * (C >> 3) + (m.c0 >> 3);
+#pragma unroll 2
+    for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
+        float d[8], f[8], o[8];
+        unpack8(dy[off], d);
+        unpack8(x[off], f);
+        if (RELU) unpack8(y[off], o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float dd = (RELU && !(o[k] > 0.f)) ? 0.f : d[k];
+            d[k] = dd;
+            f[k] = a[k] * (dd - b[k] - (f[k] - mu[k]) * is[k] * c[k]);
+        }
+        dx[off] = pack8(f);
+        if (RES) dres[off] = pack8(d);
+    }
+}
+
+struct Plan { int rows_per_block, nblk, gy; };
+static Plan bn_plan(long long R, int C) {
+    Plan p;
+    const int tpr = C >> 3;
+    const int tprb = tpr < 256 ? tpr : 256;
+    const int rpp = 256 / tprb;
+    p.gy = cfl_cdiv(tpr, 256);
+    long long want = 2048 / p.gy;                         // ~8 blocks per CU
+    long long rpb = (R + want - 1) / want;
+    const long long unit = (long long)rpp * 4;            // keep the 4x unrolled loop busy
+    rpb = ((rpb + unit - 1) / unit) * unit;
+    if (rpb < unit) rpb = unit;
+    p.rows_per_block = (int)rpb;
+    p.nblk = (int)((R + rpb - 1) / rpb);
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cfl_bn_ws_bytes(long long R, int C) {
+    if (R <= 0 || C <= 0) return 256;
+    const Plan p = bn_plan(R, C);
+    return cfl_align256((size_t)2 * p.nblk * C * sizeof(float));
+}
+
+int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
+               float* save_mean, float* save_invstd, void* ws, void* stream_) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Plan p = bn_plan(R, C);
+    float* psum = (float*)ws;
+    float* psq = psum + (size_t)p.nblk * C;
+    const dim3 grid(p.nblk, p.gy);
+    CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_kernel, grid, dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
+    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 64)), dim3(256), 0, stream, psum, psq, p.nblk, C, R, eps,
+               momentum, save_mean, save_invstd, running_mean, running_var);
+    const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
+    if (residual && relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    else if (residual)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    else if (relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    else
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    return 0;
+}
+
+int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, long long R, int C, int relu, void* y, void* stream_) {
+    if (!x || !mean || !invstd || !gamma || !beta || !y || R <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Plan p = bn_plan(R, C);
+    const dim3 grid(p.nblk, p.gy);
+    const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
+    if (residual && relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    else if (residual)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    else if (relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    else
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+    return 0;
+}
+
+int cfl_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+               const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx, void* dres,
+               float* dgamma, float* dbeta, void* ws, void* stream_) {
+    if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
+    if ((relu && !y) || (has_residual && !dres)) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Plan p = bn_plan(R, C);
+    float* pdb = (float*)ws;
+    float* pdg = pdb + (size_t)p.nblk * C;
+    const dim3 grid(p.nblk, p.gy);
+    const U4 *d = (const U4*)dy, *xx = (const U4*)x, *yy = (const U4*)y;
+    if (relu)
+        CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, R, C, p.rows_per_block, pdb, pdg);
+    else
+        CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, R, C, p.rows_per_block, pdb, pdg);
+    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 64)), dim3(256), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
+    U4 *ox = (U4*)dx, *orr = (U4*)dres;
+    if (has_residual && relu)
+        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
+    else if (has_residual)
+        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<true, false>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
+    else if (relu)
+        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
+    else
+        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
+    return 0;
+}
+
+}  // extern "C"

@@ -25,6 +25,7 @@ enum CflKernel {
     K_PIE_EPI_FWD, K_PIE_EPI_BWD, K_PIE_EPI_BWD_LN, K_L2NORM_FWD, K_L2NORM_BWD,
     K_RANK_POSMAX, K_RANK_COUNT,
     K_GRADNORM, K_ADAMP_PASS1, K_ADAMP_DECIDE, K_ADAMP_PASS3,
+    K_BN_STATS, K_BN_FINAL, K_BN_APPLY, K_BN_BWD_REDUCE, K_BN_BWD_FINAL, K_BN_BWD_APPLY,
     K_NUM
 };
 

@@ -84,15 +84,16 @@ __global__ __launch_bounds__(256) void cfl_pie_pool_kernel(const float* __restri
     }
 }
 
-// backward of the softmax: da_p = <d_pooled_n, X_np>; ds_p = attn_p (da_p - sum_q attn_q da_q). One block per n.
-__global__ __launch_bounds__(256) void cfl_pie_bwd_ds_kernel(const float* __restrict__ X, const float* __restrict__ attn,
-                                                             const float* __restrict__ dpooled, int P, int Cd, int vec, float* ds) {
+// backward of the softmax: da_p = <d_pooled_n, X_np>; ds_p = attn_p (da_p - sum_q attn_q da_q).
+// One 1024-thread block (16 waves, one wave per position p at a time) per sample n.
+__global__ __launch_bounds__(1024) void cfl_pie_bwd_ds_kernel(const float* __restrict__ X, const float* __restrict__ attn,
+                                                              const float* __restrict__ dpooled, int P, int Cd, int vec, float* ds) {
     __shared__ float sda[1024];
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float* x = X + (long long)n * P * Cd;
     const float* g = dpooled + (long long)n * Cd;
-    for (int p = w; p < P; p += 4) {
+    for (int p = w; p < P; p += 16) {
         float s = 0.f;
         if (vec) {
             for (int c = lane * 4; c < Cd; c += 256) {
@@ -107,9 +108,14 @@ __global__ __launch_bounds__(256) void cfl_pie_bwd_ds_kernel(const float* __rest
     }
     __syncthreads();
     float dot = 0.f;
-    for (int p = t; p < P; p += 256) dot = fmaf(attn[(long long)n * P + p], sda[p], dot);
-    dot = block_sum_256(dot, red);
-    for (int p = t; p < P; p += 256) ds[(long long)n * P + p] = attn[(long long)n * P + p] * (sda[p] - dot);
+    for (int p = t; p < P; p += 1024) dot = fmaf(attn[(long long)n * P + p], sda[p], dot);
+    dot = wave_sum(dot);
+    if (lane == 0) red[w] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dot += red[i];
+    for (int p = t; p < P; p += 1024) ds[(long long)n * P + p] = attn[(long long)n * P + p] * (sda[p] - dot);
 }
 
 // dX[n,p,c] = attn[n,p] * d_pooled[n,c] + d_xmean[n,c] / P.   grid (N*P, ceil(Cd/1024))
@@ -135,31 +141,57 @@ __global__ __launch_bounds__(256) void cfl_pie_bwd_dx_kernel(const float* __rest
 }
 
 // dH[row,j] = ds[row] w2[j] (1 - tanh^2 H[row,j]);  partial[chunk][j] = sum_{rows in chunk} ds[row] tanh(H[row,j])
-// grid (row chunks of RC rows, ceil(dh/256)); thread = one column j.
-constexpr int PIE_RC = 64;
+// grid (row chunks of PIE_RC rows, ceil(dh/1024)); a thread owns 4 consecutive columns (16-byte accesses).
+constexpr int PIE_RC = 32;
 __global__ __launch_bounds__(256) void cfl_pie_bwd_dh_kernel(const float* __restrict__ H, const float* __restrict__ w2,
-                                                             const float* __restrict__ ds, long long rows, int dh,
+                                                             const float* __restrict__ ds, long long rows, int dh, int vec,
                                                              float* dH, float* partial) {
-    const int j = blockIdx.y * 256 + threadIdx.x;
-    if (j >= dh) return;
     const long long r0 = (long long)blockIdx.x * PIE_RC;
     const long long r1 = min(rows, r0 + PIE_RC);
-    const float w = w2[j];
-    float acc = 0.f;
-    for (long long r = r0; r < r1; ++r) {
-        const float t = tanhf(H[r * dh + j]);
-        const float d = ds[r];                      // masked rows have attn = 0 => ds = 0
-        dH[r * dh + j] = d * w * (1.f - t * t);
-        acc = fmaf(d, t, acc);
+    if (vec) {
+        const int j = blockIdx.y * 1024 + threadIdx.x * 4;
+        if (j >= dh) return;
+        const f32x4 w = ld4(w2 + j);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (long long r = r0; r < r1; ++r) {
+            const f32x4 h = ld4(H + r * dh + j);
+            const float d = ds[r];                      // masked rows have attn = 0 => ds = 0
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = tanhf(h[k]);
+                o[k] = d * w[k] * (1.f - t * t);
+                acc[k] = fmaf(d, t, acc[k]);
+            }
+            st4(dH + r * dh + j, o);
+        }
+        st4(partial + (long long)blockIdx.x * dh + j, acc);
+    } else {
+        for (int j = blockIdx.y * 1024 + threadIdx.x; j < min(dh, (int)(blockIdx.y + 1) * 1024); j += 256) {
+            const float w = w2[j];
+            float acc = 0.f;
+            for (long long r = r0; r < r1; ++r) {
+                const float t = tanhf(H[r * dh + j]);
+                const float d = ds[r];
+                dH[r * dh + j] = d * w * (1.f - t * t);
+                acc = fmaf(d, t, acc);
+            }
+            partial[(long long)blockIdx.x * dh + j] = acc;
+        }
     }
-    partial[(long long)blockIdx.x * dh + j] = acc;
 }
+// dw2[j] = sum over chunks of partial[c][j]; block = 64 columns x 4 chunk groups
 __global__ __launch_bounds__(256) void cfl_pie_bwd_dw2_kernel(const float* __restrict__ partial, int nchunks, int dh, float* dw2) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= dh) return;
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(long long)c * dh + j];
-    dw2[j] = s;
+    if (j < dh)
+        for (int c = w; c < nchunks; c += 4) s += partial[(long long)c * dh + j];
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && j < dh) dw2[j] = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
 }
 
 // epilogue fwd: one wave per row.
@@ -332,12 +364,13 @@ int cfl_pie_pool_bwd(const float* X, const float* H, const float* w2, const unsi
     float* ds = (float*)ws;
     float* partial = ds + rows;
     const int vx = cfl_vec_ok(X, Cd) && cfl_vec_ok(d_pooled, Cd) && cfl_vec_ok(dX, Cd) && (!d_xmean || cfl_vec_ok(d_xmean, Cd));
-    CFL_LAUNCH(K_PIE_BWD_DS, cfl_pie_bwd_ds_kernel, dim3(N), dim3(256), 0, stream, X, attn, d_pooled, P, Cd, vx, ds);
+    CFL_LAUNCH(K_PIE_BWD_DS, cfl_pie_bwd_ds_kernel, dim3(N), dim3(1024), 0, stream, X, attn, d_pooled, P, Cd, vx, ds);
     CFL_LAUNCH(K_PIE_BWD_DX, cfl_pie_bwd_dx_kernel, dim3((unsigned)rows, cfl_cdiv(Cd, 1024)), dim3(256), 0, stream,
                attn, d_pooled, d_xmean, P, Cd, vx, dX);
-    CFL_LAUNCH(K_PIE_BWD_DH, cfl_pie_bwd_dh_kernel, dim3(nch, cfl_cdiv(dh, 256)), dim3(256), 0, stream,
-               H, w2, ds, rows, dh, dH, partial);
-    CFL_LAUNCH(K_PIE_BWD_DW2, cfl_pie_bwd_dw2_kernel, dim3(cfl_cdiv(dh, 256)), dim3(256), 0, stream, partial, nch, dh, dw2);
+    const int vh = cfl_vec_ok(H, dh) && cfl_vec_ok(w2, 4) && cfl_vec_ok(dH, dh);
+    CFL_LAUNCH(K_PIE_BWD_DH, cfl_pie_bwd_dh_kernel, dim3(nch, cfl_cdiv(dh, 1024)), dim3(256), 0, stream,
+               H, w2, ds, rows, dh, vh, dH, partial);
+    CFL_LAUNCH(K_PIE_BWD_DW2, cfl_pie_bwd_dw2_kernel, dim3(cfl_cdiv(dh, 64)), dim3(256), 0, stream, partial, nch, dh, dw2);
     return 0;
 }
 

@@ -14,24 +14,46 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class BNAct(nn.BatchNorm2d):
+    """BatchNorm2d whose forward can also take the residual to add and apply the ReLU: `bn(x, residual, relu)`.
+    Same parameters / buffers / state_dict as nn.BatchNorm2d.  For channels_last bf16 activations on the GPU (the
+    autocast training regime of the bench) the whole normalise -> add -> relu chain and its backward run as the fused
+    HBM-streaming kernels of csrc/bnorm.hip; any other input (fp32, NCHW, CPU) takes the plain library path."""
+
+    def forward(self, x, residual=None, relu=False):
+        from .. import ops
+        if self.track_running_stats and self.momentum is not None and self.affine and ops.bn_act_supported(x, self.num_features):
+            if self.training:
+                if self.num_batches_tracked is not None:
+                    self.num_batches_tracked.add_(1)
+                return ops.bn_act_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
+                                        self.eps, relu=relu, residual=residual)
+            if not torch.is_grad_enabled():
+                return ops.bn_act_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                       relu=relu, residual=residual)
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BNAct(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BNAct(planes)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + residual)
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), residual=residual, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -40,21 +62,20 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BNAct(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # stride on the 3x3 (torchvision v1.5)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BNAct(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = BNAct(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + residual)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=residual, relu=True)
 
 
 class ResNetTrunk(nn.Module):
@@ -64,7 +85,7 @@ class ResNetTrunk(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BNAct(64)
         self.relu = nn.ReLU(inplace=relu_inplace)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -84,14 +105,14 @@ class ResNetTrunk(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion))
+                BNAct(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     def features(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):

@@ -7,7 +7,7 @@ import math
 import torch.nn as nn
 
 from .. import ops
-from .backbones import BasicBlock, Bottleneck
+from .backbones import BasicBlock, BNAct, Bottleneck
 
 
 class ResNet(nn.Module):
@@ -49,7 +49,7 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion))
+                BNAct(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         for i in range(1, blocks):

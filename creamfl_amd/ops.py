@@ -357,6 +357,74 @@ def l2_normalize(tensor, axis=-1):
     return _L2NormFn.apply(x)
 
 
+# --------------------------------------------------------------------------- trunk glue: fused BN (+add) (+ReLU)
+def bn_act_supported(x, num_features):
+    """True when the fused NHWC bf16 BatchNorm kernels apply to `x` ([N, C, H, W] bf16, channels_last)."""
+    c8 = num_features // 8
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and num_features % 8 == 0
+            and (256 % c8 == 0 if c8 < 256 else num_features % 2048 == 0)
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        R = N * H * W
+        y = torch.empty_like(x)                           # keeps channels_last
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
+        _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                  R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(ws), _stream(x)),
+                   'cfl_bn_fwd')
+        ctx.save_for_backward(x, y if relu else x, weight, mean, invstd)
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        R = N * H * W
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgamma = torch.empty_like(weight)
+        dbeta = torch.empty_like(weight)
+        ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
+        _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(x), _ptr(y) if ctx.relu else _ptr(None), _ptr(weight), _ptr(mean),
+                                  _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res), _ptr(dx), _ptr(dres), _ptr(dgamma),
+                                  _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None):
+    """Training-mode BatchNorm2d (+ residual) (+ ReLU) on a channels_last bf16 activation (csrc/bnorm.hip)."""
+    if residual is not None and not (residual.shape == x.shape and bn_act_supported(residual, x.shape[1])):
+        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu))
+
+
+@torch.no_grad()
+def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, residual=None):
+    """Evaluation-mode BatchNorm2d (+ residual) (+ ReLU), no autograd."""
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    invstd = torch.rsqrt(running_var.float() + eps)
+    if residual is not None and not (residual.shape == x.shape and bn_act_supported(residual, C)):
+        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.cfl_bn_apply(_ptr(x), _ptr(residual), _ptr(running_mean), _ptr(invstd), _ptr(weight), _ptr(bias),
+                                N * H * W, C, int(relu), _ptr(y), _stream(x)), 'cfl_bn_apply')
+    return y
+
+
 # --------------------------------------------------------------------------- A6: retrieval ranks
 @torch.no_grad()
 def rank_count(q_features, g_features, q_labels, g_labels):

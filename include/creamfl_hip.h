@@ -154,6 +154,27 @@ size_t cfl_rank_ws_bytes(int Nq, int Ng, int D);
 int cfl_rank_count(const float* Q, const float* G, const long long* qlab, const long long* glab,
                    int Nq, int Ng, int D, int* ranks, void* ws, void* stream);
 
+/* ---- A2 trunk glue: fused BatchNorm (+ residual add) (+ ReLU), training mode, NHWC bf16 ------
+ * Replaces nn.BatchNorm2d -> (+= identity) -> nn.ReLU between the convolutions of the ResNet trunks
+ * (torchvision Bottleneck/BasicBlock as used by src/networks/models/image_encoder.py:27; src/networks/
+ * resnet_client.py:60-98).  x, residual, y, dy, dx, dres: bf16 [R, C] row-major (= channels_last [N,C,H,W] with
+ * R = N*H*W); gamma/beta/statistics fp32 [C].  C % 8 == 0 and (C/8 divides 256 or C >= 2048 in multiples of 2048).
+ * fwd:   batch statistics (biased variance), running stats updated in place when non-NULL
+ *        (unbiased variance, momentum as in torch), y = relu?((x-mean)*invstd*gamma + beta (+ residual)).
+ * apply: the same normalisation with given mean / invstd (evaluation mode).
+ * bwd:   dy' = dy * (y > 0) if relu;  dgamma = sum dy' xhat, dbeta = sum dy';
+ *        dx = gamma*invstd*(dy' - dbeta/R - xhat*dgamma/R);  dres = dy' (when has_residual).
+ */
+size_t cfl_bn_ws_bytes(long long R, int C);
+int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
+               float* save_mean, float* save_invstd, void* ws, void* stream);
+int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, long long R, int C, int relu, void* y, void* stream);
+int cfl_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+               const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx, void* dres,
+               float* dgamma, float* dbeta, void* ws, void* stream);
+
 /* ---- S1 tail: fused multi-tensor gradient clip + AdamP step ------
  * Replaces nn.utils.clip_grad_norm_(model.parameters(), 2) + AdamP.step()
  * (src/algorithms/retrieval_trainer.py:211-214; optimizer = adamp.AdamP 0.3.0, optimizers.py:24).

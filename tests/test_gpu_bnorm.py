@@ -1,0 +1,70 @@
+"""GPU: fused NHWC bf16 BatchNorm(+add)(+ReLU) (csrc/bnorm.hip) against torch's BatchNorm evaluated in fp32 on the
+same bf16-valued inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n,c,h,w', [(4, 64, 56, 56), (3, 256, 14, 14), (2, 2048, 7, 7), (5, 128, 9, 11), (2, 512, 1, 1),
+                                     (8, 1024, 14, 14)])
+@pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
+def test_bn_act_matches_torch(n, c, h, w, relu, res):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.networks.backbones import BNAct
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(c + h)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.3).to(torch.bfloat16)
+    r = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16) if res else None
+    gy = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16)
+    bn = BNAct(c)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(c, generator=g))
+        bn.bias.copy_(0.3 * torch.randn(c, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(c, generator=g))
+        bn.running_var.copy_(1 + 0.1 * torch.rand(c, generator=g))
+    ref = torch.nn.BatchNorm2d(c)
+    ref.load_state_dict(bn.state_dict())
+    # reference: fp32 math on the bf16-valued tensors (CPU)
+    xr = x.float().requires_grad_(True)
+    rr = r.float().requires_grad_(True) if res else None
+    yr = ref(xr)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    (yr * gy.float()).sum().backward()
+    # fused
+    bn = bn.to(dev).train()
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = r.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
+    yg = bn(xg, residual=rg, relu=relu)
+    assert yg.dtype == torch.bfloat16 and yg.is_contiguous(memory_format=torch.channels_last)
+    (yg.float() * gy.to(dev).float()).sum().backward()
+    tol = dict(rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(yg.detach().float().cpu().numpy(), yr.detach().numpy(), **tol)
+    np.testing.assert_allclose(xg.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=3e-2,
+                               atol=3e-2 * float(xr.grad.abs().max()) + 1e-3)
+    if res:
+        np.testing.assert_allclose(rg.grad.float().cpu().numpy(), rr.grad.numpy(), rtol=2e-2, atol=2e-2)
+    sc = float(ref.weight.grad.abs().max()) + 1e-6
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=2e-2, atol=2e-2 * sc)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=2e-2,
+                               atol=2e-2 * (float(ref.bias.grad.abs().max()) + 1e-6))
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-3, atol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+    # evaluation mode (running statistics), no grad
+    bn.eval()
+    ref.eval()
+    with torch.no_grad():
+        ye = bn(xg.detach(), residual=rg.detach() if res else None, relu=relu)
+        yre = ref(x.float())
+        if res:
+            yre = yre + r.float()
+        if relu:
+            yre = F.relu(yre)
+    np.testing.assert_allclose(ye.float().cpu().numpy(), yre.numpy(), **tol)
