@@ -117,21 +117,39 @@ __global__ __launch_bounds__(256) void cfl_bn_stats_kernel(const U4* __restrict_
     block_col_reduce(m, s, q, C, psum, psq, lds);
 }
 
-// mean / invstd (+ running statistics) from the partials; block = 64 channels x 4 partial groups
+// sum the per-block partials of two [nblk, C] arrays for 16 channels: 256 threads = 16 channels x 16 partial groups
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ pa, const float* __restrict__ pb, int nblk, int C,
+                                                int c, int grp, float& a, float& b, float (*sa)[16], float (*sb)[16]) {
+    a = 0.f; b = 0.f;
+    if (c < C) {
+        int i = grp;
+        for (; i + 48 < nblk; i += 64) {
+            const float a0 = pa[(long long)i * C + c], a1 = pa[(long long)(i + 16) * C + c];
+            const float a2 = pa[(long long)(i + 32) * C + c], a3 = pa[(long long)(i + 48) * C + c];
+            const float b0 = pb[(long long)i * C + c], b1 = pb[(long long)(i + 16) * C + c];
+            const float b2 = pb[(long long)(i + 32) * C + c], b3 = pb[(long long)(i + 48) * C + c];
+            a += (a0 + a1) + (a2 + a3); b += (b0 + b1) + (b2 + b3);
+        }
+        for (; i < nblk; i += 16) { a += pa[(long long)i * C + c]; b += pb[(long long)i * C + c]; }
+    }
+    sa[grp][threadIdx.x & 15] = a; sb[grp][threadIdx.x & 15] = b;
+    __syncthreads();
+    if (grp == 0) {
+        a = 0.f; b = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { a += sa[g][threadIdx.x & 15]; b += sb[g][threadIdx.x & 15]; }
+    }
+}
+
+// mean / invstd (+ running statistics) from the partials
 __global__ __launch_bounds__(256) void cfl_bn_final_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
                                                            int nblk, int C, long long R, float eps, float momentum,
                                                            float* mean, float* invstd, float* rmean, float* rvar) {
-    __shared__ float sa[4][64], sb[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int i = w; i < nblk; i += 4) { a += psum[(long long)i * C + c]; b += psq[(long long)i * C + c]; }
-    sa[w][lane] = a; sb[w][lane] = b;
-    __syncthreads();
-    if (w == 0 && c < C) {
-        a = sa[0][lane] + sa[1][lane] + sa[2][lane] + sa[3][lane];
-        b = sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane];
+    __shared__ float sa[16][16], sb[16][16];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+    float a, b;
+    reduce_partials(psum, psq, nblk, C, c, grp, a, b, sa, sb);
+    if (grp == 0 && c < C) {
         const float mu = a / (float)R;
         const float var = fmaxf(b / (float)R - mu * mu, 0.f);
         mean[c] = mu;
@@ -213,18 +231,11 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
 
 __global__ __launch_bounds__(256) void cfl_bn_bwd_final_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
                                                                int nblk, int C, float* dbeta, float* dgamma) {
-    __shared__ float sa[4][64], sb[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int i = w; i < nblk; i += 4) { a += pdb[(long long)i * C + c]; b += pdg[(long long)i * C + c]; }
-    sa[w][lane] = a; sb[w][lane] = b;
-    __syncthreads();
-    if (w == 0 && c < C) {
-        dbeta[c] = sa[0][lane] + sa[1][lane] + sa[2][lane] + sa[3][lane];
-        dgamma[c] = sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane];
-    }
+    __shared__ float sa[16][16], sb[16][16];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+    float a, b;
+    reduce_partials(pdb, pdg, nblk, C, c, grp, a, b, sa, sb);
+    if (grp == 0 && c < C) { dbeta[c] = a; dgamma[c] = b; }
 }
 
 template <bool RES, bool RELU>
@@ -272,7 +283,7 @@ static Plan bn_plan(long long R, int C) {
     const int tprb = tpr < 256 ? tpr : 256;
     const int rpp = 256 / tprb;
     p.gy = cfl_cdiv(tpr, 256);
-    long long want = 2048 / p.gy;                         // ~8 blocks per CU
+    long long want = 768 / p.gy;                          // ~3 blocks per CU; few partials keep the final kernels short
     long long rpb = (R + want - 1) / want;
     const long long unit = (long long)rpp * 4;            // keep the 4x unrolled loop busy
     rpb = ((rpb + unit - 1) / unit) * unit;
@@ -303,7 +314,7 @@ int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const fl
     float* psq = psum + (size_t)p.nblk * C;
     const dim3 grid(p.nblk, p.gy);
     CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_kernel, grid, dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
-    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 64)), dim3(256), 0, stream, psum, psq, p.nblk, C, R, eps,
+    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(256), 0, stream, psum, psq, p.nblk, C, R, eps,
                momentum, save_mean, save_invstd, running_mean, running_var);
     const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
     if (residual && relu)
@@ -352,7 +363,7 @@ int cfl_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma,
         CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, R, C, p.rows_per_block, pdb, pdg);
     else
         CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, R, C, p.rows_per_block, pdb, pdg);
-    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 64)), dim3(256), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
+    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(256), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
     U4 *ox = (U4*)dx, *orr = (U4*)dres;
     if (has_residual && relu)
         CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
