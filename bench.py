@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'],
                     help='encoder trunk precision (reference: apex O2 fp16); head + loss are always fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dp', action='store_true', help='exercise the multi-GPU code path even with one rank')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=2)
     args = ap.parse_args()
@@ -103,10 +104,12 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.backends.cudnn.benchmark = True
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29531')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     from creamfl_amd import _lib
     from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
@@ -121,7 +124,7 @@ def main():
     eng.model_to_device()
     if args.dtype == 'bf16':
         eng.to_half()
-    if world > 1:
+    if use_dp:
         eng.enable_data_parallel()
     eng.model.train()
 
@@ -134,7 +137,7 @@ def main():
         return eng.train_step(images, captions, words, lens)
 
     def fence():
-        if world > 1:
+        if use_dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -152,7 +155,7 @@ def main():
     prof = _lib.prof_query()
     loss_val = float(loss.detach())
 
-    if world > 1:
+    if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -215,7 +218,7 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu, 'hip_kernels_us': hip_us,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dp:
         torch.distributed.destroy_process_group()
 
 
