@@ -36,7 +36,7 @@ static BankPlan bank_plan(int B, int M) {
 }
 
 template <int TN>
-__global__ __launch_bounds__(256) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B, int M, int Bp, float inv_tau,
+__global__ __launch_bounds__(256, 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B, int M, int Bp, float inv_tau,
                                                            float* logits_t, float* part_m, float* part_l) {
     constexpr int TM = 2;
     using C = TileCfg<TM, TN, true, true>;
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B
 #pragma unroll
     for (int n = 0; n < TN; ++n) { run_m[n] = -INFINITY; run_l[n] = 0.f; }
 
-    for (int gc = sx; gc < nch; gc += S) {
-        const int row0 = gc * C::BM;
-        f32x16 acc[TM][TN];
-        tile_gemm<TM, TN, true, true>(G, F, row0, col0, 0, G.kdim, lds, acc, XfIdentity());
+    const int ntiles = sx < nch ? (nch - sx + S - 1) / S : 0;
+    auto tile_fn = [&](int i) { return TileDesc{(sx + i * S) * C::BM, col0, 0, G.kdim}; };
+    auto epi_fn = [&](int i, const f32x16 (&acc)[TM][TN]) {
+        const int row0 = (sx + i * S) * C::BM;
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
             const int f = col0 + acc_col<TN>(wc, n, lane);
@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B
                 for (int r = 0; r < 16; ++r) {
                     const int g = row0 + acc_row<TM>(wr, m, r, lane);
                     const float x = (g < M) ? acc[m][n][r] * inv_tau : -INFINITY;
-                    acc[m][n][r] = x;
                     tmax = fmaxf(tmax, x);
                     if (logits_t && g < M && f < B) logits_t[(long long)g * B + f] = x;
                 }
@@ -79,12 +78,16 @@ __global__ __launch_bounds__(256) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s += expf(acc[m][n][r] - mn);
+                    for (int r = 0; r < 16; ++r) {
+                        const int g = row0 + acc_row<TM>(wr, m, r, lane);
+                        s += (g < M) ? expf(acc[m][n][r] * inv_tau - mn) : 0.f;
+                    }
                 run_l[n] = run_l[n] * expf(run_m[n] - mn) + s;
                 run_m[n] = mn;
             }
         }
-    }
+    };
+    tile_gemm_seq<TM, TN, true, true>(G, F, ntiles, tile_fn, lds, XfIdentity(), epi_fn);
     // combine the two half-waves (they hold different bank rows of the same feature row) ...
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
@@ -285,8 +288,8 @@ static int bwd_ksplits(int B, int M, int D, int BM, int BN, int* kper) {
 
 static int launch_bank_fwd(const float* F, const float* G, int B, int M, int D, float inv_tau,
                            float* logits_t, const BankPlan& pl, const BankWs& w, hipStream_t stream) {
-    Opnd Go{G, D, M, D, cfl_vec_ok(G, D)};
-    Opnd Fo{F, D, B, D, cfl_vec_ok(F, D)};
+    Opnd Go{G, D, M, D, cfl_opnd_vec(G, D, D)};
+    Opnd Fo{F, D, B, D, cfl_opnd_vec(F, D, D)};
     const dim3 grid(pl.S, cfl_cdiv(B, pl.BN));
     if (pl.TN == 1) {
         using C = TileCfg<2, 1, true, true>;
@@ -336,8 +339,8 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
     if (!logits_t || !G || !idx || !lse || !gout_dev || !dF || !ws || B <= 0 || M <= 0 || D <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BankWs w = bank_ws(ws, bank_plan(B, M));
-    Opnd P{logits_t, B, B, M, cfl_vec_ok(logits_t, B)};
-    Opnd Go{G, D, D, M, cfl_vec_ok(G, D)};
+    Opnd P{logits_t, B, B, M, cfl_opnd_vec(logits_t, B, B)};
+    Opnd Go{G, D, D, M, cfl_opnd_vec(G, D, D)};
     int kper = 0, ks = 0;
     const bool big = (B > 64 && D > 64);
     if (big) {

@@ -26,6 +26,7 @@ enum CflKernel {
     K_RANK_POSMAX, K_RANK_COUNT,
     K_GRADNORM, K_ADAMP_PASS1, K_ADAMP_DECIDE, K_ADAMP_PASS3,
     K_BN_STATS, K_BN_FINAL, K_BN_APPLY, K_BN_BWD_REDUCE, K_BN_BWD_FINAL, K_BN_BWD_APPLY,
+    K_GEMM_PROBE,
     K_NUM
 };
 
@@ -129,51 +130,72 @@ struct TileCfg {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
-// global -> registers for one operand tile of R rows x 32 k (R/32 float4 per thread)
+// global -> registers for one operand tile of R rows x 32 k (R/32 float4 per thread).
+// Fast path (o.vec: base 16-byte aligned, ld % 4 == 0 and, for the K axis, extents % 4 == 0): branch-free --
+// the address is clamped into the tensor and the value is zeroed by a select when the row / k is out of range,
+// so the loop body carries no exec-mask branches.  Slow path: per-element bounds checks (odd shapes only).
 template <bool KCONTIG, int R, class Xf>
 __device__ __forceinline__ void g2r(const Opnd& o, int r0, int k0, f32x4 (&reg)[R / 32], Xf xf) {
     const int t = threadIdx.x;
     if (KCONTIG) {
         const int kq = (t & 7) * 4;
         const int k = k0 + kq;
+        if (o.vec) {
+            const bool kok = k < o.kdim;                       // kdim % 4 == 0 => the whole float4 is in or out
+            const int kc = kok ? k : 0;
 #pragma unroll
-        for (int p = 0; p < R / 32; ++p) {
-            const int r = r0 + p * 32 + (t >> 3);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < o.rows) {
-                const float* src = o.p + (long long)r * o.ld + k;
-                if (o.vec && k + 3 < o.kdim) {
-                    v = *reinterpret_cast<const f32x4*>(src);
-                    v[0] = xf(v[0], r, k); v[1] = xf(v[1], r, k + 1);
-                    v[2] = xf(v[2], r, k + 2); v[3] = xf(v[3], r, k + 3);
-                } else {
+            for (int p = 0; p < R / 32; ++p) {
+                const int r = r0 + p * 32 + (t >> 3);
+                const bool ok = kok && (r < o.rows);
+                const int rc = r < o.rows ? r : o.rows - 1;
+                f32x4 v = *reinterpret_cast<const f32x4*>(o.p + (long long)rc * o.ld + kc);
+                v[0] = ok ? xf(v[0], rc, kc) : 0.f; v[1] = ok ? xf(v[1], rc, kc + 1) : 0.f;
+                v[2] = ok ? xf(v[2], rc, kc + 2) : 0.f; v[3] = ok ? xf(v[3], rc, kc + 3) : 0.f;
+                reg[p] = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < R / 32; ++p) {
+                const int r = r0 + p * 32 + (t >> 3);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < o.rows) {
+                    const float* src = o.p + (long long)r * o.ld + k;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (k + e < o.kdim) v[e] = xf(src[e], r, k + e);
                 }
+                reg[p] = v;
             }
-            reg[p] = v;
         }
     } else {
         constexpr int LPR = R / 4;               // lanes per k-row
         constexpr int KPP = 256 / LPR;           // k-rows per pass
         const int rq = (t % LPR) * 4;
         const int r = r0 + rq;
+        if (o.vec) {
+            const bool rok = r < o.rows;                       // rows % 4 == 0 => the whole float4 is in or out
+            const int rc = rok ? r : 0;
 #pragma unroll
-        for (int p = 0; p < R / 32; ++p) {
-            const int k = k0 + p * KPP + t / LPR;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < o.kdim) {
-                const float* src = o.p + (long long)k * o.ld + r;
-                if (o.vec && r + 3 < o.rows) {
-                    v = *reinterpret_cast<const f32x4*>(src);
-                    v[0] = xf(v[0], r, k); v[1] = xf(v[1], r + 1, k);
-                    v[2] = xf(v[2], r + 2, k); v[3] = xf(v[3], r + 3, k);
-                } else {
+            for (int p = 0; p < R / 32; ++p) {
+                const int k = k0 + p * KPP + t / LPR;
+                const bool ok = rok && (k < o.kdim);
+                const int kc = k < o.kdim ? k : o.kdim - 1;
+                f32x4 v = *reinterpret_cast<const f32x4*>(o.p + (long long)kc * o.ld + rc);
+                v[0] = ok ? xf(v[0], rc, kc) : 0.f; v[1] = ok ? xf(v[1], rc + 1, kc) : 0.f;
+                v[2] = ok ? xf(v[2], rc + 2, kc) : 0.f; v[3] = ok ? xf(v[3], rc + 3, kc) : 0.f;
+                reg[p] = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < R / 32; ++p) {
+                const int k = k0 + p * KPP + t / LPR;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < o.kdim) {
+                    const float* src = o.p + (long long)k * o.ld + r;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (r + e < o.rows) v[e] = xf(src[e], r + e, k);
                 }
+                reg[p] = v;
             }
-            reg[p] = v;
         }
     }
 }
@@ -209,9 +231,102 @@ __device__ __forceinline__ f32x4 frag(const float* s, int tile_r0, int kk, int l
     }
 }
 
-// acc[m][n] (+)= A[row0.., k] * B[col0.., k] over k in [kbeg, kend).  All 256 threads must call.
-// `lds` needs TileCfg::LDS_FLOATS floats, 16-byte aligned.  On return the LDS stage is free again
-// (a trailing barrier has been executed).
+// One K-step of MFMAs from an LDS stage: acc[m][n] += A_tile(32 k) * B_tile(32 k)^T  (64 MFMAs for TM = TN = 2).
+// Fragments are double-buffered in registers: the ds_reads of k-chunk kk+1 are issued before the 16 MFMAs of
+// chunk kk, so LDS latency hides behind the matrix pipe; the MFMA block runs at raised wave priority so that the
+// two waves sharing a SIMD take turns on the pipe instead of advancing in lock-step into the same stall.
+template <int TM, int TN, bool A_KC, bool B_KC>
+__device__ __forceinline__ void tile_compute(const float* sa, const float* sb, f32x16 (&acc)[TM][TN], int lane, int wr, int wc) {
+    using C = TileCfg<TM, TN, A_KC, B_KC>;
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) fa[0][m] = frag<A_KC, C::A_LD>(sa, (wr * TM + m) * 32, 0, lane);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) fb[0][n] = frag<B_KC, C::B_LD>(sb, (wc * TN + n) * 32, 0, lane);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m) fa[(kk + 1) & 1][m] = frag<A_KC, C::A_LD>(sa, (wr * TM + m) * 32, kk + 1, lane);
+#pragma unroll
+            for (int n = 0; n < TN; ++n) fb[(kk + 1) & 1][n] = frag<B_KC, C::B_LD>(sb, (wc * TN + n) * 32, kk + 1, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][m][t], fb[kk & 1][n][t], acc[m][n], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+struct TileDesc { int row0, col0, kbeg, kend; };
+
+// A SEQUENCE of output tiles through one software pipeline.  tile_fn(i) -> TileDesc for i in [0, ntiles);
+// epi_fn(i, acc) consumes the finished accumulators of tile i.  The global loads of K-step s+1 -- which may
+// already belong to tile i+1 -- are issued before the MFMA block of step s and committed to the other LDS
+// buffer after it, so a new tile starts computing right after the previous tile's epilogue (no per-tile
+// load-latency bubble).  All 256 threads must call; `lds` needs TileCfg::LDS_FLOATS floats, 16-byte aligned.
+// epi_fn must not touch `lds` (the next tile's first stage is already resident); the LDS is free after return.
+template <int TM, int TN, bool A_KC, bool B_KC, class XfA, class TileFn, class EpiFn>
+__device__ __forceinline__ void tile_gemm_seq(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds,
+                                              XfA xfa, EpiFn epi_fn) {
+    using C = TileCfg<TM, TN, A_KC, B_KC>;
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    if (ntiles <= 0) return;
+    f32x4 ra[C::BM / 32], rb[C::BN / 32];
+    TileDesc cur = tile_fn(0);
+    g2r<A_KC, C::BM>(A, cur.row0, cur.kbeg, ra, xfa);
+    g2r<B_KC, C::BN>(B, cur.col0, cur.kbeg, rb, XfIdentity());
+    r2s<A_KC, C::BM, C::A_LD>(lds, ra);
+    r2s<B_KC, C::BN, C::B_LD>(lds + C::A_ELEMS, rb);
+    __syncthreads();
+    int buf = 0;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < ntiles; ++i) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        const int nk = (cur.kend - cur.kbeg + C::KC - 1) / C::KC;
+        const bool has_next_tile = (i + 1 < ntiles);
+        TileDesc nxt = cur;
+        if (has_next_tile) nxt = tile_fn(i + 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* sa = lds + buf * C::STAGE;
+            const bool in_tile = (kt + 1 < nk);
+            const bool more = in_tile || has_next_tile;
+            if (more) {
+                const int r0 = in_tile ? cur.row0 : nxt.row0;
+                const int c0 = in_tile ? cur.col0 : nxt.col0;
+                const int k0 = in_tile ? cur.kbeg + (kt + 1) * C::KC : nxt.kbeg;
+                g2r<A_KC, C::BM>(A, r0, k0, ra, xfa);
+                g2r<B_KC, C::BN>(B, c0, k0, rb, XfIdentity());
+            }
+            tile_compute<TM, TN, A_KC, B_KC>(sa, sa + C::A_ELEMS, acc, lane, wr, wc);
+            if (more) {
+                float* da = lds + (buf ^ 1) * C::STAGE;
+                r2s<A_KC, C::BM, C::A_LD>(da, ra);
+                r2s<B_KC, C::BN, C::B_LD>(da + C::A_ELEMS, rb);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        epi_fn(i, acc);
+        cur = nxt;
+    }
+    __syncthreads();
+}
+
+// Single tile: acc[m][n] = A[row0.., k] * B[col0.., k] over k in [kbeg, kend).  (kend - kbeg) must be a multiple
+// of 32 unless kend == kdim.  On return the LDS stage is free again.
 template <int TM, int TN, bool A_KC, bool B_KC, class XfA>
 __device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0, int col0,
                                           int kbeg, int kend, float* lds,
@@ -237,27 +352,12 @@ __device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const float* sa = lds + (kt & 1) * C::STAGE;
-        const float* sb = sa + C::A_ELEMS;
         const bool more = (kt + 1 < nk);
         if (more) {
             g2r<A_KC, C::BM>(A, row0, kbeg + (kt + 1) * C::KC, ra, xfa);
             g2r<B_KC, C::BN>(B, col0, kbeg + (kt + 1) * C::KC, rb, XfIdentity());
         }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int m = 0; m < TM; ++m) fa[m] = frag<A_KC, C::A_LD>(sa, (wr * TM + m) * 32, kk, lane);
-#pragma unroll
-            for (int n = 0; n < TN; ++n) fb[n] = frag<B_KC, C::B_LD>(sb, (wc * TN + n) * 32, kk, lane);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][t], fb[n][t], acc[m][n], 0, 0, 0);
-        }
+        tile_compute<TM, TN, A_KC, B_KC>(sa, sa + C::A_ELEMS, acc, lane, wr, wc);
         if (more) {
             float* da = lds + ((kt + 1) & 1) * C::STAGE;
             r2s<A_KC, C::BM, C::A_LD>(da, ra);
@@ -280,4 +380,9 @@ __device__ __forceinline__ int acc_col(int wc, int n, int lane) {
 
 static inline int cfl_vec_ok(const void* p, long long ld) {
     return ((((uintptr_t)p) & 15) == 0 && (ld % 4) == 0) ? 1 : 0;
+}
+// Opnd::vec additionally needs the extent along the contiguous axis to be a multiple of 4 (a float4 is then
+// entirely inside or entirely outside the tensor): kdim for K-contiguous operands, rows for K-strided ones.
+static inline int cfl_opnd_vec(const void* p, long long ld, int contiguous_extent) {
+    return (cfl_vec_ok(p, ld) && (contiguous_extent % 4) == 0) ? 1 : 0;
 }

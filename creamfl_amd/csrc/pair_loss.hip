@@ -208,8 +208,8 @@ int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float*
     hipStream_t stream = (hipStream_t)stream_;
     PairWs w = pair_ws(ws, N);
     CFL_LAUNCH(K_PAIR_PREP, cfl_pair_prep_kernel, dim3(cfl_cdiv(N, 4)), dim3(256), 0, stream, I, T, N, D, w.ni, w.nt, w.dd);
-    Opnd A{I, D, N, D, cfl_vec_ok(I, D)};
-    Opnd B{T, D, N, D, cfl_vec_ok(T, D)};
+    Opnd A{I, D, N, D, cfl_opnd_vec(I, D, D)};
+    Opnd B{T, D, N, D, cfl_opnd_vec(T, D, D)};
     // 128x128 tiles once they fill the chip, 64x64 tiles below that (latency-bound regime)
     const bool big = (long long)cfl_cdiv(N, 128) * cfl_cdiv(N, 128) >= 256;
     int ntr, ntc;
@@ -235,8 +235,8 @@ int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, 
     if (!I || !T || !coef || !gout_dev || !dI || !dT || !ws || N <= 0 || D <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     PairWs w = pair_ws(ws, N);
-    const int vecN = cfl_vec_ok(coef, N);
-    const int vecD = (cfl_vec_ok(I, D) && cfl_vec_ok(T, D)) ? 1 : 0;
+    const int vecN = cfl_opnd_vec(coef, N, N);
+    const int vecD = (cfl_opnd_vec(I, D, D) && cfl_opnd_vec(T, D, D)) ? 1 : 0;
     const bool big = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 128) * 2 >= 256;
     if (big) {
         using C = TileCfg<2, 2, true, false>;

@@ -40,6 +40,10 @@ int cfl_prof_enable(int on);
 int cfl_prof_reset(void);
 int cfl_prof_query(int kernel_id, long long* launches, double* total_ms);
 
+/* ---- calibration probe: C[M,N] = A[M,K] * B[N,K]^T on the fp32-MFMA tile GEMM every A1/A3/A5 kernel is built on
+ * (no reference counterpart; used by tools/kernel_bench.py and the tile_gemm parity test). */
+int cfl_gemm_nt(const float* A, const float* B, int M, int N, int K, float* C, void* stream);
+
 /* ---- A1: all-pairs soft-contrastive loss ------------------------------------------------
  * Replaces MCSoftContrastiveLoss.forward / _compute_loss / pairwise_sampling / full_sampling /
  * batchwise_cdist / soft_contrastive_nll  (src/criterions/probemb.py:7-86,150-256) for 2-D

@@ -135,6 +135,23 @@ def case_opt(cnn='resnet101'):
             'pass3_GBps': round(16 * n / prof['cfl_adamp_pass3_kernel'] / 1e3, 1)}
 
 
+def case_gemm(M, N, K):
+    import ctypes
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    A = torch.rand(M, K, generator=g, device='cuda') * 2 - 1
+    B = torch.rand(N, K, generator=g, device='cuda') * 2 - 1
+    C = torch.empty(M, N, device='cuda')
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fn = lambda: _lib.check(lib.cfl_gemm_nt(A.data_ptr(), B.data_ptr(), M, N, K, C.data_ptr(), st), 'gemm')
+    us, prof = timed(fn, iters=5, warm=2)
+    ref = A[:256] @ B[:256].T
+    err = (C[:256, :256] - ref).abs().max().item()
+    k_us = prof['cfl_gemm_nt_kernel']
+    return {'case': f'gemm_nt fp32 MFMA {M}x{N}x{K}', 'kernel_us': k_us, 'TFLOPs': round(2 * M * N * K / k_us / 1e6, 1),
+            'max_err_vs_torch': err}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', default='a1,a3,a5,a2,a6')
@@ -152,6 +169,8 @@ def main():
         out += [case_a2(256, 49, 2048, 1024, 512), case_a2(128, 49, 512, 256, 256)]
     if 'a6' in cases:
         out += [case_a6(1000, 5000, 512), case_a6(5000, 25000, 512)]
+    if 'gemm' in cases:
+        out += [case_gemm(4096, 4096, 4096), case_gemm(8192, 8192, 512), case_gemm(8192, 8192, 256)]
     if 'opt' in cases:
         out += [case_opt()]
     for r in out:
