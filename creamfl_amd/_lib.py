@@ -23,6 +23,7 @@ SIGNATURES = {
     'cfl_prof_reset': (c_int, []),
     'cfl_prof_query': (c_int, [c_int, POINTER(c_longlong), POINTER(c_double)]),
     'cfl_gemm_nt': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    'cfl_gemm_ablate': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'cfl_pair_loss_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_pair_loss_fwd': (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P]),
     'cfl_pair_loss_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),

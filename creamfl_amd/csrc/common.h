@@ -66,6 +66,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
+// Logical (XCD-contiguous) tile id -> (tile row, tile column) in super-tiles of 64 tiles (h x w, w = 8 when it
+// divides the tile-column count): the ~64 workgroups resident on one XCD at a time then touch h + w operand panels
+// per K-step instead of 2 + 32 (row-major order), i.e. far fewer L2 misses.  Falls back to row-major when the grid
+// does not divide.  Speed only.
+__device__ __forceinline__ void tile_swizzle(int v, int ntr, int ntc, int& ti, int& tj) {
+    const int sw = (ntc % 8 == 0) ? 8 : (ntc % 4 == 0) ? 4 : (ntc % 2 == 0) ? 2 : 1;
+    const int sh = 64 / sw;
+    if (ntr % sh != 0) { ti = v / ntc; tj = v % ntc; return; }
+    const int g = v >> 6, w = v & 63;
+    const int gpr = ntc / sw;                       // super-tiles per row of super-tiles
+    ti = (g / gpr) * sh + w / sw;
+    tj = (g % gpr) * sw + w % sw;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

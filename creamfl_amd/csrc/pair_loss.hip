@@ -52,9 +52,10 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
                                                            float* rowpart, float* colpart, float* part) {
     using C = TileCfg<TM, TN, true, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int ntc = (N + C::BN - 1) / C::BN;                  // tile columns
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int ti = tile / ntc, tj = tile % ntc;
+    const int ntc = (N + C::BN - 1) / C::BN, ntr = (N + C::BM - 1) / C::BM;
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const int tile = ti * ntc + tj;
     const int row0 = ti * C::BM, col0 = tj * C::BN;
     f32x16 acc[TM][TN];
     tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
@@ -156,9 +157,10 @@ __global__ __launch_bounds__(256) void cfl_pair_bwd_kernel(const float* __restri
                                                            const float* __restrict__ gout, float* dI, float* dT) {
     using C = TileCfg<TM, TN, true, false>;                   // (KS,KS) needs no more LDS than (KC,KS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int ntc = (D + C::BN - 1) / C::BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int row0 = (tile / ntc) * C::BM, col0 = (tile % ntc) * C::BN;
+    const int ntc = (D + C::BN - 1) / C::BN, ntr = (N + C::BM - 1) / C::BM;
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const int row0 = ti * C::BM, col0 = tj * C::BN;
     const bool second = blockIdx.z != 0;
     f32x16 acc[TM][TN];
     const float* X = second ? T : I;        // the tensor whose gradient this block produces
@@ -237,11 +239,18 @@ int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, 
     PairWs w = pair_ws(ws, N);
     const int vecN = cfl_opnd_vec(coef, N, N);
     const int vecD = (cfl_opnd_vec(I, D, D) && cfl_opnd_vec(T, D, D)) ? 1 : 0;
-    const bool big = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 128) * 2 >= 256;
-    if (big) {
+    // tile choice by workgroup count (two GEMMs share the launch, grid.z = 2): 128x128 when that alone gives >= 2
+    // workgroups per CU, else 128x64, else 64x64 (latency-bound small batches)
+    const long long t128 = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 128) * 2;
+    const long long t12864 = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 64) * 2;
+    if (t128 >= 512) {
         using C = TileCfg<2, 2, true, false>;
         CFL_SET_LDS((cfl_pair_bwd_kernel<2, 2>), C::LDS_BYTES);
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<2, 2>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
+                   C::LDS_BYTES, stream, I, T, coef, N, D, vecN, vecD, w.rowsum, w.colsum, gout_dev, dI, dT);
+    } else if (t12864 >= 256) {
+        using C = TileCfg<2, 1, true, false>;
+        CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<2, 1>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
                    C::LDS_BYTES, stream, I, T, coef, N, D, vecN, vecD, w.rowsum, w.colsum, gout_dev, dI, dT);
     } else {
         using C = TileCfg<1, 1, true, false>;

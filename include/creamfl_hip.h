@@ -43,6 +43,8 @@ int cfl_prof_query(int kernel_id, long long* launches, double* total_ms);
 /* ---- calibration probe: C[M,N] = A[M,K] * B[N,K]^T on the fp32-MFMA tile GEMM every A1/A3/A5 kernel is built on
  * (no reference counterpart; used by tools/kernel_bench.py and the tile_gemm parity test). */
 int cfl_gemm_nt(const float* A, const float* B, int M, int N, int K, float* C, void* stream);
+/* K-loop ablation of the same tile (mode 0 MFMA only .. 4 full loop), 1024 workgroups x nk K-steps; A, B [M>=4096, K]. */
+int cfl_gemm_ablate(const float* A, const float* B, int M, int K, int mode, int nk, float* sink, void* stream);
 
 /* ---- A1: all-pairs soft-contrastive loss ------------------------------------------------
  * Replaces MCSoftContrastiveLoss.forward / _compute_loss / pairwise_sampling / full_sampling /

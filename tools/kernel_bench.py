@@ -152,6 +152,23 @@ def case_gemm(M, N, K):
             'max_err_vs_torch': err}
 
 
+def case_ablate():
+    import ctypes
+    lib = _lib.load()
+    A = torch.rand(4096, 4096, device='cuda')
+    B = torch.rand(4096, 4096, device='cuda')
+    sink = torch.zeros(256, device='cuda')
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nk = 128
+    out = {}
+    for mode in range(5):
+        fn = lambda: _lib.check(lib.cfl_gemm_ablate(A.data_ptr(), B.data_ptr(), 4096, 4096, mode, nk, sink.data_ptr(), st), 'ablate')
+        us, prof = timed(fn, iters=5, warm=2)
+        k_us = prof['cfl_gemm_nt_kernel']
+        out[f'mode{mode}'] = round(1024 * nk * 2 * 128 * 128 * 32 / k_us / 1e6, 1)
+    return {'case': 'gemm K-loop ablation (TFLOP/s): 0 mfma, 1 +lds reads, 2 +barrier, 3 +stage writes, 4 +global loads', **out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', default='a1,a3,a5,a2,a6')
@@ -171,6 +188,8 @@ def main():
         out += [case_a6(1000, 5000, 512), case_a6(5000, 25000, 512)]
     if 'gemm' in cases:
         out += [case_gemm(4096, 4096, 4096), case_gemm(8192, 8192, 512), case_gemm(8192, 8192, 256)]
+    if 'ablate' in cases:
+        out += [case_ablate()]
     if 'opt' in cases:
         out += [case_opt()]
     for r in out:
