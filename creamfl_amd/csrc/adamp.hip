@@ -23,6 +23,10 @@ struct Hyper {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// streamed-once data (gradients, moments): non-temporal so that 3.7 GB of optimizer state does not evict the
+// activations / weights the next forward needs from L2 / Infinity Cache
+__device__ __forceinline__ f32x4 ld4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ void st4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 
 // ---- gradient norm over the tensors flagged CFL_OPT_CLIP ---------------------------------------------
 __global__ __launch_bounds__(256) void cfl_gradnorm_partial_kernel(const CflTensorMeta* __restrict__ meta,
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass1_kernel(const CflTensorMet
         if (vec) {
             for (long long e = lane * 4; e < inner; e += 256) {
                 const f32x4 pv = ld4(p + base + e);
-                f32x4 gv = ld4(g + base + e) * cc, mv = ld4(m + base + e), vv = ld4(v + base + e);
+                f32x4 gv = ld4_nt(g + base + e) * cc, mv = ld4_nt(m + base + e), vv = ld4_nt(v + base + e);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float mm = mv[k], v2 = vv[k];
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass1_kernel(const CflTensorMet
                     gp = fmaf(gv[k], pv[k], gp); gg = fmaf(gv[k], gv[k], gg);
                     pp = fmaf(pv[k], pv[k], pp); pq = fmaf(pv[k], pert, pq);
                 }
-                st4(m + base + e, mv); st4(v + base + e, vv);
+                st4_nt(m + base + e, mv); st4_nt(v + base + e, vv);
             }
         } else {
             for (long long e = lane; e < inner; e += 64) {
@@ -191,9 +195,9 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass3_kernel(const CflTensorMet
         if (vec) {
             for (long long e = lane * 4; e < inner; e += 256) {
                 f32x4 pv = ld4(p + base + e);
-                const f32x4 mv = ld4(m + base + e), vv = ld4(v + base + e);
+                const f32x4 mv = ld4_nt(m + base + e), vv = ld4_nt(v + base + e);
                 f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-                if (h.nesterov) gv = ld4(g + base + e) * cc;
+                if (h.nesterov) gv = ld4_nt(g + base + e) * cc;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float num = h.nesterov ? (h.beta1 * mv[k] + (1.f - h.beta1) * gv[k]) : mv[k];
