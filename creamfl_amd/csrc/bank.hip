@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, in
             }
         }
     };
-    tile_gemm_seq<TM, TN, true, true>(G, F, ntiles, tile_fn, lds, XfIdentity(), epi_fn);
+    if (glds_ok(G, F)) tile_gemm_seq_glds<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);
+    else tile_gemm_seq<TM, TN, true, true>(G, F, ntiles, tile_fn, lds, XfIdentity(), epi_fn);
     // combine the two half-waves (they hold different bank rows of the same feature row) ...
 #pragma unroll
     for (int n = 0; n < TN; ++n) {

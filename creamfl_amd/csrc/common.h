@@ -381,6 +381,140 @@ __device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0
     }
 }
 
+// ---- direct-to-LDS variant (both operands K-contiguous, K % 32 == 0) ---------------------------------------------
+// `global_load_lds_dwordx4` copies 64 x 16 B per wave instruction straight into LDS (no VGPR staging, no ds_write).
+// The LDS image of a wave instruction is lane-linear (base + lane*16), so the stage is unpadded [rows][32 floats]
+// and the bank-conflict fix is an XOR swizzle applied on the SOURCE side: slot c of row r holds k-chunk
+// c ^ ((r>>1)&7); fragment reads apply the same involution.  With a 128-byte row, (r&1, (r>>1)&7) is distinct for
+// the 16 rows of every ds_read_b128 lane group => conflict-free.  Out-of-range rows are clamped (duplicated) and must
+// be masked by the epilogue (every fwd epilogue here masks by index).
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+template <int R>
+__device__ __forceinline__ void glds_stage(const Opnd& o, int r0, int k0, float* stage) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int PER_WAVE = R / 32;                    // 8-row groups per wave
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int grp = w * PER_WAVE + j;
+        const int r = grp * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        int rg = r0 + r;
+        rg = rg < o.rows ? rg : o.rows - 1;
+        const float* src = o.p + (long long)rg * o.ld + k0 + q * 4;
+        __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(stage + grp * 256), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ f32x4 frag_swz(const float* s, int tile_r0, int kk, int lane) {
+    const int r = tile_r0 + (lane & 31);
+    const int slot = (kk * 2 + (lane >> 5)) ^ ((r >> 1) & 7);
+    return *reinterpret_cast<const f32x4*>(&s[r * 32 + slot * 4]);
+}
+template <int TM, int TN>
+__device__ __forceinline__ void tile_compute_swz(const float* sa, const float* sb, f32x16 (&acc)[TM][TN], int lane, int wr, int wc) {
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) fa[0][m] = frag_swz(sa, (wr * TM + m) * 32, 0, lane);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) fb[0][n] = frag_swz(sb, (wc * TN + n) * 32, 0, lane);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m) fa[(kk + 1) & 1][m] = frag_swz(sa, (wr * TM + m) * 32, kk + 1, lane);
+#pragma unroll
+            for (int n = 0; n < TN; ++n) fb[(kk + 1) & 1][n] = frag_swz(sb, (wc * TN + n) * 32, kk + 1, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][m][t], fb[kk & 1][n][t], acc[m][n], 0, 0, 0);
+    }
+}
+// true when the direct-to-LDS path applies to both operands
+__device__ __forceinline__ bool glds_ok(const Opnd& A, const Opnd& B) {
+    return A.vec && B.vec && (A.kdim % 32) == 0;
+}
+// Sequence of tiles, direct-to-LDS staging.  Same contract as tile_gemm_seq (KC/KC only, (kend-kbeg) % 32 == 0).
+template <int TM, int TN, class TileFn, class EpiFn>
+__device__ __forceinline__ void tile_gemm_seq_glds(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds,
+                                                   EpiFn epi_fn) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, STAGE = (BM + BN) * 32;
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    if (ntiles <= 0) return;
+    TileDesc cur = tile_fn(0);
+    glds_stage<BM>(A, cur.row0, cur.kbeg, lds);
+    glds_stage<BN>(B, cur.col0, cur.kbeg, lds + BM * 32);
+    __syncthreads();
+    int buf = 0;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < ntiles; ++i) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        const int nk = (cur.kend - cur.kbeg) / 32;
+        const bool has_next_tile = (i + 1 < ntiles);
+        TileDesc nxt = cur;
+        if (has_next_tile) nxt = tile_fn(i + 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* sa = lds + buf * STAGE;
+            const bool in_tile = (kt + 1 < nk);
+            if (in_tile || has_next_tile) {
+                float* da = lds + (buf ^ 1) * STAGE;
+                glds_stage<BM>(A, in_tile ? cur.row0 : nxt.row0, in_tile ? cur.kbeg + (kt + 1) * 32 : nxt.kbeg, da);
+                glds_stage<BN>(B, in_tile ? cur.col0 : nxt.col0, in_tile ? cur.kbeg + (kt + 1) * 32 : nxt.kbeg, da + BM * 32);
+            }
+            tile_compute_swz<TM, TN>(sa, sa + BM * 32, acc, lane, wr, wc);
+            __syncthreads();                 // waits for the LDS-DMA of the next stage (vmcnt) and for all readers
+            buf ^= 1;
+        }
+        epi_fn(i, acc);
+        cur = nxt;
+    }
+    __syncthreads();
+}
+
+// Single tile, direct-to-LDS staging: acc = A[row0.., k] * B[col0.., k]^T over k in [kbeg, kend), (kend-kbeg) % 32 == 0.
+template <int TM, int TN>
+__device__ __forceinline__ void tile_gemm_glds(const Opnd& A, const Opnd& B, int row0, int col0, int kbeg, int kend,
+                                               float* lds, f32x16 (&acc)[TM][TN]) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, STAGE = (BM + BN) * 32;
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int nk = (kend - kbeg) / 32;
+    if (nk <= 0) return;
+    glds_stage<BM>(A, row0, kbeg, lds);
+    glds_stage<BN>(B, col0, kbeg, lds + BM * 32);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* sa = lds + (kt & 1) * STAGE;
+        if (kt + 1 < nk) {
+            float* da = lds + ((kt + 1) & 1) * STAGE;
+            glds_stage<BM>(A, row0, kbeg + (kt + 1) * 32, da);
+            glds_stage<BN>(B, col0, kbeg + (kt + 1) * 32, da + BM * 32);
+        }
+        tile_compute_swz<TM, TN>(sa, sa + BM * 32, acc, lane, wr, wc);
+        __syncthreads();
+    }
+}
+
 // Output coordinates of accumulator element (m, n, r) held by `lane` of wave (wr, wc), relative
 // to the workgroup tile origin (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
 template <int TM>

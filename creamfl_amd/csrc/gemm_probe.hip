@@ -11,9 +11,10 @@ __global__ __launch_bounds__(256, 2) void cfl_gemm_nt_kernel(Opnd A, Opnd B, int
     int ti, tj;
     tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
     const int row0 = ti * C::BM, col0 = tj * C::BN;
-    f32x16 acc[TM][TN];
-    tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
+    f32x16 acc[TM][TN];
+    if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
+    else tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll

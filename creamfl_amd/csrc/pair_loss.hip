@@ -57,14 +57,14 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
     tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
     const int tile = ti * ntc + tj;
     const int row0 = ti * C::BM, col0 = tj * C::BN;
-    f32x16 acc[TM][TN];
-    tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
-
     const float a = a_dev[0], b = b_dev[0];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
     constexpr int CLD = C::BN + 1;
-    float* cs = lds;                                          // [BM][BN+1] coefficient tile
+    float* cs = lds;                                          // [BM][BN+1] coefficient tile (after the K loop)
     float pos = 0.f, neg = 0.f, da = 0.f, db = 0.f;
+    f32x16 acc[TM][TN];
+    if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
+    else tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
