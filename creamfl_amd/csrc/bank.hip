@@ -313,9 +313,11 @@ size_t cfl_bank_ws_bytes(int B, int M, int D) {
     if (B <= 0 || M <= 0 || D <= 0) return 256;
     const BankPlan pl = bank_plan(B, M);
     int kper;
-    const int ks = bwd_ksplits(B, M, D, 128, 128, &kper);
+    int ks = bwd_ksplits(B, M, D, 128, 128, &kper);
     const int ks2 = bwd_ksplits(B, M, D, 64, 64, &kper);
-    const size_t slab = (size_t)(ks > ks2 ? ks : ks2) * B * D;
+    const int ks3 = bwd_ksplits(B, M, D, 128, 64, &kper);
+    ks = ks > ks2 ? ks : ks2;
+    const size_t slab = (size_t)(ks > ks3 ? ks : ks3) * B * D;
     return cfl_align256((2 * (size_t)pl.S * pl.Bp + slab) * sizeof(float));
 }
 
@@ -343,12 +345,20 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
     Opnd P{logits_t, B, B, M, cfl_opnd_vec(logits_t, B, B)};
     Opnd Go{G, D, D, M, cfl_opnd_vec(G, D, D)};
     int kper = 0, ks = 0;
-    const bool big = (B > 64 && D > 64);
-    if (big) {
-        using C = TileCfg<2, 2, false, false>;
-        ks = bwd_ksplits(B, M, D, C::BM, C::BN, &kper);
-        CFL_LAUNCH(K_BANK_BWD, (cfl_bank_bwd_kernel<2, 2>), dim3(ks, cfl_cdiv(D, C::BN), cfl_cdiv(B, C::BM)), dim3(256),
-                   C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab);
+    if (B > 64 && D > 64) {
+        // 128-row feature tiles; 64-wide D tiles when 128-wide ones would leave CUs with a single workgroup
+        const bool narrow = cfl_cdiv(B, 128) * cfl_cdiv(D, 128) * 128 < 512;
+        if (narrow) {
+            using C = TileCfg<2, 1, false, false>;
+            ks = bwd_ksplits(B, M, D, C::BM, C::BN, &kper);
+            CFL_LAUNCH(K_BANK_BWD, (cfl_bank_bwd_kernel<2, 1>), dim3(ks, cfl_cdiv(D, C::BN), cfl_cdiv(B, C::BM)), dim3(256),
+                       C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab);
+        } else {
+            using C = TileCfg<2, 2, false, false>;
+            ks = bwd_ksplits(B, M, D, C::BM, C::BN, &kper);
+            CFL_LAUNCH(K_BANK_BWD, (cfl_bank_bwd_kernel<2, 2>), dim3(ks, cfl_cdiv(D, C::BN), cfl_cdiv(B, C::BM)), dim3(256),
+                       C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab);
+        }
     } else {
         using C = TileCfg<1, 1, false, false>;
         ks = bwd_ksplits(B, M, D, C::BM, C::BN, &kper);

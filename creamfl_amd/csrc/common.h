@@ -144,30 +144,37 @@ struct TileCfg {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
-// global -> registers for one operand tile of R rows x 32 k (R/32 float4 per thread).
-// Fast path (o.vec: base 16-byte aligned, ld % 4 == 0 and, for the K axis, extents % 4 == 0): branch-free --
-// the address is clamped into the tensor and the value is zeroed by a select when the row / k is out of range,
-// so the loop body carries no exec-mask branches.  Slow path: per-element bounds checks (odd shapes only).
-template <bool KCONTIG, int R, class Xf>
+// global -> registers for one operand tile of R rows x 32 k (R/32 float4 per thread), in two phases so that the
+// loads stay in flight across the MFMA block:
+//   PHASE 0 (issue): branch-free loads from clamped in-tensor addresses -- nothing consumes the values yet;
+//   PHASE 1 (finish, called after the MFMA block, right before the LDS write): staging transform `xf` and
+//            select-to-zero of out-of-range elements.
+// Fast path needs o.vec (base 16-byte aligned, ld % 4 == 0, contiguous extent % 4 == 0 => a float4 is entirely in or
+// out of the tensor).  Slow path (odd shapes): per-element bounds checks, everything done in PHASE 0.
+template <bool KCONTIG, int R, int PHASE, class Xf>
 __device__ __forceinline__ void g2r(const Opnd& o, int r0, int k0, f32x4 (&reg)[R / 32], Xf xf) {
     const int t = threadIdx.x;
     if (KCONTIG) {
         const int kq = (t & 7) * 4;
         const int k = k0 + kq;
         if (o.vec) {
-            const bool kok = k < o.kdim;                       // kdim % 4 == 0 => the whole float4 is in or out
+            const bool kok = k < o.kdim;
             const int kc = kok ? k : 0;
 #pragma unroll
             for (int p = 0; p < R / 32; ++p) {
                 const int r = r0 + p * 32 + (t >> 3);
-                const bool ok = kok && (r < o.rows);
                 const int rc = r < o.rows ? r : o.rows - 1;
-                f32x4 v = *reinterpret_cast<const f32x4*>(o.p + (long long)rc * o.ld + kc);
-                v[0] = ok ? xf(v[0], rc, kc) : 0.f; v[1] = ok ? xf(v[1], rc, kc + 1) : 0.f;
-                v[2] = ok ? xf(v[2], rc, kc + 2) : 0.f; v[3] = ok ? xf(v[3], rc, kc + 3) : 0.f;
-                reg[p] = v;
+                if (PHASE == 0) {
+                    reg[p] = *reinterpret_cast<const f32x4*>(o.p + (long long)rc * o.ld + kc);
+                } else {
+                    const bool ok = kok && (r < o.rows);
+                    f32x4 v = reg[p];
+                    v[0] = ok ? xf(v[0], rc, kc) : 0.f; v[1] = ok ? xf(v[1], rc, kc + 1) : 0.f;
+                    v[2] = ok ? xf(v[2], rc, kc + 2) : 0.f; v[3] = ok ? xf(v[3], rc, kc + 3) : 0.f;
+                    reg[p] = v;
+                }
             }
-        } else {
+        } else if (PHASE == 0) {
 #pragma unroll
             for (int p = 0; p < R / 32; ++p) {
                 const int r = r0 + p * 32 + (t >> 3);
@@ -186,19 +193,23 @@ __device__ __forceinline__ void g2r(const Opnd& o, int r0, int k0, f32x4 (&reg)[
         const int rq = (t % LPR) * 4;
         const int r = r0 + rq;
         if (o.vec) {
-            const bool rok = r < o.rows;                       // rows % 4 == 0 => the whole float4 is in or out
+            const bool rok = r < o.rows;
             const int rc = rok ? r : 0;
 #pragma unroll
             for (int p = 0; p < R / 32; ++p) {
                 const int k = k0 + p * KPP + t / LPR;
-                const bool ok = rok && (k < o.kdim);
                 const int kc = k < o.kdim ? k : o.kdim - 1;
-                f32x4 v = *reinterpret_cast<const f32x4*>(o.p + (long long)kc * o.ld + rc);
-                v[0] = ok ? xf(v[0], rc, kc) : 0.f; v[1] = ok ? xf(v[1], rc + 1, kc) : 0.f;
-                v[2] = ok ? xf(v[2], rc + 2, kc) : 0.f; v[3] = ok ? xf(v[3], rc + 3, kc) : 0.f;
-                reg[p] = v;
+                if (PHASE == 0) {
+                    reg[p] = *reinterpret_cast<const f32x4*>(o.p + (long long)kc * o.ld + rc);
+                } else {
+                    const bool ok = rok && (k < o.kdim);
+                    f32x4 v = reg[p];
+                    v[0] = ok ? xf(v[0], rc, kc) : 0.f; v[1] = ok ? xf(v[1], rc + 1, kc) : 0.f;
+                    v[2] = ok ? xf(v[2], rc + 2, kc) : 0.f; v[3] = ok ? xf(v[3], rc + 3, kc) : 0.f;
+                    reg[p] = v;
+                }
             }
-        } else {
+        } else if (PHASE == 0) {
 #pragma unroll
             for (int p = 0; p < R / 32; ++p) {
                 const int k = k0 + p * KPP + t / LPR;
@@ -295,8 +306,10 @@ __device__ __forceinline__ void tile_gemm_seq(const Opnd& A, const Opnd& B, int 
     if (ntiles <= 0) return;
     f32x4 ra[C::BM / 32], rb[C::BN / 32];
     TileDesc cur = tile_fn(0);
-    g2r<A_KC, C::BM>(A, cur.row0, cur.kbeg, ra, xfa);
-    g2r<B_KC, C::BN>(B, cur.col0, cur.kbeg, rb, XfIdentity());
+    g2r<A_KC, C::BM, 0>(A, cur.row0, cur.kbeg, ra, xfa);
+    g2r<B_KC, C::BN, 0>(B, cur.col0, cur.kbeg, rb, XfIdentity());
+    g2r<A_KC, C::BM, 1>(A, cur.row0, cur.kbeg, ra, xfa);
+    g2r<B_KC, C::BN, 1>(B, cur.col0, cur.kbeg, rb, XfIdentity());
     r2s<A_KC, C::BM, C::A_LD>(lds, ra);
     r2s<B_KC, C::BN, C::B_LD>(lds + C::A_ELEMS, rb);
     __syncthreads();
@@ -317,15 +330,17 @@ __device__ __forceinline__ void tile_gemm_seq(const Opnd& A, const Opnd& B, int 
             const float* sa = lds + buf * C::STAGE;
             const bool in_tile = (kt + 1 < nk);
             const bool more = in_tile || has_next_tile;
+            const int r0 = in_tile ? cur.row0 : nxt.row0;
+            const int c0 = in_tile ? cur.col0 : nxt.col0;
+            const int k0 = in_tile ? cur.kbeg + (kt + 1) * C::KC : nxt.kbeg;
             if (more) {
-                const int r0 = in_tile ? cur.row0 : nxt.row0;
-                const int c0 = in_tile ? cur.col0 : nxt.col0;
-                const int k0 = in_tile ? cur.kbeg + (kt + 1) * C::KC : nxt.kbeg;
-                g2r<A_KC, C::BM>(A, r0, k0, ra, xfa);
-                g2r<B_KC, C::BN>(B, c0, k0, rb, XfIdentity());
+                g2r<A_KC, C::BM, 0>(A, r0, k0, ra, xfa);
+                g2r<B_KC, C::BN, 0>(B, c0, k0, rb, XfIdentity());
             }
             tile_compute<TM, TN, A_KC, B_KC>(sa, sa + C::A_ELEMS, acc, lane, wr, wc);
             if (more) {
+                g2r<A_KC, C::BM, 1>(A, r0, k0, ra, xfa);
+                g2r<B_KC, C::BN, 1>(B, c0, k0, rb, XfIdentity());
                 float* da = lds + (buf ^ 1) * C::STAGE;
                 r2s<A_KC, C::BM, C::A_LD>(da, ra);
                 r2s<B_KC, C::BN, C::B_LD>(da + C::A_ELEMS, rb);
@@ -359,8 +374,10 @@ __device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0
     f32x4 ra[C::BM / 32], rb[C::BN / 32];
     const int nk = (kend - kbeg + C::KC - 1) / C::KC;
     if (nk <= 0) return;
-    g2r<A_KC, C::BM>(A, row0, kbeg, ra, xfa);
-    g2r<B_KC, C::BN>(B, col0, kbeg, rb, XfIdentity());
+    g2r<A_KC, C::BM, 0>(A, row0, kbeg, ra, xfa);
+    g2r<B_KC, C::BN, 0>(B, col0, kbeg, rb, XfIdentity());
+    g2r<A_KC, C::BM, 1>(A, row0, kbeg, ra, xfa);
+    g2r<B_KC, C::BN, 1>(B, col0, kbeg, rb, XfIdentity());
     r2s<A_KC, C::BM, C::A_LD>(lds, ra);
     r2s<B_KC, C::BN, C::B_LD>(lds + C::A_ELEMS, rb);
     __syncthreads();
@@ -368,11 +385,13 @@ __device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0
         const float* sa = lds + (kt & 1) * C::STAGE;
         const bool more = (kt + 1 < nk);
         if (more) {
-            g2r<A_KC, C::BM>(A, row0, kbeg + (kt + 1) * C::KC, ra, xfa);
-            g2r<B_KC, C::BN>(B, col0, kbeg + (kt + 1) * C::KC, rb, XfIdentity());
+            g2r<A_KC, C::BM, 0>(A, row0, kbeg + (kt + 1) * C::KC, ra, xfa);
+            g2r<B_KC, C::BN, 0>(B, col0, kbeg + (kt + 1) * C::KC, rb, XfIdentity());
         }
         tile_compute<TM, TN, A_KC, B_KC>(sa, sa + C::A_ELEMS, acc, lane, wr, wc);
         if (more) {
+            g2r<A_KC, C::BM, 1>(A, row0, kbeg + (kt + 1) * C::KC, ra, xfa);
+            g2r<B_KC, C::BN, 1>(B, col0, kbeg + (kt + 1) * C::KC, rb, XfIdentity());
             float* da = lds + ((kt + 1) & 1) * C::STAGE;
             r2s<A_KC, C::BM, C::A_LD>(da, ra);
             r2s<B_KC, C::BN, C::B_LD>(da + C::A_ELEMS, rb);

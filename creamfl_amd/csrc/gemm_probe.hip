@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void cfl_gemm_ablate_kernel(Opnd A, Opnd B,
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     f32x4 ra[C::BM / 32], rb[C::BN / 32];
     const int row0 = (blockIdx.x % 32) * 128, col0 = (blockIdx.x / 32 % 32) * 128;
-    if (MODE >= 3) { g2r<true, C::BM>(A, row0, 0, ra, XfIdentity()); g2r<true, C::BN>(B, col0, 0, rb, XfIdentity()); }
+    if (MODE >= 3) { g2r<true, C::BM, 0>(A, row0, 0, ra, XfIdentity()); g2r<true, C::BN, 0>(B, col0, 0, rb, XfIdentity()); }
     if (MODE == 0) {
         f32x4 fa[TM], fb[TN];
         for (int m = 0; m < TM; ++m) fa[m] = frag<true, C::A_LD>(lds, (wr * TM + m) * 32, 0, lane);
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256, 2) void cfl_gemm_ablate_kernel(Opnd A, Opnd B,
         for (int kt = 0; kt < nk; ++kt) {
             const float* sa = lds + (kt & 1) * C::STAGE;
             if (MODE >= 4) {
-                g2r<true, C::BM>(A, row0, ((kt + 1) * 32) % A.kdim, ra, XfIdentity());
-                g2r<true, C::BN>(B, col0, ((kt + 1) * 32) % A.kdim, rb, XfIdentity());
+                g2r<true, C::BM, 0>(A, row0, ((kt + 1) * 32) % A.kdim, ra, XfIdentity());
+                g2r<true, C::BN, 0>(B, col0, ((kt + 1) * 32) % A.kdim, rb, XfIdentity());
             }
             tile_compute<TM, TN, true, true>(sa, sa + C::A_ELEMS, acc, lane, wr, wc);
             if (MODE >= 3) {
