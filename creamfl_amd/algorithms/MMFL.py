@@ -273,7 +273,6 @@ class MMFL(object):
 
     def distill(self, round_n, img_vec, txt_vec, img_num, txt_num, distill_index):
         self.engine.model.train()
-        client_loss_cri = nn.MSELoss()
         img_vec, txt_vec = self.aggregation(img_vec, txt_vec)
         self.img_vec, self.txt_vec = img_vec, txt_vec
         distill_dict = {b: a for a, b in enumerate(distill_index)}
@@ -281,9 +280,10 @@ class MMFL(object):
         eng = self.engine
         model = eng.dp.module if eng.dp is not None else eng.model
 
-        def code_sim(output, target):
+        def code_sim(output, agg, d_idx):
+            """kd_weight * MSELoss(output, agg[d_idx]) (MMFL.py:352-378) as one fused gather + MSE kernel"""
             output = output.sum(axis=1) if len(output.shape) == 3 else output
-            return client_loss_cri(output, target.type_as(output))
+            return ops.kd_mse(output, agg, d_idx, self.args.kd_weight)
 
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(
                 self.dataloaders_global[self._pub_key(False)]):
@@ -296,14 +296,14 @@ class MMFL(object):
             d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
             loss = 0
             if self.args.num_img_clients > 0 and self.img_vec is not None and len(self.img_vec):
-                loss = loss + self.args.kd_weight * code_sim(output['image_features'], self.img_vec[d_idx, :])
+                loss = loss + code_sim(output['image_features'], self.img_vec, d_idx)
             if self.args.num_txt_clients > 0 and self.txt_vec is not None and len(self.txt_vec):
-                loss = loss + self.args.kd_weight * code_sim(output['caption_features'], self.txt_vec[d_idx, :])
+                loss = loss + code_sim(output['caption_features'], self.txt_vec, d_idx)
             if self.args.num_mm_clients > 0:
                 if self.img_vec is not None and len(self.img_vec):
-                    loss = loss + self.args.kd_weight * code_sim(output['image_features'], self.img_vec[d_idx, :])
+                    loss = loss + code_sim(output['image_features'], self.img_vec, d_idx)
                 if self.txt_vec is not None and len(self.txt_vec):
-                    loss = loss + self.args.kd_weight * code_sim(output['caption_features'], self.txt_vec[d_idx, :])
+                    loss = loss + code_sim(output['caption_features'], self.txt_vec, d_idx)
             if not torch.is_tensor(loss):
                 continue
             eng.optimizer.zero_grad(set_to_none=True)

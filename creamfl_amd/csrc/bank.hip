@@ -243,6 +243,34 @@ __global__ __launch_bounds__(256) void cfl_intra_loss_kernel(const float* rowlos
     if (threadIdx.x == 0) loss[0] = s / (float)Bdiv;
 }
 
+// KD distillation term: rowloss[b] = sum_d (out[b,d] - agg[idx[b],d])^2 and, optionally,
+// dout[b,:] = scale * (out[b,:] - agg[idx[b],:]).  One wave per row; the gather never materialises the target.
+__global__ __launch_bounds__(256) void cfl_kd_mse_kernel(const float* __restrict__ out, const float* __restrict__ agg,
+                                                         const long long* __restrict__ idx, int B, int D, int M,
+                                                         float scale, float* rowloss, float* dout) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const long long t = idx[b];
+    const float* o = out + (long long)b * D;
+    const float* a = agg + (t >= 0 && t < M ? t : 0) * D;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float e = o[k] - a[k];
+        s = fmaf(e, e, s);
+        if (dout) dout[(long long)b * D + k] = scale * e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) rowloss[b] = s;
+}
+__global__ __launch_bounds__(256) void cfl_kd_mse_final_kernel(const float* rowloss, int B, float scale, float* loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) s += rowloss[b];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) loss[0] = s * scale;
+}
+
 struct PtrPack { const float* p[64]; };
 
 // A5 combine: W = softmax_c L[c, n]; out[n,:] = sum_c W[c,n] V_c[n,:].  One wave per row n.
@@ -380,6 +408,18 @@ int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, cons
     CFL_LAUNCH(K_INTRA, cfl_intra_kernel, dim3(cfl_cdiv(B, 4)), dim3(256), 0, stream,
                F, Gsame, idx, Fold, B, D, B_div, inv_tau, rowloss, dF_unit);
     CFL_LAUNCH(K_INTRA, cfl_intra_loss_kernel, dim3(1), dim3(256), 0, stream, rowloss, B, B_div, loss);
+    return 0;
+}
+
+int cfl_kd_mse(const float* out, const float* agg, const long long* idx, int B, int D, int M, float weight,
+               float* loss, float* dout_unit, void* ws, void* stream_) {
+    if (!out || !agg || !idx || !loss || !ws || B <= 0 || D <= 0 || M <= 0) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* rowloss = (float*)ws;                       // cfl_intra_ws_bytes(B)
+    const float inv = weight / ((float)B * (float)D);  // nn.MSELoss(): mean over all B*D elements
+    CFL_LAUNCH(K_KD_MSE, cfl_kd_mse_kernel, dim3(cfl_cdiv(B, 4)), dim3(256), 0, stream, out, agg, idx, B, D, M, 2.f * inv,
+               rowloss, dout_unit);
+    CFL_LAUNCH(K_KD_MSE, cfl_kd_mse_final_kernel, dim3(1), dim3(256), 0, stream, rowloss, B, inv, loss);
     return 0;
 }
 

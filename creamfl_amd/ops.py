@@ -194,6 +194,35 @@ def intra_contrast(feature, global_same, d_idx, old_feature, temperature=0.5, me
                           int(mean_divisor) if mean_divisor else F.shape[0])
 
 
+class _KdMseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, agg, idx, weight):
+        lib = _lib.load()
+        B, D = out.shape
+        loss = torch.empty(1, dtype=torch.float32, device=out.device)
+        need = ctx.needs_input_grad[0]
+        dout = torch.empty_like(out) if need else None
+        ws = _ws(lib.cfl_intra_ws_bytes(B), out.device)
+        _lib.check(lib.cfl_kd_mse(_ptr(out), _ptr(agg), _ptr(idx), B, D, agg.shape[0], weight, _ptr(loss), _ptr(dout),
+                                  _ptr(ws), _stream(out)), 'cfl_kd_mse')
+        ctx.save_for_backward(dout if need else loss)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dout,) = ctx.saved_tensors
+        return dout * g, None, None, None
+
+
+def kd_mse(output, aggregate, d_idx, kd_weight=1.0):
+    """kd_weight * MSELoss(output, aggregate[d_idx]) without materialising the gathered target (MMFL.py:352-378)."""
+    out = _f32(output, 'output')
+    agg = _f32(aggregate.detach(), 'aggregate')
+    if out.dim() != 2 or agg.dim() != 2 or out.shape[1] != agg.shape[1]:
+        raise RuntimeError(f'shape mismatch {tuple(out.shape)} vs {tuple(agg.shape)}')
+    return _KdMseFn.apply(out, agg, _idx(d_idx, out.device), float(kd_weight))
+
+
 # --------------------------------------------------------------------------- A5: con_w
 @torch.no_grad()
 def conw_logprob(vec, global_other, row0=0, rows=None):

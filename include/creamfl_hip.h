@@ -97,6 +97,13 @@ int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, cons
                   int B, int D, int B_div, float inv_tau, float* loss, float* dF_unit, void* ws,
                   void* stream);
 
+/* ---- KD distillation term -------------------------------------------------------
+ * Replaces  target = agg[d_idx, :]; loss += kd_weight * nn.MSELoss()(out, target)   (src/algorithms/MMFL.py:352-378).
+ * loss[0] = weight * mean_{b,d} (out[b,d] - agg[idx[b],d])^2;  dout_unit = d loss / d out (may be NULL).
+ * ws: cfl_intra_ws_bytes(B). */
+int cfl_kd_mse(const float* out, const float* agg, const long long* idx, int B, int D, int M, float weight,
+               float* loss, float* dout_unit, void* ws, void* stream);
+
 /* ---- A5: con_w aggregation ----------------------------------------------------------------
  * Replaces the closure `aggregation` in MMFL.distill (src/algorithms/MMFL.py:298-335).
  * logprob: out_l[n - row0] = V_n.G_n - log sum_m exp(V_n.G_m)  for n in [row0, row0+rows)

@@ -343,3 +343,22 @@ def test_a6_coco_1k_fold_size(dev):
     for (q, g, ql, gl) in [(img, cap, icls, ccls), (cap, img, ccls, icls)]:
         ranks = ops.rank_count(q.to(dev), g.to(dev), ql, gl).cpu().numpy()
         assert np.array_equal(ranks.astype(np.float64), oracle.recall_ranks_count(q.numpy(), g.numpy(), ql, gl))
+
+
+# ------------------------------------------------------------------------------------------ KD term (8f-1)
+@pytest.mark.parametrize('b,m,d,w', [(1, 3, 4, 1.0), (37, 500, 100, 0.3), (128, 50000, 256, 0.3), (256, 1000, 512, 2.0)])
+def test_kd_mse_matches_torch(dev, b, m, d, w):
+    """kd_weight * nn.MSELoss()(out, agg[d_idx]) (src/algorithms/MMFL.py:352-378): value and gradient."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(b + m)
+    agg = torch.randn(m, d, generator=gen)
+    out = torch.randn(b, d, generator=gen)
+    idx = torch.randint(0, m, (b,), generator=gen)
+    og = out.to(dev).requires_grad_(True)
+    loss = ops.kd_mse(og, agg.to(dev), idx.tolist(), w)
+    (2.5 * loss).backward()
+    oc = out.double().requires_grad_(True)
+    ref = w * torch.nn.MSELoss()(oc, agg.double()[idx])
+    (2.5 * ref).backward()
+    _close(loss.item(), ref.item(), 1e-5, 0)
+    _close(og.grad.cpu().numpy(), oc.grad.numpy(), 1e-5, 1e-9)
