@@ -126,7 +126,64 @@ _RESNETS = {
 }
 
 
+class _ViTBlock(nn.Module):
+    def __init__(self, dim, heads, mlp_dim):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(dim, eps=1e-6)
+        self.heads = heads
+        self.in_proj = nn.Linear(dim, 3 * dim)
+        self.out_proj = nn.Linear(dim, dim)
+        self.ln_2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = nn.Sequential(nn.Linear(dim, mlp_dim), nn.GELU(), nn.Linear(mlp_dim, dim))
+
+    def forward(self, x):
+        B, L, D = x.shape
+        q, k, v = self.in_proj(self.ln_1(x)).view(B, L, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D)
+        x = x + self.out_proj(a)
+        return x + self.mlp(self.ln_2(x))
+
+
+class ViTTrunk(nn.Module):
+    """ViT-B/16-style image trunk (BASELINE.json configs[4], a build-defined encoder: the reference only ships
+    ResNets).  `features(x)` returns the patch tokens as a [N, D, H/16, W/16] map whose memory is [N, P, D], so the
+    PIE head sees the same [N, P, Cd] layout as with a channels_last ResNet."""
+
+    def __init__(self, dim=768, depth=12, heads=12, mlp_dim=3072, patch=16, img=224):
+        super().__init__()
+        self.patch = patch
+        self.conv_proj = nn.Conv2d(3, dim, patch, patch)
+        self.pos_embedding = nn.Parameter(torch.zeros(1, (img // patch) ** 2, dim).normal_(std=0.02))
+        self.layers = nn.ModuleList([_ViTBlock(dim, heads, mlp_dim) for _ in range(depth)])
+        self.ln = nn.LayerNorm(dim, eps=1e-6)
+        self.out_dim = dim
+
+    def features(self, x):
+        t = self.conv_proj(x)                                    # [N, D, h, w]
+        n, d, h, w = t.shape
+        t = t.flatten(2).transpose(1, 2)                         # [N, P, D]
+        pos = self.pos_embedding
+        if pos.shape[1] != h * w:                                # other resolutions: bilinear resize of the grid
+            g = int(pos.shape[1] ** 0.5)
+            pos = F.interpolate(pos.reshape(1, g, g, d).permute(0, 3, 1, 2), size=(h, w), mode='bilinear',
+                                align_corners=False).permute(0, 2, 3, 1).reshape(1, h * w, d)
+        t = t + pos
+        for blk in self.layers:
+            t = blk(t)
+        t = self.ln(t)
+        return t.transpose(1, 2).reshape(n, d, h, w)             # a view: memory stays [N, P, D]
+
+    def forward(self, x):
+        return self.features(x)
+
+
+_VITS = {'vit_b_16': dict(dim=768, depth=12, heads=12, mlp_dim=3072), 'vit_tiny_16': dict(dim=192, depth=2, heads=3, mlp_dim=384)}
+
+
 def resnet_trunk(name):
+    """Image trunk by name: torchvision-style ResNets (what the reference uses) or the build-defined ViTs."""
+    if name in _VITS:
+        return ViTTrunk(**_VITS[name])
     if name not in _RESNETS:
         raise ValueError(f'unknown cnn_type {name}')
     block, layers = _RESNETS[name]

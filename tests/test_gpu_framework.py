@@ -154,3 +154,32 @@ def test_one_communication_round(dev):
     for t in algo.total_local_trainers:
         assert t.last_contrast_loss is not None and torch.isfinite(t.last_contrast_loss)
     assert all(torch.isfinite(p).all() for p in algo.engine.model.parameters())
+
+
+def test_config4_vit_bertlarge_style_model_steps(dev):
+    """BASELINE.json configs[4] in miniature: ViT image trunk + BERT text trunk, d = 768-style head, one server step
+    plus a client-style inter + intra contrast step (weight 0.5) on the server features."""
+    from creamfl_amd.algorithms.contrast import client_contrast_loss
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.synthetic import coco_batch
+    torch.manual_seed(3)
+    cfg = _small_cfg(dim=96, cnn='vit_tiny_16')
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    eng.model.train()
+    b = coco_batch(16, dev, seed=9, img=64)
+    l0, _ = eng.train_step(b[0], b[1], None, b[3])
+    l1, _ = eng.train_step(b[0], b[1], None, b[3])
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = eng.model(b[0].contiguous(memory_format=torch.channels_last), b[1], None, b[3])
+    f = out['image_features']
+    assert f.shape == (16, 96) and f.dtype == torch.float32
+    np.testing.assert_allclose(f.detach().norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+    gen = torch.Generator().manual_seed(1)
+    G = torch.nn.functional.normalize(torch.randn(700, 96, generator=gen), dim=-1).to(dev)
+    loss, li, lm = client_contrast_loss(f, G, G.flip(0), list(range(16)), f.detach().roll(1, 0), interintra_weight=0.5)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in eng.model.img_enc.parameters() if p.grad is not None)
