@@ -144,6 +144,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    from creamfl_amd import ops as _ops
+    for k_ in _ops.BN_COUNTERS:
+        _ops.BN_COUNTERS[k_] = 0
     _lib.prof_reset()
     _lib.prof_enable(True)
     t0 = time.perf_counter()
@@ -169,11 +172,22 @@ def main():
         cand = []
         Nloss = args.batch * world
         n_model = sum(p.numel() for p in eng.model.parameters())
+        # fused BN kernels run once per BatchNorm layer with a different shape each: their algorithmic bytes are
+        # accumulated over the launches of the timed region (bf16 = 2 B / element) and divided per launch
+        bc = _ops.BN_COUNTERS
+        bn_bytes = {
+            'cfl_bn_stats_kernel': 2 * bc['fwd'],
+            'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'],
+            'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + 2 * bc['bwd_relu'],
+            'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + 2 * bc['bwd_relu'] + 2 * bc['bwd_res'],
+        }
         for name, (n, ms) in prof.items():
             base = name
             cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim, n_model + 2, n_model)
             if base.startswith('cfl_pair_'):
                 cost = algorithmic_cost(base, Nloss, 49, Cd, Cd // 2, args.dim)
+            if base in bn_bytes and bn_bytes[base] > 0:
+                cost = ('hbm', bn_bytes[base] / n)
             if cost:
                 cand.append((ms, name, n, cost))
         if cand:
@@ -183,13 +197,14 @@ def main():
                 ach = work / (us * 1e-6) / 1e9
                 roof = {'kernel': name, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
-                        'avg_launch_us': round(us, 2), 'launches': n, 'algorithmic_bytes': work}
+                        'avg_launch_us': round(us, 2), 'launches': n, 'algorithmic_bytes': int(work),
+                        'share_of_step_ms': round(ms / args.steps, 3)}
             else:
                 ach = work / (us * 1e-6) / 1e12
                 roof = {'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                         'avg_launch_us': round(us, 2), 'launches': n, 'algorithmic_flops': work}
-        if roof is not None and args.batch == 256 and args.cnn == 'resnet101':
+        if roof is not None and args.batch == 256 and args.cnn == "resnet101" and args.dtype == "bf16":
             # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this timed run, so the value
             # measured offline at this exact shape (separate rocprofv3 --pmc passes, see the file) is reported.
             try:

@@ -395,12 +395,19 @@ def bn_act_supported(x, num_features):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
+# element counters of the fused BN kernels (python ints; bench.py turns them into algorithmic bytes)
+BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0}
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
         lib = _lib.load()
         N, C, H, W = x.shape
         R = N * H * W
+        BN_COUNTERS['fwd'] += R * C
+        if residual is not None:
+            BN_COUNTERS['fwd_res'] += R * C
         y = torch.empty_like(x)                           # keeps channels_last
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -419,6 +426,11 @@ class _BNActFn(torch.autograd.Function):
         x, y, weight, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
         R = N * H * W
+        BN_COUNTERS['bwd'] += R * C
+        if ctx.relu:
+            BN_COUNTERS['bwd_relu'] += R * C
+        if ctx.has_res:
+            BN_COUNTERS['bwd_res'] += R * C
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
