@@ -40,6 +40,14 @@ __device__ __forceinline__ U4 pack8(const float (&f)[8]) {
     return u;
 }
 
+// last-use streams (activations that are dead after this kernel) bypass the caches
+__device__ __forceinline__ U4 ld_nt(const U4* p) {
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+    U4 u; u.x = v[0]; u.y = v[1]; u.z = v[2]; u.w = v[3];
+    return u;
+}
+
 // thread -> (channel group, row phase) map shared by every kernel
 struct Map {
     int tprb;     // threads per row inside this block (<= 256)
@@ -262,9 +270,9 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
 #pragma unroll 2
     for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
         float d[8], f[8], o[8];
-        unpack8(dy[off], d);
-        unpack8(x[off], f);
-        if (RELU) unpack8(y[off], o);
+        unpack8(ld_nt(dy + off), d);
+        unpack8(ld_nt(x + off), f);
+        if (RELU) unpack8(ld_nt(y + off), o);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float dd = (RELU && !(o[k] > 0.f)) ? 0.f : d[k];
