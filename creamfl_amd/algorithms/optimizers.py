@@ -33,12 +33,17 @@ class AdamP(Optimizer):
         super().__init__(params, defaults)
         self._plans = {}
 
-    META_DTYPE = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64),
+    META_DTYPE = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64), ('p16', np.uint64),
                            ('numel', np.int64), ('inner', np.int64), ('row_base', np.int64),
                            ('n0', np.int32), ('flags', np.int32)])
 
+    def make_master(self, p):
+        """Register an fp32 master copy for a parameter that is about to be converted to bf16 (call BEFORE the
+        conversion so that no precision is lost)."""
+        self.state[p]['master'] = p.detach().to(torch.float32, memory_format=torch.preserve_format).clone()
+
     def _plan(self, gi, params, clip_ids):
-        key = (gi, tuple(p.data_ptr() for p in params), tuple(sorted(clip_ids)) if clip_ids else ())
+        key = (gi, tuple((p.data_ptr(), p.dtype) for p in params), tuple(sorted(clip_ids)) if clip_ids else ())
         plan = self._plans.get(gi)
         if plan is not None and plan['key'] == key:
             return plan
@@ -68,7 +73,12 @@ class AdamP(Optimizer):
             if id(p) in clip_ids:
                 flags |= 2
             st = self.state[p]
-            meta[t]['p'] = p.data_ptr(); meta[t]['m'] = st['exp_avg'].data_ptr(); meta[t]['v'] = st['exp_avg_sq'].data_ptr()
+            if p.dtype == torch.bfloat16:            # bf16 model weight, fp32 master (apex-O2 style)
+                flags |= 4
+                meta[t]['p'] = st['master'].data_ptr(); meta[t]['p16'] = p.data_ptr()
+            else:
+                meta[t]['p'] = p.data_ptr()
+            meta[t]['m'] = st['exp_avg'].data_ptr(); meta[t]['v'] = st['exp_avg_sq'].data_ptr()
             meta[t]['numel'] = numel; meta[t]['inner'] = inner; meta[t]['n0'] = n0; meta[t]['flags'] = flags
         plan = {
             'key': key, 'meta': meta,
@@ -103,20 +113,22 @@ class AdamP(Optimizer):
             params = [p for p in group['params'] if p.grad is not None]
             if not params:
                 continue
-            if not all(p.is_cuda and p.dtype == torch.float32 for p in params):
-                raise _lib.CreamflHipError('creamfl_amd AdamP needs fp32 parameters on a HIP device (no CPU path)')
+            if not all(p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) for p in params):
+                raise _lib.CreamflHipError('creamfl_amd AdamP needs fp32 / bf16 parameters on a HIP device (no CPU path)')
             for p in params:
                 st = self.state[p]
-                if len(st) == 0:
+                if 'exp_avg' not in st:
                     st['step'] = 0
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg'] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+                    if p.dtype == torch.bfloat16 and 'master' not in st:
+                        st['master'] = p.detach().to(torch.float32, memory_format=torch.preserve_format)
                 st['step'] += 1
             plan = self._plan(gi, params, clip_ids)
             grads = []
             for p in params:
                 g = p.grad
-                if g.dtype != torch.float32 or g.stride() != p.stride():
+                if g.dtype != p.dtype or g.stride() != p.stride():
                     g2 = torch.empty_like(p, memory_format=torch.preserve_format)
                     g2.copy_(g)
                     g = g2

@@ -89,10 +89,27 @@ class EngineBase(object):
     def set_logger(self, logger):
         self.logger = logger
 
-    def to_half(self):
-        """Mixed precision without apex: bf16 autocast for the encoder trunks, channels_last convolutions."""
+    def to_half(self, bf16_weights=True):
+        """Mixed precision without apex (the reference: amp.initialize(opt_level='O2'), :107-111): bf16 autocast for
+        the encoder trunks, channels_last convolutions and -- like O2 -- low-precision trunk WEIGHTS with fp32
+        master copies owned by the optimizer (creamfl_amd AdamP only): the per-step autocast weight casts and the
+        bf16->fp32 gradient casts disappear and the data-parallel gradient all-reduce halves.  BatchNorm /
+        LayerNorm parameters, the PIE head, the projection heads and the criterion stay fp32."""
         self.autocast_dtype = torch.bfloat16
         self.model.to(memory_format=torch.channels_last)
+        if bf16_weights and isinstance(self.optimizer, AdamP):
+            trunks = [getattr(self.model, 'img_enc', None) and self.model.img_enc.cnn]
+            if not self.model.config.not_bert:
+                trunks.append(self.model.txt_enc)
+            for trunk in trunks:
+                if trunk is None:
+                    continue
+                for mod in trunk.modules():
+                    if isinstance(mod, (nn.Conv2d, nn.Linear, nn.Embedding)):
+                        for p in mod.parameters(recurse=False):
+                            if p.dtype == torch.float32 and p.requires_grad:
+                                self.optimizer.make_master(p)
+                                p.data = p.data.to(torch.bfloat16)
         if self.evaluator is not None:
             self.evaluator.autocast_dtype = self.autocast_dtype
 

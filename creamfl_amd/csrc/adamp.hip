@@ -28,6 +28,38 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 __device__ __forceinline__ f32x4 ld4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
 __device__ __forceinline__ void st4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 
+// gradient access: fp32 or bf16 storage
+typedef unsigned int u32;
+struct __attribute__((aligned(8))) U2 { u32 x, y; };
+__device__ __forceinline__ f32x4 ldg4(const void* g, long long e, bool bf) {
+    if (bf) {
+        typedef u32 v2u __attribute__((ext_vector_type(2)));
+        const v2u u = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(reinterpret_cast<const unsigned short*>(g) + e));
+        f32x4 v = {__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u),
+                   __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+        return v;
+    }
+    return ld4_nt(reinterpret_cast<const float*>(g) + e);
+}
+__device__ __forceinline__ float ldg1(const void* g, long long e, bool bf) {
+    if (bf) return __uint_as_float(((u32) reinterpret_cast<const unsigned short*>(g)[e]) << 16);
+    return reinterpret_cast<const float*>(g)[e];
+}
+__device__ __forceinline__ u32 bf16_rne(float f) {
+    u32 u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void st_shadow4(void* p16, long long e, const f32x4& v) {
+    U2 u;
+    u.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+    u.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+    *reinterpret_cast<U2*>(reinterpret_cast<unsigned short*>(p16) + e) = u;
+}
+__device__ __forceinline__ void st_shadow1(void* p16, long long e, float v) {
+    reinterpret_cast<unsigned short*>(p16)[e] = (unsigned short)bf16_rne(v);
+}
+
 // ---- gradient norm over the tensors flagged CFL_OPT_CLIP ---------------------------------------------
 __global__ __launch_bounds__(256) void cfl_gradnorm_partial_kernel(const CflTensorMeta* __restrict__ meta,
                                                                    const int* __restrict__ items, float* partial) {
@@ -39,14 +71,14 @@ __global__ __launch_bounds__(256) void cfl_gradnorm_partial_kernel(const CflTens
         long long e0, e1;
         if (tm.flags & CFL_OPT_MATRIX) { e0 = (long long)it[1] * tm.inner; e1 = e0 + (long long)it[2] * tm.inner; }
         else { e0 = it[1]; e1 = e0 + it[2]; }
-        const float* g = (const float*)tm.g;
+        const bool bf = tm.flags & CFL_OPT_GRAD_BF16;
         if (((e0 | e1) & 3) == 0) {
             for (long long e = e0 + threadIdx.x * 4; e < e1; e += 1024) {
-                const f32x4 v = ld4(g + e);
+                const f32x4 v = bf ? ldg4(tm.g, e, true) : ld4(reinterpret_cast<const float*>(tm.g) + e);
                 s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
             }
         } else {
-            for (long long e = e0 + threadIdx.x; e < e1; e += 256) s = fmaf(g[e], g[e], s);
+            for (long long e = e0 + threadIdx.x; e < e1; e += 256) { const float x = ldg1(tm.g, e, bf); s = fmaf(x, x, s); }
         }
     }
     s = block_sum_256(s, red);
@@ -78,7 +110,8 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass1_kernel(const CflTensorMet
     const int* it = items + (size_t)blockIdx.x * 3;
     const CflTensorMeta tm = meta[it[0]];
     float* p = (float*)tm.p;
-    const float* g = (const float*)tm.g;
+    const void* g = tm.g;
+    const bool bf = tm.flags & CFL_OPT_GRAD_BF16;
     float* m = (float*)tm.m;
     float* v = (float*)tm.v;
     const float cc = (clip && (tm.flags & CFL_OPT_CLIP)) ? clip[1] : 1.f;
@@ -89,9 +122,11 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass1_kernel(const CflTensorMet
         const float decay = 1.f - h.lr * h.wd;
         for (long long e = (long long)it[1] + threadIdx.x; e < e1; e += 256) {
             float mm = m[e], vv = v[e];
-            const float pert = adam_elem(g[e] * cc, mm, vv, h, rs_bc2);
+            const float pert = adam_elem(ldg1(g, e, bf) * cc, mm, vv, h, rs_bc2);
             m[e] = mm; v[e] = vv;
-            p[e] = p[e] * decay - step * pert;
+            const float pn = p[e] * decay - step * pert;
+            p[e] = pn;
+            if (tm.p16) st_shadow1(tm.p16, e, pn);
         }
         return;
     }
@@ -104,7 +139,7 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass1_kernel(const CflTensorMet
         if (vec) {
             for (long long e = lane * 4; e < inner; e += 256) {
                 const f32x4 pv = ld4(p + base + e);
-                f32x4 gv = ld4_nt(g + base + e) * cc, mv = ld4_nt(m + base + e), vv = ld4_nt(v + base + e);
+                f32x4 gv = ldg4(g, base + e, bf) * cc, mv = ld4_nt(m + base + e), vv = ld4_nt(v + base + e);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float mm = mv[k], v2 = vv[k];
@@ -117,7 +152,7 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass1_kernel(const CflTensorMet
             }
         } else {
             for (long long e = lane; e < inner; e += 64) {
-                const float pv = p[base + e], gv = g[base + e] * cc;
+                const float pv = p[base + e], gv = ldg1(g, base + e, bf) * cc;
                 float mm = m[base + e], v2 = v[base + e];
                 const float pert = adam_elem(gv, mm, v2, h, rs_bc2);
                 m[base + e] = mm; v[base + e] = v2;
@@ -179,7 +214,8 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass3_kernel(const CflTensorMet
     const CflTensorMeta tm = meta[it[0]];
     if (!(tm.flags & CFL_OPT_MATRIX)) return;
     float* p = (float*)tm.p;
-    const float* g = (const float*)tm.g;
+    const void* g = tm.g;
+    const bool bf = tm.flags & CFL_OPT_GRAD_BF16;
     const float* m = (const float*)tm.m;
     const float* v = (const float*)tm.v;
     const float cc = (clip && (tm.flags & CFL_OPT_CLIP)) ? clip[1] : 1.f;
@@ -197,7 +233,7 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass3_kernel(const CflTensorMet
                 f32x4 pv = ld4(p + base + e);
                 const f32x4 mv = ld4_nt(m + base + e), vv = ld4_nt(v + base + e);
                 f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-                if (h.nesterov) gv = ld4_nt(g + base + e) * cc;
+                if (h.nesterov) gv = ldg4(g, base + e, bf) * cc;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float num = h.nesterov ? (h.beta1 * mv[k] + (1.f - h.beta1) * gv[k]) : mv[k];
@@ -205,13 +241,16 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass3_kernel(const CflTensorMet
                     pv[k] = pv[k] * decay - step * (pert - pv[k] * coef);
                 }
                 st4(p + base + e, pv);
+                if (tm.p16) st_shadow4(tm.p16, base + e, pv);
             }
         } else {
             for (long long e = lane; e < inner; e += 64) {
                 const float pv = p[base + e];
-                const float num = h.nesterov ? (h.beta1 * m[base + e] + (1.f - h.beta1) * g[base + e] * cc) : m[base + e];
+                const float num = h.nesterov ? (h.beta1 * m[base + e] + (1.f - h.beta1) * ldg1(g, base + e, bf) * cc) : m[base + e];
                 const float pert = num / (sqrtf(v[base + e]) * rs_bc2 + h.eps);
-                p[base + e] = pv * decay - step * (pert - pv * coef);
+                const float pn = pv * decay - step * (pert - pv * coef);
+                p[base + e] = pn;
+                if (tm.p16) st_shadow1(tm.p16, base + e, pn);
             }
         }
     }

@@ -199,11 +199,16 @@ int cfl_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma,
  *                     partial_ws >= n_items floats.
  * cfl_adamp_step:     rowstats_ws >= 4 * (total rows of matrix tensors) floats, tstats_ws >= n_tensors floats;
  *                     clip_dev = out2 of cfl_grad_clip_coef or NULL; `step` is the 1-based step count.
+ * Mixed precision (the reference trains with apex O2: fp16 model weights, fp32 master weights,
+ * retrieval_trainer.py:107-111): p is the fp32 master, p16 the bf16 model weight rewritten by pass 3, and g may be
+ * bf16 (CFL_OPT_GRAD_BF16); moments are always fp32.
  */
-#define CFL_OPT_MATRIX 1
-#define CFL_OPT_CLIP   2
+#define CFL_OPT_MATRIX    1
+#define CFL_OPT_CLIP      2
+#define CFL_OPT_GRAD_BF16 4      /* g points at bf16 gradients (mixed-precision trunks: bf16 weights, fp32 masters) */
 typedef struct CflTensorMeta {
     void* p; void* g; void* m; void* v;
+    void* p16;              /* optional bf16 shadow of p (the weight the model computes with), or NULL */
     long long numel;
     long long inner;
     long long row_base;     /* first row of this tensor in rowstats_ws */

@@ -59,3 +59,42 @@ def test_fused_adamp_matches_oracle(weight_decay, nesterov, channels_last):
     # state_dict layout like adamp.AdamP
     st = ogpu.state[gpu[0]]
     assert set(st) == {'step', 'exp_avg', 'exp_avg_sq'} and st['step'] == 4
+
+
+def test_fused_adamp_bf16_weights_fp32_masters():
+    """apex-O2 style: bf16 model weights + bf16 grads, fp32 masters and moments inside the optimizer.  The master
+    trajectory must equal the fp32 oracle fed with the same (bf16-valued) gradients; the bf16 shadow must be the
+    rounded master."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from oracle.adamp import AdamP as OracleAdamP
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(3)
+    init = _make_params(gen)
+    cpu = [torch.nn.Parameter(t.clone()) for t in init]
+    gpu = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    ogpu = AdamP(gpu, lr=1e-2, weight_decay=0.01)
+    half = [0, 2, 3, 4, 6]                       # these become bf16 weights
+    for k in half:
+        ogpu.make_master(gpu[k])
+        gpu[k].data = gpu[k].data.to(torch.bfloat16)
+    ocpu = OracleAdamP(cpu, lr=1e-2, weight_decay=0.01)
+    for it in range(3):
+        grads = [torch.randn(t.shape, generator=gen) for t in init]
+        for k in half:
+            grads[k] = grads[k].to(torch.bfloat16).float()          # the values a bf16 backward would produce
+        for k, (p, q, g) in enumerate(zip(cpu, gpu, grads)):
+            p.grad = g.clone()
+            q.grad = g.to(dev).to(q.dtype)
+        norm = torch.nn.utils.clip_grad_norm_(cpu, 2.0)
+        ocpu.step()
+        ogpu.step(clip=(gpu, 2.0))
+        np.testing.assert_allclose(ogpu.last_grad_norm.item(), norm.item(), rtol=1e-5)
+        for k, (p, q) in enumerate(zip(cpu, gpu)):
+            master = ogpu.state[q]['master'] if k in half else q
+            np.testing.assert_allclose(master.detach().float().cpu().numpy(), p.detach().numpy(), rtol=2e-4, atol=2e-6,
+                                       err_msg=f'step {it} tensor {k}')
+            if k in half:
+                assert q.dtype == torch.bfloat16
+                assert torch.equal(q.detach(), master.to(torch.bfloat16))
