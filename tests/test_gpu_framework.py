@@ -183,3 +183,42 @@ def test_config4_vit_bertlarge_style_model_steps(dev):
     loss, li, lm = client_contrast_loss(f, G, G.flip(0), list(range(16)), f.detach().roll(1, 0), interintra_weight=0.5)
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in eng.model.img_enc.parameters() if p.grad is not None)
+
+
+def test_training_overfits_a_fixed_batch(dev):
+    """End-to-end sanity of every gradient path in the mixed-precision regime of the bench (bf16 trunks with fused
+    BN kernels, bf16 trunk weights + fp32 masters, HIP head / loss / clip / AdamP): repeated steps on one fixed batch
+    must drive the soft-contrastive loss down and the matched-pair similarity up."""
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.synthetic import coco_batch
+    torch.manual_seed(4)
+    cfg = _small_cfg(dim=64, cnn='resnet18')
+    cfg.optimizer.learning_rate = 5e-4
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    assert eng.model.img_enc.cnn.conv1.weight.dtype == torch.bfloat16          # O2-style trunk weights
+    assert eng.model.img_enc.cnn.bn1.weight.dtype == torch.float32 and eng.model.img_enc.fc.weight.dtype == torch.float32
+    eng.model.train()
+    for m in eng.model.modules():                     # no dropout noise in the trend
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    b = coco_batch(32, dev, seed=11, img=96)
+    images = b[0].contiguous(memory_format=torch.channels_last)
+    losses = []
+    for it in range(80):
+        loss, _ = eng.train_step(images, b[1], None, b[3])
+        losses.append(loss.item())
+    assert np.isfinite(losses).all()
+    first, last = np.mean(losses[:5]), np.mean(losses[-5:])
+    assert last < 0.25 * first, (first, last)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        out = eng.model(images, b[1], None, b[3])
+    sim = out['image_features'] @ out['caption_features'].T
+    diag = sim.diag().mean().item()
+    off = (sim.sum() - sim.diag().sum()).item() / (32 * 31)
+    assert diag > off + 0.2, (diag, off)
+    # the fp32 masters and their bf16 shadows stay in sync
+    p = eng.model.img_enc.cnn.layer1[0].conv1.weight
+    assert torch.equal(p.detach(), eng.optimizer.state[p]['master'].to(torch.bfloat16))
