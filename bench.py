@@ -53,14 +53,15 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s ac
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 
 
-def algorithmic_cost(kernel, N, P, Cd, dh, D, n_params=0, n_clip=0):
+def algorithmic_cost(kernel, N, P, Cd, dh, D, n_f32=0, n_bf16=0):
     """(bound, algorithmic bytes or flops per launch) for each hand-written kernel at this workload
     (SURVEY section 8d)."""
     f = 4
     table = {
-        'cfl_adamp_pass1_kernel': ('hbm', 6 * n_params * f),     # read p,g,m,v; write m,v
-        'cfl_adamp_pass3_kernel': ('hbm', 4 * n_params * f),     # read p,m,v; write p
-        'cfl_gradnorm_kernel': ('hbm', n_clip * f // 2),          # two launches (partial + final) share the id
+        # n_f32 fp32 parameters (fp32 grads) + n_bf16 bf16 trunk weights (bf16 grads, fp32 master, bf16 shadow)
+        'cfl_adamp_pass1_kernel': ('hbm', 24 * n_f32 + 22 * n_bf16),    # read p,g,m,v; write m,v
+        'cfl_adamp_pass3_kernel': ('hbm', 16 * n_f32 + 18 * n_bf16),    # read p,m,v; write p (+ shadow)
+        'cfl_gradnorm_kernel': ('hbm', (4 * n_f32 + 2 * n_bf16) // 2),  # two launches (partial + final) share the id
         'cfl_pie_scores_kernel': ('hbm', N * P * dh * f + N * P * f),                       # read H, write scores
         'cfl_pie_pool_kernel': ('hbm', N * P * Cd * f + 2 * N * Cd * f + N * P * f),        # read X, write pooled+mean
         'cfl_pie_bwd_ds_kernel': ('hbm', N * P * Cd * f + N * Cd * f + N * P * f),          # read X, d_pooled
@@ -141,13 +142,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
     from creamfl_amd import ops as _ops
+    # Warm-up.  Its last step is event-timed for EVERY hand-written kernel: that gives the per-kernel table and
+    # tells which kernel dominates.  In the timed region only that one kernel is bracketed by HIP events (two
+    # hipEventRecords per launch of all ~650 hand-written launches per step cost ~5 ms of host time per step).
+    for i in range(args.warmup):
+        last = (i == args.warmup - 1)
+        if last:
+            torch.cuda.synchronize()
+            _lib.prof_select(None)
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+        step()
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    warm_prof = _lib.prof_query() if args.warmup > 0 else {}
+    dominant = max(warm_prof, key=lambda k: warm_prof[k][1]) if warm_prof else 'cfl_bn_bwd_apply_kernel'
+    fence()
     for k_ in _ops.BN_COUNTERS:
         _ops.BN_COUNTERS[k_] = 0
     _lib.prof_reset()
+    _lib.prof_select(dominant)
     _lib.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -155,6 +170,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     _lib.prof_enable(False)
+    _lib.prof_select(None)
     prof = _lib.prof_query()
     loss_val = float(loss.detach())
 
@@ -171,7 +187,8 @@ def main():
         roof = None
         cand = []
         Nloss = args.batch * world
-        n_model = sum(p.numel() for p in eng.model.parameters())
+        n_bf16 = sum(p.numel() for p in eng.model.parameters() if p.dtype == torch.bfloat16)
+        n_f32 = sum(p.numel() for p in eng.model.parameters() if p.dtype == torch.float32) + 2
         # fused BN kernels run once per BatchNorm layer with a different shape each: their algorithmic bytes are
         # accumulated over the launches of the timed region (bf16 = 2 B / element) and divided per launch
         bc = _ops.BN_COUNTERS
@@ -183,7 +200,7 @@ def main():
         }
         for name, (n, ms) in prof.items():
             base = name
-            cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim, n_model + 2, n_model)
+            cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim, n_f32, n_bf16)
             if base.startswith('cfl_pair_'):
                 cost = algorithmic_cost(base, Nloss, 49, Cd, Cd // 2, args.dim)
             if base in bn_bytes and bn_bytes[base] > 0:
@@ -214,7 +231,7 @@ def main():
                     roof['traffic_source'] = 'profiles/r1_pmc_traffic.json'
             except (OSError, ValueError):
                 pass
-        hip_us = {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted(prof.items())}
+        hip_us = {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted((warm_prof or prof).items())}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -230,7 +247,7 @@ def main():
                        'global_batch': args.batch * world, 'cnn': args.cnn, 'text': 'bert-base',
                        'encoder_precision': args.dtype, 'head_loss_precision': 'f32',
                        'parallelism': 'dp%d' % world, 'loss': round(loss_val, 4)},
-            'roofline': roof, 'cpu_baseline': cpu, 'hip_kernels_us': hip_us,
+            'roofline': roof, 'cpu_baseline': cpu, 'hip_kernels_us_warmup_step': hip_us,
         }
         print(json.dumps(out))
     if use_dp:

@@ -20,6 +20,7 @@ SIGNATURES = {
     'cfl_num_kernels': (c_int, []),
     'cfl_kernel_name': (c_char_p, [c_int]),
     'cfl_prof_enable': (c_int, [c_int]),
+    'cfl_prof_select': (c_int, [c_int]),
     'cfl_prof_reset': (c_int, []),
     'cfl_prof_query': (c_int, [c_int, POINTER(c_longlong), POINTER(c_double)]),
     'cfl_gemm_nt': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
@@ -92,6 +93,12 @@ def kernel_names():
 
 def prof_enable(on=True):
     check(load().cfl_prof_enable(1 if on else 0), 'cfl_prof_enable')
+
+
+def prof_select(kernel_name=None):
+    """Restrict event timing to one kernel (by name), or to all kernels with None."""
+    kid = kernel_names().index(kernel_name) if kernel_name else -1
+    check(load().cfl_prof_select(kid), 'cfl_prof_select')
 
 
 def prof_reset():

@@ -80,8 +80,12 @@ class AdamP(Optimizer):
                 meta[t]['p'] = p.data_ptr()
             meta[t]['m'] = st['exp_avg'].data_ptr(); meta[t]['v'] = st['exp_avg_sq'].data_ptr()
             meta[t]['numel'] = numel; meta[t]['inner'] = inner; meta[t]['n0'] = n0; meta[t]['flags'] = flags
+        meta_pin = torch.empty(meta.nbytes, dtype=torch.uint8).pin_memory()
+        meta_view = meta_pin.numpy().view(self.META_DTYPE)
+        meta_view[:] = meta
+        meta = meta_view                         # the table lives in pinned memory: uploads are async (graph-capturable)
         plan = {
-            'key': key, 'meta': meta,
+            'key': key, 'meta': meta, 'meta_pin': meta_pin,
             'meta_dev': torch.empty(meta.nbytes, dtype=torch.uint8, device=dev),
             'items': torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 3).contiguous(),
             'matrix_ids': torch.tensor(matrix_ids or [0], dtype=torch.int32, device=dev),
@@ -136,7 +140,7 @@ class AdamP(Optimizer):
             gptrs = [g.data_ptr() for g in grads]
             if gptrs != plan['gptrs']:
                 plan['meta']['g'] = np.asarray(gptrs, dtype=np.uint64)
-                plan['meta_dev'].copy_(torch.from_numpy(plan['meta'].view(np.uint8).reshape(-1)), non_blocking=False)
+                plan['meta_dev'].copy_(plan['meta_pin'], non_blocking=True)
                 plan['gptrs'] = gptrs
             stream = ctypes.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
             n_items = plan['items'].shape[0]

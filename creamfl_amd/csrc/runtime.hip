@@ -21,6 +21,7 @@ namespace {
 struct Pending { int id; hipEvent_t e0, e1; };
 std::mutex g_mu;
 bool g_on = false;
+int g_only = -1;              // profile only this kernel id (-1 = every kernel)
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_pool;
 long long g_launches[K_NUM];
@@ -47,7 +48,7 @@ void drain_locked() {
 }  // namespace
 
 CflProfScope::CflProfScope(int id_, hipStream_t s_) : id(id_), s(s_), e0(nullptr), e1(nullptr), on(false) {
-    if (!g_on) return;
+    if (!g_on || (g_only >= 0 && g_only != id)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     e0 = get_event();
     e1 = get_event();
@@ -68,6 +69,11 @@ const char* cfl_kernel_name(int id) { return (id >= 0 && id < K_NUM) ? g_kernel_
 int cfl_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
+    return 0;
+}
+int cfl_prof_select(int kernel_id) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_only = (kernel_id >= 0 && kernel_id < K_NUM) ? kernel_id : -1;
     return 0;
 }
 int cfl_prof_reset(void) {

@@ -37,6 +37,7 @@ const char* cfl_kernel_name(int kernel_id);    /* name as it appears in rocprofv
 /* When enabled every kernel launch is bracketed by hipEvents recorded on the launch
  * stream; cfl_prof_query drains finished events (it synchronises on them). */
 int cfl_prof_enable(int on);
+int cfl_prof_select(int kernel_id);           /* time only this kernel (-1 = all): two hipEventRecords per launch cost host time */
 int cfl_prof_reset(void);
 int cfl_prof_query(int kernel_id, long long* launches, double* total_ms);
 
