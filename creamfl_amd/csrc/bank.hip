@@ -57,39 +57,63 @@ __global__ __launch_bounds__(256, 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, in
 
     const int ntiles = sx < nch ? (nch - sx + S - 1) / S : 0;
     auto tile_fn = [&](int i) { return TileDesc{(sx + i * S) * C::BM, col0, 0, G.kdim}; };
+    // online log-sum-exp in the base-2 domain: y = logit * log2(e); run_m holds max y, run_l = sum 2^(y - run_m)
+    // (one v_exp_f32 per element instead of a full expf); converted back to natural units after the loop.
+    const float sc2 = inv_tau * 1.4426950408889634f;
     auto epi_fn = [&](int i, const f32x16 (&acc)[TM][TN]) {
         const int row0 = (sx + i * S) * C::BM;
+        const bool full = (row0 + C::BM <= M);                 // uniform: only the last chunk needs row masks
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
             const int f = col0 + acc_col<TN>(wc, n, lane);
             float tmax = -INFINITY;
+            if (full) {
 #pragma unroll
-            for (int m = 0; m < TM; ++m)
+                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int g = row0 + acc_row<TM>(wr, m, r, lane);
-                    const float x = (g < M) ? acc[m][n][r] * inv_tau : -INFINITY;
-                    tmax = fmaxf(tmax, x);
-                    if (logits_t && g < M && f < B) logits_t[(long long)g * B + f] = x;
-                }
-            if (tmax > -INFINITY) {
-                const float mn = fmaxf(run_m[n], tmax);
-                float s = 0.f;
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, acc[m][n][r]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (row0 + acc_row<TM>(wr, m, r, lane) < M) tmax = fmaxf(tmax, acc[m][n][r]);
+            }
+            if (logits_t && f < B) {
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int g = row0 + acc_row<TM>(wr, m, r, lane);
-                        s += (g < M) ? expf(acc[m][n][r] * inv_tau - mn) : 0.f;
+                        if (full || g < M) logits_t[(long long)g * B + f] = acc[m][n][r] * inv_tau;
                     }
-                run_l[n] = run_l[n] * expf(run_m[n] - mn) + s;
+            }
+            if (tmax > -INFINITY) {
+                // inv_tau > 0, so the max of the scaled logits is the scaled max
+                const float mn = fmaxf(run_m[n], tmax * sc2);
+                float s = 0.f;
+                if (full) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(fmaf(acc[m][n][r], sc2, -mn));
+                } else {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (row0 + acc_row<TM>(wr, m, r, lane) < M) s += __builtin_amdgcn_exp2f(fmaf(acc[m][n][r], sc2, -mn));
+                }
+                run_l[n] = run_l[n] * __builtin_amdgcn_exp2f(run_m[n] - mn) + s;
                 run_m[n] = mn;
             }
         }
     };
     if (glds_ok(G, F)) tile_gemm_seq_glds<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);
     else tile_gemm_seq<TM, TN, true, true>(G, F, ntiles, tile_fn, lds, XfIdentity(), epi_fn);
-    // combine the two half-waves (they hold different bank rows of the same feature row) ...
+    // back to natural-log units, then combine the two half-waves (different bank rows of the same feature row) ...
+#pragma unroll
+    for (int n = 0; n < TN; ++n) run_m[n] *= 0.6931471805599453f;
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
         const float om = __shfl_xor(run_m[n], 32, 64), ol = __shfl_xor(run_l[n], 32, 64);
@@ -352,7 +376,7 @@ size_t cfl_bank_ws_bytes(int B, int M, int D) {
 int cfl_bank_lse_fwd(const float* F, const float* G, const long long* idx, int B, int M, int D,
                      float inv_tau, float* lse, float* pos, float* loss, float* logits_t,
                      void* ws, void* stream_) {
-    if (!F || !G || !idx || !lse || !pos || !ws || B <= 0 || M <= 0 || D <= 0) return CFL_EINVAL;
+    if (!F || !G || !idx || !lse || !pos || !ws || B <= 0 || M <= 0 || D <= 0 || !(inv_tau > 0.f)) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     const BankPlan pl = bank_plan(B, M);
     BankWs w = bank_ws(ws, pl);
