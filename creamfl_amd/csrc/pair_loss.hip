@@ -84,9 +84,14 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
                     const float s = fmaf(-a, d, b);
                     const float mm = diag ? 1.f : -1.f;
                     const float x = -2.f * mm * s;
-                    const float nll = softplusf(x);
-                    const float g = 4.f * mm * sigmoidf(x);     // dL/dd / a   (both directions)
-                    c = a * g / d;
+                    // softplus(x) and sigmoid(x) from ONE exponential e = exp(-|x|):
+                    //   softplus = max(x,0) + log1p(e),  sigmoid = (x >= 0 ? 1 : e) / (1 + e)
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
+                    const float l1p = e < 1e-2f ? e * fmaf(e, fmaf(e, 0.33333334f, -0.5f), 1.f) : __logf(1.f + e);
+                    const float nll = fmaxf(x, 0.f) + l1p;
+                    const float sg = (x >= 0.f ? 1.f : e) * __builtin_amdgcn_rcpf(1.f + e);
+                    const float g = 4.f * mm * sg;              // dL/dd / a   (both directions)
+                    c = a * g * __builtin_amdgcn_rcpf(d);
                     if (diag) pos += nll; else neg += nll;
                     da = fmaf(g, d, da);
                     db -= g;
@@ -94,14 +99,13 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
                 cs[lr * CLD + lc] = c;
             }
         }
-    __shared__ float red[4];
-    pos = block_sum_256(pos, red);
-    neg = block_sum_256(neg, red);
-    da = block_sum_256(da, red);
-    db = block_sum_256(db, red);          // (each call starts with a barrier: cs is complete here)
-    if (threadIdx.x == 0) {
-        float* p = part + (size_t)tile * 4;
-        p[0] = pos; p[1] = neg; p[2] = da; p[3] = db;
+    __shared__ float red[4][4];
+    pos = wave_sum(pos); neg = wave_sum(neg); da = wave_sum(da); db = wave_sum(db);
+    if (lane == 0) { red[wid][0] = pos; red[wid][1] = neg; red[wid][2] = da; red[wid][3] = db; }
+    __syncthreads();                      // also: the coefficient tile cs is complete
+    if (threadIdx.x < 4) {
+        const int e = threadIdx.x;
+        part[(size_t)tile * 4 + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
     }
     const int t = threadIdx.x;
     if (t < C::BM) {
