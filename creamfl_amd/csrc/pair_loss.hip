@@ -7,25 +7,44 @@
 // form when matched pairs are close, so their distances are recomputed exactly as
 // sum (I_ik - T_ik)^2 by cfl_pair_prep_kernel.
 //
-// HBM layout: I, T [N, D] row-major fp32; coef [N, N] row-major fp32; ws (floats):
-//   ni[N] nt[N] dd[N] rowsum[N] colsum[N] rowpart[NT*N] colpart[NT*N] part[NT*NT*4]
+// HBM layout: I, T [N, D] row-major fp32; coef [2, N, N] row-major fp32 (the coefficient matrix AND its
+// transpose: with the transposed features It, Tt [D, N] kept in ws, both backward GEMMs  coef @ T  and
+// coef^T @ I  read K-contiguous operands and take the direct-to-LDS path); ws (floats):
+//   ni[N] nt[N] dd[N] rowsum[N] colsum[N] rowpart[NT*N] colpart[NT*N] part[NT*NT*4] It[D*N] Tt[D*N]
 // with NT = ceil(N / 64) (sized for the smallest tile).
 #include "common.h"
 
 namespace {
 
 struct PairWs {
-    float *ni, *nt, *dd, *rowsum, *colsum, *rowpart, *colpart, *part;
+    float *ni, *nt, *dd, *rowsum, *colsum, *rowpart, *colpart, *part, *it, *tt;
 };
-static PairWs pair_ws(void* ws, int N) {
+static PairWs pair_ws(void* ws, int N, int D) {
     const int NT = cfl_cdiv(N, 64);
     float* p = (float*)ws;
     PairWs w;
     w.ni = p; p += N; w.nt = p; p += N; w.dd = p; p += N;
     w.rowsum = p; p += N; w.colsum = p; p += N;
     w.rowpart = p; p += (size_t)NT * N; w.colpart = p; p += (size_t)NT * N;
-    w.part = p;
+    w.part = p; p += (size_t)4 * NT * NT;
+    p = (float*)cfl_align256((size_t)(uintptr_t)p);          // 16-byte alignment for vector access
+    w.it = p; p += (size_t)D * N; w.tt = p;
     return w;
+}
+
+// It[k][i] = I[i][k], Tt likewise (blockIdx.z selects); 32x32 LDS tiles, coalesced both ways
+__global__ __launch_bounds__(256) void cfl_pair_transpose_kernel(const float* __restrict__ I, const float* __restrict__ T,
+                                                                 int N, int D, float* It, float* Tt) {
+    __shared__ float tile[32][33];
+    const float* src = blockIdx.z ? T : I;
+    float* dst = blockIdx.z ? Tt : It;
+    const int i0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // 32 x 8
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (i0 + r < N && k0 + tx < D) ? src[(long long)(i0 + r) * D + k0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < D && i0 + tx < N) dst[(long long)(k0 + r) * N + i0 + tx] = tile[tx][r];
 }
 
 // one wave per row: |I_i|^2, |T_i|^2 and the exact diagonal squared distance.
@@ -119,9 +138,14 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
         if (col0 + cj < N) colpart[(size_t)ti * N + col0 + cj] = s;
     }
     if (coef) {
+        float* coef_t = coef + (long long)N * N;
         for (int e = t; e < C::BM * C::BN; e += 256) {
             const int lr = e / C::BN, lc = e % C::BN;
             if (row0 + lr < N && col0 + lc < N) coef[(long long)(row0 + lr) * N + col0 + lc] = cs[lr * CLD + lc];
+        }
+        for (int e = t; e < C::BM * C::BN; e += 256) {         // transposed copy: rows of the tile are the fast axis
+            const int lc = e / C::BM, lr = e % C::BM;
+            if (row0 + lr < N && col0 + lc < N) coef_t[(long long)(col0 + lc) * N + row0 + lr] = cs[lr * CLD + lc];
         }
     }
 }
@@ -152,31 +176,27 @@ __global__ __launch_bounds__(256) void cfl_pair_final_kernel(const float* part, 
     }
 }
 
-// z = 0: dI = gout * (I * rowsum - coef   @ T)   A = coef (K contiguous), B = T (K strided)
-// z = 1: dT = gout * (T * colsum - coef^T @ I)   A = coef^T (K strided),  B = I (K strided)
+// z = 0: dI = gout * (I * rowsum - coef   @ T)   A = coef   [N, N],  B = Tt [D, N]   (both K-contiguous)
+// z = 1: dT = gout * (T * colsum - coef^T @ I)   A = coef^T [N, N],  B = It [D, N]
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void cfl_pair_bwd_kernel(const float* __restrict__ I, const float* __restrict__ T,
-                                                           const float* __restrict__ coef, int N, int D, int vecN, int vecD,
+                                                           const float* __restrict__ coef, const float* __restrict__ It,
+                                                           const float* __restrict__ Tt, int N, int D, int vecN,
                                                            const float* __restrict__ rowsum, const float* __restrict__ colsum,
                                                            const float* __restrict__ gout, float* dI, float* dT) {
-    using C = TileCfg<TM, TN, true, false>;                   // (KS,KS) needs no more LDS than (KC,KS)
+    using C = TileCfg<TM, TN, true, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ntc = (D + C::BN - 1) / C::BN, ntr = (N + C::BM - 1) / C::BM;
     int ti, tj;
     tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
     const int row0 = ti * C::BM, col0 = tj * C::BN;
     const bool second = blockIdx.z != 0;
-    f32x16 acc[TM][TN];
     const float* X = second ? T : I;        // the tensor whose gradient this block produces
-    const float* Y = second ? I : T;
-    Opnd Bo{Y, D, D, N, vecD};
-    if (!second) {
-        Opnd Ao{coef, N, N, N, vecN};
-        tile_gemm<TM, TN, true, false>(Ao, Bo, row0, col0, 0, N, lds, acc, XfIdentity());
-    } else {
-        Opnd Ao{coef, N, N, N, vecN};
-        tile_gemm<TM, TN, false, false>(Ao, Bo, row0, col0, 0, N, lds, acc, XfIdentity());
-    }
+    Opnd Ao{second ? coef + (long long)N * N : coef, N, N, N, vecN};
+    Opnd Bo{second ? It : Tt, N, D, N, vecN};
+    f32x16 acc[TM][TN];
+    if (glds_ok(Ao, Bo)) tile_gemm_glds<TM, TN>(Ao, Bo, row0, col0, 0, N, lds, acc);
+    else tile_gemm<TM, TN, true, true>(Ao, Bo, row0, col0, 0, N, lds, acc, XfIdentity());
     const float* sums = second ? colsum : rowsum;
     float* out = second ? dT : dI;
     const float g = gout[0];
@@ -205,14 +225,17 @@ size_t cfl_pair_loss_ws_bytes(int N, int D) {
     (void)D;
     if (N <= 0) return 256;
     const size_t NT = (size_t)cfl_cdiv(N, 64);
-    return cfl_align256((5 * (size_t)N + 2 * NT * N + 4 * NT * NT) * sizeof(float));
+    return cfl_align256((5 * (size_t)N + 2 * NT * N + 4 * NT * NT + 2 * (size_t)N * (D > 0 ? D : 1)) * sizeof(float)) + 512;
 }
 
 int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float* a_dev, const float* b_dev, float eps,
                       float* out8, float* coef, void* ws, void* stream_) {
     if (!I || !T || !a_dev || !b_dev || !out8 || !ws || N <= 0 || D <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    PairWs w = pair_ws(ws, N);
+    PairWs w = pair_ws(ws, N, D);
+    if (coef)
+        CFL_LAUNCH(K_PAIR_PREP, cfl_pair_transpose_kernel, dim3(cfl_cdiv(D, 32), cfl_cdiv(N, 32), 2), dim3(256), 0, stream,
+                   I, T, N, D, w.it, w.tt);
     CFL_LAUNCH(K_PAIR_PREP, cfl_pair_prep_kernel, dim3(cfl_cdiv(N, 4)), dim3(256), 0, stream, I, T, N, D, w.ni, w.nt, w.dd);
     Opnd A{I, D, N, D, cfl_opnd_vec(I, D, D)};
     Opnd B{T, D, N, D, cfl_opnd_vec(T, D, D)};
@@ -240,26 +263,25 @@ int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, 
                       const float* gout_dev, float* dI, float* dT, void* ws, void* stream_) {
     if (!I || !T || !coef || !gout_dev || !dI || !dT || !ws || N <= 0 || D <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    PairWs w = pair_ws(ws, N);
-    const int vecN = cfl_opnd_vec(coef, N, N);
-    const int vecD = (cfl_opnd_vec(I, D, D) && cfl_opnd_vec(T, D, D)) ? 1 : 0;
+    PairWs w = pair_ws(ws, N, D);
+    const int vecN = (cfl_opnd_vec(coef, N, N) && cfl_vec_ok(w.it, N) && cfl_vec_ok(w.tt, N)) ? 1 : 0;
     // tile choice by workgroup count (two GEMMs share the launch, grid.z = 2): 128x128 when that alone gives >= 2
     // workgroups per CU, else 128x64, else 64x64 (latency-bound small batches)
     const long long t128 = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 128) * 2;
     const long long t12864 = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 64) * 2;
     if (t128 >= 512) {
-        using C = TileCfg<2, 2, true, false>;
+        using C = TileCfg<2, 2, true, true>;
         CFL_SET_LDS((cfl_pair_bwd_kernel<2, 2>), C::LDS_BYTES);
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<2, 2>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
-                   C::LDS_BYTES, stream, I, T, coef, N, D, vecN, vecD, w.rowsum, w.colsum, gout_dev, dI, dT);
+                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT);
     } else if (t12864 >= 256) {
-        using C = TileCfg<2, 1, true, false>;
+        using C = TileCfg<2, 1, true, true>;
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<2, 1>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
-                   C::LDS_BYTES, stream, I, T, coef, N, D, vecN, vecD, w.rowsum, w.colsum, gout_dev, dI, dT);
+                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT);
     } else {
-        using C = TileCfg<1, 1, true, false>;
+        using C = TileCfg<1, 1, true, true>;
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<1, 1>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
-                   C::LDS_BYTES, stream, I, T, coef, N, D, vecN, vecD, w.rowsum, w.colsum, gout_dev, dI, dT);
+                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT);
     }
     return 0;
 }

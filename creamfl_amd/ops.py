@@ -72,7 +72,7 @@ class _PairLossFn(torch.autograd.Function):
         N, D = I.shape
         need_grad = any(ctx.needs_input_grad[:4])
         out8 = torch.empty(8, dtype=torch.float32, device=I.device)
-        coef = torch.empty(N, N, dtype=torch.float32, device=I.device) if need_grad else None
+        coef = torch.empty(2, N, N, dtype=torch.float32, device=I.device) if need_grad else None
         ws = _ws(lib.cfl_pair_loss_ws_bytes(N, D), I.device)
         _lib.check(lib.cfl_pair_loss_fwd(_ptr(I), _ptr(T), N, D, _ptr(a), _ptr(b), eps, _ptr(out8), _ptr(coef),
                                          _ptr(ws), _stream(I)), 'cfl_pair_loss_fwd')

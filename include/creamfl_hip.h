@@ -56,8 +56,9 @@ int cfl_gemm_ablate(const float* A, const float* B, int M, int K, int mode, int 
  *      parameters stay on the device: no host sync per step).  d_ij = sqrt(|I_i - T_j|^2 + eps), s = -a d + b, m = +1 (i == j) / -1,
  *      NLL = softplus(-2 m s).  out[8] = { loss (= 2*(pos+neg)), pos, neg, dL/da, dL/db, 0,0,0 }
  *      (pos/neg are the one-direction sums: i2t_pos_loss == t2i_pos_loss == pos).
- *      If coef != NULL it also writes coef[N, N] = (dL/dd_ij) / d_ij  (both directions, not
- *      scaled by any upstream gradient) and leaves row/column sums of coef in ws for bwd.
+ *      If coef != NULL (a [2, N, N] buffer) it also writes coef[0] = (dL/dd_ij) / d_ij (both directions, not
+ *      scaled by any upstream gradient) and coef[1] = its transpose, and leaves their row/column sums and the
+ *      transposed features in ws for bwd.
  * bwd: dI = gout * (I * rowsum(coef) - coef @ T),  dT = gout * (T * colsum(coef) - coef^T @ I).
  *      gout_dev is a device scalar (the upstream gradient of the loss).
  * ws must be the same buffer for fwd and the following bwd.
