@@ -165,14 +165,20 @@ def main():
     _lib.prof_select(dominant)
     _lib.prof_enable(True)
     t0 = time.perf_counter()
+    trace = []
     for _ in range(args.steps):
         loss, _ = step()
+        trace.append(loss.detach())              # device scalars; read after the timed region
     fence()
     dt = time.perf_counter() - t0
     _lib.prof_enable(False)
     _lib.prof_select(None)
     prof = _lib.prof_query()
     loss_val = float(loss.detach())
+    if not all(bool(torch.isfinite(t)) for t in trace):
+        raise SystemExit('bench.py: non-finite loss in the timed region -- the measurement is invalid')
+    if os.environ.get('BENCH_TRACE'):
+        sys.stderr.write('loss per timed step: %s\n' % ' '.join('%.4f' % float(t) for t in trace))
 
     if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -42,6 +42,21 @@ class AdamP(Optimizer):
         conversion so that no precision is lost)."""
         self.state[p]['master'] = p.detach().to(torch.float32, memory_format=torch.preserve_format).clone()
 
+    PIN_SLOTS = 4
+
+    @staticmethod
+    def _upload_meta(plan):
+        slot = plan['pins'][plan['pin_next']]
+        plan['pin_next'] = (plan['pin_next'] + 1) % len(plan['pins'])
+        capturing = torch.cuda.is_current_stream_capturing()
+        if slot['event'] is not None and not capturing:
+            slot['event'].synchronize()          # the previous upload from this slot has been consumed
+        slot['view'][:] = plan['meta']
+        plan['meta_dev'].copy_(slot['pin'], non_blocking=True)
+        if not capturing:
+            slot['event'] = torch.cuda.Event()
+            slot['event'].record()
+
     def _plan(self, gi, params, clip_ids):
         key = (gi, tuple((p.data_ptr(), p.dtype) for p in params), tuple(sorted(clip_ids)) if clip_ids else ())
         plan = self._plans.get(gi)
@@ -80,12 +95,14 @@ class AdamP(Optimizer):
                 meta[t]['p'] = p.data_ptr()
             meta[t]['m'] = st['exp_avg'].data_ptr(); meta[t]['v'] = st['exp_avg_sq'].data_ptr()
             meta[t]['numel'] = numel; meta[t]['inner'] = inner; meta[t]['n0'] = n0; meta[t]['flags'] = flags
-        meta_pin = torch.empty(meta.nbytes, dtype=torch.uint8).pin_memory()
-        meta_view = meta_pin.numpy().view(self.META_DTYPE)
-        meta_view[:] = meta
-        meta = meta_view                         # the table lives in pinned memory: uploads are async (graph-capturable)
+        # Uploads go through a ring of pinned staging buffers (async, graph-capturable).  The host runs up to a
+        # step ahead of the GPU, so a slot is rewritten only after the event recorded behind its last upload.
+        pins = []
+        for _ in range(self.PIN_SLOTS):
+            t_pin = torch.empty(meta.nbytes, dtype=torch.uint8).pin_memory()
+            pins.append({'pin': t_pin, 'view': t_pin.numpy().view(self.META_DTYPE), 'event': None})
         plan = {
-            'key': key, 'meta': meta, 'meta_pin': meta_pin,
+            'key': key, 'meta': meta, 'pins': pins, 'pin_next': 0,
             'meta_dev': torch.empty(meta.nbytes, dtype=torch.uint8, device=dev),
             'items': torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 3).contiguous(),
             'matrix_ids': torch.tensor(matrix_ids or [0], dtype=torch.int32, device=dev),
@@ -140,7 +157,7 @@ class AdamP(Optimizer):
             gptrs = [g.data_ptr() for g in grads]
             if gptrs != plan['gptrs']:
                 plan['meta']['g'] = np.asarray(gptrs, dtype=np.uint64)
-                plan['meta_dev'].copy_(plan['meta_pin'], non_blocking=True)
+                self._upload_meta(plan)
                 plan['gptrs'] = gptrs
             stream = ctypes.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
             n_items = plan['items'].shape[0]

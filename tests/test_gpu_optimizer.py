@@ -98,3 +98,36 @@ def test_fused_adamp_bf16_weights_fp32_masters():
             if k in half:
                 assert q.dtype == torch.bfloat16
                 assert torch.equal(q.detach(), master.to(torch.bfloat16))
+
+
+def test_fused_adamp_async_uploads_do_not_race():
+    """The gradient-pointer table is uploaded asynchronously from pinned memory while the host runs ahead of the
+    GPU; a step must still see ITS pointers (regression: a single staging buffer was overwritten by the next
+    step's pointers before the previous copy had executed)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.algorithms.optimizers import AdamP
+    dev = torch.device('cuda:0')
+
+    def run(sync_every_step):
+        gen = torch.Generator().manual_seed(3)
+        ps = [torch.nn.Parameter((torch.randn(*s, generator=gen) * 0.1).to(dev)) for s in [(96, 200), (50,), (8, 4, 3, 3)]]
+        opt = AdamP(ps, lr=1e-2)
+        grads = [[(torch.randn(p.shape, generator=gen)).to(dev) for p in ps] for _ in range(12)]   # distinct addresses
+        big = torch.randn(4096, 4096, device=dev)
+        torch.cuda.synchronize()
+        for gs in grads:
+            for _ in range(6):
+                big = (big @ big).clamp_(-1, 1)       # keep the GPU busy so that the host runs ahead
+            for p, g in zip(ps, gs):
+                p.grad = g
+            opt.step(clip=(ps, 2.0))
+            if sync_every_step:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return [p.detach().cpu().numpy() for p in ps]
+
+    ref = run(True)
+    got = run(False)
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
