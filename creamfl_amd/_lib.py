@@ -34,6 +34,9 @@ SIGNATURES = {
     'cfl_intra_ws_bytes': (c_size_t, [c_int]),
     'cfl_intra_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_kd_mse': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'cfl_sup_ws_bytes': (c_size_t, [c_int, c_int]),
+    'cfl_sup_glue_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P]),
+    'cfl_sup_glue_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     'cfl_conw_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cfl_conw_logprob': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_conw_combine': (c_int, [POINTER(c_void_p), _P, c_int, c_int, c_int, _P, _P, _P]),

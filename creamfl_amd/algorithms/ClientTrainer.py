@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from .. import losses
+from .. import losses, ops
 from ..networks.language_model import EncoderText
 from ..networks.resnet_client import resnet18_client
 from ..utils.Utils import to_one_hot
@@ -163,11 +163,10 @@ class ClientTrainer:
         return out.squeeze() if out.dim() > 2 else out
 
     def _supervised_epoch(self):
-        """ClientTrainer.py:322-365: CE with the one-hot margin + centre loss on the class weights."""
+        """ClientTrainer.py:322-365: CE with the one-hot margin + centre loss on the class weights (fused, 8f-4)."""
         self.model.train()
         for i, data in enumerate(self.train_loader or []):
             self.optimizer.zero_grad()
-            center_labels_var = self.class_label.to(torch.long).to(self.gpuid)
             if self.dset_name in IMAGE_SETS:
                 inputs_bt, labels_bt = data
                 labels_var = labels_bt.to(self.gpuid)
@@ -176,15 +175,11 @@ class ClientTrainer:
                 inputs_bt, labels_bt, caplens = data
                 labels_var = labels_bt.to(self.gpuid)
                 fvec, _, class_weight, _ = self.model(inputs_bt.to(self.gpuid).contiguous(), caplens.to(self.gpuid))
-            labels_var_one_hot = to_one_hot(labels_var.cpu(), n_dims=self.classSize)
-            fvec = fvec - self.inter_distance * labels_var_one_hot.to(self.gpuid)
-            loss = self.criterion(fvec, labels_var)
-            center_loss = self.criterion(torch.mm(class_weight, torch.t(class_weight)), center_labels_var)
-            total_loss = 0.5 * center_loss + loss
+            # one-hot margin + CE + centre loss + precision@1/@k: three fused launches (csrc/supervised.hip)
             k5 = {'Cifar100': 5, 'Cifar10': 5, 'AG_NEWS': 4, 'YelpReviewPolarity': 2}[self.dset_name]
-            prec1, prec5 = accuracy(fvec.data, labels_bt, topk=(1, k5))
-            self.top1.update(prec1[0], inputs_bt.size(0))
-            self.top5.update(prec5[0], inputs_bt.size(0))
+            total_loss, stats = ops.supervised_glue(fvec, labels_var, class_weight, self.inter_distance, topk=k5)
+            self.top1.update(stats[3], inputs_bt.size(0))
+            self.top5.update(stats[4], inputs_bt.size(0))
             self.losses.update(total_loss.detach(), inputs_bt.size(0))
             total_loss.backward()
             self.optimizer.step()

@@ -223,6 +223,50 @@ def kd_mse(output, aggregate, d_idx, kd_weight=1.0):
     return _KdMseFn.apply(out, agg, _idx(d_idx, out.device), float(kd_weight))
 
 
+class _SupGlueFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fvec, labels, class_weight, margin, topk, center_weight):
+        lib = _lib.load()
+        B, C = fvec.shape
+        Dw = class_weight.shape[1]
+        out5 = torch.empty(5, dtype=torch.float32, device=fvec.device)
+        ws = _ws(lib.cfl_sup_ws_bytes(B, C), fvec.device)
+        _lib.check(lib.cfl_sup_glue_fwd(_ptr(fvec), _ptr(labels), _ptr(class_weight), B, C, Dw, margin, topk,
+                                        center_weight, _ptr(out5), _ptr(ws), _stream(fvec)), 'cfl_sup_glue_fwd')
+        ctx.save_for_backward(fvec, labels, class_weight, ws)
+        ctx.hyper = (margin, center_weight)
+        ctx.mark_non_differentiable(out5)
+        return out5[0].clone(), out5
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        lib = _lib.load()
+        fvec, labels, class_weight, ws = ctx.saved_tensors
+        margin, center_weight = ctx.hyper
+        B, C = fvec.shape
+        Dw = class_weight.shape[1]
+        dF = torch.empty_like(fvec) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(class_weight) if ctx.needs_input_grad[2] else None
+        gg = g.reshape(1).to(torch.float32).contiguous()
+        _lib.check(lib.cfl_sup_glue_bwd(_ptr(fvec), _ptr(labels), _ptr(class_weight), B, C, Dw, margin, center_weight,
+                                        _ptr(gg), _ptr(ws), _ptr(dF), _ptr(dW), _stream(fvec)), 'cfl_sup_glue_bwd')
+        return dF, None, dW, None, None, None
+
+
+def supervised_glue(fvec, labels, class_weight, inter_distance, topk=5, center_weight=0.5):
+    """SURVEY 8f-4, the client's supervised loss glue (ClientTrainer.py:344-361): one-hot margin subtract, CE,
+    centre loss CE(class_weight @ class_weight^T, arange(C)) and precision@1 / @topk in three launches.
+    Returns (total_loss 0-d with grad to fvec and class_weight, stats[5] = {total, ce, center, prec@1 %, prec@topk %})."""
+    F = _f32(fvec, 'fvec')
+    W = _f32(class_weight, 'class_weight')
+    if F.dim() != 2 or W.dim() != 2 or W.shape[0] != F.shape[1]:
+        raise RuntimeError(f'shape mismatch: fvec {tuple(F.shape)} class_weight {tuple(W.shape)}')
+    y = _idx(labels, F.device)
+    if y.numel() != F.shape[0]:
+        raise RuntimeError(f'labels {tuple(y.shape)} do not match fvec {tuple(F.shape)}')
+    return _SupGlueFn.apply(F, y, W, float(inter_distance), int(topk), float(center_weight))
+
+
 # --------------------------------------------------------------------------- A5: con_w
 @torch.no_grad()
 def conw_logprob(vec, global_other, row0=0, rows=None):

@@ -106,6 +106,24 @@ int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, cons
 int cfl_kd_mse(const float* out, const float* agg, const long long* idx, int B, int D, int M, float weight,
                float* loss, float* dout_unit, void* ws, void* stream);
 
+/* ---- client supervised step glue ------------------------------------------------
+ * Replaces, per local batch (src/algorithms/ClientTrainer.py:344-361 with to_one_hot src/utils/Utils.py:6-13 and
+ * accuracy ClientTrainer.py:114-129):
+ *     fvec  = fvec - inter_distance * to_one_hot(labels, C)
+ *     loss  = CE(fvec, labels);  center = CE(class_weight @ class_weight^T, arange(C))
+ *     total = loss + center_weight * center          (center_weight = 0.5 in the reference)
+ *     prec1, preck = accuracy(fvec, labels, topk=(1, topk))
+ * fvec [B,C], labels int64 [B] (a label outside [0,C) makes the loss NaN), class_weight [C,Dw], all dense row-major.
+ * out5 = {total, loss, center, prec@1 in %, prec@topk in %}.  Ties in the top-k count the lower class index first.
+ * bwd: gout[0] = d/d total (device scalar); dfvec [B,C] and dclass_weight [C,Dw] may each be NULL.
+ * ws: cfl_sup_ws_bytes(B, C), written by fwd and read by bwd.  C <= 4096. */
+size_t cfl_sup_ws_bytes(int B, int C);
+int cfl_sup_glue_fwd(const float* fvec, const long long* labels, const float* class_weight, int B, int C, int Dw,
+                     float inter_distance, int topk, float center_weight, float* out5, void* ws, void* stream);
+int cfl_sup_glue_bwd(const float* fvec, const long long* labels, const float* class_weight, int B, int C, int Dw,
+                     float inter_distance, float center_weight, const float* gout, const void* ws, float* dfvec,
+                     float* dclass_weight, void* stream);
+
 /* ---- A5: con_w aggregation ----------------------------------------------------------------
  * Replaces the closure `aggregation` in MMFL.distill (src/algorithms/MMFL.py:298-335).
  * logprob: out_l[n - row0] = V_n.G_n - log sum_m exp(V_n.G_m)  for n in [row0, row0+rows)

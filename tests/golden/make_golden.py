@@ -11,6 +11,7 @@ What is imported from the reference:
   src/losses/__init__.py               create('softmax')              -> a34_*.npz
   src/algorithms/eval_coco.py          COCOEvaluator.evaluate_recall  -> a6_*.npz
   src/utils/tensor_utils.py            l2_normalize
+  src/utils/Utils.py                   to_one_hot (+ create('softmax'))  -> f4_*.npz
 Rows A3/A4/A5 are inline loop bodies in the reference (ClientTrainer.py:369-429,
 MMFL.py:298-335); here their literal statement sequence is evaluated with the
 imported criterion object and plain torch ops, which is what pins the oracle.
@@ -196,6 +197,40 @@ def make_a6(eval_coco):
                  t2i=np.array([t2i[k] for k in keys], dtype=np.float64))
 
 
+def make_f4(losses_mod, utils_mod):
+    """literal statement sequence of ClientTrainer.py:344-357 with the reference's own to_one_hot
+    and criterion objects (the ClientTrainer module itself needs apex/torchvision and cannot be imported)."""
+    criterion = losses_mod.create('softmax')
+    for (tag, b, c, dw, margin, k5, seed) in [('cifar100', 64, 100, 512, 4.0, 5, 0), ('cifar10', 50, 10, 512, 4.0, 5, 1),
+                                              ('agnews', 33, 4, 256, 4.0, 4, 2), ('yelp', 16, 2, 256, 4.0, 2, 3),
+                                              ('wide', 7, 300, 96, 1.5, 5, 4)]:
+        gen = torch.Generator().manual_seed(100 + seed)
+        labels_var = torch.randint(0, c, (b,), generator=gen)
+        class_weight = torch.relu(torch.randn(c, dw, generator=gen) * 0.05).requires_grad_(True)
+        fvec0 = (torch.randn(b, c, generator=gen) * 2.0)
+        fvec0[torch.arange(b), labels_var] += 3.0               # mostly-right classifier: precision is not trivial
+        fvec0.requires_grad_(True)
+        class_label = torch.Tensor(np.array(range(c)))          # ClientTrainer.py:266
+        center_labels_var = class_label.to(torch.long)
+        labels_var_one_hot = utils_mod.to_one_hot(labels_var, n_dims=c)
+        fvec = fvec0 - margin * labels_var_one_hot
+        loss = criterion(fvec, labels_var)
+        center_loss = criterion(torch.mm(class_weight, torch.t(class_weight)), center_labels_var)
+        total_loss = 0.5 * center_loss + loss
+        # accuracy(fvec.data, labels_bt, topk=(1, k5))  (ClientTrainer.py:114-129; `.to(gpuid)` is the identity on CPU)
+        maxk = max((1, k5))
+        _, pred = fvec.data.topk(maxk, 1, True, True)
+        pred = pred.t()
+        correct = pred.eq(labels_var.view(1, -1).expand_as(pred))
+        prec = [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / b) for k in (1, k5)]
+        total_loss.backward()
+        np.savez(os.path.join(OUT, f'f4_{tag}.npz'), fvec=fvec0.detach().numpy(), labels=labels_var.numpy(),
+                 class_weight=class_weight.detach().numpy(), margin=np.float32(margin), topk=np.int64(k5),
+                 total=total_loss.detach().numpy(), ce=loss.detach().numpy(), center=center_loss.detach().numpy(),
+                 prec1=prec[0].numpy(), preck=prec[1].numpy(), dfvec=fvec0.grad.numpy(),
+                 dclass_weight=class_weight.grad.numpy())
+
+
 def main():
     assert os.path.isdir(REF), 'reference checkout not present (build container only)'
     sys.path[:0] = [REF, os.path.join(REF, 'src')]
@@ -212,6 +247,8 @@ def main():
     make_a34(losses_mod)
     make_a5()
     make_a6(eval_coco)
+    import src.utils.Utils as utils_mod
+    make_f4(losses_mod, utils_mod)
     print('golden vectors written to', OUT)
 
 

@@ -362,3 +362,56 @@ def test_kd_mse_matches_torch(dev, b, m, d, w):
     (2.5 * ref).backward()
     _close(loss.item(), ref.item(), 1e-5, 0)
     _close(og.grad.cpu().numpy(), oc.grad.numpy(), 1e-5, 1e-9)
+
+
+# ------------------------------------------------------------------------------------------ supervised glue (8f-4)
+@pytest.mark.parametrize('fname', golden_files('f4_'))
+def test_f4_supervised_glue_golden(dev, fname):
+    """cfl_sup_glue_fwd/bwd against the reference-generated vectors (ClientTrainer.py:344-357)."""
+    from creamfl_amd import ops
+    z = _load(fname)
+    fvec = torch.from_numpy(z['fvec']).to(dev).requires_grad_(True)
+    W = torch.from_numpy(z['class_weight']).to(dev).requires_grad_(True)
+    labels = torch.from_numpy(z['labels']).to(dev)
+    total, stats = ops.supervised_glue(fvec, labels, W, float(z['margin']), int(z['topk']))
+    total.backward()
+    st = stats.cpu().numpy()
+    _close(total.item(), float(z['total']), 1e-5, 0)
+    _close(st[1], float(z['ce']), 1e-5, 0)
+    _close(st[2], float(z['center']), 1e-5, 0)
+    assert st[3] == np.float32(z['prec1'][0]) and st[4] == np.float32(z['preck'][0])      # counts: exact
+    _close(fvec.grad.cpu().numpy(), z['dfvec'], 1e-4, 1e-8)
+    _close(W.grad.cpu().numpy(), z['dclass_weight'], 1e-4, 1e-8)
+
+
+@pytest.mark.parametrize('b,c,dw,k', [(1, 2, 1, 1), (512, 100, 512, 5), (513, 80, 2048, 5), (64, 1000, 300, 7), (3, 4096, 8, 2)])
+def test_f4_supervised_glue_vs_oracle(dev, b, c, dw, k):
+    """Shapes beyond the goldens (batch 512 of the reference, ragged C / Dw, the C limit), fp64 oracle."""
+    from creamfl_amd import ops
+    from oracle import supervised
+    gen = torch.Generator().manual_seed(b * 7 + c)
+    labels = torch.randint(0, c, (b,), generator=gen)
+    fv = torch.randn(b, c, generator=gen) * 3
+    W = torch.relu(torch.randn(c, dw, generator=gen) * (2.0 / dw ** 0.5))
+    fg = fv.to(dev).requires_grad_(True)
+    Wg = W.to(dev).requires_grad_(True)
+    total, stats = ops.supervised_glue(fg, labels.to(dev), Wg, 4.0, k)
+    (1.7 * total).backward()
+    fc = fv.double().requires_grad_(True)
+    Wc = W.double().requires_grad_(True)
+    t, ce, cen, p1, pk = supervised.supervised_glue(fc, labels, Wc, 4.0, k)
+    (1.7 * t).backward()
+    st = stats.cpu().numpy()
+    _close(total.item(), t.item(), 2e-5, 0)
+    _close(st[:3], [t.item(), ce.item(), cen.item()], 2e-5, 0)
+    _close(st[3:], [float(p1), float(pk)], 1e-6, 0)
+    _close(fg.grad.cpu().numpy(), fc.grad.numpy(), 1e-4, 1e-8)
+    _close(Wg.grad.cpu().numpy(), Wc.grad.numpy(), 1e-4, 1e-8 + 1e-5 * float(Wc.grad.abs().max()))
+
+
+def test_f4_supervised_glue_bad_label_is_loud(dev):
+    from creamfl_amd import ops
+    fv = torch.randn(4, 3, device=dev)
+    W = torch.rand(3, 8, device=dev)
+    total, _ = ops.supervised_glue(fv, torch.tensor([0, 1, 3, 2], device=dev), W, 4.0, 2)
+    assert torch.isnan(total)

@@ -139,3 +139,21 @@ def test_a6_recall(fname):
         assert np.array_equal(lit, cnt)
         sc = oracle.recall_scores(cnt)
         np.testing.assert_array_equal(np.array([sc[k] for k in keys]), want)
+
+
+@pytest.mark.parametrize('fname', golden_files('f4_'))
+def test_f4_supervised_glue(fname):
+    """oracle/supervised.py against the reference's to_one_hot + criterion statement sequence."""
+    from oracle import supervised
+    z = _load(fname)
+    fvec = torch.from_numpy(z['fvec']).requires_grad_(True)
+    W = torch.from_numpy(z['class_weight']).requires_grad_(True)
+    labels = torch.from_numpy(z['labels'])
+    total, ce, center, p1, pk = supervised.supervised_glue(fvec, labels, W, float(z['margin']), int(z['topk']))
+    total.backward()
+    np.testing.assert_allclose(total.item(), float(z['total']), rtol=1e-6)
+    np.testing.assert_allclose(ce.item(), float(z['ce']), rtol=1e-6)
+    np.testing.assert_allclose(center.item(), float(z['center']), rtol=1e-6)
+    assert float(p1) == float(z['prec1'][0]) and float(pk) == float(z['preck'][0])
+    np.testing.assert_allclose(fvec.grad.numpy(), z['dfvec'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(W.grad.numpy(), z['dclass_weight'], rtol=1e-5, atol=1e-8)

@@ -116,6 +116,34 @@ def case_a6(Nq, Ng, D):
             'fp64_TFLOPs_two_pass': round(flops / us / 1e6, 2)}
 
 
+def case_f4(B, C, Dw, k=5):
+    """Client supervised glue: fused vs the reference's torch op sequence (wall time per fwd+bwd)."""
+    g = torch.Generator(device='cuda').manual_seed(4)
+    fv = (torch.randn(B, C, generator=g, device='cuda') * 3).requires_grad_(True)
+    W = torch.relu(torch.randn(C, Dw, generator=g, device='cuda') * 0.05).requires_grad_(True)
+    y = torch.randint(0, C, (B,), generator=g, device='cuda')
+    crit = torch.nn.CrossEntropyLoss()
+    center = torch.arange(C, device='cuda')
+
+    def fused():
+        loss, _ = ops.supervised_glue(fv, y, W, 4.0, k)
+        loss.backward()
+
+    def eager():                                   # ClientTrainer.py:344-357 statement by statement
+        one_hot = torch.zeros(B, C).scatter_(1, y.cpu().view(-1, 1), 1)
+        f2 = fv - 4.0 * one_hot.to('cuda')
+        loss = crit(f2, y) + 0.5 * crit(torch.mm(W, W.t()), center)
+        _, pred = f2.data.topk(k, 1, True, True)
+        correct = pred.t().eq(y.view(1, -1).expand(k, B))
+        correct[:1].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / B)
+        correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / B)
+        loss.backward()
+    us, prof = timed(fused)
+    us_eager, _ = timed(eager)
+    return {'case': f'f4_supervised_glue B={B} C={C} Dw={Dw}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'eager_torch_us_per_step': round(us_eager, 1)}
+
+
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -171,7 +199,7 @@ def case_ablate():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', default='a1,a3,a5,a2,a6')
+    ap.add_argument('--cases', default='a1,a3,a5,a2,a6,f4')
     ap.add_argument('--conw-m', type=int, default=50000)
     args = ap.parse_args()
     cases = args.cases.split(',')
@@ -186,6 +214,8 @@ def main():
         out += [case_a2(256, 49, 2048, 1024, 512), case_a2(128, 49, 512, 256, 256)]
     if 'a6' in cases:
         out += [case_a6(1000, 5000, 512), case_a6(5000, 25000, 512)]
+    if 'f4' in cases:
+        out += [case_f4(512, 100, 512), case_f4(512, 10, 512), case_f4(512, 4, 512, 4)]
     if 'gemm' in cases:
         out += [case_gemm(4096, 4096, 4096), case_gemm(8192, 8192, 512), case_gemm(8192, 8192, 256)]
     if 'ablate' in cases:
