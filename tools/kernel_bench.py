@@ -144,6 +144,35 @@ def case_f4(B, C, Dw, k=5):
             'eager_torch_us_per_step': round(us_eager, 1)}
 
 
+def case_bn(N, H, C, res, relu=True):
+    """Fused BN(+add)(+ReLU) fwd+bwd on one ResNet-101 activation shape (NHWC bf16): GB/s of each kernel."""
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(N, C, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    r = None
+    if res:
+        r = torch.randn(N, C, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        r.requires_grad_(True)
+    w = torch.ones(C, device='cuda', requires_grad=True)
+    b = torch.zeros(C, device='cuda', requires_grad=True)
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    dy = torch.randn(N, C, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def step():
+        y = ops.bn_act_train(x, w, b, rm, rv, 0.1, 1e-5, relu=relu, residual=r)
+        y.backward(dy)
+        x.grad = None
+        if r is not None:
+            r.grad = None
+    us, prof = timed(step, iters=10)
+    E = N * H * H * C * 2                                   # bytes of one bf16 activation pass
+    passes = {'cfl_bn_stats_kernel': 1, 'cfl_bn_apply_kernel': 3 if res else 2, 'cfl_bn_bwd_reduce_kernel': 3 if relu else 2,
+              'cfl_bn_bwd_apply_kernel': (5 if res else 4) if relu else 3}
+    gbps = {k: round(passes[k] * E / v / 1e3) for k, v in prof.items() if k in passes}
+    return {'case': f'bn N={N} HxW={H}x{H} C={C} res={int(res)} relu={int(relu)}', 'MB_per_pass': round(E / 1e6, 1),
+            'kernels_us': prof, 'kernels_GBps': gbps}
+
+
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -216,6 +245,11 @@ def main():
         out += [case_a6(1000, 5000, 512), case_a6(5000, 25000, 512)]
     if 'f4' in cases:
         out += [case_f4(512, 100, 512), case_f4(512, 10, 512), case_f4(512, 4, 512, 4)]
+    if 'bn' in cases:
+        for (H, C, res) in [(112, 64, False), (56, 64, False), (56, 256, True), (56, 128, False), (28, 128, False),
+                            (28, 512, True), (28, 256, False), (14, 256, False), (14, 1024, True), (14, 512, False),
+                            (7, 512, False), (7, 2048, True)]:
+            out.append(case_bn(256, H, C, res))
     if 'gemm' in cases:
         out += [case_gemm(4096, 4096, 4096), case_gemm(8192, 8192, 512), case_gemm(8192, 8192, 256)]
     if 'ablate' in cases:
