@@ -34,6 +34,7 @@ SIGNATURES = {
     'cfl_intra_ws_bytes': (c_size_t, [c_int]),
     'cfl_intra_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_kd_mse': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'cfl_gemm_bf16_nt': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, _P]),
     'cfl_sup_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_sup_glue_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P]),
     'cfl_sup_glue_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),

@@ -106,6 +106,16 @@ int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, cons
 int cfl_kd_mse(const float* out, const float* agg, const long long* idx, int B, int D, int M, float weight,
                float* loss, float* dout_unit, void* ws, void* stream);
 
+/* ---- bf16 MFMA GEMM probe ------------------------------------------------------------------------------
+ * C[M,N] = A[M,K] * B[N,K]^T, bf16 in / bf16 out, fp32 accumulation: the 1x1 convolutions of the torchvision
+ * Bottleneck blocks (src/networks/models/image_encoder.py:27-36) on the NHWC-flattened activation (forward:
+ * A = x[M,Ci], B = w[Co,Ci]).  It ties MIOpen on ResNet-101's shapes and does not beat it, so the product path keeps
+ * MIOpen; this entry point is the bf16 calibration probe (tools/kernel_bench.py --cases gemm16).
+ * lda/ldb/ldc in elements; K % 64 == 0, N % 8 == 0, lda % 8 == ldb % 8 == ldc % 8 == 0, 16-byte aligned pointers.
+ * variant 0 = pick by shape; 21 / 22 / 41 / 42 / 44 select the wave tile (TM,TN) for benchmarking. */
+int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
+                     int M, int N, int K, int variant, void* stream);
+
 /* ---- client supervised step glue ------------------------------------------------
  * Replaces, per local batch (src/algorithms/ClientTrainer.py:344-361 with to_one_hot src/utils/Utils.py:6-13 and
  * accuracy ClientTrainer.py:114-129):

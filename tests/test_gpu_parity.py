@@ -415,3 +415,23 @@ def test_f4_supervised_glue_bad_label_is_loud(dev):
     W = torch.rand(3, 8, device=dev)
     total, _ = ops.supervised_glue(fv, torch.tensor([0, 1, 3, 2], device=dev), W, 4.0, 2)
     assert torch.isnan(total)
+
+
+# ------------------------------------------------------------------------------------------ bf16 GEMM probe
+@pytest.mark.parametrize('m,n,k,variant', [(256, 64, 64, 0), (1000, 128, 256, 0), (50176, 1024, 256, 22), (12544, 512, 2048, 0),
+                                           (777, 72, 128, 21), (4096, 256, 1024, 44), (3000, 256, 512, 42), (513, 64, 320, 41)])
+def test_gemm_bf16_nt_matches_torch(dev, m, n, k, variant):
+    """cfl_gemm_bf16_nt vs an fp32 matmul of the same bf16 inputs (asymmetric random operands, ragged M / N);
+    tolerance = one bf16 rounding of the output."""
+    from creamfl_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=gen)).to(torch.bfloat16).to(dev)
+    b = (torch.randn(n, k, generator=gen) * 0.1).to(torch.bfloat16).to(dev)
+    c = torch.full((m, n), float('nan'), dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.cfl_gemm_bf16_nt(a.data_ptr(), k, b.data_ptr(), k, c.data_ptr(), n, m, n, k, variant, st), 'cfl_gemm_bf16_nt')
+    ref = a.float() @ b.float().t()
+    scale = float(ref.abs().max())
+    err = float((c.float() - ref).abs().max())
+    assert err <= 2 ** -8 * scale + 1e-6, (err, scale)

@@ -173,6 +173,36 @@ def case_bn(N, H, C, res, relu=True):
             'kernels_us': prof, 'kernels_GBps': gbps}
 
 
+def case_gemm16(H, Ci, Co, variants=(0,), N=256):
+    """1x1 convolution as bf16 NT GEMM on the NHWC-flattened activation vs MIOpen's conv (forward)."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    M = N * H * H
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randn(M, Ci, generator=g, device='cuda').to(torch.bfloat16)
+    w = (torch.randn(Co, Ci, generator=g, device='cuda') * 0.05).to(torch.bfloat16)
+    y = torch.empty(M, Co, device='cuda', dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = (x[:4096].float() @ w.float().t())
+    out = {'case': f'gemm16 1x1 {H}x{H} {Ci}->{Co} M={M}', 'roof_us': round(M * (Ci + Co) * 2 / 6.0e6, 1)}
+    for var in variants:
+        def run():
+            _lib.check(lib.cfl_gemm_bf16_nt(x.data_ptr(), Ci, w.data_ptr(), Ci, y.data_ptr(), Co, M, Co, Ci, var, st), 'gemm16')
+        run()
+        err = (y[:4096].float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+        us, prof = timed(run, iters=20)
+        k_us = prof.get('cfl_gemm_bf16_kernel', us)
+        out[f'v{var}_us'] = k_us
+        out[f'v{var}_TF'] = round(2 * M * Ci * Co / k_us / 1e6)
+        out[f'v{var}_relerr'] = round(err, 5)
+    x4 = x.view(N, H, H, Ci).permute(0, 3, 1, 2)
+    w4 = w.view(Co, Ci, 1, 1).contiguous(memory_format=torch.channels_last)
+    torch.backends.cudnn.benchmark = True
+    us_conv, _ = timed(lambda: F.conv2d(x4, w4), iters=20)
+    out['miopen_conv_us'] = round(us_conv, 1)
+    return out
+
+
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -250,6 +280,12 @@ def main():
                             (28, 512, True), (28, 256, False), (14, 256, False), (14, 1024, True), (14, 512, False),
                             (7, 512, False), (7, 2048, True)]:
             out.append(case_bn(256, H, C, res))
+    if 'gemm16' in cases:
+        os.environ.setdefault('MIOPEN_FIND_MODE', '2')
+        for (H, Ci, Co) in [(56, 64, 64), (56, 64, 256), (56, 256, 64), (28, 128, 512), (28, 512, 128),
+                            (14, 256, 1024), (14, 1024, 256), (7, 512, 2048), (7, 2048, 512)]:
+            vs = [v for v in (44, 42, 22, 21, 41) if not (v in (44, 42, 22) and Co < 128)]
+            out.append(case_gemm16(H, Ci, Co, vs))
     if 'gemm' in cases:
         out += [case_gemm(4096, 4096, 4096), case_gemm(8192, 8192, 512), case_gemm(8192, 8192, 256)]
     if 'ablate' in cases:
