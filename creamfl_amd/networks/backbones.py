@@ -20,17 +20,38 @@ class BNAct(nn.BatchNorm2d):
     autocast training regime of the bench) the whole normalise -> add -> relu chain and its backward run as the fused
     HBM-streaming kernels of csrc/bnorm.hip; any other input (fp32, NCHW, CPU) takes the plain library path."""
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # `num_batches_tracked += 1` is a one-element kernel per BN layer per step (105 launches, 0.5 ms of the
+        # ResNet-101 step); with a fixed momentum nothing reads it during training, so the increments are counted
+        # on the host and folded into the buffer whenever the state is observed (state_dict) or the library path runs.
+        self._nbt_pending = 0
+        self.register_state_dict_pre_hook(BNAct._flush_hook)
+
+    @staticmethod
+    def _flush_hook(module, prefix, keep_vars):
+        module.flush_num_batches_tracked()
+
+    def flush_num_batches_tracked(self):
+        if self._nbt_pending and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._nbt_pending)
+        self._nbt_pending = 0
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, x, residual=None, relu=False):
         from .. import ops
         if self.track_running_stats and self.momentum is not None and self.affine and ops.bn_act_supported(x, self.num_features):
             if self.training:
-                if self.num_batches_tracked is not None:
-                    self.num_batches_tracked.add_(1)
+                self._nbt_pending += 1
                 return ops.bn_act_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
                                         self.eps, relu=relu, residual=residual)
             if not torch.is_grad_enabled():
                 return ops.bn_act_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                        relu=relu, residual=residual)
+        self.flush_num_batches_tracked()
         y = super().forward(x)
         if residual is not None:
             y = y + residual
@@ -231,12 +252,13 @@ class _SelfAttention(nn.Module):
         self.key = nn.Linear(c.hidden_size, c.hidden_size)
         self.value = nn.Linear(c.hidden_size, c.hidden_size)
 
-    def forward(self, x, mask):
+    def forward(self, x, mask, cls_only=False):
         B, L, H = x.shape
         def split(t):
-            return t.view(B, L, self.h, H // self.h).transpose(1, 2)
-        o = F.scaled_dot_product_attention(split(self.query(x)), split(self.key(x)), split(self.value(x)), attn_mask=mask)
-        return o.transpose(1, 2).reshape(B, L, H)
+            return t.view(B, t.shape[1], self.h, H // self.h).transpose(1, 2)
+        xq = x[:, :1] if cls_only else x                   # only the [CLS] query is consumed downstream
+        o = F.scaled_dot_product_attention(split(self.query(xq)), split(self.key(x)), split(self.value(x)), attn_mask=mask)
+        return o.transpose(1, 2).reshape(B, xq.shape[1], H)
 
 
 class _SelfOutput(nn.Module):
@@ -256,8 +278,8 @@ class _Attention(nn.Module):
         self.self = _SelfAttention(c)
         self.output = _SelfOutput(c, c.hidden_size)
 
-    def forward(self, x, mask):
-        return self.output(self.self(x, mask), x)
+    def forward(self, x, mask, cls_only=False):
+        return self.output(self.self(x, mask, cls_only), x[:, :1] if cls_only else x)
 
 
 class _Intermediate(nn.Module):
@@ -276,8 +298,8 @@ class _BertLayer(nn.Module):
         self.intermediate = _Intermediate(c)
         self.output = _SelfOutput(c, c.intermediate_size)
 
-    def forward(self, x, mask):
-        x = self.attention(x, mask)
+    def forward(self, x, mask, cls_only=False):
+        x = self.attention(x, mask, cls_only)
         return self.output(self.intermediate(x), x)
 
 
@@ -286,9 +308,10 @@ class _BertEncoder(nn.Module):
         super().__init__()
         self.layer = nn.ModuleList([_BertLayer(c) for _ in range(c.num_hidden_layers)])
 
-    def forward(self, x, mask):
-        for l in self.layer:
-            x = l(x, mask)
+    def forward(self, x, mask, cls_only=False):
+        last = len(self.layer) - 1
+        for i, l in enumerate(self.layer):
+            x = l(x, mask, cls_only and i == last)
         return x
 
 
@@ -318,9 +341,12 @@ class BertModel(nn.Module):
     def from_pretrained(cls, name):
         return cls(name)
 
-    def forward(self, input_ids, attention_mask=None, token_type_ids=None, **_):
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, cls_only=False, **_):
+        """`cls_only=True`: the last layer is evaluated for the [CLS] position only and `last_hidden_state` is
+        [B, 1, H] -- identical values and gradients for everything PCME consumes (it reads [:, 0, :] only,
+        src/networks/models/pcme.py:44), 1/12 less work in the tower."""
         mask = None
         if attention_mask is not None:
             mask = attention_mask[:, None, None, :].to(torch.bool)
         x = self.embeddings(input_ids, token_type_ids)
-        return {'last_hidden_state': self.encoder(x, mask)}
+        return {'last_hidden_state': self.encoder(x, mask, cls_only)}

@@ -55,7 +55,8 @@ class PCME(nn.Module):
         if self.config.not_bert:
             caption_output = self.txt_enc(sentences, lengths)
         else:
-            hidden = self.txt_enc(**self._bert_inputs(sentences, captions_word, lengths))['last_hidden_state']
+            extra = {'cls_only': True} if isinstance(self.txt_enc, BertModel) else {}     # only [:, 0, :] is read
+            hidden = self.txt_enc(**self._bert_inputs(sentences, captions_word, lengths), **extra)['last_hidden_state']
             caption_output = {'embedding': ops.l2_normalize(self.linear(hidden[:, 0, :]))}
         return {
             'image_features': image_output['embedding'],

@@ -56,7 +56,7 @@ def test_bn_act_matches_torch(n, c, h, w, relu, res):
                                atol=2e-2 * (float(ref.bias.grad.abs().max()) + 1e-6))
     np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-3, atol=1e-4)
-    assert int(bn.num_batches_tracked) == 1
+    assert int(bn.state_dict()['num_batches_tracked']) == 1          # counted on the host, folded in when observed
     # evaluation mode (running statistics), no grad
     bn.eval()
     ref.eval()
