@@ -6,7 +6,7 @@ returns non-zero, this module raises.  Build the library with
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_uint, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcreamfl_hip.so')
@@ -35,6 +35,13 @@ SIGNATURES = {
     'cfl_intra_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_kd_mse': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_gemm_bf16_nt': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, _P]),
+    'cfl_daln_ws_bytes': (c_size_t, [c_int, c_int]),
+    'cfl_daln_fwd': (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint, _P, _P, _P, _P, _P]),
+    'cfl_daln_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint, _P, _P, _P, _P, c_int, _P, _P]),
+    'cfl_bias_gelu_ws_bytes': (c_size_t, [c_longlong, c_int]),
+    'cfl_bias_gelu_fwd': (c_int, [_P, _P, c_int, c_longlong, c_int, _P, _P]),
+    'cfl_bias_gelu_bwd': (c_int, [_P, _P, c_int, _P, c_longlong, c_int, _P, _P, c_int, _P, _P]),
+    'cfl_dropout_mask': (c_int, [c_uint, c_float, c_longlong, _P, _P]),
     'cfl_sup_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_sup_glue_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P]),
     'cfl_sup_glue_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),

@@ -227,6 +227,15 @@ BERT_CONFIGS = {
 }
 
 
+def _bert_fusable(x, weight, max_out=1 << 30):
+    """The fused glue kernels (csrc/bertfuse.hip) take bf16 GEMM outputs on the GPU: bf16 weights, or bf16 autocast."""
+    if not (x.is_cuda and weight.shape[0] % 8 == 0 and weight.shape[0] <= max_out):
+        return False
+    if weight.dtype == torch.bfloat16 and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled('cuda')):
+        return True
+    return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
 class _BertEmbeddings(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -269,7 +278,15 @@ class _SelfOutput(nn.Module):
         self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
     def forward(self, h, residual):
-        return self.LayerNorm(self.dropout(self.dense(h)) + residual)
+        """Returns (input of the next GEMM, next residual): one buffer under two tensor objects on the fused path
+        (csrc/bertfuse.hip sums their gradients in its backward), the same tensor twice on the library path."""
+        if _bert_fusable(h, self.dense.weight, max_out=2048):
+            from .. import ops
+            g = F.linear(h, self.dense.weight)                        # bias joins the fused kernel
+            return ops.bert_dropout_add_layernorm(g, self.dense.bias, residual, self.LayerNorm.weight, self.LayerNorm.bias,
+                                                  self.dropout.p if self.training else 0.0, self.LayerNorm.eps)
+        y = self.LayerNorm(self.dropout(self.dense(h)) + residual)
+        return y, y
 
 
 class _Attention(nn.Module):
@@ -278,8 +295,8 @@ class _Attention(nn.Module):
         self.self = _SelfAttention(c)
         self.output = _SelfOutput(c, c.hidden_size)
 
-    def forward(self, x, mask, cls_only=False):
-        return self.output(self.self(x, mask, cls_only), x[:, :1] if cls_only else x)
+    def forward(self, x, res, mask, cls_only=False):
+        return self.output(self.self(x, mask, cls_only), res[:, :1] if cls_only else res)
 
 
 class _Intermediate(nn.Module):
@@ -288,6 +305,9 @@ class _Intermediate(nn.Module):
         self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
 
     def forward(self, x):
+        if _bert_fusable(x, self.dense.weight):
+            from .. import ops
+            return ops.bert_bias_gelu(F.linear(x, self.dense.weight), self.dense.bias)
         return F.gelu(self.dense(x))
 
 
@@ -298,9 +318,9 @@ class _BertLayer(nn.Module):
         self.intermediate = _Intermediate(c)
         self.output = _SelfOutput(c, c.intermediate_size)
 
-    def forward(self, x, mask, cls_only=False):
-        x = self.attention(x, mask, cls_only)
-        return self.output(self.intermediate(x), x)
+    def forward(self, x, res, mask, cls_only=False):
+        x, res = self.attention(x, res, mask, cls_only)
+        return self.output(self.intermediate(x), res)
 
 
 class _BertEncoder(nn.Module):
@@ -310,8 +330,9 @@ class _BertEncoder(nn.Module):
 
     def forward(self, x, mask, cls_only=False):
         last = len(self.layer) - 1
+        res = x
         for i, l in enumerate(self.layer):
-            x = l(x, mask, cls_only and i == last)
+            x, res = l(x, res, mask, cls_only and i == last)
         return x
 
 

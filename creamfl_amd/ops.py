@@ -510,6 +510,133 @@ def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, res
     return y
 
 
+# --------------------------------------------------------------------------- BERT tower glue (csrc/bertfuse.hip)
+_DROPOUT_CALLS = [0]
+
+
+def _next_dropout_seed():
+    """Deterministic per call: a counter mixed with torch's seed (torch.manual_seed reproduces the masks)."""
+    _DROPOUT_CALLS[0] += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _DROPOUT_CALLS[0] * 0x85EBCA6B) & 0xFFFFFFFF
+
+
+def _bf16c(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise _lib.CreamflHipError(f'{name}: expected a CUDA/HIP tensor (no CPU fallback in creamfl_amd)')
+    if t.dtype != torch.bfloat16:
+        t = t.to(torch.bfloat16)
+    return t.contiguous()
+
+
+def _alias(t):
+    """A second tensor object on the same storage (not an autograd view): lets one buffer be returned as two
+    outputs of an autograd Function, so that their gradients arrive separately."""
+    return t.new_empty(0).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+
+
+class _DalnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, bias, residual, gamma, beta, p, eps, seed):
+        lib = _lib.load()
+        H = g.shape[-1]
+        T = g.numel() // H
+        need = any(ctx.needs_input_grad[:5])
+        z = torch.empty_like(g)
+        s = torch.empty_like(g) if need else None
+        stats = torch.empty(2, T, dtype=torch.float32, device=g.device) if need else None
+        _lib.check(lib.cfl_daln_fwd(_ptr(g), _ptr(bias), int(bias is not None and bias.dtype == torch.bfloat16), _ptr(residual),
+                                    _ptr(gamma), _ptr(beta), T, H, eps, p, seed, _ptr(z), _ptr(s),
+                                    _ptr(stats), _ptr(stats[1]) if need else None, _stream(g)), 'cfl_daln_fwd')
+        if need:
+            ctx.save_for_backward(s, gamma, stats)
+        ctx.hyper = (p, seed, T, H, None if bias is None else (bias.dtype, bias.shape))
+        return z, _alias(z)
+
+    @staticmethod
+    def backward(ctx, dza, dzb):
+        lib = _lib.load()
+        s, gamma, stats = ctx.saved_tensors
+        p, seed, T, H, bias_meta = ctx.hyper
+        if dza is None:
+            dza, dzb = dzb, None
+        if dza is None:
+            return (None,) * 8
+        dza = _bf16c(dza, 'dz')
+        dzb = _bf16c(dzb, 'dz') if dzb is not None else None
+        ds = torch.empty_like(s)
+        dy = torch.empty_like(s) if p > 0 else None
+        dgb = torch.empty(2, H, dtype=torch.float32, device=s.device)
+        dbias = torch.empty(bias_meta[1], dtype=bias_meta[0], device=s.device) if (bias_meta and ctx.needs_input_grad[1]) else None
+        ws = _ws(lib.cfl_daln_ws_bytes(T, H), s.device)
+        _lib.check(lib.cfl_daln_bwd(_ptr(s), _ptr(dza), _ptr(dzb), _ptr(gamma), _ptr(stats), _ptr(stats[1]), T, H, p, seed,
+                                    _ptr(ds), _ptr(dy), _ptr(dgb), _ptr(dbias),
+                                    int(dbias is not None and dbias.dtype == torch.bfloat16), _ptr(ws), _stream(s)), 'cfl_daln_bwd')
+        return (dy if dy is not None else ds), dbias, ds, dgb[0], dgb[1], None, None, None
+
+
+def bert_dropout_add_layernorm(g, bias, residual, gamma, beta, p=0.0, eps=1e-12, seed=None):
+    """LayerNorm(dropout(g + bias) + residual) for the BertSelfOutput / BertOutput sub-layers (csrc/bertfuse.hip).
+    g: bias-free GEMM output, bf16 [..., H].  Returns TWO tensors on the same buffer: feed the first to the next
+    GEMM and use the second as the next residual -- their gradients are summed inside the fused backward."""
+    g = _bf16c(g, 'g')
+    residual = _bf16c(residual, 'residual')
+    if residual.shape != g.shape:
+        raise RuntimeError(f'shape mismatch {tuple(g.shape)} vs {tuple(residual.shape)}')
+    if bias is not None and not bias.is_contiguous():
+        bias = bias.contiguous()
+    if seed is None:
+        seed = _next_dropout_seed() if p > 0 else 0
+    return _DalnFn.apply(g, bias, residual, _f32(gamma, 'gamma'), _f32(beta, 'beta'), float(p), float(eps), int(seed))
+
+
+class _BiasGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, bias):
+        lib = _lib.load()
+        I = g.shape[-1]
+        T = g.numel() // I
+        h = torch.empty_like(g)
+        _lib.check(lib.cfl_bias_gelu_fwd(_ptr(g), _ptr(bias), int(bias is not None and bias.dtype == torch.bfloat16), T, I,
+                                         _ptr(h), _stream(g)), 'cfl_bias_gelu_fwd')
+        ctx.save_for_backward(g, bias)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        g, bias = ctx.saved_tensors
+        I = g.shape[-1]
+        T = g.numel() // I
+        dh = _bf16c(dh, 'dh')
+        du = torch.empty_like(g)
+        dbias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[1]) else None
+        ws = _ws(lib.cfl_bias_gelu_ws_bytes(T, I), g.device)
+        _lib.check(lib.cfl_bias_gelu_bwd(_ptr(g), _ptr(bias), int(bias is not None and bias.dtype == torch.bfloat16), _ptr(dh),
+                                         T, I, _ptr(du), _ptr(dbias), int(dbias is not None and dbias.dtype == torch.bfloat16),
+                                         _ptr(ws), _stream(g)), 'cfl_bias_gelu_bwd')
+        return du, dbias
+
+
+def bert_bias_gelu(g, bias):
+    """gelu(g + bias) (exact erf form) for BertIntermediate; the backward also yields the bias gradient."""
+    g = _bf16c(g, 'g')
+    if bias is not None and not bias.is_contiguous():
+        bias = bias.contiguous()
+    return _BiasGeluFn.apply(g, bias)
+
+
+@torch.no_grad()
+def dropout_keep_mask(seed, p, shape, device):
+    """The keep mask bert_dropout_add_layernorm uses for (seed, p) on a tensor of this shape (test helper)."""
+    lib = _lib.load()
+    n = 1
+    for d in shape:
+        n *= int(d)
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    _lib.check(lib.cfl_dropout_mask(int(seed), float(p), n, _ptr(keep), _stream(keep)), 'cfl_dropout_mask')
+    return keep.view(*shape).bool()
+
+
 # --------------------------------------------------------------------------- A6: retrieval ranks
 @torch.no_grad()
 def rank_count(q_features, g_features, q_labels, g_labels):

@@ -106,6 +106,31 @@ int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, cons
 int cfl_kd_mse(const float* out, const float* agg, const long long* idx, int B, int D, int M, float weight,
                float* loss, float* dout_unit, void* ws, void* stream);
 
+/* ---- BERT text tower glue (row A2: src/networks/models/pcme.py:36-44 builds transformers' BertModel) ------------
+ * The element-wise work between the GEMMs of a BertLayer (third-party `transformers`, restated in csrc/bertfuse.hip):
+ *   daln : z = LayerNorm(dropout(g + bias) + residual)            BertSelfOutput / BertOutput
+ *   bgelu: h = gelu(g + bias)   (exact erf form)                  BertIntermediate
+ * g is the bias-free GEMM output.  All activations bf16 row-major [T, H] / [T, I]; gamma/beta fp32; bias bf16 or fp32
+ * (bias_bf16 flag; NULL = none).  Dropout keep flags are a counter hash of (seed, element index), never stored.
+ * daln_fwd: writes z, and for a later backward s = bf16(dropout(g+bias) + residual), mean[T], rstd[T] (s/mean/rstd
+ *           may be NULL).  H % 4 == 0, H <= 2048, 0 <= p < 1.
+ * daln_bwd: dz = dz_a + dz_b (dz_b may be NULL): the two gradients reaching z (through the next GEMM and through
+ *           the residual connection).  Writes ds = d/d residual, dy = d/d g (NULL when p == 0: identical to ds),
+ *           dgamma_dbeta[2H] fp32, dbias[H] (dbias_bf16 selects its dtype; NULL = skip).  ws: cfl_daln_ws_bytes.
+ * bias_gelu_bwd: du = dh * gelu'(g + bias), dbias[I] = column sums of du.  I % 8 == 0.  ws: cfl_bias_gelu_ws_bytes.
+ * dropout_mask: test helper, the keep flags of n elements (n % 4 == 0). */
+size_t cfl_daln_ws_bytes(int T, int H);
+int cfl_daln_fwd(const void* g, const void* bias, int bias_bf16, const void* residual, const float* gamma, const float* beta,
+                 int T, int H, float eps, float p, unsigned seed, void* z, void* s, float* mean, float* rstd, void* stream);
+int cfl_daln_bwd(const void* s, const void* dz_a, const void* dz_b, const float* gamma, const float* mean, const float* rstd,
+                 int T, int H, float p, unsigned seed, void* ds, void* dy, float* dgamma_dbeta, void* dbias, int dbias_bf16,
+                 void* ws, void* stream);
+size_t cfl_bias_gelu_ws_bytes(long long T, int I);
+int cfl_bias_gelu_fwd(const void* g, const void* bias, int bias_bf16, long long T, int I, void* h, void* stream);
+int cfl_bias_gelu_bwd(const void* g, const void* bias, int bias_bf16, const void* dh, long long T, int I, void* du, void* dbias,
+                      int dbias_bf16, void* ws, void* stream);
+int cfl_dropout_mask(unsigned seed, float p, long long n, unsigned char* keep, void* stream);
+
 /* ---- bf16 MFMA GEMM probe ------------------------------------------------------------------------------
  * C[M,N] = A[M,K] * B[N,K]^T, bf16 in / bf16 out, fp32 accumulation: the 1x1 convolutions of the torchvision
  * Bottleneck blocks (src/networks/models/image_encoder.py:27-36) on the NHWC-flattened activation (forward:
