@@ -266,7 +266,14 @@ class _SelfAttention(nn.Module):
         def split(t):
             return t.view(B, t.shape[1], self.h, H // self.h).transpose(1, 2)
         xq = x[:, :1] if cls_only else x                   # only the [CLS] query is consumed downstream
-        o = F.scaled_dot_product_attention(split(self.query(xq)), split(self.key(x)), split(self.value(x)), attn_mask=mask)
+        if not cls_only and _bert_fusable(x, self.query.weight):
+            # one [3H, H] GEMM instead of three (and one dX GEMM, one bias-gradient reduction, no dX adds in backward)
+            w = torch.cat([self.query.weight, self.key.weight, self.value.weight], 0)
+            b = torch.cat([self.query.bias, self.key.bias, self.value.bias], 0)
+            q, k, v = F.linear(x, w, b).split(H, dim=-1)
+        else:
+            q, k, v = self.query(xq), self.key(x), self.value(x)
+        o = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=mask)
         return o.transpose(1, 2).reshape(B, xq.shape[1], H)
 
 
