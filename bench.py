@@ -201,8 +201,9 @@ def main():
         bn_bytes = {
             'cfl_bn_stats_kernel': 2 * bc['fwd'],
             'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'],
-            'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + 2 * bc['bwd_relu'],
-            'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + 2 * bc['bwd_relu'] + 2 * bc['bwd_res'],
+            # bwd: read dy (+ second upstream gradient), x, (+ y only when the mask cannot be recomputed from x)
+            'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + 2 * bc['bwd_relu'] + 2 * bc['bwd_two'],
+            'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + 2 * bc['bwd_relu'] + 2 * bc['bwd_res'] + 2 * bc['bwd_two'],
         }
         for name, (n, ms) in prof.items():
             base = name

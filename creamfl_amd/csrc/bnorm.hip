@@ -13,6 +13,7 @@
 //         final  mean, invstd, running stats
 //         apply  y = relu?( (x-mean)*invstd*gamma + beta (+ residual) )     (read x (+res), write y)
 //   bwd : reduce (read dy, x, y)               -> partial sum(dy'), sum(dy' * xhat),  dy' = dy * (y > 0) if relu
+//         (without a residual the mask is recomputed from x and y is not read; dy may arrive as two tensors)
 //         final  dgamma, dbeta
 //         apply  dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat));  dres = dy'   (write dx (+ dres))
 #include "common.h"
@@ -112,18 +113,26 @@ __global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const U4* __restrict_
     }
 }
 
-template <bool RELU>
-__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __restrict__ dy, const U4* __restrict__ x,
-                                                                const U4* __restrict__ y, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, long long R, int C,
-                                                                int rows_per_block, float* pdb, float* pdg) {
+// XMASK: the ReLU mask is recomputed from x (y is not read) -- only without a residual, where y = relu(x*sc + sh) with
+// exactly the forward's sc/sh, so (x*sc + sh > 0) == (y > 0).  dy2 (may be NULL) is a second upstream gradient that is
+// added on the fly: the block output feeds the next convolution AND the next residual add, and autograd would
+// otherwise spend a separate read-read-write kernel on summing the two gradients.
+template <bool RELU, bool XMASK>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
+                                                                const U4* __restrict__ x, const U4* __restrict__ y,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                long long R, int C, int rows_per_block, float* pdb, float* pdg) {
     __shared__ float lds[4096];
     const Map m = make_map(C);
     float db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (m.active) {
-        float mu[8], is[8];
+        float mu[8], is[8], sc[8], sh[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { mu[k] = mean[m.c0 + k]; is[k] = invstd[m.c0 + k]; }
+        for (int k = 0; k < 8; ++k) {
+            mu[k] = mean[m.c0 + k]; is[k] = invstd[m.c0 + k];
+            if (XMASK) { sc[k] = gamma[m.c0 + k] * is[k]; sh[k] = beta[m.c0 + k] - mu[k] * sc[k]; }
+        }
         const long long rb = (long long)blockIdx.x * rows_per_block;
         const long long re = min(R, rb + rows_per_block);
         const long long stride = (long long)m.rpp * (C >> 3);
@@ -133,10 +142,17 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
             float d[8], f[8], o[8];
             unpack8(dy[off], d);
             unpack8(x[off], f);
-            if (RELU) unpack8(y[off], o);
+            if (RELU && !XMASK) unpack8(y[off], o);
+            if (dy2) {
+                float d2[8];
+                unpack8(dy2[off], d2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] += d2[k];
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float dd = (RELU && !(o[k] > 0.f)) ? 0.f : d[k];
+                const bool on = !RELU || (XMASK ? fmaf(f[k], sc[k], sh[k]) > 0.f : o[k] > 0.f);
+                const float dd = on ? d[k] : 0.f;
                 db[k] += dd;
                 dg[k] = fmaf(dd, (f[k] - mu[k]) * is[k], dg[k]);
             }
@@ -154,22 +170,24 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_final_kernel(const float* __re
     if (grp == 0 && c < C) { dbeta[c] = a; dgamma[c] = b; }
 }
 
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restrict__ dy, const U4* __restrict__ x,
-                                                               const U4* __restrict__ y, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+template <bool RES, bool RELU, bool XMASK>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
+                                                               const U4* __restrict__ x, const U4* __restrict__ y,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                                long long R, int C, int rows_per_block, U4* dx, U4* dres) {
     const Map m = make_map(C);
     if (!m.active) return;
-    float mu[8], is[8], a[8], b[8], c[8];
+    float mu[8], is[8], a[8], b[8], c[8], sh[8];
     const float invR = 1.f / (float)R;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[m.c0 + k]; is[k] = invstd[m.c0 + k];
-        a[k] = gamma[m.c0 + k] * is[k];                 // dx = a * (dy' - b - xhat * c)
+        a[k] = gamma[m.c0 + k] * is[k];                 // dx = a * (dy' - b - xhat * c); also the forward's scale
         b[k] = dbeta[m.c0 + k] * invR;
         c[k] = dgamma[m.c0 + k] * invR;
+        if (XMASK) sh[k] = beta[m.c0 + k] - mu[k] * a[k];
     }
     const long long rb = (long long)blockIdx.x * rows_per_block;
     const long long re = min(R, rb + rows_per_block);
@@ -180,10 +198,17 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
         float d[8], f[8], o[8];
         unpack8(ld_nt(dy + off), d);
         unpack8(ld_nt(x + off), f);
-        if (RELU) unpack8(ld_nt(y + off), o);
+        if (RELU && !XMASK) unpack8(ld_nt(y + off), o);
+        if (dy2) {
+            float d2[8];
+            unpack8(ld_nt(dy2 + off), d2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] += d2[k];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float dd = (RELU && !(o[k] > 0.f)) ? 0.f : d[k];
+            const bool on = !RELU || (XMASK ? fmaf(f[k], a[k], sh[k]) > 0.f : o[k] > 0.f);
+            const float dd = on ? d[k] : 0.f;
             d[k] = dd;
             f[k] = a[k] * (dd - b[k] - (f[k] - mu[k]) * is[k] * c[k]);
         }
@@ -263,32 +288,33 @@ int cfl_bn_apply(const void* x, const void* residual, const float* mean, const f
     return 0;
 }
 
-int cfl_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-               const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx, void* dres,
-               float* dgamma, float* dbeta, void* ws, void* stream_) {
+int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const float* gamma, const float* beta,
+               const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx,
+               void* dres, float* dgamma, float* dbeta, void* ws, void* stream_) {
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
-    if ((relu && !y) || (has_residual && !dres)) return CFL_EINVAL;
+    const bool xmask = relu && !y;                       // ReLU mask recomputed from x: needs beta, and no residual
+    if ((xmask && (has_residual || !beta)) || (has_residual && !dres)) return CFL_EINVAL;
     if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;
     const Plan p = bn_plan(R, C);
     float* pdb = (float*)ws;
     float* pdg = pdb + (size_t)p.nblk * C;
     const dim3 grid(p.nblk, p.gy);
-    const U4 *d = (const U4*)dy, *xx = (const U4*)x, *yy = (const U4*)y;
-    if (relu)
-        CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, R, C, p.rows_per_block, pdb, pdg);
-    else
-        CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, R, C, p.rows_per_block, pdb, pdg);
+    const U4 *d = (const U4*)dy, *d2 = (const U4*)dy2, *xx = (const U4*)x, *yy = (const U4*)y;
+#define BN_REDUCE(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, xx, yy, \
+                                         save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg)
+    if (xmask) BN_REDUCE(true, true); else if (relu) BN_REDUCE(true, false); else BN_REDUCE(false, false);
+#undef BN_REDUCE
     CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(256), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
     U4 *ox = (U4*)dx, *orr = (U4*)dres;
-    if (has_residual && relu)
-        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
-    else if (has_residual)
-        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<true, false>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
-    else if (relu)
-        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
-    else
-        CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, stream, d, xx, yy, save_mean, save_invstd, gamma, dbeta, dgamma, R, C, p.rows_per_block, ox, orr);
+#define BN_APPLY(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<RES_, RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, \
+                                              xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr)
+    if (xmask) BN_APPLY(false, true, true);
+    else if (has_residual && relu) BN_APPLY(true, true, false);
+    else if (has_residual) BN_APPLY(true, false, false);
+    else if (relu) BN_APPLY(false, true, false);
+    else BN_APPLY(false, false, false);
+#undef BN_APPLY
     return 0;
 }
 

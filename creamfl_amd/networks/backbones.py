@@ -41,21 +41,31 @@ class BNAct(nn.BatchNorm2d):
         self._nbt_pending = 0
         return super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, two=False):
+        """`two=True` (block outputs): returns (y, y') -- on the fused training path one buffer under two tensor
+        objects, so that the gradient from the next convolution and the one from the next residual add reach the
+        fused backward separately and are summed there; otherwise the same tensor twice."""
         from .. import ops
         if self.track_running_stats and self.momentum is not None and self.affine and ops.bn_act_supported(x, self.num_features):
             if self.training:
                 self._nbt_pending += 1
                 return ops.bn_act_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
-                                        self.eps, relu=relu, residual=residual)
+                                        self.eps, relu=relu, residual=residual, two=two)
             if not torch.is_grad_enabled():
-                return ops.bn_act_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                                       relu=relu, residual=residual)
+                y = ops.bn_act_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                    relu=relu, residual=residual)
+                return (y, y) if two else y
         self.flush_num_batches_tracked()
         y = super().forward(x)
         if residual is not None:
             y = y + residual
-        return F.relu(y) if relu else y
+        y = F.relu(y) if relu else y
+        return (y, y) if two else y
+
+
+def first_of(x):
+    """Residual blocks hand (conv input, residual input) pairs to each other; consumers outside take the first."""
+    return x[0] if isinstance(x, tuple) else x
 
 
 class BasicBlock(nn.Module):
@@ -72,9 +82,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        residual = x if self.downsample is None else self.downsample(x)
+        x, x_res = x if isinstance(x, tuple) else (x, x)        # (conv input, residual input): see BNAct.forward(two=)
+        residual = x_res if self.downsample is None else self.downsample(x_res)
         out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), residual=residual, relu=True)
+        return self.bn2(self.conv2(out), residual=residual, relu=True, two=True)
 
 
 class Bottleneck(nn.Module):
@@ -93,10 +104,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        residual = x if self.downsample is None else self.downsample(x)
+        x, x_res = x if isinstance(x, tuple) else (x, x)        # (conv input, residual input): see BNAct.forward(two=)
+        residual = x_res if self.downsample is None else self.downsample(x_res)
         out = self.bn1(self.conv1(x), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=residual, relu=True)
+        return self.bn3(self.conv3(out), residual=residual, relu=True, two=True)
 
 
 class ResNetTrunk(nn.Module):
@@ -134,7 +146,7 @@ class ResNetTrunk(nn.Module):
 
     def features(self, x):
         x = self.maxpool(self.bn1(self.conv1(x), relu=True))
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return first_of(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
 
     def forward(self, x):
         return self.features(x)

@@ -7,7 +7,7 @@ import math
 import torch.nn as nn
 
 from .. import ops
-from .backbones import BasicBlock, BNAct, Bottleneck
+from .backbones import BasicBlock, BNAct, Bottleneck, first_of
 
 
 class ResNet(nn.Module):
@@ -58,7 +58,7 @@ class ResNet(nn.Module):
 
     def extract_conv_feature(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return first_of(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
 
     def forward(self, x):
         x = self.extract_conv_feature(x)

@@ -440,7 +440,7 @@ def bn_act_supported(x, num_features):
 
 
 # element counters of the fused BN kernels (python ints; bench.py turns them into algorithmic bytes)
-BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0}
+BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
 
 
 class _BNActFn(torch.autograd.Function):
@@ -459,41 +459,56 @@ class _BNActFn(torch.autograd.Function):
         _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                                   R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(ws), _stream(x)),
                    'cfl_bn_fwd')
-        ctx.save_for_backward(x, y if relu else x, weight, mean, invstd)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
-        return y
+        # the ReLU mask needs y only with a residual; otherwise the backward recomputes it from x, gamma, beta
+        ctx.save_for_backward(x, y if (relu and ctx.has_res) else x, weight, bias, mean, invstd)
+        ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
+        return y, _alias(y)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2):
         lib = _lib.load()
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
         R = N * H * W
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            return (None,) * 9
         BN_COUNTERS['bwd'] += R * C
-        if ctx.relu:
-            BN_COUNTERS['bwd_relu'] += R * C
+        if ctx.relu and ctx.has_res:
+            BN_COUNTERS['bwd_relu'] += R * C              # passes that read y
         if ctx.has_res:
             BN_COUNTERS['bwd_res'] += R * C
-        if dy.dtype != torch.bfloat16:
-            dy = dy.to(torch.bfloat16)
-        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy2 is not None:
+            BN_COUNTERS['bwd_two'] += R * C
+
+        def prep(t):
+            if t.dtype != torch.bfloat16:
+                t = t.to(torch.bfloat16)
+            return t.contiguous(memory_format=torch.channels_last)
+        dy = prep(dy)
+        dy2 = prep(dy2) if dy2 is not None else None
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         dgamma = torch.empty_like(weight)
         dbeta = torch.empty_like(weight)
         ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
-        _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(x), _ptr(y) if ctx.relu else _ptr(None), _ptr(weight), _ptr(mean),
-                                  _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res), _ptr(dx), _ptr(dres), _ptr(dgamma),
-                                  _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
+        _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(y) if (ctx.relu and ctx.has_res) else _ptr(None),
+                                  _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res),
+                                  _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
         return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
-def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None):
-    """Training-mode BatchNorm2d (+ residual) (+ ReLU) on a channels_last bf16 activation (csrc/bnorm.hip)."""
+def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None, two=False):
+    """Training-mode BatchNorm2d (+ residual) (+ ReLU) on a channels_last bf16 activation (csrc/bnorm.hip).
+    `two=True` returns the output as two tensor objects on one buffer: give one to the next convolution and the other
+    to the next residual add, and their two gradients are summed inside the fused backward (no autograd add kernel)."""
     if residual is not None and not (residual.shape == x.shape and bn_act_supported(residual, x.shape[1])):
         residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    return _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu))
+    y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu))
+    return (y, y2) if two else y
 
 
 @torch.no_grad()
@@ -550,6 +565,7 @@ class _DalnFn(torch.autograd.Function):
         if need:
             ctx.save_for_backward(s, gamma, stats)
         ctx.hyper = (p, seed, T, H, None if bias is None else (bias.dtype, bias.shape))
+        ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
         return z, _alias(z)
 
     @staticmethod

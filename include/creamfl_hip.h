@@ -232,6 +232,9 @@ int cfl_rank_count(const float* Q, const float* G, const long long* qlab, const 
  * apply: the same normalisation with given mean / invstd (evaluation mode).
  * bwd:   dy' = dy * (y > 0) if relu;  dgamma = sum dy' xhat, dbeta = sum dy';
  *        dx = gamma*invstd*(dy' - dbeta/R - xhat*dgamma/R);  dres = dy' (when has_residual).
+ *        dy2 (may be NULL) is a second upstream gradient, added on the fly (the block output feeds the next
+ *        convolution and the next residual add).  y may be NULL for relu without residual: the mask is then
+ *        recomputed from x (needs beta), one activation read less in each of the two passes.
  */
 size_t cfl_bn_ws_bytes(long long R, int C);
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
@@ -239,9 +242,9 @@ int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const fl
                float* save_mean, float* save_invstd, void* ws, void* stream);
 int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
                  const float* beta, long long R, int C, int relu, void* y, void* stream);
-int cfl_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-               const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx, void* dres,
-               float* dgamma, float* dbeta, void* ws, void* stream);
+int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const float* gamma, const float* beta,
+               const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx,
+               void* dres, float* dgamma, float* dbeta, void* ws, void* stream);
 
 /* ---- S1 tail: fused multi-tensor gradient clip + AdamP step ------
  * Replaces nn.utils.clip_grad_norm_(model.parameters(), 2) + AdamP.step()

@@ -68,3 +68,43 @@ def test_bn_act_matches_torch(n, c, h, w, relu, res):
         if relu:
             yre = F.relu(yre)
     np.testing.assert_allclose(ye.float().cpu().numpy(), yre.numpy(), **tol)
+
+
+@pytest.mark.parametrize('n,c,h,w,relu,res', [(4, 256, 14, 14, True, True), (3, 64, 28, 28, True, False), (2, 512, 7, 7, False, True)])
+def test_bn_act_two_gradient_branches(n, c, h, w, relu, res):
+    """`two=True`: the output is handed out as two tensors on one buffer (next convolution / next residual add); the
+    fused backward must treat their two gradients exactly like the single summed gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.networks.backbones import BNAct
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(n * c + h)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.5).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last) if res else None
+    ga = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    gb = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    bn = BNAct(c).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(c, generator=g))
+        bn.bias.copy_(0.3 * torch.randn(c, generator=g))
+
+    def run(two):
+        bn.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        rg = r.clone().requires_grad_(True) if res else None
+        if two:
+            ya, yb = bn(xg, residual=rg, relu=relu, two=True)
+            assert ya.data_ptr() == yb.data_ptr()
+            torch.autograd.backward([ya, yb], [ga, gb])
+        else:
+            y = bn(xg, residual=rg, relu=relu)
+            y.backward((ga.float() + gb.float()).to(torch.bfloat16))
+        return xg.grad.float(), (rg.grad.float() if res else None), bn.weight.grad.clone(), bn.bias.grad.clone()
+    two, one = run(True), run(False)
+    # the only difference: the single-gradient run rounds ga + gb to bf16 before the kernel
+    sc = float(one[0].abs().max())
+    np.testing.assert_allclose(two[0].cpu().numpy(), one[0].cpu().numpy(), rtol=2e-2, atol=2e-2 * sc)
+    if res:
+        np.testing.assert_allclose(two[1].cpu().numpy(), one[1].cpu().numpy(), rtol=2e-2, atol=3e-2)
+    for a, b in zip(two[2:], one[2:]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-2, atol=2e-2 * (float(b.abs().max()) + 1e-6))
