@@ -42,6 +42,9 @@ SIGNATURES = {
     'cfl_bias_gelu_fwd': (c_int, [_P, _P, c_int, c_longlong, c_int, _P, _P]),
     'cfl_bias_gelu_bwd': (c_int, [_P, _P, c_int, _P, c_longlong, c_int, _P, _P, c_int, _P, _P]),
     'cfl_dropout_mask': (c_int, [c_uint, c_float, c_longlong, _P, _P]),
+    'cfl_attn_small_fwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong, _P]),
+    'cfl_attn_small_bwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong,
+                                   _P, _P, _P, c_longlong, c_longlong, _P]),
     'cfl_sup_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_sup_glue_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P]),
     'cfl_sup_glue_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),

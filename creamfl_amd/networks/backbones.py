@@ -8,6 +8,7 @@ names (embeddings.*, encoder.layer.{i}.attention.self.{query,key,value}, ...) fo
 and uses F.scaled_dot_product_attention.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -239,6 +240,9 @@ BERT_CONFIGS = {
 }
 
 
+_NO_ATTN_SMALL = bool(os.environ.get('CFL_NO_ATTN_SMALL'))       # A/B switch for measurements
+
+
 def _bert_fusable(x, weight, max_out=1 << 30):
     """The fused glue kernels (csrc/bertfuse.hip) take bf16 GEMM outputs on the GPU: bf16 weights, or bf16 autocast."""
     if not (x.is_cuda and weight.shape[0] % 8 == 0 and weight.shape[0] <= max_out):
@@ -282,7 +286,12 @@ class _SelfAttention(nn.Module):
             # one [3H, H] GEMM instead of three (and one dX GEMM, one bias-gradient reduction, no dX adds in backward)
             w = torch.cat([self.query.weight, self.key.weight, self.value.weight], 0)
             b = torch.cat([self.query.bias, self.key.bias, self.value.bias], 0)
-            q, k, v = F.linear(x, w, b).split(H, dim=-1)
+            qkv = F.linear(x, w, b)
+            from .. import ops
+            if qkv.dtype == torch.bfloat16 and ops.bert_attention_supported(L, H // self.h) and not _NO_ATTN_SMALL:
+                # short captions: one wavefront per (batch, head), MFMA, no saved probabilities (csrc/attn_small.hip)
+                return ops.bert_attention(qkv, None if mask is None else mask.reshape(B, L), self.h)
+            q, k, v = qkv.split(H, dim=-1)
         else:
             q, k, v = self.query(xq), self.key(x), self.value(x)
         o = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=mask)

@@ -641,6 +641,54 @@ def bert_bias_gelu(g, bias):
     return _BiasGeluFn.apply(g, bias)
 
 
+class _AttnSmallFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, mask, heads):
+        lib = _lib.load()
+        B, L, H3 = qkv.shape
+        H = H3 // 3
+        o = torch.empty(B, L, H, dtype=torch.bfloat16, device=qkv.device)
+        base = qkv.data_ptr()
+        _lib.check(lib.cfl_attn_small_fwd(ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * H), ctypes.c_void_p(base + 4 * H), H3,
+                                          L * H3, _ptr(mask), B, L, heads, H // heads, _ptr(o), H, L * H, _stream(qkv)),
+                   'cfl_attn_small_fwd')
+        ctx.save_for_backward(qkv, mask)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _lib.load()
+        qkv, mask = ctx.saved_tensors
+        B, L, H3 = qkv.shape
+        H = H3 // 3
+        do = _bf16c(do, 'do')
+        dqkv = torch.empty_like(qkv)
+        base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+        _lib.check(lib.cfl_attn_small_bwd(ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * H), ctypes.c_void_p(base + 4 * H), H3,
+                                          L * H3, _ptr(mask), B, L, ctx.heads, H // ctx.heads, _ptr(do), H, L * H,
+                                          ctypes.c_void_p(gbase), ctypes.c_void_p(gbase + 2 * H), ctypes.c_void_p(gbase + 4 * H),
+                                          H3, L * H3, _stream(qkv)), 'cfl_attn_small_bwd')
+        return dqkv, None, None
+
+
+def bert_attention_supported(L, head_dim):
+    return L <= 32 and head_dim == 64
+
+
+def bert_attention(qkv, key_mask, heads):
+    """softmax(Q K^T / sqrt(d) + key-padding mask) V for a fused projection qkv [B, L, 3H] (Q | K | V along the last
+    axis), L <= 32, head dim 64 (csrc/attn_small.hip).  key_mask: [B, L] bool (True = attend) or None.  -> [B, L, H]."""
+    qkv = _bf16c(qkv, 'qkv')
+    B, L, H3 = qkv.shape
+    if H3 % 3 or (H3 // 3) % heads or not bert_attention_supported(L, H3 // 3 // heads):
+        raise _lib.CreamflHipError(f'bert_attention: unsupported shape {tuple(qkv.shape)} with {heads} heads')
+    m = None
+    if key_mask is not None:
+        m = key_mask.reshape(B, L).to(device=qkv.device, dtype=torch.uint8).contiguous()
+    return _AttnSmallFn.apply(qkv, m, int(heads))
+
+
 @torch.no_grad()
 def dropout_keep_mask(seed, p, shape, device):
     """The keep mask bert_dropout_add_layernorm uses for (seed, p) on a tensor of this shape (test helper)."""

@@ -131,6 +131,18 @@ int cfl_bias_gelu_bwd(const void* g, const void* bias, int bias_bf16, const void
                       int dbias_bf16, void* ws, void* stream);
 int cfl_dropout_mask(unsigned seed, float p, long long n, unsigned char* keep, void* stream);
 
+/* ---- BERT self-attention for short sequences (L <= 32 tokens, head_dim 64) -------------------------------------
+ * softmax(Q K^T / sqrt(64) + key-padding mask) V per (batch, head): BertSelfAttention of the BertModel built at
+ * src/networks/models/pcme.py:36-38 (captions are ~12-30 tokens).  One wavefront per (batch, head), MFMA, nothing
+ * saved for the backward but the inputs.  bf16; element (b, t, h*64 + d) of q/k/v at b*bs + t*ld + h*64 + d (so the
+ * three may be slices of one fused [B, L, 3H] projection), of o/dout at b*bso + t*ldo + ..., of dq/dk/dv at
+ * b*bsg + t*ldg + ...; mask [B][L] bytes (1 = key takes part) or NULL.  All strides % 8 == 0, 16-byte aligned bases. */
+int cfl_attn_small_fwd(const void* q, const void* k, const void* v, long long ld, long long bs, const unsigned char* mask,
+                       int B, int L, int heads, int head_dim, void* o, long long ldo, long long bso, void* stream);
+int cfl_attn_small_bwd(const void* q, const void* k, const void* v, long long ld, long long bs, const unsigned char* mask,
+                       int B, int L, int heads, int head_dim, const void* dout, long long ldo, long long bso, void* dq, void* dk,
+                       void* dv, long long ldg, long long bsg, void* stream);
+
 /* ---- bf16 MFMA GEMM probe ------------------------------------------------------------------------------
  * C[M,N] = A[M,K] * B[N,K]^T, bf16 in / bf16 out, fp32 accumulation: the 1x1 convolutions of the torchvision
  * Bottleneck blocks (src/networks/models/image_encoder.py:27-36) on the NHWC-flattened activation (forward:
