@@ -45,6 +45,8 @@ SIGNATURES = {
     'cfl_attn_small_fwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong, _P]),
     'cfl_attn_small_bwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong,
                                    _P, _P, _P, c_longlong, c_longlong, _P]),
+    'cfl_maxpool3s2_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'cfl_maxpool3s2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'cfl_sup_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_sup_glue_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P]),
     'cfl_sup_glue_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),

@@ -1,0 +1,113 @@
+// pool.hip -- 3x3 / stride 2 / pad 1 max pooling on NHWC bf16 activations: the ResNet stem pool
+// (torchvision ResNet.maxpool inside the trunk built at src/networks/models/image_encoder.py:27-36 and
+// src/networks/resnet_client.py:19).  torch's NHWC kernels take 257 us forward / 614 us backward on the bench's
+// [256, 112, 112, 64] stem output (0.85-1.9 TB/s); this is pure streaming: 565 MB each way.
+//   fwd: thread = 8 channels of one output pixel; the 9 taps are 16-byte loads; the arg-max tap (0..8, first maximum
+//        in row-major window order like torch; NaN wins) is kept as one byte per element for the backward.
+//   bwd: gather form, thread = 8 channels of one INPUT pixel: the <= 4 windows that cover it are checked against
+//        their stored tap -- no atomics, every dx element written exactly once.
+#include "common.h"
+#include "colmap.h"
+
+namespace {
+
+struct __attribute__((aligned(8))) B8 { unsigned int lo, hi; };          // 8 tap indices
+
+__global__ __launch_bounds__(256) void cfl_maxpool_fwd_kernel(const U4* __restrict__ x, int N, int H, int W, int C8, int Ho, int Wo,
+                                                              U4* __restrict__ y, B8* __restrict__ idx) {
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        long long p = i / C8;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float best[8];
+        unsigned int tap[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; tap[k] = 0; }
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int ih = 2 * oh - 1 + dh;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int iw = 2 * ow - 1 + dw;
+                if (iw < 0 || iw >= W) continue;
+                float v[8];
+                unpack8(x[(((long long)n * H + ih) * W + iw) * C8 + c], v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; tap[k] = dh * 3 + dw; }
+            }
+        }
+        y[i] = pack8(best);
+        B8 t;
+        t.lo = tap[0] | (tap[1] << 8) | (tap[2] << 16) | (tap[3] << 24);
+        t.hi = tap[4] | (tap[5] << 8) | (tap[6] << 16) | (tap[7] << 24);
+        idx[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void cfl_maxpool_bwd_kernel(const U4* __restrict__ dy, const B8* __restrict__ idx, int N, int H, int W,
+                                                              int C8, int Ho, int Wo, U4* __restrict__ dx) {
+    const long long total = (long long)N * H * W * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        long long p = i / C8;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // windows oh with 2*oh - 1 <= h <= 2*oh + 1
+        const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            if (oh >= Ho) continue;
+            const unsigned int th = (unsigned int)(h - (2 * oh - 1));
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                if (ow >= Wo) continue;
+                const unsigned int t = th * 3 + (unsigned int)(w - (2 * ow - 1));
+                const long long o = (((long long)n * Ho + oh) * Wo + ow) * C8 + c;
+                const B8 tp = idx[o];
+                float g[8];
+                unpack8(dy[o], g);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned int tk = ((k < 4 ? tp.lo : tp.hi) >> (8 * (k & 3))) & 0xffu;
+                    if (tk == t) acc[k] += g[k];
+                }
+            }
+        }
+        dx[i] = pack8(acc);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cfl_maxpool3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void* idx, void* stream_) {
+    if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    const long long blocks = (total + 255) / 256;
+    CFL_LAUNCH(K_MAXPOOL, cfl_maxpool_fwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream,
+               (const U4*)x, N, H, W, C / 8, Ho, Wo, (U4*)y, (B8*)idx);
+    return 0;
+}
+
+int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int C, void* dx, void* stream_) {
+    if (!dy || !idx || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * H * W * (C / 8);
+    const long long blocks = (total + 255) / 256;
+    CFL_LAUNCH(K_MAXPOOL, cfl_maxpool_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream,
+               (const U4*)dy, (const B8*)idx, N, H, W, C / 8, Ho, Wo, (U4*)dx);
+    return 0;
+}
+
+}  // extern "C"

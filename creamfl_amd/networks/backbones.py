@@ -64,6 +64,20 @@ class BNAct(nn.BatchNorm2d):
         return (y, y) if two else y
 
 
+class MaxPool3s2(nn.MaxPool2d):
+    """nn.MaxPool2d(3, 2, 1) (the ResNet stem pool); channels_last bf16 activations on the GPU take the streaming
+    kernels of csrc/pool.hip, anything else the library path."""
+
+    def __init__(self):
+        super().__init__(3, 2, 1)
+
+    def forward(self, x):
+        from .. import ops
+        if ops.bn_act_supported(x, x.shape[1]):
+            return ops.maxpool3s2(x)
+        return super().forward(x)
+
+
 def first_of(x):
     """Residual blocks hand (conv input, residual input) pairs to each other; consumers outside take the first."""
     return x[0] if isinstance(x, tuple) else x
@@ -121,7 +135,7 @@ class ResNetTrunk(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = BNAct(64)
         self.relu = nn.ReLU(inplace=relu_inplace)
-        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.maxpool = MaxPool3s2()
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], 2)
         self.layer3 = self._make_layer(block, 256, layers[2], 2)

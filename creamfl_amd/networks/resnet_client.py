@@ -7,7 +7,7 @@ import math
 import torch.nn as nn
 
 from .. import ops
-from .backbones import BasicBlock, BNAct, Bottleneck, first_of
+from .backbones import BasicBlock, BNAct, Bottleneck, MaxPool3s2, first_of
 
 
 class ResNet(nn.Module):
@@ -17,7 +17,7 @@ class ResNet(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=False)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = MaxPool3s2()
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)

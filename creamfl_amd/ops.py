@@ -525,6 +525,40 @@ def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, res
     return y
 
 
+# --------------------------------------------------------------------------- ResNet stem max pooling (csrc/pool.hip)
+class _MaxPool3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(N, C, Ho, Wo, dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        idx = torch.empty(N * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.cfl_maxpool3s2_fwd(_ptr(x), N, H, W, C, _ptr(y), _ptr(idx), _stream(x)), 'cfl_maxpool3s2_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(N, C, H, W, dtype=torch.bfloat16, device=dy.device).contiguous(memory_format=torch.channels_last)
+        _lib.check(lib.cfl_maxpool3s2_bwd(_ptr(dy), _ptr(idx), N, H, W, C, _ptr(dx), _stream(dy)), 'cfl_maxpool3s2_bwd')
+        return dx
+
+
+def maxpool3s2(x):
+    """3x3 / stride 2 / pad 1 max pooling of a channels_last bf16 activation (the ResNet stem pool)."""
+    if not bn_act_supported(x, x.shape[1]):
+        raise _lib.CreamflHipError('maxpool3s2: expected a channels_last bf16 HIP tensor with C % 8 == 0')
+    return _MaxPool3s2Fn.apply(x)
+
+
 # --------------------------------------------------------------------------- BERT tower glue (csrc/bertfuse.hip)
 _DROPOUT_CALLS = [0]
 

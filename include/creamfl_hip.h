@@ -143,6 +143,14 @@ int cfl_attn_small_bwd(const void* q, const void* k, const void* v, long long ld
                        int B, int L, int heads, int head_dim, const void* dout, long long ldo, long long bso, void* dq, void* dk,
                        void* dv, long long ldg, long long bsg, void* stream);
 
+/* ---- ResNet stem max pooling, 3x3 / stride 2 / pad 1, NHWC bf16 ---------------------------------------------------
+ * torchvision ResNet.maxpool of the trunk built at src/networks/models/image_encoder.py:27-36 (and the client trunk,
+ * src/networks/resnet_client.py:19).  x [N,H,W,C] -> y [N,Ho,Wo,C], Ho = (H-1)/2+1; idx: one byte per output element
+ * (the winning tap 0..8, first maximum in row-major window order, NaN wins -- torch's rule).  C % 8 == 0.
+ * bwd: dx [N,H,W,C] from dy and idx, gather form (no atomics). */
+int cfl_maxpool3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void* idx, void* stream);
+int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int C, void* dx, void* stream);
+
 /* ---- bf16 MFMA GEMM probe ------------------------------------------------------------------------------
  * C[M,N] = A[M,K] * B[N,K]^T, bf16 in / bf16 out, fp32 accumulation: the 1x1 convolutions of the torchvision
  * Bottleneck blocks (src/networks/models/image_encoder.py:27-36) on the NHWC-flattened activation (forward:

@@ -108,3 +108,27 @@ def test_bn_act_two_gradient_branches(n, c, h, w, relu, res):
         np.testing.assert_allclose(two[1].cpu().numpy(), one[1].cpu().numpy(), rtol=2e-2, atol=3e-2)
     for a, b in zip(two[2:], one[2:]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-2, atol=2e-2 * (float(b.abs().max()) + 1e-6))
+
+
+@pytest.mark.parametrize('n,c,h,w', [(4, 64, 112, 112), (3, 64, 9, 11), (2, 8, 1, 1), (2, 128, 2, 5), (1, 64, 7, 8)])
+def test_maxpool3s2_matches_torch(n, c, h, w):
+    """csrc/pool.hip vs F.max_pool2d(3, 2, 1): values and arg-max routing of the gradient, bit-exact (ReLU-like inputs
+    with many ties: the first maximum in window order must win, as in torch)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(h * 31 + w)
+    x = torch.relu(torch.randn(n, c, h, w, generator=g)).to(torch.bfloat16)          # ~half zeros => ties
+    x = x.to(dev).contiguous(memory_format=torch.channels_last)
+    xg = x.clone().requires_grad_(True)
+    y = ops.maxpool3s2(xg)
+    gy = torch.randn(y.shape, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    xr = x.float().cpu().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    yr.backward(gy.float().cpu())
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y.detach().float().cpu(), yr.detach())
+    # torch accumulates in fp32 and this kernel too, then rounds once to bf16
+    np.testing.assert_allclose(xg.grad.float().cpu().numpy(), xr.grad.to(torch.bfloat16).float().numpy(), rtol=0, atol=0)
