@@ -64,6 +64,20 @@ class BNAct(nn.BatchNorm2d):
         return (y, y) if two else y
 
 
+class Conv1x1(nn.Conv2d):
+    """nn.Conv2d(cin, cout, 1, bias=False).  On the bf16 channels_last training path its data gradient runs on the
+    hand-written MFMA GEMM (ops.conv1x1); forward and weight gradient stay on MIOpen."""
+
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 1, bias=False)
+
+    def forward(self, x):
+        from .. import ops
+        if torch.is_grad_enabled() and not _NO_CONV1X1 and ops.conv1x1_supported(x, self.weight):
+            return ops.conv1x1(x, self.weight)
+        return super().forward(x)
+
+
 class MaxPool3s2(nn.MaxPool2d):
     """nn.MaxPool2d(3, 2, 1) (the ResNet stem pool); channels_last bf16 activations on the GPU take the streaming
     kernels of csrc/pool.hip, anything else the library path."""
@@ -108,11 +122,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = Conv1x1(inplanes, planes)
         self.bn1 = BNAct(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # stride on the 3x3 (torchvision v1.5)
         self.bn2 = BNAct(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv1x1(planes, planes * 4)
         self.bn3 = BNAct(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -254,7 +268,8 @@ BERT_CONFIGS = {
 }
 
 
-_NO_ATTN_SMALL = bool(os.environ.get('CFL_NO_ATTN_SMALL'))       # A/B switch for measurements
+_NO_ATTN_SMALL = bool(os.environ.get('CFL_NO_ATTN_SMALL'))       # A/B switches for measurements
+_NO_CONV1X1 = bool(os.environ.get('CFL_NO_CONV1X1'))
 
 
 def _bert_fusable(x, weight, max_out=1 << 30):

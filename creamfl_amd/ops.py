@@ -525,6 +525,60 @@ def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, res
     return y
 
 
+# --------------------------------------------------------------------------- 1x1 convolution: data gradient (csrc/gemm_bf16.hip)
+def gemm_bf16_nt(a, b, out=None, variant=0):
+    """out[M, N] = a[M, K] @ b[N, K]^T, bf16 (csrc/gemm_bf16.hip: cfl_gemm_bf16_nt)."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    _lib.check(lib.cfl_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K, variant,
+                                    _stream(a)), 'cfl_gemm_bf16_nt')
+    return out
+
+
+def conv1x1_supported(x, weight):
+    """1x1 / stride 1 convolution of a channels_last bf16 activation with a bf16 weight whose channel counts fit the
+    GEMM kernel (Co % 64 == 0 for the reduction of the data gradient, Ci % 8 == 0)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and weight.shape[0] % 64 == 0 and weight.shape[1] % 8 == 0)
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """y = conv2d(x, w) for a 1x1 / stride-1 kernel.  Forward and weight gradient stay on MIOpen; the DATA gradient
+    dX[M, Ci] = dY[M, Co] @ W[Co, Ci] runs on the hand-written bf16 MFMA GEMM, which beats MIOpen's backward-data
+    kernels on every ResNet-101 shape (tools/wgrad_probe.py vs tools/kernel_bench.py --cases gemm16: e.g.
+    14x14 1024->256: 78 -> 48 us, 56x56 256->64: 184 -> 110 us)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)                                    # channels_last: the [M, Ci] matrix
+            wt = weight.reshape(Co, Ci).t().contiguous()                # [Ci, Co]: reduction axis contiguous
+            gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return dx, dw
+
+
+def conv1x1(x, weight):
+    return _Conv1x1Fn.apply(x, weight)
+
+
 # --------------------------------------------------------------------------- ResNet stem max pooling (csrc/pool.hip)
 class _MaxPool3s2Fn(torch.autograd.Function):
     @staticmethod

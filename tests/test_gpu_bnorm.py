@@ -132,3 +132,29 @@ def test_maxpool3s2_matches_torch(n, c, h, w):
     assert torch.equal(y.detach().float().cpu(), yr.detach())
     # torch accumulates in fp32 and this kernel too, then rounds once to bf16
     np.testing.assert_allclose(xg.grad.float().cpu().numpy(), xr.grad.to(torch.bfloat16).float().numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('n,cin,cout,h', [(4, 256, 64, 14), (3, 64, 256, 9), (2, 1024, 256, 7), (5, 128, 512, 5), (1, 64, 64, 1)])
+def test_conv1x1_data_gradient_matches_miopen(n, cin, cout, h):
+    """Conv1x1 (hand-written bf16 MFMA GEMM for the data gradient) against nn.Conv2d on the same weights."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.networks.backbones import Conv1x1
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(cin + cout + h)
+    conv = Conv1x1(cin, cout).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn(n, cin, h, h, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cout, h, h, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    ya = conv(xa)
+    ya.backward(gy)
+    ga, gwa = xa.grad.float(), conv.weight.grad.float().clone()
+    conv.weight.grad = None
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(xr, conv.weight.detach().float())
+    yr.backward(gy.float())
+    np.testing.assert_allclose(ya.detach().float().cpu().numpy(), yr.detach().cpu().numpy(), rtol=2e-2, atol=2e-2 * float(yr.abs().max()))
+    sc = float(xr.grad.abs().max())
+    np.testing.assert_allclose(ga.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-2, atol=1e-2 * sc)
+    assert xa.grad.is_contiguous(memory_format=torch.channels_last)
+    assert gwa.shape == conv.weight.shape

@@ -30,6 +30,8 @@ shapes = [  # (H_in, Ci, Co, k, stride)
     (28, 512, 256, 1, 1), (28, 256, 256, 3, 2), (14, 256, 1024, 1, 1), (28, 512, 1024, 1, 2), (14, 1024, 256, 1, 1), (14, 256, 256, 3, 1),
     (14, 1024, 512, 1, 1), (14, 512, 512, 3, 2), (7, 512, 2048, 1, 1), (14, 1024, 2048, 1, 2), (7, 2048, 512, 1, 1), (7, 512, 512, 3, 1),
 ]
+if os.environ.get('ONLY_LAYER3'):
+    shapes = [sh for sh in shapes if sh[0] == 14 and sh[4] == 1]
 for (H, Ci, Co, k, s) in shapes:
     x = torch.randn(N, Ci, H, H, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
