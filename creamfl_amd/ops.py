@@ -538,6 +538,18 @@ def gemm_bf16_nt(a, b, out=None, variant=0):
     return out
 
 
+def gemm_bf16_tn(a, b, out_dtype=torch.bfloat16):
+    """out[N1, N2] = a[M, N1]^T @ b[M, N2] (reduction along the slow axis; csrc/gemm_bf16.hip: cfl_gemm_bf16_tn)."""
+    lib = _lib.load()
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    out = torch.empty(N1, N2, dtype=out_dtype, device=a.device)
+    ws = _ws(lib.cfl_gemm_bf16_tn_ws_bytes(M, N1, N2), a.device)
+    _lib.check(lib.cfl_gemm_bf16_tn(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(out_dtype == torch.bfloat16), M, N1, N2,
+                                    _ptr(ws), _stream(a)), 'cfl_gemm_bf16_tn')
+    return out
+
+
 def conv1x1_supported(x, weight):
     """1x1 / stride 1 convolution of a channels_last bf16 activation with a bf16 weight whose channel counts fit the
     GEMM kernel (Co % 64 == 0 for the reduction of the data gradient, Ci % 8 == 0)."""

@@ -160,6 +160,12 @@ int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int
  * variant 0 = pick by shape; 21 / 22 / 41 / 42 / 44 select the wave tile (TM,TN) for benchmarking. */
 int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
                      int M, int N, int K, int variant, void* stream);
+/* tn: C[N1,N2] = A[M,N1]^T * B[M,N2] (reduction along the slow axis M): the weight gradient dW[Co,Ci] = dy^T x of a 1x1
+ * convolution.  C dense row-major, bf16 (c_bf16 = 1) or fp32; split-K over M with fp32 partials in ws
+ * (cfl_gemm_bf16_tn_ws_bytes) and a fixed-order reduction.  N1 % 8 == N2 % 8 == 0, lda % 8 == ldb % 8 == 0. */
+size_t cfl_gemm_bf16_tn_ws_bytes(long long M, int N1, int N2);
+int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, long long ldb, void* C, int c_bf16, long long M, int N1, int N2,
+                     void* ws, void* stream);
 
 /* ---- client supervised step glue ------------------------------------------------
  * Replaces, per local batch (src/algorithms/ClientTrainer.py:344-361 with to_one_hot src/utils/Utils.py:6-13 and

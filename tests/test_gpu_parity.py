@@ -435,3 +435,22 @@ def test_gemm_bf16_nt_matches_torch(dev, m, n, k, variant):
     scale = float(ref.abs().max())
     err = float((c.float() - ref).abs().max())
     assert err <= 2 ** -8 * scale + 1e-6, (err, scale)
+
+
+@pytest.mark.parametrize('m,n1,n2', [(64, 64, 64), (1000, 128, 72), (50176, 1024, 256), (12544, 512, 2048), (777, 8, 264), (200, 136, 128)])
+def test_gemm_bf16_tn_matches_torch(dev, m, n1, n2):
+    """cfl_gemm_bf16_tn (C = A^T B, reduction along the slow axis, split-K) vs an fp32 matmul of the same bf16 inputs:
+    ragged M (not a multiple of 64), ragged tile edges, asymmetric operands; fp32 output."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(m + n1 + n2)
+    a = torch.randn(m, n1, generator=gen).to(torch.bfloat16).to(dev)
+    b = (torch.randn(m, n2, generator=gen) * 0.3).to(torch.bfloat16).to(dev)
+    c = ops.gemm_bf16_tn(a, b, torch.float32)
+    if m <= 4096:
+        ref = a.float().t() @ b.float()
+    else:
+        ref = a.double().t() @ b.double()
+    scale = float(ref.abs().max())
+    assert float((c.double() - ref.double()).abs().max()) <= 2e-5 * scale + 1e-4
+    cb = ops.gemm_bf16_tn(a, b, torch.bfloat16)
+    assert float((cb.double() - ref.double()).abs().max()) <= 2 ** -8 * scale + 1e-4
