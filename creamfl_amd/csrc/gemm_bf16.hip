@@ -1,14 +1,15 @@
-// gemm_bf16.hip -- bf16 MFMA "NT" GEMM probe:  C[M,N] = A[M,K] * B[N,K]^T  (bf16 in/out, fp32 accumulation).
+// gemm_bf16.hip -- bf16 MFMA GEMMs for the 1x1 convolutions of the ResNet trunk (bf16 in/out, fp32 accumulation).
 //
-// Why it exists: a 1x1 convolution on a channels_last activation is exactly this GEMM on the [M = N*H*W, C] view
-// (torchvision Bottleneck conv1 / conv3 inside src/networks/models/image_encoder.py:27-36), and the trunk
-// convolutions are ~45 % of the bench step.  tools/conv_probe.py shows MIOpen at the HBM roofline only in layer1 and
-// at 2-3 TB/s / 550-700 TFLOP/s in layer3, so this kernel was written to see whether the shared tile machine beats
-// it.  Measured (tools/kernel_bench.py --cases gemm16, MI355X): it ties MIOpen (e.g. 14x14 256->1024: 49 vs 46 us,
-// 1024->256: 46 vs 39 us, 56x56 64->64: 35 vs 34 us) and does not beat it, so THE PRODUCT PATH KEEPS MIOpen for
-// convolutions; the entry point stays as the calibration point for bf16 MFMA work.
-// Why it stalls: with 128x128 workgroup tiles the LDS pipe (fragment reads 128 KB + direct-to-LDS writes 64 KB per
-// CU per K step vs 1024 MFMA cycles) caps the matrix pipe at ~1/3; 256x256 tiles lift that cap but leave one
+// A 1x1 convolution on a channels_last activation is a GEMM on the [M = N*H*W, C] view (torchvision Bottleneck conv1 /
+// conv3 inside src/networks/models/image_encoder.py:27-36), and the trunk convolutions are ~45 % of the bench step.
+// tools/conv_probe.py / wgrad_probe.py show MIOpen at the HBM roofline only in layer1 and at 2-3 TB/s /
+// 550-700 TFLOP/s in layer3.  Measured (tools/kernel_bench.py --cases gemm16 / wgrad16, MI355X):
+//   NT  C[M,N] = A[M,K] B[N,K]^T : ties MIOpen's FORWARD (14x14 256->1024: 49 vs 46 us; 56x56 64->64: 35 vs 34 us) but
+//       beats its BACKWARD-DATA kernels on every ResNet-101 shape (14x14 1024->256: 78 -> 48 us; 56x56 256->64:
+//       184 -> 110 us)  => the product routes the data gradient of the 1x1 convolutions here (ops.conv1x1).
+//   TN  C[N1,N2] = A[M,N1]^T B[M,N2] (weight gradient): on par with MIOpen, not used (see below).
+// Why the forward stalls: with 128x128 workgroup tiles the LDS pipe (fragment reads 128 KB + direct-to-LDS writes 64 KB
+// per CU per K step vs 1024 MFMA cycles) caps the matrix pipe at ~1/3; 256x256 tiles lift that cap but leave one
 // workgroup per CU and 1-16 K steps per tile, where prologue / epilogue latency dominates.
 //
 // Tile machine: v_mfma_f32_32x32x16_bf16, 4 waves as 2x2, wave tile TM x TN of 32x32, K step 64 bf16 (= one 128-byte

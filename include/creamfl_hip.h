@@ -151,11 +151,11 @@ int cfl_attn_small_bwd(const void* q, const void* k, const void* v, long long ld
 int cfl_maxpool3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void* idx, void* stream);
 int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int C, void* dx, void* stream);
 
-/* ---- bf16 MFMA GEMM probe ------------------------------------------------------------------------------
- * C[M,N] = A[M,K] * B[N,K]^T, bf16 in / bf16 out, fp32 accumulation: the 1x1 convolutions of the torchvision
- * Bottleneck blocks (src/networks/models/image_encoder.py:27-36) on the NHWC-flattened activation (forward:
- * A = x[M,Ci], B = w[Co,Ci]).  It ties MIOpen on ResNet-101's shapes and does not beat it, so the product path keeps
- * MIOpen; this entry point is the bf16 calibration probe (tools/kernel_bench.py --cases gemm16).
+/* ---- bf16 MFMA GEMMs for the 1x1 convolutions of the ResNet trunk -------------------------------------------------
+ * nt: C[M,N] = A[M,K] * B[N,K]^T, bf16 in / bf16 out, fp32 accumulation.  On the NHWC-flattened activation a 1x1
+ * convolution of the torchvision Bottleneck blocks (src/networks/models/image_encoder.py:27-36) is this GEMM:
+ * forward A = x[M,Ci], B = w[Co,Ci]; data gradient A = dy[M,Co], B = w^T[Ci,Co].  It ties MIOpen's forward and beats
+ * its backward-data kernels on every ResNet-101 shape, so the product uses it for the DATA GRADIENT (ops.conv1x1).
  * lda/ldb/ldc in elements; K % 64 == 0, N % 8 == 0, lda % 8 == ldb % 8 == ldc % 8 == 0, 16-byte aligned pointers.
  * variant 0 = pick by shape; 21 / 22 / 41 / 42 / 44 select the wave tile (TM,TN) for benchmarking. */
 int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
