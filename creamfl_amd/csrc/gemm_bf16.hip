@@ -146,6 +146,25 @@ int launch_nt(const Opnd& A, const Opnd& B, int M, int N, u16* C, long long ldc,
     return 0;
 }
 
+// dst[C][R] = src[R][C]^T for a small bf16 matrix (the 1x1 convolution weight [Co][Ci] -> [Ci][Co] that the data
+// gradient needs K-contiguous): 64x64 tiles through LDS, 2-byte elements, coalesced on both sides.
+__global__ __launch_bounds__(256) void cfl_transpose_bf16_kernel(const u16* __restrict__ src, int R, int C, u16* __restrict__ dst) {
+    __shared__ u16 tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        tile[ty * 16 + i][tx] = (r < R && c < C) ? src[(long long)r * C + c] : (u16)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (r < R && c < C) dst[(long long)c * R + r] = tile[tx][ty * 16 + i];
+    }
+}
+
 // ---- "TN": C[N1, N2] = A[M, N1]^T * B[M, N2] -- the weight gradient dW[Co, Ci] = dY^T X of a 1x1 convolution ------------
 // The reduction runs along M, the slow axis of both operands, so the MFMA fragments (8 consecutive reduction elements
 // per lane) cannot be read from the global layout.  The loader transposes on the way in: a thread fetches an 8 (m) x
@@ -346,5 +365,13 @@ extern "C" int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, lon
     const long long n = (long long)N1 * N2;
     CFL_LAUNCH(K_GEMM_BF16, cfl_gemm_tn_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)ws,
                p.nsplit, n, C, c_bf16);
+    return 0;
+}
+
+extern "C" int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream_) {
+    if (!src || !dst || R <= 0 || C <= 0) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    CFL_LAUNCH(K_GEMM_BF16, cfl_transpose_bf16_kernel, dim3(cfl_cdiv(C, 64), cfl_cdiv(R, 64)), dim3(256), 0, stream, (const u16*)src, R,
+               C, (u16*)dst);
     return 0;
 }

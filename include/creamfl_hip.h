@@ -163,6 +163,8 @@ int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb,
 /* tn: C[N1,N2] = A[M,N1]^T * B[M,N2] (reduction along the slow axis M): the weight gradient dW[Co,Ci] = dy^T x of a 1x1
  * convolution.  C dense row-major, bf16 (c_bf16 = 1) or fp32; split-K over M with fp32 partials in ws
  * (cfl_gemm_bf16_tn_ws_bytes) and a fixed-order reduction.  N1 % 8 == N2 % 8 == 0, lda % 8 == ldb % 8 == 0. */
+/* dst[C][R] = src[R][C]^T, dense bf16 (the weight transpose the data gradient needs). */
+int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream);
 size_t cfl_gemm_bf16_tn_ws_bytes(long long M, int N1, int N2);
 int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, long long ldb, void* C, int c_bf16, long long M, int N1, int N2,
                      void* ws, void* stream);
