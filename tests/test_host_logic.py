@@ -101,3 +101,74 @@ def test_adamp_oracle_matches_literal_algorithm():
         ps = [_literal_adamp_step(p, g, st, 1e-2, wd=0.01) for p, g, st in zip(ps, gs, sts)]
         for q, p in zip(tp, ps):
             np.testing.assert_allclose(q.detach().numpy(), p, rtol=1e-9, atol=1e-12)
+
+
+def test_bert_cls_only_equals_full_forward_on_cpu():
+    """`cls_only=True` evaluates the last layer for [CLS] only: same values and parameter gradients for everything PCME
+    consumes (it reads [:, 0, :] only, src/networks/models/pcme.py:44)."""
+    import torch
+    from creamfl_amd.networks.backbones import BertModel
+    torch.manual_seed(0)
+    m = BertModel('bert-mini').train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    ids = torch.randint(1, 1000, (3, 9))
+    mask = torch.arange(9)[None] < torch.tensor([9, 5, 7])[:, None]
+    w = torch.randn(3, 256)
+    outs, grads = [], []
+    for cls_only in (False, True):
+        m.zero_grad(set_to_none=True)
+        o = m(ids, attention_mask=mask, cls_only=cls_only)['last_hidden_state'][:, 0]
+        (o * w).sum().backward()
+        outs.append(o.detach())
+        grads.append({n: (p.grad.clone() if p.grad is not None else None) for n, p in m.named_parameters()})
+    assert outs[1].shape == (3, 256)
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        if a is None or b is None:
+            assert (a is None or float(a.abs().max()) < 1e-6) and (b is None or float(b.abs().max()) < 1e-6), n
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * (float(a.abs().max()) + 1e-3), msg=n)
+
+
+def test_bnact_counts_batches_on_the_host_and_folds_them_into_the_state():
+    """BNAct keeps `num_batches_tracked` increments of the fused path on the host; state_dict / load_state_dict /
+    the library path must observe exactly what nn.BatchNorm2d would."""
+    import copy
+    import torch
+    from creamfl_amd.networks.backbones import BNAct
+    bn = BNAct(8).train()
+    x = torch.randn(4, 8, 3, 3)
+    bn(x)
+    bn(x)                                   # CPU input -> library path, counts directly
+    assert int(bn.state_dict()['num_batches_tracked']) == 2
+    bn._nbt_pending = 5                     # what the fused GPU path does: count on the host
+    assert int(bn.state_dict()['num_batches_tracked']) == 7 and bn._nbt_pending == 0
+    other = copy.deepcopy(bn)
+    other._nbt_pending = 3
+    other.load_state_dict(bn.state_dict())  # a load replaces the counter, pending increments are dropped
+    assert int(other.state_dict()['num_batches_tracked']) == 7
+    ref = torch.nn.BatchNorm2d(8)
+    ref.load_state_dict(bn.state_dict())    # identical key set / shapes
+    assert int(ref.num_batches_tracked) == 7
+
+
+def test_residual_blocks_pass_pairs_and_match_plain_composition_on_cpu():
+    """Bottleneck / BasicBlock hand (conv input, residual input) pairs to each other; on the library path that must be
+    the ordinary ResNet block arithmetic."""
+    import torch
+    import torch.nn.functional as F
+    from creamfl_amd.networks.backbones import Bottleneck, first_of
+    torch.manual_seed(1)
+    blk = Bottleneck(64, 16).eval()
+    x = torch.randn(2, 64, 5, 5)
+    y = blk(x)
+    assert isinstance(y, tuple) and y[0] is y[1]
+    y2 = blk((x, x))
+    torch.testing.assert_close(first_of(y), first_of(y2))
+    o = F.relu(blk.bn1(blk.conv1(x)))
+    o = F.relu(blk.bn2(blk.conv2(o)))
+    ref = F.relu(blk.bn3(blk.conv3(o)) + x)
+    torch.testing.assert_close(first_of(y), ref)
