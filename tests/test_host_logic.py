@@ -126,6 +126,8 @@ def test_bert_cls_only_equals_full_forward_on_cpu():
     assert outs[1].shape == (3, 256)
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-6)
     for n in grads[0]:
+        if n.endswith('key.bias'):
+            continue                                  # analytically zero (softmax is shift-invariant): rounding noise
         a, b = grads[0][n], grads[1][n]
         if a is None or b is None:
             assert (a is None or float(a.abs().max()) < 1e-6) and (b is None or float(b.abs().max()) < 1e-6), n
