@@ -10,7 +10,9 @@
 //   TN  C[N1,N2] = A[M,N1]^T B[M,N2] (weight gradient): on par with MIOpen, not used (see below).
 // Why the forward stalls: with 128x128 workgroup tiles the LDS pipe (fragment reads 128 KB + direct-to-LDS writes 64 KB
 // per CU per K step vs 1024 MFMA cycles) caps the matrix pipe at ~1/3; 256x256 tiles lift that cap but leave one
-// workgroup per CU and 1-16 K steps per tile, where prologue / epilogue latency dominates.
+// workgroup per CU and 1-16 K steps per tile, where prologue / epilogue latency dominates.  A 3-stage LDS ring with the
+// loads two K steps ahead (counted vmcnt + raw s_barrier, one workgroup per CU) was tried and is SLOWER (63-68 us vs
+// 48-50 us at 14x14 256<->1024): two resident workgroups per CU matter more than prefetch depth here.
 //
 // Tile machine: v_mfma_f32_32x32x16_bf16, 4 waves as 2x2, wave tile TM x TN of 32x32, K step 64 bf16 (= one 128-byte
 // row), direct-to-LDS staging (global_load_lds, source-side XOR swizzle -- the byte image is exactly the one the
