@@ -7,6 +7,8 @@ no vocabulary, so when no tokenizer is attached the COCO-vocabulary `sentences` 
 space (`_bert_inputs`) and `lengths` gives the attention mask.  Attach a tokenizer with `model.tokenizer = ...` to get the
 reference behaviour.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -14,6 +16,9 @@ from ... import ops
 from ..backbones import BertModel
 from .caption_encoder import EncoderText
 from .image_encoder import EncoderImage
+
+
+_NO_TWO_STREAM = bool(os.environ.get('CFL_NO_TWO_STREAM'))         # A/B switch for measurements
 
 
 class PCME(nn.Module):
@@ -34,6 +39,7 @@ class PCME(nn.Module):
             self.txt_enc = BertModel.from_pretrained(config.get('bert_name', 'bert-base-uncased'))
             self.tokenizer = None
             self.linear = nn.Linear(self.txt_enc.config.hidden_size, self.embed_dim)
+        self._side_streams = {}
 
     def _bert_inputs(self, sentences, captions_word, lengths):
         if getattr(self, 'tokenizer', None) is not None and captions_word is not None:
@@ -50,14 +56,35 @@ class PCME(nn.Module):
         ids = ids.clamp_max(self.txt_enc.config.vocab_size - 1)
         return {'input_ids': ids, 'attention_mask': mask}
 
-    def forward(self, images, sentences, captions_word, lengths):
-        image_output = self.img_enc(images)
+    def _text_tower(self, sentences, captions_word, lengths):
         if self.config.not_bert:
-            caption_output = self.txt_enc(sentences, lengths)
+            return self.txt_enc(sentences, lengths)
+        extra = {'cls_only': True} if isinstance(self.txt_enc, BertModel) else {}     # only [:, 0, :] is read
+        hidden = self.txt_enc(**self._bert_inputs(sentences, captions_word, lengths), **extra)['last_hidden_state']
+        return {'embedding': ops.l2_normalize(self.linear(hidden[:, 0, :]))}
+
+    def forward(self, images, sentences, captions_word, lengths):
+        # The two towers are independent until the loss.  On the GPU the text tower (many small, latency-bound kernels)
+        # runs on a second HIP stream next to the image tower (large HBM-bound kernels); autograd replays each
+        # backward op on the stream of its forward, so the two backward passes overlap as well.
+        side = None
+        if images.is_cuda and not _NO_TWO_STREAM and torch.is_tensor(sentences) and sentences.is_cuda:
+            side = self._side_streams.get(images.device)
+            if side is None:
+                side = self._side_streams[images.device] = torch.cuda.Stream(device=images.device)
+        if side is None:
+            image_output = self.img_enc(images)
+            caption_output = self._text_tower(sentences, captions_word, lengths)
         else:
-            extra = {'cls_only': True} if isinstance(self.txt_enc, BertModel) else {}     # only [:, 0, :] is read
-            hidden = self.txt_enc(**self._bert_inputs(sentences, captions_word, lengths), **extra)['last_hidden_state']
-            caption_output = {'embedding': ops.l2_normalize(self.linear(hidden[:, 0, :]))}
+            main = torch.cuda.current_stream(images.device)
+            side.wait_stream(main)                          # the inputs (and the weights of the last step) are ready
+            with torch.cuda.stream(side):
+                caption_output = self._text_tower(sentences, captions_word, lengths)
+            image_output = self.img_enc(images)
+            main.wait_stream(side)
+            for t in caption_output.values():               # allocated on the side stream, consumed on the main one
+                if torch.is_tensor(t):
+                    t.record_stream(main)
         return {
             'image_features': image_output['embedding'],
             'image_attentions': image_output.get('attention'),
