@@ -19,6 +19,7 @@ from .image_encoder import EncoderImage
 
 
 _NO_TWO_STREAM = bool(os.environ.get('CFL_NO_TWO_STREAM'))         # A/B switch for measurements
+_SIDE_STREAMS = {}                  # one side stream per device, shared by all models (kept off the modules: deepcopy)
 
 
 class PCME(nn.Module):
@@ -39,7 +40,6 @@ class PCME(nn.Module):
             self.txt_enc = BertModel.from_pretrained(config.get('bert_name', 'bert-base-uncased'))
             self.tokenizer = None
             self.linear = nn.Linear(self.txt_enc.config.hidden_size, self.embed_dim)
-        self._side_streams = {}
 
     def _bert_inputs(self, sentences, captions_word, lengths):
         if getattr(self, 'tokenizer', None) is not None and captions_word is not None:
@@ -69,9 +69,9 @@ class PCME(nn.Module):
         # backward op on the stream of its forward, so the two backward passes overlap as well.
         side = None
         if images.is_cuda and not _NO_TWO_STREAM and torch.is_tensor(sentences) and sentences.is_cuda:
-            side = self._side_streams.get(images.device)
+            side = _SIDE_STREAMS.get(images.device)
             if side is None:
-                side = self._side_streams[images.device] = torch.cuda.Stream(device=images.device)
+                side = _SIDE_STREAMS[images.device] = torch.cuda.Stream(device=images.device)
         if side is None:
             image_output = self.img_enc(images)
             caption_output = self._text_tower(sentences, captions_word, lengths)
