@@ -91,6 +91,17 @@ class DataParallelContext:
             dev_ids = [p.device.index]
         self.module = DDP(model, device_ids=dev_ids, process_group=group, bucket_cap_mb=bucket_cap_mb,
                           gradient_as_bucket_view=True, broadcast_buffers=False)
+        if p.is_cuda:
+            # Gradients are produced on more than one HIP stream (the text tower and the weight gradients run beside
+            # the image tower, see streams.py); DDP synchronises a bucket's all-reduce only with the stream of the
+            # backward node that completed the bucket.  This hook makes that stream wait for every gradient stream first.
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            from . import streams
+
+            def _hook(state, bucket):
+                streams.join_into_current(bucket.buffer().device)
+                return default_hooks.allreduce_hook(state, bucket)
+            self.module.register_comm_hook(group, _hook)
 
     def gather_features(self, image_features, caption_features):
         return (gather_with_grad(image_features.float(), self.group),

@@ -64,18 +64,26 @@ class BNAct(nn.BatchNorm2d):
         return (y, y) if two else y
 
 
-class Conv1x1(nn.Conv2d):
-    """nn.Conv2d(cin, cout, 1, bias=False).  On the bf16 channels_last training path its data gradient runs on the
-    hand-written MFMA GEMM (ops.conv1x1); forward and weight gradient stay on MIOpen."""
+class TrunkConv(nn.Conv2d):
+    """nn.Conv2d(cin, cout, k, stride, padding, bias=False) of the ResNet trunks.  On the channels_last GPU training
+    path the backward is split (ops.conv_split): data gradient on the critical path -- for 1x1 / stride-1 kernels on the
+    hand-written MFMA GEMM --, weight gradient on an auxiliary stream where it overlaps the HBM-bound kernels of the
+    layers below.  Forward (and everything on other inputs) is the library convolution."""
 
-    def __init__(self, cin, cout):
-        super().__init__(cin, cout, 1, bias=False)
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__(cin, cout, k, stride, padding, bias=False)
 
     def forward(self, x):
-        from .. import ops
-        if torch.is_grad_enabled() and not _NO_CONV1X1 and ops.conv1x1_supported(x, self.weight):
-            return ops.conv1x1(x, self.weight)
+        if (torch.is_grad_enabled() and not _NO_CONV_SPLIT and x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            from .. import ops
+            return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD)
         return super().forward(x)
+
+
+class Conv1x1(TrunkConv):
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 1)
 
 
 class MaxPool3s2(nn.MaxPool2d):
@@ -102,10 +110,10 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.conv1 = TrunkConv(inplanes, planes, 3, stride, 1)
         self.bn1 = BNAct(planes)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = TrunkConv(planes, planes, 3, 1, 1)
         self.bn2 = BNAct(planes)
         self.downsample = downsample
         self.stride = stride
@@ -124,7 +132,7 @@ class Bottleneck(nn.Module):
         super().__init__()
         self.conv1 = Conv1x1(inplanes, planes)
         self.bn1 = BNAct(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # stride on the 3x3 (torchvision v1.5)
+        self.conv2 = TrunkConv(planes, planes, 3, stride, 1)                 # stride on the 3x3 (torchvision v1.5)
         self.bn2 = BNAct(planes)
         self.conv3 = Conv1x1(planes, planes * 4)
         self.bn3 = BNAct(planes * 4)
@@ -146,7 +154,7 @@ class ResNetTrunk(nn.Module):
     def __init__(self, block, layers, relu_inplace=True):
         super().__init__()
         self.inplanes = 64
-        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.conv1 = TrunkConv(3, 64, 7, 2, 3)
         self.bn1 = BNAct(64)
         self.relu = nn.ReLU(inplace=relu_inplace)
         self.maxpool = MaxPool3s2()
@@ -166,7 +174,7 @@ class ResNetTrunk(nn.Module):
         downsample = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                TrunkConv(self.inplanes, planes * block.expansion, 1, stride),
                 BNAct(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
@@ -269,7 +277,8 @@ BERT_CONFIGS = {
 
 
 _NO_ATTN_SMALL = bool(os.environ.get('CFL_NO_ATTN_SMALL'))       # A/B switches for measurements
-_NO_CONV1X1 = bool(os.environ.get('CFL_NO_CONV1X1'))
+_NO_CONV_SPLIT = bool(os.environ.get('CFL_NO_CONV_SPLIT'))
+_NO_SIDE_WGRAD = bool(os.environ.get('CFL_NO_SIDE_WGRAD'))
 
 
 def _bert_fusable(x, weight, max_out=1 << 30):

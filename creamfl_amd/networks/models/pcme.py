@@ -12,14 +12,13 @@ import os
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, streams
 from ..backbones import BertModel
 from .caption_encoder import EncoderText
 from .image_encoder import EncoderImage
 
 
 _NO_TWO_STREAM = bool(os.environ.get('CFL_NO_TWO_STREAM'))         # A/B switch for measurements
-_SIDE_STREAMS = {}                  # one side stream per device, shared by all models (kept off the modules: deepcopy)
 
 
 class PCME(nn.Module):
@@ -69,9 +68,7 @@ class PCME(nn.Module):
         # backward op on the stream of its forward, so the two backward passes overlap as well.
         side = None
         if images.is_cuda and not _NO_TWO_STREAM and torch.is_tensor(sentences) and sentences.is_cuda:
-            side = _SIDE_STREAMS.get(images.device)
-            if side is None:
-                side = _SIDE_STREAMS[images.device] = torch.cuda.Stream(device=images.device)
+            side = streams.get(images.device, 'text')
         if side is None:
             image_output = self.img_enc(images)
             caption_output = self._text_tower(sentences, captions_word, lengths)

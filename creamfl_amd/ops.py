@@ -557,39 +557,80 @@ def conv1x1_supported(x, weight):
             and x.is_contiguous(memory_format=torch.channels_last) and weight.shape[0] % 64 == 0 and weight.shape[1] % 8 == 0)
 
 
-class _Conv1x1Fn(torch.autograd.Function):
-    """y = conv2d(x, w) for a 1x1 / stride-1 kernel.  Forward and weight gradient stay on MIOpen; the DATA gradient
-    dX[M, Ci] = dY[M, Co] @ W[Co, Ci] runs on the hand-written bf16 MFMA GEMM, which beats MIOpen's backward-data
-    kernels on every ResNet-101 shape (tools/wgrad_probe.py vs tools/kernel_bench.py --cases gemm16: e.g.
-    14x14 1024->256: 78 -> 48 us, 56x56 256->64: 184 -> 110 us)."""
+_JOIN_QUEUED = [False]
+
+
+def _queue_stream_join(device):
+    """At the end of the running backward pass make the caller's stream wait for the auxiliary gradient streams."""
+    if _JOIN_QUEUED[0]:
+        return
+    _JOIN_QUEUED[0] = True
+
+    def _join():
+        _JOIN_QUEUED[0] = False
+        from . import streams
+        streams.join_into_current(device)
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
+class _ConvSplitFn(torch.autograd.Function):
+    """y = conv2d(x, w, stride, padding) (no bias, groups 1) with the backward split in two:
+      * the DATA gradient stays on the critical path (main stream); for 1x1 / stride-1 kernels it runs on the
+        hand-written bf16 MFMA GEMM (dX[M, Ci] = dY[M, Co] @ W[Co, Ci]), which beats MIOpen's backward-data kernels on
+        every ResNet-101 shape (tools/wgrad_probe.py vs tools/kernel_bench.py --cases gemm16);
+      * the WEIGHT gradient, which nothing but the optimizer waits for, is issued on the auxiliary 'wgrad' stream and
+        overlaps the HBM-bound BN / data-gradient kernels of the layers below (streams.py).  MIOpen computes it."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad):
         ctx.save_for_backward(x, weight)
-        return torch.nn.functional.conv2d(x, weight)
+        ctx.cfg = (stride, padding, gemm_dgrad, side_wgrad)
+        return torch.nn.functional.conv2d(x, weight, None, stride, padding)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        stride, padding, gemm_dgrad, side_wgrad = ctx.cfg
         N, Ci, H, W = x.shape
         Co = weight.shape[0]
-        if dy.dtype != torch.bfloat16:
-            dy = dy.to(torch.bfloat16)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         dy = dy.contiguous(memory_format=torch.channels_last)
+        args = (dy, x, weight, None, [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1)
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)                                    # channels_last: the [M, Ci] matrix
-            wt = torch.empty(Ci, Co, dtype=torch.bfloat16, device=x.device)   # [Ci, Co]: reduction axis contiguous
-            _lib.check(_lib.load().cfl_transpose_bf16(_ptr(weight), Co, Ci, _ptr(wt), _stream(x)), 'cfl_transpose_bf16')
-            gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
-        return dx, dw
+            if side_wgrad:
+                from . import streams
+                main = torch.cuda.current_stream(x.device)
+                side = streams.get(x.device, 'wgrad')
+                side.wait_stream(main)                                   # dy (and x) are ready on the main stream
+                with torch.cuda.stream(side):
+                    dw = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                dy.record_stream(side)
+                x.record_stream(side)
+                dw.record_stream(main)
+                _queue_stream_join(x.device)
+            else:
+                dw = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+        if ctx.needs_input_grad[0]:
+            if gemm_dgrad:
+                dx = torch.empty_like(x)                                 # channels_last: the [M, Ci] matrix
+                wt = torch.empty(Ci, Co, dtype=torch.bfloat16, device=x.device)   # [Ci, Co]: reduction axis contiguous
+                _lib.check(_lib.load().cfl_transpose_bf16(_ptr(weight), Co, Ci, _ptr(wt), _stream(x)), 'cfl_transpose_bf16')
+                gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
+            else:
+                dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
+        return dx, dw, None, None, None, None
+
+
+def conv_split(x, weight, stride=1, padding=0, side_wgrad=True):
+    """Trunk convolution with the split backward of _ConvSplitFn (x: channels_last HIP tensor; weight [Co, Ci, k, k])."""
+    gemm = (weight.shape[2] == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0 and conv1x1_supported(x, weight))
+    return _ConvSplitFn.apply(x, weight, int(stride), int(padding), bool(gemm), bool(side_wgrad))
 
 
 def conv1x1(x, weight):
-    return _Conv1x1Fn.apply(x, weight)
+    return conv_split(x, weight, 1, 0)
 
 
 # --------------------------------------------------------------------------- ResNet stem max pooling (csrc/pool.hip)
