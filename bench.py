@@ -238,9 +238,10 @@ def main():
                     roof['traffic_source'] = 'profiles/r1_pmc_traffic.json'
             except (OSError, ValueError):
                 pass
-        if roof is not None and not os.environ.get('CFL_NO_TWO_STREAM') and not cfg.model.not_bert:
-            # the text tower runs on a second HIP stream: part of these launches share HBM with its kernels, so the
-            # per-launch rate is a lower bound of what the kernel reaches alone (CFL_NO_TWO_STREAM=1 measures that)
+        if roof is not None and not (os.environ.get('CFL_NO_TWO_STREAM') and os.environ.get('CFL_NO_SIDE_WGRAD')):
+            # the text tower and the convolution weight gradients run on auxiliary HIP streams: part of these launches
+            # share HBM with their kernels, so the per-launch rate is a lower bound of what the kernel reaches alone
+            # (CFL_NO_TWO_STREAM=1 CFL_NO_SIDE_WGRAD=1 measures that)
             roof['concurrent_stream'] = True
         hip_us = {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted((warm_prof or prof).items())}
 
