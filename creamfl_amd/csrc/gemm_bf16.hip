@@ -373,7 +373,7 @@ extern "C" int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, lon
 extern "C" int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream_) {
     if (!src || !dst || R <= 0 || C <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    CFL_LAUNCH(K_GEMM_BF16, cfl_transpose_bf16_kernel, dim3(cfl_cdiv(C, 64), cfl_cdiv(R, 64)), dim3(256), 0, stream, (const u16*)src, R,
+    CFL_LAUNCH(K_TRANSPOSE, cfl_transpose_bf16_kernel, dim3(cfl_cdiv(C, 64), cfl_cdiv(R, 64)), dim3(256), 0, stream, (const u16*)src, R,
                C, (u16*)dst);
     return 0;
 }

@@ -526,11 +526,16 @@ def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, res
 
 
 # --------------------------------------------------------------------------- 1x1 convolution: data gradient (csrc/gemm_bf16.hip)
+GEMM_COUNTERS = {'flops': 0, 'bytes': 0}   # python ints; bench.py turns them into algorithmic work per launch
+
+
 def gemm_bf16_nt(a, b, out=None, variant=0):
     """out[M, N] = a[M, K] @ b[N, K]^T, bf16 (csrc/gemm_bf16.hip: cfl_gemm_bf16_nt)."""
     lib = _lib.load()
     M, K = a.shape
     N = b.shape[0]
+    GEMM_COUNTERS['flops'] += 2 * M * N * K
+    GEMM_COUNTERS['bytes'] += 2 * (M * K + N * K + M * N)
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     _lib.check(lib.cfl_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K, variant,
