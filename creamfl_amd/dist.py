@@ -97,6 +97,7 @@ class DataParallelContext:
             # backward node that completed the bucket.  This hook makes that stream wait for every gradient stream first.
             from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
             from . import streams
+            streams.DEFER_WGRAD[0] = False        # a bucket may be reduced as soon as autograd has seen its gradients
 
             def _hook(state, bucket):
                 streams.join_into_current(bucket.buffer().device)

@@ -476,6 +476,9 @@ class _BNActFn(torch.autograd.Function):
             dy, dy2 = dy2, None
         if dy is None:
             return (None,) * 9
+        if ctx.has_res:
+            from . import streams
+            streams.flush(x.device)          # a long HBM-bound phase starts: let the queued weight gradients run beside it
         BN_COUNTERS['bwd'] += R * C
         if ctx.relu and ctx.has_res:
             BN_COUNTERS['bwd_relu'] += R * C              # passes that read y
@@ -574,6 +577,7 @@ def _queue_stream_join(device):
     def _join():
         _JOIN_QUEUED[0] = False
         from . import streams
+        streams.flush(device)
         streams.join_into_current(device)
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
@@ -606,14 +610,31 @@ class _ConvSplitFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if side_wgrad:
                 from . import streams
-                main = torch.cuda.current_stream(x.device)
-                side = streams.get(x.device, 'wgrad')
-                side.wait_stream(main)                                   # dy (and x) are ready on the main stream
-                with torch.cuda.stream(side):
-                    dw = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
-                dy.record_stream(side)
-                x.record_stream(side)
-                dw.record_stream(main)
+                if streams.DEFER_WGRAD[0]:
+                    # Autograd gets no weight gradient from this node (None = zero); when the queue is flushed the
+                    # gradient is computed on the 'wgrad' stream and accumulated into `weight.grad` directly, exactly
+                    # what AccumulateGrad would have done (a tensor handed over now and filled later does not work:
+                    # AccumulateGrad clones a gradient that something else still references).
+                    def task(main, side, args=args, weight=weight):
+                        g = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                        args[0].record_stream(side)
+                        args[1].record_stream(side)
+                        g.record_stream(main)
+                        with torch.no_grad():
+                            if weight.grad is None:
+                                weight.grad = g
+                            else:
+                                weight.grad.add_(g)
+                    streams.defer(task)
+                else:
+                    main = torch.cuda.current_stream(x.device)
+                    side = streams.get(x.device, 'wgrad')
+                    side.wait_stream(main)                               # dy (and x) are ready on the main stream
+                    with torch.cuda.stream(side):
+                        dw = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                    dy.record_stream(side)
+                    x.record_stream(side)
+                    dw.record_stream(main)
                 _queue_stream_join(x.device)
             else:
                 dw = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]

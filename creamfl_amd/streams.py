@@ -30,3 +30,31 @@ def join_into_current(device):
     for s in existing(device):
         if s != cur:
             cur.wait_stream(s)
+
+
+# ---- deferred weight gradients --------------------------------------------------------------------------------------
+# A convolution's weight gradient is off the critical path, but when it runs concurrently with the (LDS/MFMA-bound)
+# data-gradient GEMMs it slows exactly the kernels that ARE on the critical path.  The backward of a convolution
+# therefore only queues its weight-gradient launch; the queue is flushed onto the 'wgrad' stream when the main stream
+# enters a long HBM-bound phase (the backward of a residual BatchNorm) and at the end of the backward pass.
+# Not under DDP: a bucket may be all-reduced as soon as autograd has SEEN every gradient in it (see dist.py).
+DEFER_WGRAD = [True]
+_PENDING = []
+
+
+def defer(task):
+    _PENDING.append(task)
+
+
+def flush(device):
+    """Launch every queued weight gradient on the 'wgrad' stream, after everything queued so far on the current one."""
+    if not _PENDING:
+        return
+    main = torch.cuda.current_stream(device)
+    side = get(device, 'wgrad')
+    side.wait_stream(main)
+    tasks = list(_PENDING)
+    del _PENDING[:]
+    with torch.cuda.stream(side):
+        for t in tasks:
+            t(main, side)
