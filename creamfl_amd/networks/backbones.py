@@ -68,7 +68,10 @@ class TrunkConv(nn.Conv2d):
     """nn.Conv2d(cin, cout, k, stride, padding, bias=False) of the ResNet trunks.  On the channels_last GPU training
     path the backward is split (ops.conv_split): data gradient on the critical path -- for 1x1 / stride-1 kernels on the
     hand-written MFMA GEMM --, weight gradient on an auxiliary stream where it overlaps the HBM-bound kernels of the
-    layers below.  Forward (and everything on other inputs) is the library convolution."""
+    layers below.  Forward (and everything on other inputs) is the library convolution.
+    Note: outside DDP the deferred weight gradient is accumulated into `weight.grad` at the end of `backward()` (what
+    AccumulateGrad does) rather than returned through autograd, so `torch.autograd.grad(..., conv.weight)` sees None;
+    set CFL_NO_SIDE_WGRAD=1 for the plain behaviour."""
 
     def __init__(self, cin, cout, k, stride=1, padding=0):
         super().__init__(cin, cout, k, stride, padding, bias=False)

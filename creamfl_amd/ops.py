@@ -565,17 +565,19 @@ def conv1x1_supported(x, weight):
             and x.is_contiguous(memory_format=torch.channels_last) and weight.shape[0] % 64 == 0 and weight.shape[1] % 8 == 0)
 
 
-_JOIN_QUEUED = [False]
+_JOIN_QUEUED_FOR = [-1]
 
 
 def _queue_stream_join(device):
-    """At the end of the running backward pass make the caller's stream wait for the auxiliary gradient streams."""
-    if _JOIN_QUEUED[0]:
+    """At the end of the running backward pass (once per pass: keyed by the autograd graph-task id, so an aborted
+    pass cannot leave a stale flag behind) make the caller's stream wait for the auxiliary gradient streams."""
+    gid = torch._C._current_graph_task_id()
+    if gid >= 0 and _JOIN_QUEUED_FOR[0] == gid:
         return
-    _JOIN_QUEUED[0] = True
+    _JOIN_QUEUED_FOR[0] = gid
 
     def _join():
-        _JOIN_QUEUED[0] = False
+        _JOIN_QUEUED_FOR[0] = -1
         from . import streams
         streams.flush(device)
         streams.join_into_current(device)

@@ -40,9 +40,14 @@ def join_into_current(device):
 # Not under DDP: a bucket may be all-reduced as soon as autograd has SEEN every gradient in it (see dist.py).
 DEFER_WGRAD = [True]
 _PENDING = []
+_PENDING_FOR = [-1]
 
 
 def defer(task):
+    gid = torch._C._current_graph_task_id()
+    if gid != _PENDING_FOR[0]:
+        del _PENDING[:]                  # leftovers of a backward pass that was aborted: their gradients are void
+        _PENDING_FOR[0] = gid
     _PENDING.append(task)
 
 
