@@ -205,10 +205,10 @@ def main():
         bc = _ops.BN_COUNTERS
         bn_bytes = {
             'cfl_bn_stats_kernel': 2 * bc['fwd'],
-            'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'],
+            'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'] + bc['fwd_mask'] // 8,   # + the 1-bit ReLU mask
             # bwd: read dy (+ second upstream gradient), x, (+ y only when the mask cannot be recomputed from x)
-            'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + 2 * bc['bwd_relu'] + 2 * bc['bwd_two'],
-            'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + 2 * bc['bwd_relu'] + 2 * bc['bwd_res'] + 2 * bc['bwd_two'],
+            'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_two'],
+            'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_res'] + 2 * bc['bwd_two'],
         }
         for name, (n, ms) in prof.items():
             base = name

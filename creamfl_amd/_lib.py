@@ -66,9 +66,9 @@ SIGNATURES = {
     'cfl_rank_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cfl_rank_count': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_bn_ws_bytes': (c_size_t, [c_longlong, c_int]),
-    'cfl_bn_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P]),
+    'cfl_bn_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, _P]),
-    'cfl_bn_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'cfl_bn_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_grad_clip_coef': (c_int, [_P, _P, c_int, c_float, _P, _P, _P]),
     'cfl_adamp_step': (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P, c_float, c_float, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int, _P, _P]),

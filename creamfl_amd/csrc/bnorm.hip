@@ -83,7 +83,8 @@ template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const U4* __restrict__ x, const U4* __restrict__ res,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           long long R, int C, int rows_per_block, U4* y) {
+                                                           long long R, int C, int rows_per_block, U4* y,
+                                                           unsigned char* __restrict__ relu_mask) {
     const Map m = make_map(C);
     if (!m.active) return;
     float sc[8], sh[8];
@@ -109,7 +110,16 @@ __global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const U4* __restrict_
             if (RELU) v = fmaxf(v, 0.f);
             f[k] = v;
         }
-        y[off] = pack8(f);
+        const U4 o = pack8(f);
+        y[off] = o;
+        if (RELU && relu_mask) {                           // bit k = (y_k > 0) of the STORED bf16 value: the backward reads
+            unsigned b = 0;                                // one byte per 8 outputs instead of the 16 bytes of y
+            b |= (o.x & 0xffffu) ? 1u : 0u;  b |= (o.x >> 16) ? 2u : 0u;
+            b |= (o.y & 0xffffu) ? 4u : 0u;  b |= (o.y >> 16) ? 8u : 0u;
+            b |= (o.z & 0xffffu) ? 16u : 0u; b |= (o.z >> 16) ? 32u : 0u;
+            b |= (o.w & 0xffffu) ? 64u : 0u; b |= (o.w >> 16) ? 128u : 0u;
+            relu_mask[off] = (unsigned char)b;
+        }
     }
 }
 
@@ -122,7 +132,8 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
                                                                 const U4* __restrict__ x, const U4* __restrict__ y,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                long long R, int C, int rows_per_block, float* pdb, float* pdg) {
+                                                                long long R, int C, int rows_per_block, float* pdb, float* pdg,
+                                                                const unsigned char* __restrict__ relu_mask) {
     __shared__ float lds[4096];
     const Map m = make_map(C);
     float db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -142,7 +153,11 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
             float d[8], f[8], o[8];
             unpack8(dy[off], d);
             unpack8(x[off], f);
-            if (RELU && !XMASK) unpack8(y[off], o);
+            unsigned mb = 0;
+            if (RELU && !XMASK) {
+                if (relu_mask) mb = relu_mask[off];
+                else unpack8(y[off], o);
+            }
             if (dy2) {
                 float d2[8];
                 unpack8(dy2[off], d2);
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const bool on = !RELU || (XMASK ? fmaf(f[k], sc[k], sh[k]) > 0.f : o[k] > 0.f);
+                const bool on = !RELU || (XMASK ? fmaf(f[k], sc[k], sh[k]) > 0.f : (relu_mask ? ((mb >> k) & 1u) != 0 : o[k] > 0.f));
                 const float dd = on ? d[k] : 0.f;
                 db[k] += dd;
                 dg[k] = fmaf(dd, (f[k] - mu[k]) * is[k], dg[k]);
@@ -176,7 +191,8 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ dbeta, const float* __restrict__ dgamma,
-                                                               long long R, int C, int rows_per_block, U4* dx, U4* dres) {
+                                                               long long R, int C, int rows_per_block, U4* dx, U4* dres,
+                                                               const unsigned char* __restrict__ relu_mask) {
     const Map m = make_map(C);
     if (!m.active) return;
     float mu[8], is[8], a[8], b[8], c[8], sh[8];
@@ -198,7 +214,11 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
         float d[8], f[8], o[8];
         unpack8(ld_nt(dy + off), d);
         unpack8(ld_nt(x + off), f);
-        if (RELU && !XMASK) unpack8(ld_nt(y + off), o);
+        unsigned mb = 0;
+        if (RELU && !XMASK) {
+            if (relu_mask) mb = relu_mask[off];
+            else unpack8(ld_nt(y + off), o);
+        }
         if (dy2) {
             float d2[8];
             unpack8(ld_nt(dy2 + off), d2);
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const bool on = !RELU || (XMASK ? fmaf(f[k], a[k], sh[k]) > 0.f : o[k] > 0.f);
+            const bool on = !RELU || (XMASK ? fmaf(f[k], a[k], sh[k]) > 0.f : (relu_mask ? ((mb >> k) & 1u) != 0 : o[k] > 0.f));
             const float dd = on ? d[k] : 0.f;
             d[k] = dd;
             f[k] = a[k] * (dd - b[k] - (f[k] - mu[k]) * is[k] * c[k]);
@@ -246,7 +266,7 @@ size_t cfl_bn_ws_bytes(long long R, int C) {
 
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
-               float* save_mean, float* save_invstd, void* ws, void* stream_) {
+               float* save_mean, float* save_invstd, unsigned char* relu_mask, void* ws, void* stream_) {
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
     if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;
@@ -259,18 +279,19 @@ int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const fl
                momentum, save_mean, save_invstd, running_mean, running_var);
     const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
     if (residual && relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else if (residual)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else if (relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     return 0;
 }
 
 int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
                  const float* beta, long long R, int C, int relu, void* y, void* stream_) {
+    unsigned char* relu_mask = nullptr;
     if (!x || !mean || !invstd || !gamma || !beta || !y || R <= 0 || C <= 0) return CFL_EINVAL;
     if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;
@@ -278,21 +299,21 @@ int cfl_bn_apply(const void* x, const void* residual, const float* mean, const f
     const dim3 grid(p.nblk, p.gy);
     const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
     if (residual && relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else if (residual)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else if (relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     return 0;
 }
 
-int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const float* gamma, const float* beta,
-               const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx,
-               void* dres, float* dgamma, float* dbeta, void* ws, void* stream_) {
+int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,
+               const float* beta, const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual,
+               void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream_) {
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
-    const bool xmask = relu && !y;                       // ReLU mask recomputed from x: needs beta, and no residual
+    const bool xmask = relu && !y && !relu_mask;         // ReLU mask recomputed from x: needs beta, and no residual
     if ((xmask && (has_residual || !beta)) || (has_residual && !dres)) return CFL_EINVAL;
     if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;
@@ -302,13 +323,13 @@ int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, co
     const dim3 grid(p.nblk, p.gy);
     const U4 *d = (const U4*)dy, *d2 = (const U4*)dy2, *xx = (const U4*)x, *yy = (const U4*)y;
 #define BN_REDUCE(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, xx, yy, \
-                                         save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg)
+                                         save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, relu_mask)
     if (xmask) BN_REDUCE(true, true); else if (relu) BN_REDUCE(true, false); else BN_REDUCE(false, false);
 #undef BN_REDUCE
     CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(256), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
     U4 *ox = (U4*)dx, *orr = (U4*)dres;
 #define BN_APPLY(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<RES_, RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, \
-                                              xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr)
+                                              xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr, relu_mask)
     if (xmask) BN_APPLY(false, true, true);
     else if (has_residual && relu) BN_APPLY(true, true, false);
     else if (has_residual) BN_APPLY(true, false, false);

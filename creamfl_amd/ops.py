@@ -440,7 +440,7 @@ def bn_act_supported(x, num_features):
 
 
 # element counters of the fused BN kernels (python ints; bench.py turns them into algorithmic bytes)
-BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
+BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
 
 
 class _BNActFn(torch.autograd.Function):
@@ -456,20 +456,25 @@ class _BNActFn(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
-        _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                  R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(ws), _stream(x)),
-                   'cfl_bn_fwd')
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
-        # the ReLU mask needs y only with a residual; otherwise the backward recomputes it from x, gamma, beta
-        ctx.save_for_backward(x, y if (relu and ctx.has_res) else x, weight, bias, mean, invstd)
+        # ReLU mask for the backward: without a residual it is recomputed from x, gamma, beta; with one the forward
+        # packs it into 1 bit per element (R*C/8 bytes) so that the backward does not re-read y (16x fewer bytes, twice)
+        need_mask = ctx.relu and ctx.has_res and any(ctx.needs_input_grad[:4])
+        mask = torch.empty(R * C // 8, dtype=torch.uint8, device=x.device) if need_mask else None
+        if need_mask:
+            BN_COUNTERS['fwd_mask'] += R * C
+        _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                  R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(mask), _ptr(ws),
+                                  _stream(x)), 'cfl_bn_fwd')
+        ctx.save_for_backward(x, mask if need_mask else x, weight, bias, mean, invstd)
         ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
         return y, _alias(y)
 
     @staticmethod
     def backward(ctx, dy, dy2):
         lib = _lib.load()
-        x, y, weight, bias, mean, invstd = ctx.saved_tensors
+        x, mask, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
         R = N * H * W
         if dy is None:
@@ -481,7 +486,7 @@ class _BNActFn(torch.autograd.Function):
             streams.flush(x.device)          # a long HBM-bound phase starts: let the queued weight gradients run beside it
         BN_COUNTERS['bwd'] += R * C
         if ctx.relu and ctx.has_res:
-            BN_COUNTERS['bwd_relu'] += R * C              # passes that read y
+            BN_COUNTERS['bwd_relu'] += R * C              # passes that read the 1-bit ReLU mask
         if ctx.has_res:
             BN_COUNTERS['bwd_res'] += R * C
         if dy2 is not None:
@@ -498,7 +503,7 @@ class _BNActFn(torch.autograd.Function):
         dgamma = torch.empty_like(weight)
         dbeta = torch.empty_like(weight)
         ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
-        _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(y) if (ctx.relu and ctx.has_res) else _ptr(None),
+        _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(None), _ptr(mask) if (ctx.relu and ctx.has_res) else _ptr(None),
                                   _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res),
                                   _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
         return dx, dres, dgamma, dbeta, None, None, None, None, None

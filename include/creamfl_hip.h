@@ -263,16 +263,18 @@ int cfl_rank_count(const float* Q, const float* G, const long long* qlab, const 
  *        dy2 (may be NULL) is a second upstream gradient, added on the fly (the block output feeds the next
  *        convolution and the next residual add).  y may be NULL for relu without residual: the mask is then
  *        recomputed from x (needs beta), one activation read less in each of the two passes.
+ *        relu_mask (fwd: optional output, R*C/8 bytes; bwd: optional input replacing y): bit k of byte i = (y > 0) of
+ *        element 8i+k -- with a residual the backward then reads 1 byte instead of 16 per 8 outputs, twice.
  */
 size_t cfl_bn_ws_bytes(long long R, int C);
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
-               float* save_mean, float* save_invstd, void* ws, void* stream);
+               float* save_mean, float* save_invstd, unsigned char* relu_mask, void* ws, void* stream);
 int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
                  const float* beta, long long R, int C, int relu, void* y, void* stream);
-int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const float* gamma, const float* beta,
-               const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual, void* dx,
-               void* dres, float* dgamma, float* dbeta, void* ws, void* stream);
+int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,
+               const float* beta, const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual,
+               void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream);
 
 /* ---- S1 tail: fused multi-tensor gradient clip + AdamP step ------
  * Replaces nn.utils.clip_grad_norm_(model.parameters(), 2) + AdamP.step()
