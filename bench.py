@@ -202,16 +202,17 @@ def main():
         n_f32 = sum(p.numel() for p in eng.model.parameters() if p.dtype == torch.float32) + 2
         # fused BN kernels run once per BatchNorm layer with a different shape each: their algorithmic bytes are
         # accumulated over the launches of the timed region (bf16 = 2 B / element) and divided per launch
-        bc = _ops.BN_COUNTERS
-        bn_bytes = {
-            'cfl_bn_stats_kernel': 2 * bc['fwd'],
-            'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'] + bc['fwd_mask'] // 8,   # + the 1-bit ReLU mask
-            # bwd: read dy (+ second upstream gradient), x, (+ y only when the mask cannot be recomputed from x)
-            'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_two'],
-            'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_res'] + 2 * bc['bwd_two'],
-        }
-        for name, (n, ms) in prof.items():
-            base = name
+        def kernel_cost(base, n):
+            """(bound, algorithmic bytes or FLOP per launch) of a hand-written kernel over the launches just profiled"""
+            bc = _ops.BN_COUNTERS
+            bn_bytes = {
+                'cfl_bn_stats_kernel': 2 * bc['fwd'],
+                'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'] + bc['fwd_mask'] // 8,   # + the 1-bit ReLU mask
+                # bwd reduce: read dy (+ second upstream gradient), x and the ReLU mask bits (with a residual; otherwise
+                # the mask comes from x); bwd apply: the same reads, write dx (+ the residual gradient)
+                'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_two'],
+                'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_res'] + 2 * bc['bwd_two'],
+            }
             cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim, n_f32, n_bf16)
             if base.startswith('cfl_pair_'):
                 cost = algorithmic_cost(base, Nloss, 49, Cd, Cd // 2, args.dim)
@@ -222,6 +223,10 @@ def main():
                 # 312 FLOP/B), i.e. the binding roof is HBM unless the FLOP time is the larger one
                 gf, gb = _ops.GEMM_COUNTERS['flops'] / n, _ops.GEMM_COUNTERS['bytes'] / n
                 cost = ('mfma_bf16', gf) if gf / (BF16_MFMA_PEAK_TFLOPS * 1e12) > gb / (HBM_PEAK_GBPS * 1e9) else ('hbm', gb)
+            return cost
+
+        for name, (n, ms) in prof.items():
+            cost = kernel_cost(name, n)
             if cost:
                 cand.append((ms, name, n, cost))
         if cand:
@@ -255,6 +260,35 @@ def main():
             # share HBM with their kernels, so the per-launch rate is a lower bound of what the kernel reaches alone
             # (CFL_NO_TWO_STREAM=1 CFL_NO_SIDE_WGRAD=1 measures that)
             roof['concurrent_stream'] = True
+            if world == 1:
+                # the same kernel with the auxiliary streams switched off (3 extra steps, outside the timed region)
+                from creamfl_amd.networks import backbones as _bb
+                from creamfl_amd.networks.models import pcme as _pc
+                saved = (_pc._NO_TWO_STREAM, _bb._NO_SIDE_WGRAD)
+                _pc._NO_TWO_STREAM, _bb._NO_SIDE_WGRAD = True, True
+                try:
+                    step()
+                    fence()
+                    for k_ in _ops.BN_COUNTERS:
+                        _ops.BN_COUNTERS[k_] = 0
+                    _ops.GEMM_COUNTERS['flops'] = _ops.GEMM_COUNTERS['bytes'] = 0
+                    _lib.prof_reset()
+                    _lib.prof_select(roof['kernel'])
+                    _lib.prof_enable(True)
+                    for _ in range(3):
+                        step()
+                    fence()
+                    _lib.prof_enable(False)
+                    _lib.prof_select(None)
+                    n1, ms1 = _lib.prof_query()[roof['kernel']]
+                    bound1, work1 = kernel_cost(roof['kernel'], n1)
+                    us1 = ms1 / n1 * 1e3
+                    ach1 = work1 / (us1 * 1e-6) / (1e9 if bound1 == 'hbm' else 1e12)
+                    roof['alone'] = {'achieved': round(ach1, 1), 'frac': round(ach1 / roof['peak'], 4),
+                                     'avg_launch_us': round(us1, 2), 'launches': n1,
+                                     'how': 'same step with the text-tower and weight-gradient streams off'}
+                finally:
+                    _pc._NO_TWO_STREAM, _bb._NO_SIDE_WGRAD = saved
         hip_us = {k: round(ms / n * 1e3, 2) for k, (n, ms) in sorted((warm_prof or prof).items())}
 
         cpu = None
