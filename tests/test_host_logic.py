@@ -174,3 +174,40 @@ def test_residual_blocks_pass_pairs_and_match_plain_composition_on_cpu():
     o = F.relu(blk.bn2(blk.conv2(o)))
     ref = F.relu(blk.bn3(blk.conv3(o)) + x)
     torch.testing.assert_close(first_of(y), ref)
+
+
+def test_bert_mirror_matches_transformers_on_cpu():
+    """The text tower is third-party code in the reference (`transformers.BertModel`, src/networks/models/pcme.py:36-38).
+    The mirror in networks/backbones.py loads the library's own state_dict and must reproduce its hidden states and
+    parameter gradients (CPU, fp32, dropout off, ragged attention masks) -- this pins the restated BertLayer arithmetic
+    that csrc/bertfuse.hip and csrc/attn_small.hip are tested against."""
+    import pytest
+    import torch
+    transformers = pytest.importorskip('transformers')
+    from creamfl_amd.networks import backbones as bb
+    kw = dict(vocab_size=3000, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+              max_position_embeddings=64)
+    torch.manual_seed(0)
+    hf = transformers.BertModel(transformers.BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **kw),
+                                add_pooling_layer=False).train()
+    mine = bb.BertModel(bb.BertConfig(hidden_dropout_prob=0.0, **kw)).train()
+    res = mine.load_state_dict(hf.state_dict(), strict=True)           # same parameter names
+    assert not res.missing_keys and not res.unexpected_keys
+    ids = torch.randint(1, 3000, (3, 11))
+    mask = torch.arange(11)[None] < torch.tensor([11, 6, 9])[:, None]
+    w = torch.randn(3, 128)
+    a = hf(input_ids=ids, attention_mask=mask.long()).last_hidden_state
+    b = mine(ids, attention_mask=mask)['last_hidden_state']
+    torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5)
+    (a[:, 0] * w).sum().backward()
+    (b[:, 0] * w).sum().backward()
+    ga = dict(hf.named_parameters())
+    for n, p in mine.named_parameters():
+        if n.endswith('key.bias'):
+            continue                                                     # analytically zero
+        g_ref = ga[n].grad
+        assert (p.grad is None) == (g_ref is None), n
+        if g_ref is not None:
+            torch.testing.assert_close(p.grad, g_ref, rtol=1e-4, atol=1e-5 * (float(g_ref.abs().max()) + 1e-3), msg=n)
+    c = mine(ids, attention_mask=mask, cls_only=True)['last_hidden_state'][:, 0]
+    torch.testing.assert_close(c, a[:, 0].detach(), rtol=1e-5, atol=1e-5)
