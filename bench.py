@@ -86,6 +86,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--no-alone', action='store_true', help='skip the 4 extra steps that measure the dominant kernel with the auxiliary streams off')
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (pairs)')
     ap.add_argument('--dim', type=int, default=512)
@@ -260,7 +261,7 @@ def main():
             # share HBM with their kernels, so the per-launch rate is a lower bound of what the kernel reaches alone
             # (CFL_NO_TWO_STREAM=1 CFL_NO_SIDE_WGRAD=1 measures that)
             roof['concurrent_stream'] = True
-            if world == 1:
+            if world == 1 and not args.no_alone:
                 # the same kernel with the auxiliary streams switched off (3 extra steps, outside the timed region)
                 from creamfl_amd.networks import backbones as _bb
                 from creamfl_amd.networks.models import pcme as _pc

@@ -339,7 +339,10 @@ class _SelfAttention(nn.Module):
             from .. import ops
             if qkv.dtype == torch.bfloat16 and ops.bert_attention_supported(L, H // self.h) and not _NO_ATTN_SMALL:
                 # short captions: one wavefront per (batch, head), MFMA, no saved probabilities (csrc/attn_small.hip)
-                return ops.bert_attention(qkv, None if mask is None else mask.reshape(B, L), self.h)
+                km = None if mask is None else getattr(mask, '_cfl_u8', None)
+                if mask is not None and km is None:             # converted once per forward, reused by every layer
+                    km = mask._cfl_u8 = mask.reshape(B, L).to(torch.uint8).contiguous()
+                return ops.bert_attention(qkv, km, self.h)
             q, k, v = qkv.split(H, dim=-1)
         else:
             q, k, v = self.query(xq), self.key(x), self.value(x)

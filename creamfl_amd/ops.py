@@ -887,7 +887,9 @@ def bert_attention(qkv, key_mask, heads):
         raise _lib.CreamflHipError(f'bert_attention: unsupported shape {tuple(qkv.shape)} with {heads} heads')
     m = None
     if key_mask is not None:
-        m = key_mask.reshape(B, L).to(device=qkv.device, dtype=torch.uint8).contiguous()
+        m = key_mask.reshape(B, L)
+        if m.dtype != torch.uint8 or m.device != qkv.device or not m.is_contiguous():
+            m = m.to(device=qkv.device, dtype=torch.uint8).contiguous()
     return _AttnSmallFn.apply(qkv, m, int(heads))
 
 
