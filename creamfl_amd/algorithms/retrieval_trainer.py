@@ -45,6 +45,7 @@ class EngineBase(object):
         self.partition_train_distill = partition_train_distill
         self.autocast_dtype = None
         self.dp = None                       # creamfl_amd.dist.DataParallelContext when enabled
+        self._conv1x1_weights = None         # weights whose transposes are prepared in one launch before backward
 
     def create(self, config, word2idx, evaluator, mlp_local):
         self.config = config
@@ -182,7 +183,18 @@ class TrainerEngine(EngineBase):
             images = images.contiguous(memory_format=torch.channels_last)
         loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens)
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if loss.is_cuda:
+            from .. import ops
+            if self._conv1x1_weights is None:
+                self._conv1x1_weights = [m.weight for m in self.model.modules()
+                                         if isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1)]
+            ops.prepare_weight_transposes(self._conv1x1_weights)     # every data-gradient GEMM's W^T in one launch
+            try:
+                loss.backward()
+            finally:
+                ops.release_weight_transposes()
+        else:
+            loss.backward()
         if self.dp is not None:
             self.dp.finish_backward(list(self.criterion.parameters()))
         self.optimizer_step()

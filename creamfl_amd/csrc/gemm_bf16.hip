@@ -196,6 +196,32 @@ __global__ __launch_bounds__(256) void cfl_transpose_bf16_kernel(const u16* __re
     }
 }
 
+// All weight transposes of a backward pass in ONE launch (66 of them at ResNet-101: as separate kernels they are 66 small
+// launches on the critical path of the backward).  meta[t] = {src, dst, R, C, first tile}; a workgroup finds its tensor by
+// a linear scan (a few dozen entries) and transposes one 64x64 tile.
+struct TrMeta { const u16* src; u16* dst; int R, C, tile0, tiles_c; };
+
+__global__ __launch_bounds__(256) void cfl_transpose_multi_kernel(const TrMeta* __restrict__ meta, int ntensors) {
+    __shared__ u16 tile[64][66];
+    int t = 0;
+    while (t + 1 < ntensors && (int)blockIdx.x >= meta[t + 1].tile0) ++t;
+    const TrMeta m = meta[t];
+    const int local = blockIdx.x - m.tile0;
+    const int r0 = (local / m.tiles_c) * 64, c0 = (local % m.tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        tile[ty * 16 + i][tx] = (r < m.R && c < m.C) ? m.src[(long long)r * m.C + c] : (u16)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (r < m.R && c < m.C) m.dst[(long long)c * m.R + r] = tile[tx][ty * 16 + i];
+    }
+}
+
 // ---- "TN": C[N1, N2] = A[M, N1]^T * B[M, N2] -- the weight gradient dW[Co, Ci] = dY^T X of a 1x1 convolution ------------
 // The reduction runs along M, the slow axis of both operands, so the MFMA fragments (8 consecutive reduction elements
 // per lane) cannot be read from the global layout.  The loader transposes on the way in: a thread fetches an 8 (m) x
@@ -428,4 +454,13 @@ extern "C" int cfl_gemm_bf16_nt_stats(const void* A, long long lda, const void* 
     Opnd Bo{(const float*)B, ldb / 2, N, K / 2, 1};
     if (N >= 128) return launch_nt<2, 2, 2>(Ao, Bo, M, N, (u16*)C, ldc, stream, psum, psq);
     return launch_nt<2, 1, 2>(Ao, Bo, M, N, (u16*)C, ldc, stream, psum, psq);
+}
+
+// meta: device array of ntensors records {src ptr, dst ptr, int R, int C, int tile0, int tiles_c} (32 bytes each, tile0
+// ascending, tiles of tensor t = ceil(R/64) * tiles_c with tiles_c = ceil(C/64)); total_tiles = sum of tiles.
+extern "C" int cfl_transpose_bf16_multi(const void* meta, int ntensors, int total_tiles, void* stream_) {
+    if (!meta || ntensors <= 0 || total_tiles <= 0) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    CFL_LAUNCH(K_TRANSPOSE, cfl_transpose_multi_kernel, dim3(total_tiles), dim3(256), 0, stream, (const TrMeta*)meta, ntensors);
+    return 0;
 }

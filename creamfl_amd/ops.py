@@ -570,6 +570,46 @@ def gemm_bf16_tn(a, b, out_dtype=torch.bfloat16):
     return out
 
 
+# ---- all weight transposes of a backward pass in one launch -----------------------------------------------------------
+_WT = {'key': None, 'meta': None, 'flat': None, 'views': {}, 'tiles': 0, 'n': 0, 'valid': False}
+
+
+def prepare_weight_transposes(weights):
+    """Transpose every 1x1-convolution weight in `weights` ([Co, Ci, 1, 1] bf16) with ONE kernel launch; the data-gradient
+    GEMMs of the backward pass that follows pick the results up (otherwise each of them launches its own small
+    transpose on the critical path).  Call right before `loss.backward()`; `release_weight_transposes()` after it."""
+    import numpy as np
+    ws = [w for w in weights if w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1
+          and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0]
+    if not ws:
+        return
+    lib = _lib.load()
+    key = tuple((w.data_ptr(), w.shape[0], w.shape[1]) for w in ws)
+    if key != _WT['key']:
+        dev = ws[0].device
+        total = sum(w.shape[0] * w.shape[1] for w in ws)
+        flat = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        meta = np.zeros(len(ws), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('R', '<i4'), ('C', '<i4'), ('tile0', '<i4'),
+                                                  ('tiles_c', '<i4')]))
+        views, off, tile0 = {}, 0, 0
+        for t, w in enumerate(ws):
+            Co, Ci = w.shape[0], w.shape[1]
+            v = flat[off:off + Co * Ci].view(Ci, Co)
+            views[w.data_ptr()] = v
+            tc = (Ci + 63) // 64
+            meta[t] = (w.data_ptr(), v.data_ptr(), Co, Ci, tile0, tc)
+            tile0 += ((Co + 63) // 64) * tc
+            off += Co * Ci
+        _WT.update(key=key, flat=flat, views=views, tiles=tile0, n=len(ws),
+                   meta=torch.from_numpy(meta.view(np.uint8).copy()).to(dev))
+    _lib.check(lib.cfl_transpose_bf16_multi(_ptr(_WT['meta']), _WT['n'], _WT['tiles'], _stream(ws[0])), 'cfl_transpose_bf16_multi')
+    _WT['valid'] = True
+
+
+def release_weight_transposes():
+    _WT['valid'] = False
+
+
 def conv1x1_supported(x, weight):
     """1x1 / stride 1 convolution of a channels_last bf16 activation with a bf16 weight whose channel counts fit the
     GEMM kernel (Co % 64 == 0 for the reduction of the data gradient, Ci % 8 == 0)."""
@@ -671,8 +711,10 @@ class _ConvSplitFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if gemm_dgrad:
                 dx = torch.empty_like(x)                                 # channels_last: the [M, Ci] matrix
-                wt = torch.empty(Ci, Co, dtype=torch.bfloat16, device=x.device)   # [Ci, Co]: reduction axis contiguous
-                _lib.check(_lib.load().cfl_transpose_bf16(_ptr(weight), Co, Ci, _ptr(wt), _stream(x)), 'cfl_transpose_bf16')
+                wt = _WT['views'].get(weight.data_ptr()) if _WT['valid'] else None     # prepared in one launch?
+                if wt is None:
+                    wt = torch.empty(Ci, Co, dtype=torch.bfloat16, device=x.device)   # [Ci, Co]: reduction axis contiguous
+                    _lib.check(_lib.load().cfl_transpose_bf16(_ptr(weight), Co, Ci, _ptr(wt), _stream(x)), 'cfl_transpose_bf16')
                 gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
             else:
                 dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
