@@ -210,3 +210,39 @@ def test_bottleneck_fused_conv_stats_matches_unfused(n, cin, planes, h):
         close_but_for_relu_flips(gpf[k], gpu_[k], 5e-2, 6e-2 * s2, frac=5e-3)
     for k in rsu:
         np.testing.assert_allclose(rsf[k].cpu().numpy(), rsu[k].cpu().numpy(), rtol=2e-3, atol=2e-3, err_msg=k)
+
+
+def test_prepared_weight_transposes_match_individual_ones():
+    """ops.prepare_weight_transposes: every 1x1-convolution weight transposed by ONE launch; the data gradient computed
+    with the prepared W^T must equal the one computed with the per-layer transpose (bit-exact), ragged shapes included."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    from creamfl_amd.networks.backbones import Conv1x1
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    convs = [Conv1x1(ci, co).to(dev).to(torch.bfloat16) for ci, co in [(64, 64), (256, 64), (72, 192), (1024, 256), (8, 64)]]
+    xs = [torch.randn(3, c.weight.shape[1], 5, 7, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+          for c in convs]
+    gys = [torch.randn(3, c.weight.shape[0], 5, 7, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+           for c in convs]
+
+    def grads(prepared):
+        out = []
+        if prepared:
+            ops.prepare_weight_transposes([c.weight for c in convs])
+        try:
+            for c, x, gy in zip(convs, xs, gys):
+                xg = x.clone().requires_grad_(True)
+                c(xg).backward(gy)
+                out.append(xg.grad.clone())
+                c.weight.grad = None
+        finally:
+            ops.release_weight_transposes()
+        return out
+    a, b = grads(True), grads(False)
+    for c in convs:                                        # the prepared transposes themselves
+        wt = ops._WT['views'][c.weight.data_ptr()]
+        assert torch.equal(wt, c.weight.detach().reshape(c.weight.shape[0], -1).t())
+    for ga, gb in zip(a, b):
+        assert torch.equal(ga, gb)
