@@ -62,7 +62,7 @@ __device__ __forceinline__ void tile_compute_bf16(const float* sa, const float* 
 // load latency / store drain of a tile-per-workgroup launch would dominate.
 template <int TM, int TN, int OCC>
 __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd B, int M, int N, u16* __restrict__ C, long long ldc,
-                                                                    int ntiles, float* __restrict__ psum, float* __restrict__ psq) {
+                                                                    int ntiles) {
     constexpr int BM = 64 * TM, BN = 64 * TN, STAGE = (BM + BN) * 32;
     constexpr int PITCH = 64 * TN + 16;                   // bytes per band row (+16: de-phase the banks)
     constexpr int CPR = 4 * TN;                           // 16-byte chunks per band row
@@ -82,11 +82,6 @@ __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd
     __syncthreads();
     int buf = 0;
     f32x16 acc[TM][TN];
-    // fused BatchNorm statistics: the grid size is a multiple of the number of column tiles, so all tiles of a workgroup
-    // cover the same columns and the per-column sums are carried across its tiles (one partial row per workgroup and wave row)
-    float cs[TN], cq[TN];
-#pragma unroll
-    for (int n = 0; n < TN; ++n) { cs[n] = 0.f; cq[n] = 0.f; }
     for (int i = 0; i < my; ++i) {
 #pragma unroll
         for (int m = 0; m < TM; ++m)
@@ -112,9 +107,6 @@ __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd
         // Epilogue: each wave transposes its accumulators through its own LDS band, 16 rows at a time, so that the
         // global stores are 16 bytes per lane and whole 64*TN-byte row segments (the C/D layout holds one column per
         // lane: storing it directly would be 2-byte scattered writes).
-        // Optional fused BatchNorm statistics (psum != NULL): per-column sum and sum of squares of the STORED bf16
-        // values; the BN final kernel reduces the partial rows, and the separate statistics pass over the convolution
-        // output disappears.
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -126,11 +118,6 @@ __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd
                         const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);           // 0..15
                         const u16 hv = f2bf(acc[m][n][h * 8 + r]);
                         *reinterpret_cast<u16*>(band + rr * PITCH + (n * 32 + (lane & 31)) * 2) = hv;
-                        if (psum) {
-                            const float fv = (row0 + (wr * TM + m) * 32 + h * 16 + rr < M) ? __uint_as_float((unsigned)hv << 16) : 0.f;
-                            cs[n] += fv;
-                            cq[n] = fmaf(fv, fv, cq[n]);
-                        }
                     }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -149,31 +136,17 @@ __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd
             }
         row0 = nrow0; col0 = ncol0;
     }
-    if (psum) {
-        const long long prow = (long long)(vb / ntc) * 2 + wr;
-        const int pcol0 = (vb % ntc) * BN;
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-            const float a = cs[n] + __shfl_xor(cs[n], 32, 64), b = cq[n] + __shfl_xor(cq[n], 32, 64);
-            const int j = pcol0 + wc * TN * 32 + n * 32 + (lane & 31);
-            if (lane < 32 && j < N) { psum[prow * N + j] = a; psq[prow * N + j] = b; }
-        }
-    }
 }
 
 template <int TM, int TN, int OCC>
-int launch_nt(const Opnd& A, const Opnd& B, int M, int N, u16* C, long long ldc, hipStream_t stream, float* psum = nullptr,
-              float* psq = nullptr) {
+int launch_nt(const Opnd& A, const Opnd& B, int M, int N, u16* C, long long ldc, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t LDS = (size_t)2 * (BM + BN) * 32 * sizeof(float) + (size_t)4 * 16 * (64 * TN + 16);
     const int ntc = cfl_cdiv(N, BN);
     const int ntiles = cfl_cdiv(M, BM) * ntc;
     int grid = ntiles < 256 * OCC ? ntiles : 256 * OCC;
-    grid -= grid % ntc;                                   // (needed by the fused statistics: constant column tile per workgroup)
-    if (grid < ntc) grid = ntc;
     CFL_SET_LDS((cfl_gemm_bf16_nt_kernel<TM, TN, OCC>), LDS);
-    CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_kernel<TM, TN, OCC>), dim3(grid), dim3(256), LDS, stream, A, B, M, N, C, ldc, ntiles,
-               psum, psq);
+    CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_kernel<TM, TN, OCC>), dim3(grid), dim3(256), LDS, stream, A, B, M, N, C, ldc, ntiles);
     return 0;
 }
 
@@ -431,29 +404,6 @@ extern "C" int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void
     CFL_LAUNCH(K_TRANSPOSE, cfl_transpose_bf16_kernel, dim3(cfl_cdiv(C, 64), cfl_cdiv(R, 64)), dim3(256), 0, stream, (const u16*)src, R,
                C, (u16*)dst);
     return 0;
-}
-
-// nt + fused BatchNorm statistics of the output (the 1x1 convolution in front of a BatchNorm): psum / psq are
-// [cfl_gemm_bf16_nt_stats_rows(M)][N] partial column sums, in the layout cfl_bn_fwd_pre consumes.
-extern "C" int cfl_gemm_bf16_nt_stats_rows(int M, int N) {
-    const int bn = N >= 128 ? 128 : 64, ntc = cfl_cdiv(N, bn);
-    const int ntiles = cfl_cdiv(M, 128) * ntc;
-    int grid = ntiles < 512 ? ntiles : 512;
-    grid -= grid % ntc;
-    if (grid < ntc) grid = ntc;
-    return grid / ntc * 2;
-}
-
-extern "C" int cfl_gemm_bf16_nt_stats(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N,
-                                      int K, float* psum, float* psq, void* stream_) {
-    if (!A || !B || !C || !psum || !psq || M <= 0 || N <= 0 || K <= 0) return CFL_EINVAL;
-    if (K % 64 != 0 || N % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 ||
-        (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    Opnd Ao{(const float*)A, lda / 2, M, K / 2, 1};
-    Opnd Bo{(const float*)B, ldb / 2, N, K / 2, 1};
-    if (N >= 128) return launch_nt<2, 2, 2>(Ao, Bo, M, N, (u16*)C, ldc, stream, psum, psq);
-    return launch_nt<2, 1, 2>(Ao, Bo, M, N, (u16*)C, ldc, stream, psum, psq);
 }
 
 // meta: device array of ntensors records {src ptr, dst ptr, int R, int C, int tile0, int tiles_c} (32 bytes each, tile0

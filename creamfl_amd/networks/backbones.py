@@ -51,8 +51,7 @@ class BNAct(nn.BatchNorm2d):
             if self.training:
                 self._nbt_pending += 1
                 return ops.bn_act_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
-                                        self.eps, relu=relu, residual=residual, two=two,
-                                        stats=getattr(x, '_cfl_bn_partials', None))
+                                        self.eps, relu=relu, residual=residual, two=two)
             if not torch.is_grad_enabled():
                 y = ops.bn_act_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                     relu=relu, residual=residual)
@@ -74,24 +73,20 @@ class TrunkConv(nn.Conv2d):
     AccumulateGrad does) rather than returned through autograd, so `torch.autograd.grad(..., conv.weight)` sees None;
     set CFL_NO_SIDE_WGRAD=1 for the plain behaviour."""
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, bn_follows=False):
+    def __init__(self, cin, cout, k, stride=1, padding=0):
         super().__init__(cin, cout, k, stride, padding, bias=False)
-        # a 1x1 convolution directly followed by a BNAct: its forward runs on the GEMM whose epilogue also produces the
-        # BatchNorm statistics of the output (ops.conv_split(fwd_stats=True)); the BN then skips its statistics pass
-        self.bn_follows = bn_follows
 
     def forward(self, x):
         if (torch.is_grad_enabled() and not _NO_CONV_SPLIT and x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype
                 and x.is_contiguous(memory_format=torch.channels_last)):
             from .. import ops
-            return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD,
-                                  fwd_stats=self.bn_follows and self.training and not _NO_FWD_STATS)
+            return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD)
         return super().forward(x)
 
 
 class Conv1x1(TrunkConv):
-    def __init__(self, cin, cout, bn_follows=False):
-        super().__init__(cin, cout, 1, bn_follows=bn_follows)
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 1)
 
 
 class MaxPool3s2(nn.MaxPool2d):
@@ -138,11 +133,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = Conv1x1(inplanes, planes, bn_follows=True)
+        self.conv1 = Conv1x1(inplanes, planes)
         self.bn1 = BNAct(planes)
         self.conv2 = TrunkConv(planes, planes, 3, stride, 1)                 # stride on the 3x3 (torchvision v1.5)
         self.bn2 = BNAct(planes)
-        self.conv3 = Conv1x1(planes, planes * 4, bn_follows=True)
+        self.conv3 = Conv1x1(planes, planes * 4)
         self.bn3 = BNAct(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -287,9 +282,6 @@ BERT_CONFIGS = {
 _NO_ATTN_SMALL = bool(os.environ.get('CFL_NO_ATTN_SMALL'))       # A/B switches for measurements
 _NO_CONV_SPLIT = bool(os.environ.get('CFL_NO_CONV_SPLIT'))
 _NO_SIDE_WGRAD = bool(os.environ.get('CFL_NO_SIDE_WGRAD'))
-# fused 1x1-forward + BN statistics: measured neutral at the bench shape (the statistics pass it removes, 1.3 ms, is paid
-# back by the GEMM forward being slower than MIOpen's), so it is opt-in
-_NO_FWD_STATS = not os.environ.get('CFL_FWD_STATS')
 
 
 def _bert_fusable(x, weight, max_out=1 << 30):

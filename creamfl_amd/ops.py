@@ -440,12 +440,12 @@ def bn_act_supported(x, num_features):
 
 
 # element counters of the fused BN kernels (python ints; bench.py turns them into algorithmic bytes)
-BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'fwd_mask': 0, 'fwd_pre': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
+BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
 
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, partials=None):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
         lib = _lib.load()
         N, C, H, W = x.shape
         R = N * H * W
@@ -464,16 +464,9 @@ class _BNActFn(torch.autograd.Function):
         mask = torch.empty(R * C // 8, dtype=torch.uint8, device=x.device) if need_mask else None
         if need_mask:
             BN_COUNTERS['fwd_mask'] += R * C
-        if partials is not None:             # statistics already reduced to partials by the producing GEMM's epilogue
-            BN_COUNTERS['fwd_pre'] += R * C
-            _lib.check(lib.cfl_bn_fwd_pre(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
-                                          _ptr(running_var), R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd),
-                                          _ptr(mask), _ptr(partials), _ptr(partials[1]), partials.shape[1], _stream(x)),
-                       'cfl_bn_fwd_pre')
-        else:
-            _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                      R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(mask), _ptr(ws),
-                                      _stream(x)), 'cfl_bn_fwd')
+        _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                  R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(mask), _ptr(ws),
+                                  _stream(x)), 'cfl_bn_fwd')
         ctx.save_for_backward(x, mask if need_mask else x, weight, bias, mean, invstd)
         ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
         return y, _alias(y)
@@ -487,7 +480,7 @@ class _BNActFn(torch.autograd.Function):
         if dy is None:
             dy, dy2 = dy2, None
         if dy is None:
-            return (None,) * 10
+            return (None,) * 9
         if ctx.has_res:
             from . import streams
             streams.flush(x.device)          # a long HBM-bound phase starts: let the queued weight gradients run beside it
@@ -513,16 +506,16 @@ class _BNActFn(torch.autograd.Function):
         _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(None), _ptr(mask) if (ctx.relu and ctx.has_res) else _ptr(None),
                                   _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res),
                                   _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
-def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None, two=False, stats=None):
+def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None, two=False):
     """Training-mode BatchNorm2d (+ residual) (+ ReLU) on a channels_last bf16 activation (csrc/bnorm.hip).
     `two=True` returns the output as two tensor objects on one buffer: give one to the next convolution and the other
     to the next residual add, and their two gradients are summed inside the fused backward (no autograd add kernel)."""
     if residual is not None and not (residual.shape == x.shape and bn_act_supported(residual, x.shape[1])):
         residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), stats)
+    y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu))
     return (y, y2) if two else y
 
 
@@ -645,29 +638,13 @@ class _ConvSplitFn(torch.autograd.Function):
         overlaps the HBM-bound BN / data-gradient kernels of the layers below (streams.py).  MIOpen computes it."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad, gemm_fwd_stats):
+    def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, gemm_dgrad, side_wgrad)
-        if gemm_fwd_stats:
-            # 1x1 forward on the hand-written GEMM whose epilogue also produces the BatchNorm statistics of the
-            # output (per-block partial sums): the BN that follows skips its statistics pass (bn_act_train(stats=...))
-            lib = _lib.load()
-            N, Ci, H, W = x.shape
-            Co = weight.shape[0]
-            M = N * H * W
-            y = torch.empty((N, Co, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-            nblk = lib.cfl_gemm_bf16_nt_stats_rows(M, Co)
-            part = torch.empty(2, nblk, Co, dtype=torch.float32, device=x.device)
-            GEMM_COUNTERS['flops'] += 2 * M * Co * Ci
-            GEMM_COUNTERS['bytes'] += 2 * (M * Ci + Co * Ci + M * Co)
-            _lib.check(lib.cfl_gemm_bf16_nt_stats(_ptr(x), Ci, _ptr(weight), Ci, _ptr(y), Co, M, Co, Ci, _ptr(part), _ptr(part[1]),
-                                                  _stream(x)), 'cfl_gemm_bf16_nt_stats')
-            ctx.mark_non_differentiable(part)
-            return y, part
-        return torch.nn.functional.conv2d(x, weight, None, stride, padding), None
+        return torch.nn.functional.conv2d(x, weight, None, stride, padding)
 
     @staticmethod
-    def backward(ctx, dy, _dpart=None):
+    def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         stride, padding, gemm_dgrad, side_wgrad = ctx.cfg
         N, Ci, H, W = x.shape
@@ -718,17 +695,13 @@ class _ConvSplitFn(torch.autograd.Function):
                 gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
             else:
                 dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def conv_split(x, weight, stride=1, padding=0, side_wgrad=True, fwd_stats=False):
+def conv_split(x, weight, stride=1, padding=0, side_wgrad=True):
     """Trunk convolution with the split backward of _ConvSplitFn (x: channels_last HIP tensor; weight [Co, Ci, k, k])."""
     gemm = (weight.shape[2] == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0 and conv1x1_supported(x, weight))
-    stats = bool(fwd_stats and gemm and x.shape[1] % 64 == 0)
-    y, part = _ConvSplitFn.apply(x, weight, int(stride), int(padding), bool(gemm), bool(side_wgrad), stats)
-    if part is not None:
-        y._cfl_bn_partials = part            # picked up by BNAct.forward / bn_act_train(stats=...)
-    return y
+    return _ConvSplitFn.apply(x, weight, int(stride), int(padding), bool(gemm), bool(side_wgrad))
 
 
 def conv1x1(x, weight):

@@ -163,12 +163,6 @@ int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb,
 /* tn: C[N1,N2] = A[M,N1]^T * B[M,N2] (reduction along the slow axis M): the weight gradient dW[Co,Ci] = dy^T x of a 1x1
  * convolution.  C dense row-major, bf16 (c_bf16 = 1) or fp32; split-K over M with fp32 partials in ws
  * (cfl_gemm_bf16_tn_ws_bytes) and a fixed-order reduction.  N1 % 8 == N2 % 8 == 0, lda % 8 == ldb % 8 == 0. */
-/* nt + fused BatchNorm statistics of the OUTPUT: psum / psq [cfl_gemm_bf16_nt_stats_rows(M, N)][N] = per-column sum and
- * sum of squares of the stored bf16 values, per block of rows -- what cfl_bn_fwd_pre consumes.  Forward of a 1x1
- * convolution that is followed by a BatchNorm: the separate statistics pass over its output disappears. */
-int cfl_gemm_bf16_nt_stats_rows(int M, int N);
-int cfl_gemm_bf16_nt_stats(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
-                           float* psum, float* psq, void* stream);
 /* dst[C][R] = src[R][C]^T, dense bf16 (the weight transpose the data gradient needs). */
 int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream);
 /* every weight transpose of a backward pass in one launch: meta = device array of ntensors 32-byte records
@@ -279,11 +273,6 @@ size_t cfl_bn_ws_bytes(long long R, int C);
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
                float* save_mean, float* save_invstd, unsigned char* relu_mask, void* ws, void* stream);
-/* fwd_pre: like fwd, but the statistics come as per-block partials psum/psq [nblk][C] from the producer of x
- * (cfl_gemm_bf16_nt_stats): no statistics pass over x. */
-int cfl_bn_fwd_pre(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
-                   float* running_var, long long R, int C, float eps, float momentum, int relu, void* y, float* save_mean,
-                   float* save_invstd, unsigned char* relu_mask, const float* psum, const float* psq, int nblk, void* stream);
 int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
                  const float* beta, long long R, int C, int relu, void* y, void* stream);
 int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,

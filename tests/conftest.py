@@ -1,5 +1,7 @@
 import os
+import shutil
 import sys
+import tempfile
 
 import pytest
 
@@ -10,8 +12,42 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+def _miopen_env():
+    """Same MIOpen setup as bench.py: (fast) find mode with workspace instead of the immediate-mode fallback kernels,
+    and the find-db recorded on an MI355X (creamfl_amd/miopen_db) so that the library convolutions the trunk tests
+    compare against are the ones the bench runs.  Must happen before the first convolution."""
+    os.environ.setdefault('MIOPEN_FIND_MODE', '2')
+    os.environ.setdefault('MIOPEN_LOG_LEVEL', '1')       # the fallback warnings otherwise bury the test log
+    src = os.path.join(ROOT, 'creamfl_amd', 'miopen_db')
+    if 'MIOPEN_USER_DB_PATH' in os.environ or not os.path.isdir(src):
+        return
+    dst = os.path.join(tempfile.gettempdir(), 'creamfl_miopen_db_%d' % os.getuid(), 'tests')
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src):
+        if not os.path.exists(os.path.join(dst, f)):
+            shutil.copy(os.path.join(src, f), dst)
+    os.environ['MIOPEN_USER_DB_PATH'] = dst
+
+
+_miopen_env()
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu via gpurun)')
+
+
+# Collection order: the tests that compare a HIP kernel with the oracle / the reference-generated goldens come first,
+# the trunk-glue tests (BatchNorm, BERT glue, pooling vs the library kernels) last -- with `-x` a glue failure must not
+# hide the parity run.
+_ORDER = ['test_oracle_golden', 'test_abi', 'test_host_logic', 'test_gpu_parity', 'test_gpu_configs', 'test_gpu_framework',
+          'test_gpu_optimizer', 'test_dist_gloo', 'test_gpu_bert', 'test_gpu_bnorm']
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(mod) if mod in _ORDER else len(_ORDER)
+    items.sort(key=key)                      # stable: the order inside a module is kept
 
 
 @pytest.fixture(scope='session')
