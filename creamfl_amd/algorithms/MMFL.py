@@ -252,9 +252,9 @@ class MMFL(object):
             metadata['best_epoch'] = round_n + 1
             self.best_metadata, self.best_scores = metadata, test_scores
             if rank == 0 and getattr(self.args, 'save_checkpoints', True):
-                torch.save({'net': self.engine.model.state_dict()}, self.args.name + '-best_model.pt')
+                torch.save({'net': self.engine.model_state_dict()}, self.args.name + '-best_model.pt')
         if round_n == self.args.comm_rounds - 1 and rank == 0 and getattr(self.args, 'save_checkpoints', True):
-            torch.save({'net': self.engine.model.state_dict()}, self.args.name + '-last_model.pt')
+            torch.save({'net': self.engine.model_state_dict()}, self.args.name + '-last_model.pt')
         self.engine.lr_scheduler.step()
         del img_vec, txt_vec
         gc.collect()
@@ -271,6 +271,29 @@ class MMFL(object):
             t_vec = cdist.conw_aggregate_sharded(t_vec, self.global_img_feature)
         return i_vec, t_vec
 
+    def kd_terms(self, output, d_idx):
+        """The KD loss of one public batch (MMFL.py:355-378): one `kd_weight * MSELoss(output, agg[d_idx])` per client
+        type, each a fused gather + MSE kernel (ops.kd_mse).  As in the reference the image term appears once in the
+        image-client block and once more in the multimodal block, so it counts twice when both kinds of client exist.
+        Returns 0 (python int) when no term applies."""
+        def code_sim(output, agg):
+            output = output.sum(axis=1) if len(output.shape) == 3 else output
+            return ops.kd_mse(output, agg, d_idx, self.args.kd_weight)
+
+        has_img = self.img_vec is not None and len(self.img_vec)
+        has_txt = self.txt_vec is not None and len(self.txt_vec)
+        loss = 0
+        if self.args.num_img_clients > 0 and has_img:
+            loss = loss + code_sim(output['image_features'], self.img_vec)
+        if self.args.num_txt_clients > 0 and has_txt:
+            loss = loss + code_sim(output['caption_features'], self.txt_vec)
+        if self.args.num_mm_clients > 0:
+            if has_img:
+                loss = loss + code_sim(output['image_features'], self.img_vec)
+            if has_txt:
+                loss = loss + code_sim(output['caption_features'], self.txt_vec)
+        return loss
+
     def distill(self, round_n, img_vec, txt_vec, img_num, txt_num, distill_index):
         self.engine.model.train()
         img_vec, txt_vec = self.aggregation(img_vec, txt_vec)
@@ -279,11 +302,6 @@ class MMFL(object):
         self.logger.log("start distilling")
         eng = self.engine
         model = eng.dp.module if eng.dp is not None else eng.model
-
-        def code_sim(output, agg, d_idx):
-            """kd_weight * MSELoss(output, agg[d_idx]) (MMFL.py:352-378) as one fused gather + MSE kernel"""
-            output = output.sum(axis=1) if len(output.shape) == 3 else output
-            return ops.kd_mse(output, agg, d_idx, self.args.kd_weight)
 
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(
                 self.dataloaders_global[self._pub_key(False)]):
@@ -294,16 +312,7 @@ class MMFL(object):
                 output = model(images, captions.to(eng.device), captions_word, caption_lens.to(eng.device))
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
-            loss = 0
-            if self.args.num_img_clients > 0 and self.img_vec is not None and len(self.img_vec):
-                loss = loss + code_sim(output['image_features'], self.img_vec, d_idx)
-            if self.args.num_txt_clients > 0 and self.txt_vec is not None and len(self.txt_vec):
-                loss = loss + code_sim(output['caption_features'], self.txt_vec, d_idx)
-            if self.args.num_mm_clients > 0:
-                if self.img_vec is not None and len(self.img_vec):
-                    loss = loss + code_sim(output['image_features'], self.img_vec, d_idx)
-                if self.txt_vec is not None and len(self.txt_vec):
-                    loss = loss + code_sim(output['caption_features'], self.txt_vec, d_idx)
+            loss = self.kd_terms(output, d_idx)
             if not torch.is_tensor(loss):
                 continue
             eng.optimizer.zero_grad(set_to_none=True)

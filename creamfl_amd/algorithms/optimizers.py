@@ -35,12 +35,76 @@ class AdamP(Optimizer):
 
     META_DTYPE = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64), ('p16', np.uint64),
                            ('numel', np.int64), ('inner', np.int64), ('row_base', np.int64),
-                           ('n0', np.int32), ('flags', np.int32)])
+                           ('n0', np.int32), ('flags', np.int32), ('step', np.int32), ('reserved', np.int32)])
 
     def make_master(self, p):
         """Register an fp32 master copy for a parameter that is about to be converted to bf16 (call BEFORE the
         conversion so that no precision is lost)."""
         self.state[p]['master'] = p.detach().to(torch.float32, memory_format=torch.preserve_format).clone()
+
+    FP32_STATE = ('master', 'exp_avg', 'exp_avg_sq')
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict casts every floating-point state tensor to the PARAMETER's dtype, i.e.
+        the fp32 master / moments of a bf16 trunk weight would come back as bf16 -- and the kernels, which address them
+        as fp32, would write past the buffers.  Restore them from the incoming state dict as fp32, in the parameter's
+        memory layout."""
+        from itertools import chain
+        incoming = {pid: {k: v for k, v in st.items() if k in self.FP32_STATE and torch.is_tensor(v)}
+                    for pid, st in state_dict['state'].items()}
+        saved_ids = list(chain.from_iterable(g['params'] for g in state_dict['param_groups']))
+        super().load_state_dict(state_dict)
+        params = list(chain.from_iterable(g['params'] for g in self.param_groups))
+        for pid, p in zip(saved_ids, params):
+            for k, v in incoming.get(pid, {}).items():
+                t = torch.empty_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+                t.copy_(v.reshape(p.shape) if v.shape != p.shape else v)
+                self.state[p][k] = t
+        self._plans = {}
+
+    @torch.no_grad()
+    def refresh_masters(self, fp32_values=None):
+        """After weights were loaded INTO THE MODEL (model.load_state_dict): re-derive the fp32 master of every bf16
+        parameter from the loaded weight -- or from `fp32_values` {parameter: fp32 tensor} when the checkpoint carried
+        full-precision values -- so that the next step does not overwrite the loaded weights from a stale master."""
+        for group in self.param_groups:
+            for p in group['params']:
+                st = self.state.get(p)
+                if st is not None and 'master' in st:
+                    src = fp32_values.get(p) if fp32_values else None
+                    st['master'].copy_(p.detach() if src is None else src)
+        self._plans = {}
+
+    def master_state_dict(self, model):
+        """model.state_dict() with every bf16 trunk weight replaced by its fp32 master (what an apex-O2 checkpoint of
+        the reference holds, retrieval_trainer.py:107-111): checkpoints do not lose the low mantissa bits."""
+        sd = model.state_dict()
+        by_ptr = {p.data_ptr(): p for g in self.param_groups for p in g['params']}
+        for k, v in list(sd.items()):
+            p = by_ptr.get(v.data_ptr()) if torch.is_tensor(v) else None
+            if p is not None and 'master' in self.state.get(p, {}):
+                sd[k] = self.state[p]['master'].detach().clone()
+        return sd
+
+    @torch.no_grad()
+    def broadcast_state(self, src=0, group=None):
+        """Multi-rank replicas: make the optimizer state (fp32 masters, both moments, step counts) identical to rank
+        `src`'s.  Broadcasting the bf16 weights alone is not enough: the next step rewrites each weight from the
+        rank's own master."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        for g in self.param_groups:
+            for p in g['params']:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                for k in self.FP32_STATE:
+                    if k in st:
+                        dist.broadcast(st[k], src, group=group)
+                step = torch.tensor([int(st.get('step', 0))], dtype=torch.int64, device=p.device)
+                dist.broadcast(step, src, group=group)
+                st['step'] = int(step.item())
 
     PIN_SLOTS = 4
 
@@ -88,6 +152,11 @@ class AdamP(Optimizer):
             if id(p) in clip_ids:
                 flags |= 2
             st = self.state[p]
+            for k in self.FP32_STATE:                # the kernels address these as fp32 in the parameter's layout
+                if k in st and (st[k].dtype != torch.float32 or st[k].stride() != p.stride() or st[k].device != p.device):
+                    raise _lib.CreamflHipError(f'AdamP: state[{k!r}] of a {tuple(p.shape)} parameter is {st[k].dtype} / strides '
+                                               f'{st[k].stride()} (need fp32 / {p.stride()}): was it loaded through '
+                                               f'torch.optim.Optimizer.load_state_dict instead of AdamP.load_state_dict?')
             if p.dtype == torch.bfloat16:            # bf16 model weight, fp32 master (apex-O2 style)
                 flags |= 4
                 meta[t]['p'] = st['master'].data_ptr(); meta[t]['p16'] = p.data_ptr()
@@ -155,8 +224,14 @@ class AdamP(Optimizer):
                     g = g2
                 grads.append(g)
             gptrs = [g.data_ptr() for g in grads]
-            if gptrs != plan['gptrs']:
+            # adamp.AdamP keeps `step` per parameter; parameters whose gradient was None in some steps (the criterion's
+            # scalars during the KD phase, a whole tower when only one kind of client exists) lag behind.  Uniform steps
+            # travel as the launch argument; otherwise every tensor's own count goes into its meta record.
+            steps = [int(self.state[p]['step']) for p in params]
+            tsteps = np.zeros(len(params), dtype=np.int32) if min(steps) == max(steps) else np.asarray(steps, dtype=np.int32)
+            if gptrs != plan['gptrs'] or not np.array_equal(plan['meta']['step'], tsteps):
                 plan['meta']['g'] = np.asarray(gptrs, dtype=np.uint64)
+                plan['meta']['step'] = tsteps
                 self._upload_meta(plan)
                 plan['gptrs'] = gptrs
             stream = ctypes.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
@@ -174,7 +249,7 @@ class AdamP(Optimizer):
                                           plan['tstats'].data_ptr(), float(group['lr']), float(beta1), float(beta2),
                                           float(group['eps']), float(group['weight_decay']), float(group['delta']),
                                           float(group['wd_ratio']), int(bool(group['nesterov'])),
-                                          int(self.state[params[0]]['step']), clip_ptr, stream), 'cfl_adamp_step')
+                                          max(steps), clip_ptr, stream), 'cfl_adamp_step')
             del grads
         return loss
 

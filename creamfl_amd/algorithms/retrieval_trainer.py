@@ -140,7 +140,7 @@ class EngineBase(object):
 
     def save_models(self, save_to, metadata=None):
         state_dict = {
-            'model': self.model.state_dict(), 'criterion': self.criterion.state_dict(),
+            'model': self.model_state_dict(), 'criterion': self.criterion.state_dict(),
             'optimizer': self.optimizer.state_dict(), 'lr_scheduler': self.lr_scheduler.state_dict(),
             'config': json.loads(json.dumps(self.config, default=str)), 'word2idx': self.word2idx, 'metadata': metadata,
         }
@@ -148,14 +148,44 @@ class EngineBase(object):
         if self.logger is not None:
             self.logger.log('state dict is saved to {}, metadata: {}'.format(save_to, json.dumps(metadata, indent=4)))
 
+    def model_state_dict(self):
+        """The model's state dict with full-precision weights: after to_half() the trunk weights the model computes
+        with are bf16 and their fp32 masters live in the optimizer -- checkpoints store the masters (what the
+        reference's apex-O2 checkpoints hold)."""
+        if isinstance(self.optimizer, AdamP):
+            return self.optimizer.master_state_dict(self.model)
+        return self.model.state_dict()
+
+    def load_model_weights(self, model_state, strict=True):
+        """model.load_state_dict + re-derivation of the optimizer's fp32 masters from the loaded values (fp32 values
+        of the checkpoint where it has them), so that the next step does not restore stale weights."""
+        res = self.model.load_state_dict(model_state, strict=strict)
+        if isinstance(self.optimizer, AdamP):
+            named = dict(self.model.named_parameters())
+            fp32 = {named[k]: v for k, v in model_state.items()
+                    if k in named and torch.is_tensor(v) and v.dtype == torch.float32 and named[k].dtype == torch.bfloat16}
+            self.optimizer.refresh_masters(fp32)
+        return res
+
     def load_models(self, state_dict_path, load_keys=None):
         with open(state_dict_path, 'rb') as fin:
             self.metadata['pretrain_hash'] = hashlib.sha1(fin.read()).hexdigest()
         state_dict = torch.load(state_dict_path, map_location='cpu')
         if 'model' not in state_dict:
-            self.model.load_state_dict(state_dict, strict=False)
+            self.load_model_weights(state_dict.get('net', state_dict), strict=False)
             return
-        for key in (load_keys or ['model', 'criterion', 'optimizer', 'lr_scheduler']):
+        # optimizer BEFORE model: the optimizer state carries the masters of the step the checkpoint was taken at; loading
+        # the model afterwards re-derives them from the (fp32) checkpoint weights, which are the same values
+        keys = list(load_keys or ['model', 'criterion', 'optimizer', 'lr_scheduler'])
+        for key in sorted(keys, key=lambda k: k == 'model'):
+            if key == 'model':
+                try:
+                    self.load_model_weights(state_dict[key])
+                except RuntimeError as e:
+                    if self.logger is not None:
+                        self.logger.log('Unable to import state_dict, missing keys are found. {}'.format(e))
+                    self.load_model_weights(state_dict[key], strict=False)
+                continue
             try:
                 getattr(self, key).load_state_dict(state_dict[key])
             except RuntimeError as e:

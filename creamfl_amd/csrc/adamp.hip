@@ -96,6 +96,17 @@ __global__ __launch_bounds__(256) void cfl_gradnorm_final_kernel(const float* pa
     }
 }
 
+// bias corrections of ONE tensor: its own step count when the host filled it in (steps differ inside the group), else the
+// launch-wide one
+__device__ __forceinline__ void bias_corr(const CflTensorMeta& tm, const Hyper& h, float& bc1, float& bc2) {
+    if (tm.step > 0) {
+        bc1 = 1.f - powf(h.beta1, (float)tm.step);
+        bc2 = 1.f - powf(h.beta2, (float)tm.step);
+    } else {
+        bc1 = h.bc1; bc2 = h.bc2;
+    }
+}
+
 // ---- pass 1 -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float adam_elem(float g, float& m, float& v, const Hyper& h, float rs_bc2) {
     m = h.beta1 * m + (1.f - h.beta1) * g;
@@ -115,8 +126,10 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass1_kernel(const CflTensorMet
     float* m = (float*)tm.m;
     float* v = (float*)tm.v;
     const float cc = (clip && (tm.flags & CFL_OPT_CLIP)) ? clip[1] : 1.f;
-    const float rs_bc2 = 1.f / sqrtf(h.bc2);
-    const float step = h.lr / h.bc1;
+    float bc1, bc2;
+    bias_corr(tm, h, bc1, bc2);
+    const float rs_bc2 = 1.f / sqrtf(bc2);
+    const float step = h.lr / bc1;
     if (!(tm.flags & CFL_OPT_MATRIX)) {
         const long long e1 = (long long)it[1] + it[2];
         const float decay = 1.f - h.lr * h.wd;
@@ -219,8 +232,10 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass3_kernel(const CflTensorMet
     const float* m = (const float*)tm.m;
     const float* v = (const float*)tm.v;
     const float cc = (clip && (tm.flags & CFL_OPT_CLIP)) ? clip[1] : 1.f;
-    const float rs_bc2 = 1.f / sqrtf(h.bc2);
-    const float step = h.lr / h.bc1;
+    float bc1, bc2;
+    bias_corr(tm, h, bc1, bc2);
+    const float rs_bc2 = 1.f / sqrtf(bc2);
+    const float step = h.lr / bc1;
     const float decay = 1.f - h.lr * h.wd * tstats[it[0]];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long inner = tm.inner;

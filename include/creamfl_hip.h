@@ -305,6 +305,9 @@ typedef struct CflTensorMeta {
     long long row_base;     /* first row of this tensor in rowstats_ws */
     int n0;
     int flags;
+    int step;               /* this tensor's own 1-based step count for the bias corrections (adamp.AdamP keeps `step` per
+                             * parameter: tensors whose gradient was None in some steps lag behind); 0 = use the `step` argument */
+    int reserved;
 } CflTensorMeta;
 int cfl_grad_clip_coef(const CflTensorMeta* meta_dev, const int* items_dev, int n_items, float max_norm,
                        float* partial_ws, float* out2, void* stream);

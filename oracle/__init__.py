@@ -26,6 +26,8 @@ from .bank_contrast import (inter_contrast, intra_contrast, client_contrast_loss
 from .conw import conw_logprob, conw_weights, conw_aggregate
 from .pie import (pie_attention_pool, pie_head, l2_normalize,
                   image_head_glue)
+from .client_encoders import resnet_client_forward, text_client_forward, pcme_towers_forward
+from .kd import kd_loss, code_sim
 from .recall import recall_ranks_literal, recall_ranks_count, recall_scores
 
 __all__ = [n for n in dir() if not n.startswith('_')]

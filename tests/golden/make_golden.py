@@ -12,6 +12,14 @@ What is imported from the reference:
   src/algorithms/eval_coco.py          COCOEvaluator.evaluate_recall  -> a6_*.npz
   src/utils/tensor_utils.py            l2_normalize
   src/utils/Utils.py                   to_one_hot (+ create('softmax'))  -> f4_*.npz
+  src/networks/resnet_client.py        ResNet.forward, both phases (by path)        -> a2c_img_*.npz
+  src/networks/language_model.py       EncoderText.forward, both modes (by path)    -> a2c_txt_*.npz
+  src/networks/models/{image_encoder,caption_encoder,pcme}.py  the reference's own EncoderImage.forward /
+      EncoderText.forward / PCME.forward run on a synthetic 7x7 feature map (the torchvision trunk is replaced by
+      nn.Identity; `torchvision` / `torchtext` are import-time stubs only)                      -> tower_*.npz
+  MMFL.py:346-378 (KD terms; inline, literal statement sequence with nn.MSELoss as at :296)      -> kd_*.npz
+Parameters of the encoder fixtures are not stored: they are regenerated from the state_dict key names by
+tests/golden/seeded.py on both sides.
 Rows A3/A4/A5 are inline loop bodies in the reference (ClientTrainer.py:369-429,
 MMFL.py:298-335); here their literal statement sequence is evaluated with the
 imported criterion object and plain torch ops, which is what pins the oracle.
@@ -231,6 +239,210 @@ def make_f4(losses_mod, utils_mod):
                  dclass_weight=class_weight.grad.numpy())
 
 
+def _stub_vision_text():
+    """Import-time stand-ins for the two absent packages.  Nothing of them is CALLED: resnet_client.py:7 imports an
+    unused name, image_encoder.py's torchvision trunk is replaced by nn.Identity below, GloVe is skipped by
+    wemb_type=None.  transformers must be imported first (it probes torchvision's import spec)."""
+    import transformers  # noqa: F401
+    from transformers import BertModel, BertTokenizer  # noqa: F401
+    for n in ['torchvision', 'torchvision.models', 'torchtext']:
+        if n not in sys.modules:
+            m = types.ModuleType(n)
+            m.__path__ = []
+            sys.modules[n] = m
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    sys.modules['torchvision.models'].resnet18 = None
+
+
+def _grad_dict(model, names):
+    named = dict(model.named_parameters())
+    return {('g_' + n.replace('.', '__')): named[n].grad.detach().numpy().copy() for n in names}
+
+
+def make_a2c_img(resnet_client):
+    """resnet_client.ResNet.forward :175-201: phase 'extract_conv_feature' (l2-normalised embedding) and the classifier
+    phase with its `weight.data = relu(weight)` side effect, in train mode (batch statistics) and in eval mode."""
+    from seeded import seeded_state_dict, checksum
+    for (tag, d, train, seed) in [('d64_train', 64, True, 21), ('d512_eval', 512, False, 22)]:
+        model = resnet_client.ResNet(resnet_client.BasicBlock, [1, 1, 1, 1], embed_dim=d, num_class=10, is_train=True,
+                                     scale=128, phase='none')
+        sd = seeded_state_dict(model.state_dict(), seed)
+        model.load_state_dict(sd)
+        model.train(train)
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(4, 3, 64, 64, generator=gen)
+        gnames = ['conv1.weight', 'bn1.weight', 'layer4.0.bn2.bias', 'layer2.0.downsample.0.weight'] + (['linear.weight'] if d != 512 else [])
+        # --- ClientTrainer.py:372-375: model.phase = 'extract_conv_feature'
+        model.phase = 'extract_conv_feature'
+        feat = model(x)
+        gy = torch.randn(feat.shape, generator=gen)
+        model.zero_grad()
+        (feat * gy).sum().backward()
+        g_feat = _grad_dict(model, gnames)
+        rm_after = model.bn1.running_mean.detach().numpy().copy()
+        # --- supervised phase (ClientTrainer.py:344): returns (x1, x2, relu(W), relu(W2)) and clamps the weights
+        model.phase = 'none'
+        model.zero_grad()
+        x1, x2, w, w2 = model(x)
+        g1 = torch.randn(x1.shape, generator=gen)
+        g2 = torch.randn(x2.shape, generator=gen)
+        ((x1 * g1).sum() + (x2 * g2).sum() + 0.1 * (w ** 2).sum()).backward()
+        g_cls = _grad_dict(model, ['class_fc_2.weight', 'class_fc_2.bias', 'class_fc_22.weight', 'conv1.weight'])
+        np.savez(os.path.join(OUT, f'a2c_img_{tag}.npz'), seed=np.int64(seed), embed_dim=np.int64(d), train=np.bool_(train),
+                 wsum=np.float64(checksum(sd)), x=x.numpy(), feat=feat.detach().numpy(), gy=gy.numpy(),
+                 bn1_running_mean_after_feat=rm_after, x1=x1.detach().numpy(), x2=x2.detach().numpy(),
+                 w=w.detach().numpy(), w2=w2.detach().numpy(), g1=g1.numpy(), g2=g2.numpy(),
+                 class_fc_2_weight_after=model.class_fc_2.weight.detach().numpy(),
+                 class_fc_22_weight_after=model.class_fc_22.weight.detach().numpy(),
+                 **{('feat__' + k): v for k, v in g_feat.items()}, **{('cls__' + k): v for k, v in g_cls.items()})
+
+
+def make_a2c_txt(language_model):
+    """language_model.EncoderText.forward :93-130: is_train heads (with the ReLU weight clamp) and the l2norm path."""
+    from seeded import seeded_state_dict, checksum
+    cwd = os.getcwd()
+    os.chdir(REF)                                              # opens src/datasets/vocabs/coco_vocab.pkl (:31)
+    try:
+        for (tag, d, seed) in [('d64', 64, 31), ('d256', 256, 32)]:
+            model = language_model.EncoderText(wemb_type=None, word_dim=300, embed_dim=d, num_class=4, scale=128)
+            sd = seeded_state_dict(model.state_dict(), seed)
+            model.load_state_dict(sd)
+            model.train()
+            gen = torch.Generator().manual_seed(seed)
+            lengths = torch.tensor([12, 9, 7, 4, 1])
+            x = torch.randint(4, model.embed.weight.shape[0], (5, 12), generator=gen)
+            x = x * (torch.arange(12)[None, :] < lengths[:, None])       # 0 = <pad>
+            gnames = ['pie_net.fc.weight', 'pie_net.attention.w_1.weight', 'pie_net.layer_norm.weight', 'rnn.weight_hh_l0']
+            model.is_train = False
+            feat = model(x, lengths)
+            gy = torch.randn(feat.shape, generator=gen)
+            model.zero_grad()
+            (feat * gy).sum().backward()
+            g_feat = _grad_dict(model, gnames)
+            model.is_train = True
+            model.zero_grad()
+            x1, x2, w, w2 = model(x, lengths)
+            g1 = torch.randn(x1.shape, generator=gen)
+            g2 = torch.randn(x2.shape, generator=gen)
+            ((x1 * g1).sum() + (x2 * g2).sum() + 0.1 * (w ** 2).sum()).backward()
+            g_cls = _grad_dict(model, ['class_fc.weight', 'class_fc.bias', 'class_fc_2.weight', 'pie_net.fc.weight'])
+            np.savez(os.path.join(OUT, f'a2c_txt_{tag}.npz'), seed=np.int64(seed), embed_dim=np.int64(d),
+                     vocab=np.int64(model.embed.weight.shape[0]), wsum=np.float64(checksum(sd)), x=x.numpy(),
+                     lengths=lengths.numpy(), feat=feat.detach().numpy(), gy=gy.numpy(), x1=x1.detach().numpy(),
+                     x2=x2.detach().numpy(), w=w.detach().numpy(), w2=w2.detach().numpy(), g1=g1.numpy(), g2=g2.numpy(),
+                     class_fc_weight_after=model.class_fc.weight.detach().numpy(),
+                     **{('feat__' + k): v for k, v in g_feat.items()}, **{('cls__' + k): v for k, v in g_cls.items()})
+    finally:
+        os.chdir(cwd)
+
+
+def make_tower(pcme_mod, image_encoder, caption_encoder):
+    """The reference's own PCME.forward (pcme.py:35-57) -> EncoderImage.forward (image_encoder.py:54-71) +
+    EncoderText.forward (caption_encoder.py:87-116) on a synthetic [N, Cd, 7, 7] trunk output (cnn = nn.Identity).
+    'mlp' exercises head_proj (hard-wired 512, image_encoder.py:42-48) and the caption tower's l2norm-BEFORE-head_proj
+    order (caption_encoder.py:109-112)."""
+    import torch.nn as nn
+    from seeded import seeded_state_dict, checksum
+    for (tag, cd, d, mlp, seed) in [('d32', 64, 32, False, 41), ('d512_mlp', 128, 512, True, 42), ('r18_d256', 512, 256, False, 43)]:
+        cfg = _Cfg(embed_dim=d, wemb_type=None, word_dim=300, cache_dir=None, not_bert=True, n_samples_inference=7,
+                   cnn_type='resnet18')
+        word2idx = {str(i): i for i in range(60)}
+        txt = caption_encoder.EncoderText(word2idx, cfg, mlp)
+        img = image_encoder.EncoderImage.__new__(image_encoder.EncoderImage)
+        nn.Module.__init__(img)
+        img.cnn = nn.Identity()                                # the torchvision trunk: outside the glue under test
+        img.cnn_dim = cd
+        img.avgpool = nn.AdaptiveAvgPool2d((1, 1))             # what torchvision's resnet.avgpool is
+        img.fc = nn.Linear(cd, d)
+        img.pie_net = image_encoder.PIENet(1, cd, d, cd // 2)
+        img.mlp_local = mlp
+        if mlp:
+            img.head_proj = nn.Sequential(nn.Linear(512, 512), nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Linear(512, 512))
+        model = pcme_mod.PCME.__new__(pcme_mod.PCME)
+        nn.Module.__init__(model)
+        model.config, model.embed_dim, model.n_embeddings = cfg, d, 7
+        model.img_enc, model.txt_enc = img, txt
+        sd = seeded_state_dict(model.state_dict(), seed)
+        model.load_state_dict(sd)
+        model.train()
+        gen = torch.Generator().manual_seed(seed)
+        n = 6
+        fmap = torch.randn(n, cd, 7, 7, generator=gen).requires_grad_(True)
+        lengths = torch.tensor([9, 8, 6, 5, 3, 2])
+        sent = torch.randint(1, 60, (n, 9), generator=gen) * (torch.arange(9)[None, :] < lengths[:, None])
+        out = model(fmap, sent, None, lengths)
+        keys = list(out.keys())
+        gi = torch.randn(n, d, generator=gen)
+        gc = torch.randn(n, d, generator=gen)
+        ((out['image_features'] * gi).sum() + (out['caption_features'] * gc).sum()).backward()
+        gn = ['img_enc.fc.weight', 'img_enc.pie_net.attention.w_1.weight', 'img_enc.pie_net.layer_norm.bias',
+              'txt_enc.pie_net.fc.weight', 'txt_enc.rnn.weight_ih_l0'] + (['img_enc.head_proj.0.weight', 'txt_enc.head_proj.3.weight'] if mlp else [])
+        np.savez(os.path.join(OUT, f'tower_{tag}.npz'), seed=np.int64(seed), cd=np.int64(cd), embed_dim=np.int64(d),
+                 mlp_local=np.bool_(mlp), wsum=np.float64(checksum(sd)), fmap=fmap.detach().numpy(), sentences=sent.numpy(),
+                 lengths=lengths.numpy(), keys=np.array(keys), none_keys=np.array([k for k in keys if out[k] is None]),
+                 image_features=out['image_features'].detach().numpy(), caption_features=out['caption_features'].detach().numpy(),
+                 gi=gi.numpy(), gc=gc.numpy(), dfmap=fmap.grad.numpy(), **_grad_dict(model, gn))
+
+
+def make_kd():
+    """MMFL.py:346-378, literal statement sequence of the KD terms with client_loss_cri = nn.MSELoss() (:296):
+    one `kd_weight * code_sim` per client type -- the image term is added TWICE when image and multimodal clients
+    both exist (:361-378)."""
+    import operator
+    import torch.nn as nn
+    client_loss_cri = nn.MSELoss()
+    for (tag, m, b, d, n_img, n_txt, n_mm, kd_weight, three_d, seed) in [
+            ('all_types', 300, 16, 64, 2, 2, 1, 0.3, False, 51), ('img_only', 200, 8, 32, 3, 0, 0, 1.0, False, 52),
+            ('txt_mm', 257, 5, 48, 0, 1, 2, 0.5, False, 53), ('three_d', 128, 6, 16, 1, 1, 0, 0.3, True, 54)]:
+        gen = torch.Generator().manual_seed(seed)
+        img_vec = _unit(gen, m, d)
+        txt_vec = _unit(gen, m, d)
+        distill_index = [int(v) for v in torch.randperm(10 * m, generator=gen)[:m]]     # coco ids of the public set
+        distill_dict = {b_: a for a, b_ in enumerate(distill_index)}                   # MMFL.py:342
+        index = [distill_index[int(i)] for i in torch.randperm(m, generator=gen)[:b]]   # ids of this batch
+        shape = (b, 7, d) if three_d else (b, d)
+        oi = torch.randn(*shape, generator=gen)
+        ot = torch.randn(*shape, generator=gen)
+        if not three_d:
+            oi, ot = torch.nn.functional.normalize(oi, dim=-1), torch.nn.functional.normalize(ot, dim=-1)
+        oi.requires_grad_(True)
+        ot.requires_grad_(True)
+        output = {'image_features': oi, 'caption_features': ot}
+        loss = 0
+
+        def code_sim(output, target, config):
+            output = output.sum(axis=1) if len(output.shape) == 3 else output
+            target = target.type_as(output)
+            return client_loss_cri(output, target.type_as(output))
+
+        if n_img > 0:
+            out_img = output['image_features']
+            d_idx = operator.itemgetter(*index)(distill_dict)
+            target_img = img_vec[d_idx, :].type_as(out_img)
+            loss += kd_weight * code_sim(out_img, target_img, None)
+        if n_txt > 0:
+            out_txt = output['caption_features']
+            d_idx = operator.itemgetter(*index)(distill_dict)
+            target_txt = txt_vec[d_idx, :].type_as(out_txt)
+            loss += kd_weight * code_sim(out_txt, target_txt, None)
+        if n_mm > 0:
+            out_img = output['image_features']
+            d_idx = operator.itemgetter(*index)(distill_dict)
+            target_img = img_vec[d_idx, :].type_as(out_img)
+            out_txt = output['caption_features']
+            target_txt = txt_vec[d_idx, :].type_as(out_txt)
+            loss += kd_weight * code_sim(out_img, target_img, None)
+            loss += kd_weight * code_sim(out_txt, target_txt, None)
+        loss.backward()
+        np.savez(os.path.join(OUT, f'kd_{tag}.npz'), img_vec=img_vec.numpy(), txt_vec=txt_vec.numpy(),
+                 distill_index=np.array(distill_index, dtype=np.int64), index=np.array(index, dtype=np.int64),
+                 d_idx=np.array(d_idx, dtype=np.int64), out_img=oi.detach().numpy(), out_txt=ot.detach().numpy(),
+                 num_img_clients=np.int64(n_img), num_txt_clients=np.int64(n_txt), num_mm_clients=np.int64(n_mm),
+                 kd_weight=np.float32(kd_weight), loss=loss.detach().numpy(),
+                 d_out_img=(oi.grad.numpy() if oi.grad is not None else np.zeros(shape, np.float32)),
+                 d_out_txt=(ot.grad.numpy() if ot.grad is not None else np.zeros(shape, np.float32)))
+
+
 def main():
     assert os.path.isdir(REF), 'reference checkout not present (build container only)'
     sys.path[:0] = [REF, os.path.join(REF, 'src')]
@@ -249,6 +461,17 @@ def main():
     make_a6(eval_coco)
     import src.utils.Utils as utils_mod
     make_f4(losses_mod, utils_mod)
+    sys.path.insert(0, OUT)                                   # seeded.py
+    _stub_vision_text()
+    resnet_client = _load_by_path('ref_resnet_client', 'src/networks/resnet_client.py')
+    language_model = _load_by_path('ref_language_model', 'src/networks/language_model.py')   # finds `pie_model` above
+    make_a2c_img(resnet_client)
+    make_a2c_txt(language_model)
+    import src.networks.models.pcme as pcme_mod
+    import src.networks.models.image_encoder as image_encoder
+    import src.networks.models.caption_encoder as caption_encoder
+    make_tower(pcme_mod, image_encoder, caption_encoder)
+    make_kd()
     print('golden vectors written to', OUT)
 
 

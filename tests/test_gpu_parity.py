@@ -454,3 +454,169 @@ def test_gemm_bf16_tn_matches_torch(dev, m, n1, n2):
     assert float((c.double() - ref.double()).abs().max()) <= 2e-5 * scale + 1e-4
     cb = ops.gemm_bf16_tn(a, b, torch.bfloat16)
     assert float((cb.double() - ref.double()).abs().max()) <= 2 ** -8 * scale + 1e-4
+
+
+# ------------------------------------------------------------- A2c / tower glue / KD vs the reference-generated fixtures
+import sys as _sys
+_sys.path.insert(0, GOLDEN)
+from seeded import seeded_state_dict, checksum, resnet_client_template, text_client_template, tower_template  # noqa: E402
+
+
+def _gradkeys(z, prefix):
+    return {k[len(prefix):].replace('__', '.'): z[k] for k in z.files if k.startswith(prefix)}
+
+
+def _scale_close(got, want, rel, msg='', floor=0.0):
+    """|got - want| <= rel * (|want| + max|want|); `floor` = absolute noise level for quantities that are zero in exact
+    arithmetic (e.g. the gradient of a bias in front of a train-mode BatchNorm1d: pure round-off on both sides)."""
+    want = np.asarray(want, dtype=np.float64)
+    np.testing.assert_allclose(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got, dtype=np.float64), want, rtol=rel,
+                               atol=max(rel * (np.abs(want).max() + 1e-30), floor), err_msg=msg)
+
+
+@pytest.mark.parametrize('fname', golden_files('a2c_img_'))
+def test_a2c_resnet_client_mirror(dev, fname):
+    """creamfl_amd.networks.resnet_client.ResNet (fp32 on the GPU; l2norm on the HIP kernel) vs the reference's
+    resnet_client.ResNet.forward: state_dict keys load strictly, both phases, running statistics, weight clamp."""
+    from creamfl_amd.networks import resnet_client as rc
+    z = _load(fname)
+    d, train = int(z['embed_dim']), bool(z['train'])
+    sd = seeded_state_dict(resnet_client_template(d), int(z['seed']))
+    np.testing.assert_allclose(checksum(sd), float(z['wsum']), rtol=1e-12)
+    torch.backends.cudnn.allow_tf32 = False
+    model = rc.resnet10_client(embed_dim=d, num_class=10, is_train=True, scale=128, phase='none')
+    model.load_state_dict(sd, strict=True)                 # key-name parity with the reference's module
+    model = model.to(dev).train(train)
+    x = torch.from_numpy(z['x']).to(dev)
+    named = dict(model.named_parameters())
+    model.phase = 'extract_conv_feature'                   # ClientTrainer.py:372-375 switches modes by mutation
+    feat = model(x)
+    _scale_close(feat, z['feat'], 1e-4)
+    (feat * torch.from_numpy(z['gy']).to(dev)).sum().backward()
+    for k, g in _gradkeys(z, 'feat__g_').items():
+        _scale_close(named[k].grad, g, 1e-3, k)
+    if train:
+        _scale_close(model.state_dict()['bn1.running_mean'], z['bn1_running_mean_after_feat'], 1e-4)
+    model.phase = 'none'
+    model.zero_grad()
+    x1, x2, w, w2 = model(x)
+    for got, key in ((x1, 'x1'), (x2, 'x2'), (w, 'w'), (w2, 'w2')):
+        _scale_close(got, z[key], 1e-4, key)
+    np.testing.assert_array_equal(model.class_fc_2.weight.detach().cpu().numpy(), z['class_fc_2_weight_after'])
+    np.testing.assert_array_equal(model.class_fc_22.weight.detach().cpu().numpy(), z['class_fc_22_weight_after'])
+    ((x1 * torch.from_numpy(z['g1']).to(dev)).sum() + (x2 * torch.from_numpy(z['g2']).to(dev)).sum() + 0.1 * (w ** 2).sum()).backward()
+    for k, g in _gradkeys(z, 'cls__g_').items():
+        _scale_close(named[k].grad, g, 1e-3, k)
+
+
+@pytest.mark.parametrize('fname', golden_files('a2c_txt_'))
+def test_a2c_text_client_mirror(dev, fname):
+    """creamfl_amd.networks.language_model.EncoderText (HIP PIE head + l2norm) vs the reference's EncoderText.forward."""
+    from creamfl_amd.networks.language_model import EncoderText
+    z = _load(fname)
+    d = int(z['embed_dim'])
+    sd = seeded_state_dict(text_client_template(d, int(z['vocab'])), int(z['seed']))
+    np.testing.assert_allclose(checksum(sd), float(z['wsum']), rtol=1e-12)
+    model = EncoderText(wemb_type=None, word_dim=300, embed_dim=d, num_class=4, scale=128, vocab_size=int(z['vocab']))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    named = dict(model.named_parameters())
+    x, lengths = torch.from_numpy(z['x']).to(dev), torch.from_numpy(z['lengths'])
+    model.is_train = False
+    feat = model(x, lengths)
+    _scale_close(feat, z['feat'], 1e-4)
+    (feat * torch.from_numpy(z['gy']).to(dev)).sum().backward()
+    for k, g in _gradkeys(z, 'feat__g_').items():
+        _scale_close(named[k].grad, g, 1e-3, k)
+    model.is_train = True
+    model.zero_grad()
+    x1, x2, w, w2 = model(x, lengths)
+    for got, key in ((x1, 'x1'), (x2, 'x2'), (w, 'w'), (w2, 'w2')):
+        _scale_close(got, z[key], 1e-4, key)
+    np.testing.assert_array_equal(model.class_fc.weight.detach().cpu().numpy(), z['class_fc_weight_after'])
+    ((x1 * torch.from_numpy(z['g1']).to(dev)).sum() + (x2 * torch.from_numpy(z['g2']).to(dev)).sum() + 0.1 * (w ** 2).sum()).backward()
+    for k, g in _gradkeys(z, 'cls__g_').items():
+        _scale_close(named[k].grad, g, 1e-3, k)
+
+
+class _IdentityTrunk(torch.nn.Module):
+    """Stands where the ResNet trunk is: the fixtures hold the trunk's OUTPUT map (as the reference generator did)."""
+
+    def __init__(self, out_dim):
+        super().__init__()
+        self.out_dim = out_dim
+
+    def features(self, x):
+        return x
+
+
+@pytest.mark.parametrize('fname', golden_files('tower_'))
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_a2_pcme_tower_glue_mirror(dev, fname, channels_last):
+    """creamfl_amd PCME.forward / EncoderImage.forward / EncoderText.forward (fused HIP PIE head, mean-pool + fc,
+    head_proj, l2norm) vs the reference's own PCME.forward run on the same trunk output; 10-key dict, both memory
+    formats of the trunk output (the channels_last one is the zero-copy [N, 49, Cd] view)."""
+    from creamfl_amd.networks.models.pcme import PCME
+    from creamfl_amd.networks.models.image_encoder import EncoderImage
+    from creamfl_amd.networks.models.caption_encoder import EncoderText
+    from creamfl_amd.networks.models.pie_model import PIENet
+    from creamfl_amd.utils.config import Config as AttrDict
+    nn = torch.nn
+    z = _load(fname)
+    cd, d, mlp = int(z['cd']), int(z['embed_dim']), bool(z['mlp_local'])
+    sd = seeded_state_dict(tower_template(cd, d, mlp), int(z['seed']))
+    np.testing.assert_allclose(checksum(sd), float(z['wsum']), rtol=1e-12)
+    cfg = AttrDict(embed_dim=d, wemb_type=None, word_dim=300, cache_dir=None, not_bert=True, n_samples_inference=7,
+                   cnn_type='resnet18')
+    img = EncoderImage.__new__(EncoderImage)
+    nn.Module.__init__(img)
+    img.cnn, img.cnn_dim = _IdentityTrunk(cd), cd
+    img.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+    img.fc = nn.Linear(cd, d)
+    img.pie_net = PIENet(1, cd, d, cd // 2)
+    img.mlp_local = mlp
+    if mlp:
+        img.head_proj = nn.Sequential(nn.Linear(512, 512), nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Linear(512, 512))
+    model = PCME.__new__(PCME)
+    nn.Module.__init__(model)
+    model.config, model.embed_dim, model.n_embeddings = cfg, d, 7
+    model.img_enc = img
+    model.txt_enc = EncoderText({str(i): i for i in range(60)}, cfg, mlp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    fmap = torch.from_numpy(z['fmap']).to(dev)
+    if channels_last:
+        fmap = fmap.contiguous(memory_format=torch.channels_last)
+    fmap.requires_grad_(True)
+    out = model(fmap, torch.from_numpy(z['sentences']).to(dev), None, torch.from_numpy(z['lengths']).to(dev))
+    assert list(out.keys()) == [str(k) for k in z['keys']]
+    assert [k for k in out if out[k] is None] == [str(k) for k in z['none_keys']]
+    _scale_close(out['image_features'], z['image_features'], 1e-4)
+    _scale_close(out['caption_features'], z['caption_features'], 1e-4)
+    ((out['image_features'] * torch.from_numpy(z['gi']).to(dev)).sum()
+     + (out['caption_features'] * torch.from_numpy(z['gc']).to(dev)).sum()).backward()
+    _scale_close(fmap.grad, z['dfmap'], 1e-3)
+    named = dict(model.named_parameters())
+    for k, g in _gradkeys(z, 'g_').items():
+        _scale_close(named[k].grad, g, 1e-3, k, floor=1e-6)
+
+
+@pytest.mark.parametrize('fname', golden_files('kd_'))
+def test_f1_kd_terms_golden(dev, fname):
+    """MMFL.kd_terms (fused gather + MSE kernel per term) vs the literal MMFL.py:346-378 sequence: every combination
+    of client types incl. the doubled image term, [B, 7, D] outputs summed over axis 1."""
+    from types import SimpleNamespace
+    from creamfl_amd.algorithms.MMFL import MMFL
+    z = _load(fname)
+    me = SimpleNamespace(args=SimpleNamespace(num_img_clients=int(z['num_img_clients']), num_txt_clients=int(z['num_txt_clients']),
+                                              num_mm_clients=int(z['num_mm_clients']), kd_weight=float(z['kd_weight'])),
+                         img_vec=torch.from_numpy(z['img_vec']).to(dev), txt_vec=torch.from_numpy(z['txt_vec']).to(dev))
+    oi = torch.from_numpy(z['out_img']).to(dev).requires_grad_(True)
+    ot = torch.from_numpy(z['out_txt']).to(dev).requires_grad_(True)
+    dd = {int(b): a for a, b in enumerate(z['distill_index'])}
+    d_idx = torch.as_tensor([dd[int(i)] for i in z['index']], device=dev)
+    loss = MMFL.kd_terms(me, {'image_features': oi, 'caption_features': ot}, d_idx)
+    loss.backward()
+    _close(loss.item(), float(z['loss']), 1e-5, 0)
+    _scale_close(oi.grad if oi.grad is not None else torch.zeros_like(oi), z['d_out_img'], 1e-5)
+    _scale_close(ot.grad if ot.grad is not None else torch.zeros_like(ot), z['d_out_txt'], 1e-5)

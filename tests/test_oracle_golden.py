@@ -157,3 +157,117 @@ def test_f4_supervised_glue(fname):
     assert float(p1) == float(z['prec1'][0]) and float(pk) == float(z['preck'][0])
     np.testing.assert_allclose(fvec.grad.numpy(), z['dfvec'], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(W.grad.numpy(), z['dclass_weight'], rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------ A2c / tower glue / KD (round 2 fixtures)
+import sys
+sys.path.insert(0, GOLDEN)
+from seeded import (seeded_state_dict, checksum, resnet_client_template, text_client_template,  # noqa: E402
+                    tower_template)
+
+
+def _gradkeys(z, prefix):
+    return {k[len(prefix):].replace('__', '.'): z[k] for k in z.files if k.startswith(prefix)}
+
+
+def _scale_close(got, want, rel, msg=''):
+    want = np.asarray(want, dtype=np.float64)
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), want, rtol=rel, atol=rel * (np.abs(want).max() + 1e-30),
+                               err_msg=msg)
+
+
+
+def _leafify(sd):
+    return {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone()) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize('fname', golden_files('a2c_img_'))
+def test_a2c_resnet_client_both_phases(fname):
+    """oracle.resnet_client_forward vs the reference's resnet_client.ResNet.forward (:175-201), both phases, incl. the
+    BatchNorm running-statistics update and the `weight.data = relu(weight)` side effect."""
+    z = _load(fname)
+    d, train = int(z['embed_dim']), bool(z['train'])
+    sd = seeded_state_dict(resnet_client_template(d), int(z['seed']))
+    np.testing.assert_allclose(checksum(sd), float(z['wsum']), rtol=1e-12)          # same weights as the generator's
+    x = torch.from_numpy(z['x'])
+    p = _leafify(sd)
+    feat, new = oracle.resnet_client_forward(p, x, 'extract_conv_feature', train_mode=train)
+    _scale_close(feat.detach().numpy(), z['feat'], 2e-5)
+    (feat * torch.from_numpy(z['gy'])).sum().backward()
+    for k, g in _gradkeys(z, 'feat__g_').items():
+        _scale_close(p[k].grad.numpy(), g, 2e-4, k)
+    if train:
+        _scale_close(new['bn1.running_mean'].numpy(), z['bn1_running_mean_after_feat'], 1e-5)
+        sd['bn1.running_mean'] = new['bn1.running_mean']                               # the reference's second forward starts here
+    p = _leafify({**sd, **{k: v for k, v in new.items() if 'running' in k}})
+    (x1, x2, w, w2), new2 = oracle.resnet_client_forward(p, x, 'none', is_train=True, train_mode=train)
+    for got, key in ((x1, 'x1'), (x2, 'x2'), (w, 'w'), (w2, 'w2')):
+        _scale_close(got.detach().numpy(), z[key], 2e-5, key)
+    np.testing.assert_array_equal(new2['class_fc_2.weight'].numpy(), z['class_fc_2_weight_after'])
+    np.testing.assert_array_equal(new2['class_fc_22.weight'].numpy(), z['class_fc_22_weight_after'])
+    assert (z['class_fc_2_weight_after'] >= 0).all() and (sd['class_fc_2.weight'].numpy() < 0).any()
+    ((x1 * torch.from_numpy(z['g1'])).sum() + (x2 * torch.from_numpy(z['g2'])).sum() + 0.1 * (w ** 2).sum()).backward()
+    for k, g in _gradkeys(z, 'cls__g_').items():
+        _scale_close(p[k].grad.numpy(), g, 2e-4, k)
+
+
+@pytest.mark.parametrize('fname', golden_files('a2c_txt_'))
+def test_a2c_text_client_both_modes(fname):
+    """oracle.text_client_forward vs the reference's language_model.EncoderText.forward (:93-130)."""
+    z = _load(fname)
+    d = int(z['embed_dim'])
+    sd = seeded_state_dict(text_client_template(d, int(z['vocab'])), int(z['seed']))
+    np.testing.assert_allclose(checksum(sd), float(z['wsum']), rtol=1e-12)
+    x, lengths = torch.from_numpy(z['x']), torch.from_numpy(z['lengths'])
+    p = _leafify(sd)
+    feat, _ = oracle.text_client_forward(p, x, lengths, is_train=False)
+    _scale_close(feat.detach().numpy(), z['feat'], 2e-5)
+    (feat * torch.from_numpy(z['gy'])).sum().backward()
+    for k, g in _gradkeys(z, 'feat__g_').items():
+        _scale_close(p[k].grad.numpy(), g, 2e-4, k)
+    p = _leafify(sd)
+    (x1, x2, w, w2), new = oracle.text_client_forward(p, x, lengths, is_train=True)
+    for got, key in ((x1, 'x1'), (x2, 'x2'), (w, 'w'), (w2, 'w2')):
+        _scale_close(got.detach().numpy(), z[key], 2e-5, key)
+    np.testing.assert_array_equal(new['class_fc.weight'].numpy(), z['class_fc_weight_after'])
+    ((x1 * torch.from_numpy(z['g1'])).sum() + (x2 * torch.from_numpy(z['g2'])).sum() + 0.1 * (w ** 2).sum()).backward()
+    for k, g in _gradkeys(z, 'cls__g_').items():
+        _scale_close(p[k].grad.numpy(), g, 2e-4, k)
+
+
+@pytest.mark.parametrize('fname', golden_files('tower_'))
+def test_a2_pcme_tower_glue(fname):
+    """oracle.pcme_towers_forward vs the reference's own PCME.forward / EncoderImage.forward / EncoderText.forward run on a
+    synthetic trunk output: 10-key dict, fc(avgpool) + PIE + (head_proj) + l2norm ordering of both towers."""
+    z = _load(fname)
+    cd, d, mlp = int(z['cd']), int(z['embed_dim']), bool(z['mlp_local'])
+    sd = seeded_state_dict(tower_template(cd, d, mlp), int(z['seed']))
+    np.testing.assert_allclose(checksum(sd), float(z['wsum']), rtol=1e-12)
+    p = _leafify(sd)
+    fmap = torch.from_numpy(z['fmap']).requires_grad_(True)
+    out = oracle.pcme_towers_forward(p, fmap, torch.from_numpy(z['sentences']), torch.from_numpy(z['lengths']), mlp_local=mlp)
+    assert list(out.keys()) == [str(k) for k in z['keys']]
+    assert [k for k in out if out[k] is None] == [str(k) for k in z['none_keys']]
+    _scale_close(out['image_features'].detach().numpy(), z['image_features'], 2e-5)
+    _scale_close(out['caption_features'].detach().numpy(), z['caption_features'], 2e-5)
+    ((out['image_features'] * torch.from_numpy(z['gi'])).sum() + (out['caption_features'] * torch.from_numpy(z['gc'])).sum()).backward()
+    _scale_close(fmap.grad.numpy(), z['dfmap'], 2e-4)
+    for k, g in _gradkeys(z, 'g_').items():
+        _scale_close(p[k].grad.numpy(), g, 2e-4, k)
+
+
+@pytest.mark.parametrize('fname', golden_files('kd_'))
+def test_f1_kd_terms(fname):
+    """oracle.kd_loss vs the literal MMFL.py:346-378 sequence (incl. the doubled image term)."""
+    z = _load(fname)
+    oi = torch.from_numpy(z['out_img']).requires_grad_(True)
+    ot = torch.from_numpy(z['out_txt']).requires_grad_(True)
+    dd = {int(b): a for a, b in enumerate(z['distill_index'])}
+    d_idx = [dd[int(i)] for i in z['index']]
+    assert d_idx == [int(v) for v in z['d_idx']]
+    loss = oracle.kd_loss(oi, ot, torch.from_numpy(z['img_vec']), torch.from_numpy(z['txt_vec']), d_idx,
+                          int(z['num_img_clients']), int(z['num_txt_clients']), int(z['num_mm_clients']), float(z['kd_weight']))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z['loss']), rtol=1e-6)
+    _scale_close((oi.grad if oi.grad is not None else torch.zeros_like(oi)).numpy(), z['d_out_img'], 1e-6)
+    _scale_close((ot.grad if ot.grad is not None else torch.zeros_like(ot)).numpy(), z['d_out_txt'], 1e-6)
