@@ -246,6 +246,11 @@ class ClientTrainer:
         self.test_top1, self.test_top5 = AverageMeter(), AverageMeter()
         self.model.train()
 
+    @property
+    def modalities(self):
+        """Which representations generate_logits returns (host knowledge used by dist.client_plan)."""
+        return ('img',) if self.dset_name in IMAGE_SETS else ('txt',)
+
     def generate_logits(self, dataloader):
         vec, idx = self.extract_pub_feature(dataloader)
         if self.dset_name in IMAGE_SETS:

@@ -87,6 +87,8 @@ class MMClientTrainer(EngineBase):
             if is_test:
                 break
 
+    modalities = ('img', 'txt')          # generate_logits returns both representations (dist.client_plan)
+
     def generate_logits(self, dataloader):
         self.model.to(self.device)
         was_training = self.model.training

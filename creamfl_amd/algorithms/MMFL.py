@@ -189,8 +189,7 @@ class MMFL(object):
         self.cur_epoch = round_n
         self.cur_trainers = self.total_local_trainers
         # multi-rank: the server phases are replicated on every rank; re-synchronise the replicas each round
-        cdist.broadcast_module(self.engine.model)
-        cdist.broadcast_module(self.engine.criterion)
+        self.engine.sync_replicas()
         if not is_test:
             self.logger.log(f"Round {round_n + 1}!")
             self.engine.train(tr_loader=self._dataloaders[self._pub_key(False)])
@@ -202,7 +201,6 @@ class MMFL(object):
 
         rank, world = cdist._world()
         my_trainers = cdist.shard_clients(self.cur_trainers, rank, world)
-        slots = -(-len(self.cur_trainers) // world) if self.cur_trainers else 0
         local_reps = []
         for trainer in my_trainers:
             self.logger.log(f"Training Client {trainer.client_idx}!")
@@ -217,10 +215,9 @@ class MMFL(object):
                 assert i == self.distill_index
             local_reps.append(_vec)
         if world > 1:
-            while len(local_reps) < slots:
-                local_reps.append({'img': None, 'txt': None})
             M, D = self.args.pub_data_num, self.args.feature_dim
-            img_vec, txt_vec = cdist.allgather_client_reps(local_reps, M, D, self.engine.device)
+            img_vec, txt_vec = cdist.allgather_client_reps(local_reps, cdist.client_plan(self.cur_trainers, world), M, D,
+                                                           self.engine.device)
         else:
             img_vec = [v['img'] for v in local_reps if v['img'] is not None]
             txt_vec = [v['txt'] for v in local_reps if v['txt'] is not None]

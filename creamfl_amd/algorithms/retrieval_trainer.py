@@ -114,6 +114,21 @@ class EngineBase(object):
         if self.evaluator is not None:
             self.evaluator.autocast_dtype = self.autocast_dtype
 
+    def sync_replicas(self, src=0, group=None):
+        """Multi-rank: make this rank's server replica identical to rank `src`'s -- parameters and buffers (with the
+        BatchNorm batch counters flushed first), and the optimizer state: with bf16 trunk weights the next step
+        rewrites every weight from the rank's own fp32 master, so the masters and moments must travel too."""
+        from .. import dist as cdist
+        if cdist._world(group)[1] == 1:
+            return
+        for m in self.model.modules():
+            if hasattr(m, 'flush_num_batches_tracked'):
+                m.flush_num_batches_tracked()
+        cdist.broadcast_module(self.model, src, group)
+        cdist.broadcast_module(self.criterion, src, group)
+        if isinstance(self.optimizer, AdamP):
+            self.optimizer.broadcast_state(src, group)
+
     def enable_data_parallel(self, process_group=None, bucket_cap_mb=128):
         from ..dist import DataParallelContext
         self.dp = DataParallelContext(self.model, process_group, bucket_cap_mb=bucket_cap_mb)

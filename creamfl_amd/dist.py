@@ -2,9 +2,10 @@
 xGMI mesh.  The reference is strictly single-GPU and time-multiplexes clients on cuda:0
 (src/algorithms/MMFL.py:226-247); everything here is the build's own design:
 
-  1. clients          -- `shard_clients`: the independent `for trainer in cur_trainers` bodies run one client
-                         per rank; `allgather_client_reps` is the ONE all-gather of each rank's [M, D] public-set
-                         representation (a modality a client does not have travels as a zero block + a flag).
+  1. clients          -- `shard_clients`: the independent `for trainer in cur_trainers` bodies run on the rank that
+                         OWNS the client (stable: client_idx % W, so a client's model persists across rounds);
+                         `allgather_client_reps` all-gathers each rank's [M, D] public-set representations following
+                         a host-known plan (no flags, no host sync, no zero blocks for uni-modal clients).
   2. con_w            -- `conw_aggregate_sharded`: the M rows of the log-prob are independent, so every rank
                          computes rows [r0, r1) for all C clients against the full (resident) global bank,
                          combines them locally and all-gathers its [M/W, D] block of the aggregate.
@@ -115,34 +116,72 @@ class DataParallelContext:
 
 
 # ------------------------------------------------------------------------------------- clients per GPU
+def client_owner(trainer, position, world):
+    """Rank that owns a client.  Keyed by the client's STABLE identity (`client_idx`, MMFL.py:176-178), not by its
+    position in this round's `random.sample`: a client's model, optimizer state and epoch counter live only in the
+    process that trains it and must be the ones it continues from in later rounds (MMFL.py:226-247 trains persistent
+    trainer objects).  Objects without a `client_idx` fall back to their position."""
+    key = getattr(trainer, 'client_idx', None)
+    if key is None and isinstance(trainer, dict):
+        key = trainer.get('client_idx')
+    return (int(key) if key is not None else position) % world
+
+
+def client_modalities(trainer):
+    """('img',) | ('txt',) | ('img', 'txt'): which representations `generate_logits` of this client returns.  Known on
+    the host of every rank (it is a property of the client's type), so nothing about it has to be communicated."""
+    m = getattr(trainer, 'modalities', None)
+    if m is None and isinstance(trainer, dict):
+        m = trainer.get('modalities', tuple(k for k in ('img', 'txt') if trainer.get(k) is not None))
+    if m is None:
+        raise ValueError(f'cannot tell the modalities of client {trainer!r}')
+    return tuple(m)
+
+
+def client_plan(trainers, world):
+    """plan[r] = [(position in `trainers`, modalities), ...] of the clients rank r owns this round, for EVERY rank
+    (identical on all ranks: they sample the same client list)."""
+    plan = [[] for _ in range(world)]
+    for pos, t in enumerate(trainers):
+        plan[client_owner(t, pos, world)].append((pos, client_modalities(t)))
+    return plan
+
+
 def shard_clients(trainers, rank=None, world=None, group=None):
-    """Round-robin assignment of this round's sampled clients to ranks (client i -> rank i % W)."""
+    """This round's clients owned by this rank (stable ownership: client_owner)."""
     if rank is None or world is None:
         rank, world = _world(group)
-    return [t for i, t in enumerate(trainers) if i % world == rank]
+    return [t for pos, t in enumerate(trainers) if client_owner(t, pos, world) == rank]
 
 
-def allgather_client_reps(local_reps, M, D, device, group=None):
-    """local_reps: list (one entry per client trained on this rank, equal length on every rank; pad with
-    {'img': None, 'txt': None}) of {'img': [M, D] | None, 'txt': [M, D] | None}.
-    Returns (img_vecs, txt_vecs): lists of [M, D] tensors from ALL ranks, in (slot-major, rank-minor) =
-    global client order for round-robin sharding."""
+def allgather_client_reps(local_reps, plan, M, D, device, group=None):
+    """All-gather of the public-set representations of this round's clients.
+    local_reps: one {'img': [M, D] | None, 'txt': [M, D] | None} per client this rank trained, in plan[rank] order.
+    plan: client_plan(...) -- who holds which modality is host knowledge, so there is no flag exchange and no
+    device->host synchronisation.  Per slot (the k-th client of every rank) one all-gather moves the FIRST representation
+    of each rank's client, whatever its modality, and a second one only if some rank's client in that slot is
+    multimodal; a rank contributes a zero block only where it has nothing for that (slot, sub-slot).
+    Returns (img_vecs, txt_vecs): lists of [M, D] tensors in the order of the sampled client list."""
     rank, world = _world(group)
-    img_vecs, txt_vecs = [], []
-    for rep in local_reps:
-        buf = torch.zeros(2, M, D, dtype=torch.float32, device=device)
-        flag = torch.zeros(2, dtype=torch.float32, device=device)
-        for j, k in enumerate(('img', 'txt')):
-            if rep.get(k) is not None:
-                buf[j] = rep[k].to(device=device, dtype=torch.float32)
-                flag[j] = 1.0
-        bufs = all_gather_cat(buf.reshape(1, 2, M, D), group)            # [W, 2, M, D]
-        flags = all_gather_cat(flag.reshape(1, 2), group).cpu()          # [W, 2]
-        for r in range(world):
-            if flags[r, 0] > 0:
-                img_vecs.append(bufs[r, 0])
-            if flags[r, 1] > 0:
-                txt_vecs.append(bufs[r, 1])
+    slots = max((len(p) for p in plan), default=0)
+    got = {}
+    for s in range(slots):
+        nsub = max((len(p[s][1]) if s < len(p) else 0) for p in plan)
+        for k in range(nsub):
+            mine = None
+            if s < len(plan[rank]) and k < len(plan[rank][s][1]):
+                mine = local_reps[s][plan[rank][s][1][k]]
+                if mine is None or tuple(mine.shape) != (M, D):
+                    raise RuntimeError(f'client in slot {s} did not return a [{M}, {D}] {plan[rank][s][1][k]} representation')
+                mine = mine.to(device=device, dtype=torch.float32)
+            else:
+                mine = torch.zeros(M, D, dtype=torch.float32, device=device)
+            bufs = all_gather_cat(mine.reshape(1, M, D), group)              # [W, M, D]
+            for r in range(world):
+                if s < len(plan[r]) and k < len(plan[r][s][1]):
+                    got[(plan[r][s][0], plan[r][s][1][k])] = bufs[r]
+    img_vecs = [got[key] for key in sorted(got) if key[1] == 'img']
+    txt_vecs = [got[key] for key in sorted(got) if key[1] == 'txt']
     return img_vecs, txt_vecs
 
 

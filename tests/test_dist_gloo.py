@@ -77,14 +77,14 @@ def _worker_clients_conw(rank, world, path, out):
     M, D = 300, 16
     gen = torch.Generator().manual_seed(7)
     G_img, G_txt = _unit(gen, M, D), _unit(gen, M, D)
-    # 3 clients this round: img, txt, mm  -> rank 0 gets clients 0 and 2, rank 1 gets client 1
+    # 3 clients this round: img, txt, mm  -> rank 0 gets clients 0 and 2, rank 1 gets client 1 (no client_idx: positional)
     reps_all = [{'img': _unit(gen, M, D), 'txt': None}, {'img': None, 'txt': _unit(gen, M, D)},
                 {'img': _unit(gen, M, D), 'txt': _unit(gen, M, D)}]
     mine = cdist.shard_clients(reps_all)
-    while len(mine) < 2:
-        mine.append({'img': None, 'txt': None})
-    img_vecs, txt_vecs = cdist.allgather_client_reps(mine, M, D, torch.device('cpu'))
-    ok = len(img_vecs) == 2 and len(txt_vecs) == 2
+    plan = cdist.client_plan(reps_all, world)
+    ok = plan == [[(0, ('img',)), (2, ('img', 'txt'))], [(1, ('txt',))]]
+    img_vecs, txt_vecs = cdist.allgather_client_reps(mine, plan, M, D, torch.device('cpu'))
+    ok &= len(img_vecs) == 2 and len(txt_vecs) == 2
     ok &= torch.equal(img_vecs[0], reps_all[0]['img']) and torch.equal(img_vecs[1], reps_all[2]['img'])
     ok &= torch.equal(txt_vecs[0], reps_all[1]['txt']) and torch.equal(txt_vecs[1], reps_all[2]['txt'])
 
@@ -111,7 +111,66 @@ def _worker_clients_conw(rank, world, path, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('worker', [_worker_global_contrast, _worker_clients_conw])
+# ------------------------------------------------------------------------------ BASELINE configs[2]: 8 clients / round
+class _FakeClient:
+    """Stands for a ClientTrainer / MMClientTrainer: a stable `client_idx`, host-known `modalities`, per-process training
+    state that must persist on the owning rank, and a deterministic representation."""
+
+    def __init__(self, client_idx, modalities, M, D):
+        self.client_idx, self.modalities, self.M, self.D = client_idx, modalities, M, D
+        self.rounds_trained = 0                              # lives only in the process that trains the client
+
+    def run_and_generate(self, round_n):
+        self.rounds_trained += 1
+        out = {'img': None, 'txt': None}
+        for j, k in enumerate(self.modalities):
+            gen = torch.Generator().manual_seed(1000 * self.client_idx + 10 * self.rounds_trained + (0 if k == 'img' else 1))
+            out[k] = _unit(gen, self.M, self.D)
+        return out
+
+
+def _worker_config2_eight_clients(rank, world, path, out):
+    """10 image + 10 text + 5 multimodal clients, 8 sampled per round (BASELINE configs[2]), two rounds with different
+    samples: ownership is stable (client_idx % W), every representation arrives exactly once in sampled order, and a
+    client sampled in both rounds continues from ITS OWN state on its owner (rounds_trained == 2 there, 0 elsewhere)."""
+    import random
+    _init(rank, world, path)
+    M, D = 64, 8
+    pool = ([_FakeClient(i + 1, ('img',), M, D) for i in range(10)] + [_FakeClient(11 + i, ('txt',), M, D) for i in range(10)]
+            + [_FakeClient(21 + i, ('img', 'txt'), M, D) for i in range(5)])
+    ok = True
+    rng = random.Random(5)                                   # every rank samples the same clients (MMFL.train)
+    seen_twice = None
+    times = {}                                               # how often each client has been sampled (host knowledge)
+    for round_n in range(2):
+        cur = rng.sample(pool, 8) if round_n == 0 else ([seen_twice] + rng.sample([c for c in pool if c is not seen_twice], 7))
+        if round_n == 0:
+            seen_twice = cur[3]
+        mine = cdist.shard_clients(cur)
+        ok &= all(c.client_idx % world == rank for c in mine)
+        plan = cdist.client_plan(cur, world)
+        ok &= sorted(pos for p in plan for pos, _ in p) == list(range(8))
+        local = [c.run_and_generate(round_n) for c in mine]
+        img_vecs, txt_vecs = cdist.allgather_client_reps(local, plan, M, D, torch.device('cpu'))
+        want_img, want_txt = [], []
+        for c in cur:                                        # what a single process would have collected, in sampled order
+            trained = times[c.client_idx] = times.get(c.client_idx, 0) + 1
+            for k in c.modalities:
+                gen = torch.Generator().manual_seed(1000 * c.client_idx + 10 * trained + (0 if k == 'img' else 1))
+                (want_img if k == 'img' else want_txt).append(_unit(gen, M, D))
+        ok &= len(img_vecs) == len(want_img) and len(txt_vecs) == len(want_txt)
+        ok &= all(torch.equal(a, b) for a, b in zip(img_vecs, want_img))
+        ok &= all(torch.equal(a, b) for a, b in zip(txt_vecs, want_txt))
+    owner = seen_twice.client_idx % world
+    ok &= seen_twice.rounds_trained == (2 if rank == owner else 0)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(bool(flag.item() == 1.0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('worker', [_worker_global_contrast, _worker_clients_conw, _worker_config2_eight_clients])
 def test_two_rank_gloo(worker):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
