@@ -31,8 +31,13 @@ SIGNATURES = {
     'cfl_bank_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cfl_bank_lse_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
     'cfl_bank_lse_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'cfl_bank_attn_supported': (c_int, [c_int, c_int, c_int]),
+    'cfl_bank_attn_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'cfl_client_contrast_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int,
+                                        _P, _P, _P, _P, _P, _P, _P, _P]),
+    'cfl_client_contrast_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     'cfl_intra_ws_bytes': (c_size_t, [c_int]),
-    'cfl_intra_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'cfl_intra_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_kd_mse': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_gemm_bf16_nt': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, _P]),
     'cfl_transpose_bf16': (c_int, [_P, c_int, c_int, _P, _P]),

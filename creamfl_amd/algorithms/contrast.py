@@ -19,6 +19,15 @@ def client_contrast_loss(feature, global_same, global_other, d_idx, old_feature=
     intra : loss_moon (:470)        inter : loss_inter (:502)
     """
     loss_inter = loss_moon = None
+    if not (use_inter or use_intra):
+        raise ValueError('no contrast term selected')
+    bank = global_other if use_inter else global_same
+    if ops.bank_attn_supported(feature.shape[0], bank.shape[0], feature.shape[1]):
+        # one pass over the bank + one epilogue launch: both terms, their combination and all gradients (csrc/bank_attn.hip)
+        loss, loss_inter, loss_moon, _, _ = ops.client_contrast_fused(
+            feature, global_same, global_other, d_idx, old_feature, temperature, weight=interintra_weight,
+            loss_scale=loss_scale, use_inter=use_inter, use_intra=use_intra)
+        return loss, loss_inter, loss_moon
     if use_inter:
         loss_inter = ops.inter_contrast(feature, global_other, d_idx, temperature)[0]
     if use_intra:

@@ -242,21 +242,23 @@ __global__ __launch_bounds__(256) void cfl_bank_bwd_reduce_kernel(const float* _
 // A4: one wave per row
 __global__ __launch_bounds__(256) void cfl_intra_kernel(const float* __restrict__ F, const float* __restrict__ Gs,
                                                         const long long* __restrict__ idx, const float* __restrict__ Fo,
-                                                        int B, int D, int Bdiv, float inv_tau, float* rowloss, float* dF) {
+                                                        int B, int D, int M, int Bdiv, float inv_tau, float* rowloss, float* dF) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= B) return;
     const float* f = F + (long long)b * D;
-    const float* g = Gs + idx[b] * D;
+    const long long tgt = idx[b];
+    const bool ok = tgt >= 0 && tgt < M;             // an out-of-range index contributes a zero positive, never an address
+    const float* g = Gs + (ok ? tgt : 0) * D;
     const float* o = Fo + (long long)b * D;
     float pos = 0.f, neg = 0.f;
-    for (int k = lane; k < D; k += 64) { pos = fmaf(f[k], g[k], pos); neg = fmaf(f[k], o[k], neg); }
+    for (int k = lane; k < D; k += 64) { pos = fmaf(f[k], ok ? g[k] : 0.f, pos); neg = fmaf(f[k], o[k], neg); }
     pos = wave_sum(pos); neg = wave_sum(neg);
     const float z = (neg - pos) * inv_tau;
     if (lane == 0) rowloss[b] = softplusf(z);
     if (dF) {
         const float c = sigmoidf(z) * inv_tau / (float)Bdiv;
-        for (int k = lane; k < D; k += 64) dF[(long long)b * D + k] = c * (o[k] - g[k]);
+        for (int k = lane; k < D; k += 64) dF[(long long)b * D + k] = c * (o[k] - (ok ? g[k] : 0.f));
     }
 }
 __global__ __launch_bounds__(256) void cfl_intra_loss_kernel(const float* rowloss, int B, int Bdiv, float* loss) {
@@ -424,13 +426,13 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
 }
 
 int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, const float* Fold,
-                  int B, int D, int B_div, float inv_tau, float* loss, float* dF_unit, void* ws,
+                  int B, int D, int M, int B_div, float inv_tau, float* loss, float* dF_unit, void* ws,
                   void* stream_) {
-    if (!F || !Gsame || !idx || !Fold || !loss || !ws || B <= 0 || D <= 0 || B_div <= 0) return CFL_EINVAL;
+    if (!F || !Gsame || !idx || !Fold || !loss || !ws || B <= 0 || D <= 0 || M <= 0 || B_div <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     float* rowloss = (float*)ws;
     CFL_LAUNCH(K_INTRA, cfl_intra_kernel, dim3(cfl_cdiv(B, 4)), dim3(256), 0, stream,
-               F, Gsame, idx, Fold, B, D, B_div, inv_tau, rowloss, dF_unit);
+               F, Gsame, idx, Fold, B, D, M, B_div, inv_tau, rowloss, dF_unit);
     CFL_LAUNCH(K_INTRA, cfl_intra_loss_kernel, dim3(1), dim3(256), 0, stream, rowloss, B, B_div, loss);
     return 0;
 }

@@ -111,7 +111,101 @@ def pair_loss(image_features, caption_features, negative_scale, shift, eps=1e-6)
 
 
 # --------------------------------------------------------------------------- A3/A4: client contrast
+# Persistent per-device state of the fused path: cached workspaces (keyed by size) and the zero-initialised election
+# counter of the epilogue kernel (include/creamfl_hip.h: `sync` must be 0 before the first call and is left 0).
+_CONTRAST_STATE = {}
+
+
+def _contrast_state(device, ws_bytes):
+    st = _CONTRAST_STATE.get(device)
+    if st is None:
+        st = _CONTRAST_STATE[device] = {'sync': torch.zeros(1, dtype=torch.int32, device=device), 'ws': None}
+    if st['ws'] is None or st['ws'].numel() < ws_bytes:
+        st['ws'] = torch.empty(max(int(ws_bytes), 256), dtype=torch.uint8, device=device)
+    return st
+
+
+import os as _os
+_BANK_EXACT = bool(_os.environ.get('CFL_BANK_EXACT'))       # A/B switch: round-1 exact-fp32 two-pass kernels
+
+
+def bank_attn_supported(B, M, D):
+    """True when the single-pass 3 x bf16-split kernels (csrc/bank_attn.hip) take this shape (D <= 256, D % 4 == 0)."""
+    return (not _BANK_EXACT) and bool(_lib.load().cfl_bank_attn_supported(int(B), int(M), int(D)))
+
+
+class _ClientContrastFn(torch.autograd.Function):
+    """Fused A3 (+ A4): one pass over the bank gives the log-sum-exp and the unit gradient; one epilogue launch gives the
+    positive dots, the intra term, the means and the combined loss (csrc/bank_attn.hip)."""
+
+    @staticmethod
+    def forward(ctx, F, G_other, G_same, idx, F_old, inv_tau, weight, mode, b_div):
+        lib = _lib.load()
+        B, D = F.shape
+        M = (G_other if (mode & 1) else G_same).shape[0]
+        dev = F.device
+        need = ctx.needs_input_grad[0]
+        out5 = torch.empty(5, dtype=torch.float32, device=dev)
+        aux = torch.empty(2, B, dtype=torch.float32, device=dev) if (mode & 1) else None        # lse, pos
+        dFs = torch.empty(2, B, D, dtype=torch.float32, device=dev) if need else None            # inter, moon unit gradients
+        st = _contrast_state(dev, lib.cfl_bank_attn_ws_bytes(B, M, D, int(need)))
+        _lib.check(lib.cfl_client_contrast_fwd(
+            _ptr(F), _ptr(G_other), _ptr(G_same), _ptr(idx), _ptr(F_old), B, M, D, b_div, inv_tau, weight, mode, int(need),
+            _ptr(out5), _ptr(aux[0]) if aux is not None else _ptr(None), _ptr(aux[1]) if aux is not None else _ptr(None),
+            _ptr(dFs[0]) if (need and (mode & 1)) else _ptr(None), _ptr(dFs[1]) if (need and (mode & 2)) else _ptr(None),
+            _ptr(st['ws']), _ptr(st['sync']), _stream(F)), 'cfl_client_contrast_fwd')
+        ctx.mode = mode
+        ctx.save_for_backward(out5, dFs if need else out5)
+        ctx.has = need
+        ctx.mark_non_differentiable(out5)
+        if aux is not None:
+            ctx.mark_non_differentiable(aux)
+        return out5[0].clone(), out5, aux
+
+    @staticmethod
+    def backward(ctx, gloss, _g5, _gaux):
+        lib = _lib.load()
+        out5, dFs = ctx.saved_tensors
+        if not ctx.has:
+            raise _lib.CreamflHipError('client_contrast backward without saved gradients')
+        _, B, D = dFs.shape
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        dF = torch.empty(B, D, dtype=torch.float32, device=dFs.device)
+        _lib.check(lib.cfl_client_contrast_bwd(_ptr(dFs[0]) if (ctx.mode & 1) else _ptr(None),
+                                               _ptr(dFs[1]) if (ctx.mode & 2) else _ptr(None), _ptr(out5), _ptr(g), B, D, _ptr(dF),
+                                               _stream(dFs)), 'cfl_client_contrast_bwd')
+        return dF, None, None, None, None, None, None, None, None
+
+
+def client_contrast_fused(feature, global_same, global_other, d_idx, old_feature, temperature=0.5, weight=1.0, loss_scale=False,
+                          use_inter=True, use_intra=True, mean_divisor=None):
+    """Rows A3 + A4 and their combination (ClientTrainer.py:386-419) in three launches (bank pass, split merge,
+    epilogue).  Returns (loss, loss_inter | None, loss_moon | None, lse | None, pos | None).  Needs
+    bank_attn_supported(B, M, D)."""
+    F = _f32(feature, 'feature')
+    mode = (1 if use_inter else 0) | (2 if use_intra else 0) | (4 if loss_scale else 0)
+    if not (mode & 3):
+        raise ValueError('no contrast term selected')
+    Go = _f32(global_other.detach(), 'global_other') if use_inter else None
+    Gs = _f32(global_same.detach(), 'global_same') if use_intra else None
+    Fo = _f32(old_feature.detach(), 'old_feature') if use_intra else None
+    for G in (Go, Gs):
+        if G is not None and (G.dim() != 2 or F.dim() != 2 or G.shape[1] != F.shape[1]):
+            raise RuntimeError(f'shape mismatch {tuple(F.shape)} vs {tuple(G.shape)}')
+    if Go is not None and Gs is not None and Go.shape != Gs.shape:
+        raise RuntimeError(f'the two global banks differ in shape: {tuple(Go.shape)} vs {tuple(Gs.shape)}')
+    if Fo is not None and Fo.shape != F.shape:
+        raise RuntimeError(f'shape mismatch {tuple(F.shape)} vs {tuple(Fo.shape)}')
+    loss, out5, aux = _ClientContrastFn.apply(F, Go, Gs, _idx(d_idx, F.device), Fo, 1.0 / float(temperature), float(weight), mode,
+                                             int(mean_divisor) if mean_divisor else F.shape[0])
+    return (loss, out5[1] if use_inter else None, out5[2] if use_intra else None,
+            aux[0] if aux is not None else None, aux[1] if aux is not None else None)
+
+
 class _BankInterFn(torch.autograd.Function):
+    """Round-1 exact-fp32 two-pass path (v_mfma_f32_32x32x2_f32): kept for D > 256 / D % 4 != 0 and as the A/B reference
+    (CFL_BANK_EXACT=1)."""
+
     @staticmethod
     def forward(ctx, F, G, idx, inv_tau):
         lib = _lib.load()
@@ -145,6 +239,8 @@ class _BankInterFn(torch.autograd.Function):
 
 
 def _idx(d_idx, device):
+    """int64 device tensor of bank positions.  A device tensor passes through without any host work; host sequences are
+    range-checked here (the kernels treat an out-of-range index as 'no positive', never as an address)."""
     if torch.is_tensor(d_idx):
         return d_idx.to(device=device, dtype=torch.int64).contiguous()
     return torch.as_tensor(list(d_idx) if not isinstance(d_idx, (list, tuple)) else d_idx,
@@ -158,6 +254,9 @@ def inter_contrast(feature, global_other, d_idx, temperature=0.5):
     G = _f32(global_other.detach(), 'global_other')
     if F.dim() != 2 or G.dim() != 2 or F.shape[1] != G.shape[1]:
         raise RuntimeError(f'shape mismatch {tuple(F.shape)} vs {tuple(G.shape)}')
+    if bank_attn_supported(F.shape[0], G.shape[0], F.shape[1]):
+        loss, _, _, lse, pos = client_contrast_fused(F, None, G, d_idx, None, temperature, use_inter=True, use_intra=False)
+        return loss, lse, pos
     return _BankInterFn.apply(F, G, _idx(d_idx, F.device), 1.0 / float(temperature))
 
 
@@ -170,7 +269,7 @@ class _IntraFn(torch.autograd.Function):
         need = ctx.needs_input_grad[0]
         dF = torch.empty_like(F) if need else None
         ws = _ws(lib.cfl_intra_ws_bytes(B), F.device)
-        _lib.check(lib.cfl_intra_fwd(_ptr(F), _ptr(Gs), _ptr(idx), _ptr(Fo), B, D, b_div, inv_tau, _ptr(loss), _ptr(dF),
+        _lib.check(lib.cfl_intra_fwd(_ptr(F), _ptr(Gs), _ptr(idx), _ptr(Fo), B, D, Gs.shape[0], b_div, inv_tau, _ptr(loss), _ptr(dF),
                                      _ptr(ws), _stream(F)), 'cfl_intra_fwd')
         ctx.save_for_backward(dF if need else loss)
         return loss[0].clone()

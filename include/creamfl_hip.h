@@ -94,10 +94,33 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
  * (Fold_b - G_same[idx_b])  (gradient for an upstream gradient of 1; may be NULL).
  * `B_div` is the CE mean divisor (B, or 2B when two modalities are stacked, MMClientTrainer.py:188).
  */
+/* ---- A3 + A4 fused, single pass over the bank (csrc/bank_attn.hip) -------------------------
+ * Replaces the loop body src/algorithms/ClientTrainer.py:386-419 (and the inter-only :493-502 / intra-only :458-468
+ * variants, and MMClientTrainer.py:173-206 with B_div = 2B) for D <= 256, D % 4 == 0 (cfl_bank_attn_supported):
+ *   inter:  li = mean_b [ LSE_m(inv_tau F_b.G_other_m) - inv_tau F_b.G_other_idx[b] ]          (mode bit 0)
+ *   intra:  lm = (1/B_div) sum_b softplus(inv_tau (F_b.Fold_b - F_b.G_same_idx[b]))             (mode bit 1)
+ *   loss = (lm + li) w | (lm + li / (li/lm)) w with mode bit 2 (--loss_scale) | li | lm
+ * G is streamed ONCE: the same pass accumulates softmax . G, so the gradient needs no second pass and no [B, M] tensor.
+ * Logits use 3 x bf16-split MFMA (hi.hi + lo.hi + hi.lo, fp32 accumulation, |error| ~ 1e-6 on unit-norm features); the
+ * positive dot and the intra term are exact fp32.
+ * out5 = {loss, li, lm, c_inter, c_moon}; dF_inter / dF_moon [B, D] are the UNIT gradients of li / lm (want_grad), and
+ * cfl_client_contrast_bwd writes dF = gout * (c_inter dF_inter + c_moon dF_moon).
+ * lse [B] (required with bit 0), pos [B] (optional).  ws >= cfl_bank_attn_ws_bytes; `sync` points at an int that is 0
+ * before the first call (left 0).  idx outside [0, M) contributes a zero positive (as cfl_bank_lse_fwd).
+ */
+int cfl_bank_attn_supported(int B, int M, int D);
+size_t cfl_bank_attn_ws_bytes(int B, int M, int D, int want_grad);
+int cfl_client_contrast_fwd(const float* F, const float* G_other, const float* G_same, const long long* idx, const float* F_old,
+                            int B, int M, int D, int B_div, float inv_tau, float weight, int mode, int want_grad,
+                            float* out5, float* lse, float* pos, float* dF_inter, float* dF_moon, void* ws, int* sync,
+                            void* stream);
+int cfl_client_contrast_bwd(const float* dF_inter, const float* dF_moon, const float* out5, const float* gout_dev, int B, int D,
+                            float* dF, void* stream);
+
 size_t cfl_intra_ws_bytes(int B);
 int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, const float* Fold,
-                  int B, int D, int B_div, float inv_tau, float* loss, float* dF_unit, void* ws,
-                  void* stream);
+                  int B, int D, int M, int B_div, float inv_tau, float* loss, float* dF_unit, void* ws,
+                  void* stream);   /* M = rows of Gsame: idx outside [0, M) contributes a zero positive */
 
 /* ---- KD distillation term -------------------------------------------------------
  * Replaces  target = agg[d_idx, :]; loss += kd_weight * nn.MSELoss()(out, target)   (src/algorithms/MMFL.py:352-378).

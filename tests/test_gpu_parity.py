@@ -197,11 +197,15 @@ def test_a3_inter_shapes(dev, b, m, d):
     loss, lse, pos = ops.inter_contrast(fg, G.to(dev), idx.tolist(), 0.5)
     loss.backward()
     cf = oracle.client_contrast_grads_closed_form(f, G, G, idx.tolist(), f)
-    _close(loss.item(), cf['loss_inter'].item(), 2e-5, 0)
+    # atol: the log-sum-exp uses the 3 x bf16-split logits (|error| ~ 2e-6 at |logit| <= 2), the positive dot is exact fp32;
+    # their difference is the whole loss when it is ~0 (M = 1)
+    _close(loss.item(), cf['loss_inter'].item(), 2e-5, 1e-5)
     _close(lse.cpu().numpy(), cf['lse'].numpy(), 1e-5, 1e-5)
     _close(pos.cpu().numpy(), cf['pos_inter'].numpy(), 1e-5, 1e-5)
     dref = cf['d_inter'].numpy()
-    _close(fg.grad.cpu().numpy(), dref, 1e-4, 3e-5 * np.abs(dref).max())
+    # atol floor: softmax . G runs on G = hi + lo (two bf16, residual 2^-17 |G|); it only shows where the gradient itself
+    # cancels to ~0 (M = 1: softmax = onehot = the target)
+    _close(fg.grad.cpu().numpy(), dref, 1e-4, 3e-5 * np.abs(dref).max() + 2e-5 / (0.5 * b))
 
 
 def test_a3_online_lse_rescale_branch(dev):

@@ -290,6 +290,8 @@ def main():
         out += [case_a1(256, 512), case_a1(128, 256), case_a1(4096, 512)]
     if 'a3' in cases:
         out += [case_a3(128, 50000, 256), case_a3(256, 50000, 512), case_a3(128, 50000, 768), case_a3(32, 50000, 256)]
+    if 'a3one' in cases:
+        out += [case_a3(128, 50000, 256)]
     if 'a5' in cases:
         out += [case_a5(args.conw_m, 256)]
     if 'a2' in cases:
