@@ -11,20 +11,21 @@
 //   * every fp32 operand is split x = hi + lo (two bf16, 16 mantissa bits) while it is staged into LDS, and each
 //     product runs as 3 v_mfma_f32_32x32x16_bf16 (hi.hi + lo.hi + hi.lo; the dropped lo.lo term is 2^-16 relative):
 //     logits to ~1e-6 absolute on unit-norm features, 5.3x fewer matrix-pipe cycles than the fp32 MFMA;
-//   * a workgroup = 4 waves = 128 feature rows (32 per wave, held as MFMA B-fragments in registers for the whole
-//     kernel); it walks its share of 32-row bank chunks; per chunk and wave: S^T[32 g, 32 f] = G F^T (swapped operands:
-//     a lane owns ONE feature row, so running max / sum are lane-local), online soft-max with deferred rescaling,
-//     O^T[D, 32 f] += G^T P^T.  P^T goes from the S accumulators straight into the B-operand registers of the second
+//   * a workgroup = 8 waves = 128 feature rows (16 per wave, held as MFMA B-fragments in registers for the whole
+//     kernel; two waves per SIMD so that one wave's LDS / VALU / exp work hides behind the other's MFMAs); it walks its
+//     share of 32-row bank chunks; per chunk and wave: S^T[32 g, 16 f] = G F^T (swapped operands: a lane owns ONE
+//     feature row, so running max / sum need two lane exchanges), online soft-max with deferred rescaling,
+//     O^T[D, 16 f] += G^T P^T on v_mfma_f32_16x16x32_bf16.  P^T goes from the S accumulators straight into the B-operand registers of the second
 //     MFMA (the contraction index is permuted consistently on both operands: no cross-lane traffic);
 //   * the chunk is staged through registers (fp32 -> bf16 hi/lo) into TWO LDS images: [g][d] for the logits and a
 //     transposed [d][g] one (in the permuted g order) for G^T, both XOR-swizzled so that every ds_read_b128 /
 //     ds_write_b64 lane group is bank-conflict free (checked exhaustively offline); double-buffered, one barrier per chunk,
 //     the next chunk's global loads in flight during the MFMA block;
-//   * partial (max, sum, O) of the S splits are merged by a combine kernel that also emits the gradient, and ONE epilogue
-//     kernel does the exact-fp32 positive dot, the intra / MOON term (A4), the means and the loss combination.
+//   * ONE finish kernel merges the (max, sum, O) partials of the S splits into lse + the unit gradient, does the exact-fp32
+//     positive dot and the intra / MOON term (A4) per row, and -- last block to finish -- the means and the loss combination.
 // HBM traffic: G once (M D 4 bytes) + the split partials; no [B, M] tensor exists.
 //
-// Workspace layout (floats): part_m[RG][S][128] part_l[RG][S][128] part_o[RG][S][DP][128] rowbuf[2][Bp]; `sync` is a
+// Workspace layout (floats): part_m[RG][S][128] part_l[RG][S][128] rowbuf[2][Bp] part_o[RG][128][S][DP]; `sync` is a
 // caller-owned int that must be 0 before the first call and is left 0 (last-block election of the epilogue kernel).
 #include "common.h"
 
@@ -46,7 +47,7 @@ static AttnPlan attn_plan(int B, int M, int D) {
     p.RG = cfl_cdiv(B, BR);
     p.Bp = p.RG * BR;
     const int nch = cfl_cdiv(M, GC);
-    int s = cfl_cdiv(256, p.RG);          // one workgroup per CU (the kernel owns the whole register file)
+    int s = cfl_cdiv(256, p.RG);          // one workgroup per CU (128 KB of LDS each); the finish kernel assumes S <= 256
     if (s > nch) s = nch;
     if (s < 1) s = 1;
     p.S = s;
@@ -71,12 +72,15 @@ template <int DP>
 __device__ __forceinline__ int row_off(int plane, int g, int slot) {
     return plane * (GC * DP * 2) + g * (DP * 2) + ((slot ^ swz_row<DP>(g)) << 4);
 }
-// transposed image: [d >> 2][(d & 3) ^ cx][slot 0..7][8 bf16]; slot = 4 * plane + 2 * t + h holds, for MFMA t and lane half h,
-// the 8 bank rows g = 16 t + 4 h + (j & 3) + 8 (j >> 2), j = 0..7 -- the rows whose probabilities that lane half already owns
+// transposed image: 128 bytes per column d = 8 slots of 16 bytes, slot = 4 * plane + kg; slot kg holds the 8 bank rows
+//   g = 16 u + 4 kg + r  at position j = 4 u + r  (u = 0, 1; r = 0..3)
+// i.e. exactly the rows whose probabilities lane group kg of the 16x16x32 MFMA already owns in its two S^T accumulators.
+// Placement [d >> 2][(d & 3) ^ cx][slot ^ sig]: conflict-free for the ds_read_b128 fragment reads AND the ds_write_b64
+// staging writes (searched / checked exhaustively offline).
 __device__ __forceinline__ int t_off(int d, int slot) {
     const int dq = d >> 2, c = d & 3;
-    const int cx = (dq >> 2) & 1;
-    const int sig = ((dq & 7) ^ (((c >> 1) | (((dq >> 3) & 1) << 1)) << 1)) & 7;
+    const int cx = (dq >> 3) & 1;
+    const int sig = ((dq & 7) ^ (((c >> 1) | ((dq & 1) << 1)) << 1)) & 7;
     return dq * 512 + ((c ^ cx) << 7) + ((slot ^ sig) << 4);
 }
 
@@ -89,76 +93,90 @@ struct Smem {
     static constexpr int TOTAL = 2 * BUF;
 };
 
-// global -> registers: thread (q, rsub) fetches the 8 (g) x 4 (d) block of chunk rows 8 rsub .. + 7, columns 4 q .. + 3
+// global -> registers: thread (q, rs) fetches the 4 (g) x 4 (d) block of chunk rows 4 rs .. + 3, columns 4 q .. + 3
+// (one wave instruction = one full bank row when D = 256: perfectly coalesced)
 template <int DP>
-__device__ __forceinline__ void chunk_load(const float* __restrict__ G, int M, int D, int g0, f32x4 (&r)[8]) {
+__device__ __forceinline__ void chunk_load(const float* __restrict__ G, int M, int D, int g0, f32x4 (&r)[4]) {
     constexpr int QPR = DP / 4;
-    const int q = threadIdx.x % QPR, rsub = threadIdx.x / QPR;
-    if (rsub >= 4) return;
+    const int q = threadIdx.x % QPR, rs = threadIdx.x / QPR;
+    if (rs >= 8) return;
     int d0 = 4 * q;
     d0 = d0 < D ? d0 : D - 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int g = g0 + 8 * rsub + i;
+    for (int i = 0; i < 4; ++i) {
+        int g = g0 + 4 * rs + i;
         g = g < M ? g : M - 1;
         r[i] = *reinterpret_cast<const f32x4*>(G + (long long)g * D + d0);
     }
 }
 
 template <int DP, bool GRAD>
-__device__ __forceinline__ void chunk_store(char* buf, int M, int D, int g0, const f32x4 (&r)[8]) {
+__device__ __forceinline__ void chunk_store(char* buf, int M, int D, int g0, const f32x4 (&r)[4]) {
     constexpr int QPR = DP / 4;
-    const int q = threadIdx.x % QPR, rsub = threadIdx.x / QPR;
-    if (rsub >= 4) return;
+    const int q = threadIdx.x % QPR, rs = threadIdx.x / QPR;
+    if (rs >= 8) return;
     const bool colok = 4 * q < D;
-    bf16x4 hi[8], lo[8];
+    bf16x4 hi[4], lo[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) split4(r[i], colok && (g0 + 8 * rsub + i < M), hi[i], lo[i]);
+    for (int i = 0; i < 4; ++i) split4(r[i], colok && (g0 + 4 * rs + i < M), hi[i], lo[i]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int gl = 8 * rsub + i;
+    for (int i = 0; i < 4; ++i) {
+        const int gl = 4 * rs + i;
         *reinterpret_cast<bf16x4*>(buf + row_off<DP>(0, gl, q >> 1) + (q & 1) * 8) = hi[i];
         *reinterpret_cast<bf16x4*>(buf + row_off<DP>(1, gl, q >> 1) + (q & 1) * 8) = lo[i];
     }
     if (GRAD) {
+        // rows 4 rs .. + 3 = (u = rs >> 2, kg = rs & 3, r = 0..3): one 8-byte piece of slot kg at byte 8 u, per column and plane
         char* tb = buf + 2 * GC * DP * 2;
-        const int t = rsub >> 1, piece = 8 * (rsub & 1);
+        const int kg = rs & 3, piece = 8 * (rs >> 2);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int d = 4 * q + c;
+            bf16x4 vh, vl;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bf16x4 vh, vl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vh[e] = hi[4 * h + e][c]; vl[e] = lo[4 * h + e][c]; }
-                *reinterpret_cast<bf16x4*>(tb + t_off(d, 2 * t + h) + piece) = vh;
-                *reinterpret_cast<bf16x4*>(tb + t_off(d, 4 + 2 * t + h) + piece) = vl;
-            }
+            for (int e = 0; e < 4; ++e) { vh[e] = hi[e][c]; vl[e] = lo[e][c]; }
+            *reinterpret_cast<bf16x4*>(tb + t_off(d, kg) + piece) = vh;
+            *reinterpret_cast<bf16x4*>(tb + t_off(d, 4 + kg) + piece) = vl;
         }
     }
 }
 
-// grid (S, RG).  F [B, D], G [M, D] fp32 row-major, D % 4 == 0, D <= DP.
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// 16-byte write-through store (sc1): the split partials are consumed by the NEXT kernel, possibly on another XCD; written
+// through they leave the L2 as they are produced instead of as a dirty-line flush at the kernel boundary (cdna guide:
+// "publish-large", 8.2 -> 3.0 us per 64 KB per workgroup).
+__device__ __forceinline__ void store_wt_x4(float* p, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// grid (S, RG), 512 threads = 8 waves of 16 feature rows, two waves per SIMD (256 registers each) so that one wave's LDS /
+// VALU / exp work hides behind the other's MFMAs.  F [B, D], G [M, D] fp32 row-major, D % 4 == 0, D <= DP.
+// v_mfma_f32_16x16x32_bf16: A lane (i = l & 15, kg = l >> 4) holds k = 8 kg + j; B likewise with n = l & 15;
+// C / D: 4 registers, column n = l & 15, row 4 (l >> 4) + r.
 template <int DT, bool GRAD>
-__global__ __launch_bounds__(256, 1) void cfl_bank_attn_kernel(const float* __restrict__ F, const float* __restrict__ G, int B, int M,
+__global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __restrict__ F, const float* __restrict__ G, int B, int M,
                                                             int D, float sc2, float* __restrict__ part_m,
                                                             float* __restrict__ part_l, float* __restrict__ part_o) {
-    constexpr int DP = 32 * DT, KS = DP / 16;
+    constexpr int DP = 32 * DT, KS = DP / 32, NDT = DP / 16;
     using SM = Smem<DT, GRAD>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int S = gridDim.x, x = blockIdx.x, rg = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, kg = lane >> 4;
     const int nch = (M + GC - 1) / GC;
     const int ntiles = x < nch ? (nch - x + S - 1) / S : 0;
 
-    // this wave's 32 feature rows as B-operand fragments: lane (f, h) holds k = 16 kk + 8 h + j
+    f32x4 stage[4];
+    if (ntiles > 0) chunk_load<DP>(G, M, D, x * GC, stage);        // in flight while the feature fragments are fetched
+
+    // this wave's 16 feature rows as B-operand fragments: lane (f, kg) holds k = 32 ks + 8 kg + j
     bf16x8 fh[KS], fl[KS];
     {
-        const int fr = rg * BR + 32 * w + fi;
+        const int fr = rg * BR + 16 * w + fi;
         const float* fp = F + (long long)(fr < B ? fr : B - 1) * D;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const int k0 = 16 * kk + 8 * h;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 32 * ks + 8 * kg;
             const bool ok0 = fr < B && k0 < D, ok1 = fr < B && k0 + 4 < D;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
@@ -166,22 +184,16 @@ __global__ __launch_bounds__(256, 1) void cfl_bank_attn_kernel(const float* __re
             split4(v0, ok0, h0, l0);
             split4(v1, ok1, h1, l1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { fh[kk][e] = h0[e]; fh[kk][4 + e] = h1[e]; fl[kk][e] = l0[e]; fl[kk][4 + e] = l1[e]; }
+            for (int e = 0; e < 4; ++e) { fh[ks][e] = h0[e]; fh[ks][4 + e] = h1[e]; fl[ks][e] = l0[e]; fl[ks][4 + e] = l1[e]; }
         }
     }
 
-    f32x16 O[GRAD ? DT : 1];
+    f32x4 O[GRAD ? NDT : 1];
 #pragma unroll
-    for (int i = 0; i < (GRAD ? DT : 1); ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) O[i][r] = 0.f;
+    for (int i = 0; i < (GRAD ? NDT : 1); ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float run_m = -INFINITY, run_l = 0.f;
 
-    f32x4 stage[8];
-    if (ntiles > 0) {
-        chunk_load<DP>(G, M, D, x * GC, stage);
-        chunk_store<DP, GRAD>(lds, M, D, x * GC, stage);
-    }
+    if (ntiles > 0) chunk_store<DP, GRAD>(lds, M, D, x * GC, stage);
     __syncthreads();
     int buf = 0;
     for (int i = 0; i < ntiles; ++i) {
@@ -190,222 +202,240 @@ __global__ __launch_bounds__(256, 1) void cfl_bank_attn_kernel(const float* __re
         const int g0n = (x + (i + 1) * S) * GC;
         if (more) chunk_load<DP>(G, M, D, g0n, stage);
         const char* rb = lds + buf * SM::BUF;
-        // ---- logits S^T[g, f] = sum_k G[g, k] F[f, k]: hi.hi on one accumulator, the two cross terms on another
-        f32x16 sa, sb;
+        // ---- logits S^T[g, f] = sum_k G[g, k] F[f, k], two 16-row tiles u; hi.hi on one accumulator, cross terms on another
+        // three independent accumulator chains per tile (hi.hi, lo.hi, hi.lo): no MFMA waits for the one before it
+        f32x4 sa[2], sb[2], sc[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+        for (int u = 0; u < 2; ++u) { sa[u] = f32x4{0.f, 0.f, 0.f, 0.f}; sb[u] = sa[u]; sc[u] = sa[u]; }
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(rb + row_off<DP>(0, fi, 2 * kk + h));
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(rb + row_off<DP>(1, fi, 2 * kk + h));
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, fh[kk], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, fh[kk], sb, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, fl[kk], sb, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ah[u] = *reinterpret_cast<const bf16x8*>(rb + row_off<DP>(0, 16 * u + fi, 4 * ks + kg));
+                al[u] = *reinterpret_cast<const bf16x8*>(rb + row_off<DP>(1, 16 * u + fi, 4 * ks + kg));
+            }
+            sa[0] = MFMA16(ah[0], fh[ks], sa[0]);
+            sa[1] = MFMA16(ah[1], fh[ks], sa[1]);
+            sb[0] = MFMA16(al[0], fh[ks], sb[0]);
+            sb[1] = MFMA16(al[1], fh[ks], sb[1]);
+            sc[0] = MFMA16(ah[0], fl[ks], sc[0]);
+            sc[1] = MFMA16(ah[1], fl[ks], sc[1]);
         }
-        // ---- online log-sum-exp in the base-2 domain; element r of this lane is bank row g0 + (r&3) + 8 (r>>2) + 4 h
-        // (everything in place in `sa`: the kernel lives at the edge of the register file)
+        // ---- online log-sum-exp in the base-2 domain; element (u, r) of this lane is bank row g0 + 16 u + 4 kg + r
         const bool full = g0 + GC <= M;
         float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sa[r] = (sa[r] + sb[r]) * sc2;
-            if (!full && g0 + (r & 3) + 8 * (r >> 2) + 4 * h >= M) sa[r] = -INFINITY;
-            mx = fmaxf(mx, sa[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));               // the other half-wave holds the other 16 bank rows of f
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = (sa[u][r] + (sb[u][r] + sc[u][r])) * sc2;
+                if (!full && g0 + 16 * u + 4 * kg + r >= M) y = -INFINITY;
+                sa[u][r] = y;
+                mx = fmaxf(mx, y);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));              // the 4 lanes l, l^16, l^32, l^48 share feature row f
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // Deferred rescaling: keep the old reference while no probability would exceed 2^THR.  The decision is taken
-        // per wave (uniform branch); both half-waves of a feature row always agree on its reference.
+        // per wave (uniform branch); the four lanes of a feature row always agree on its reference.
         if (__any(mx > run_m + RESCALE_THR)) {
             const float mn = fmaxf(run_m, mx);
             const float alpha = __builtin_amdgcn_exp2f(run_m - mn);        // 0 for the first chunk (run_m = -inf)
             run_l *= alpha;
             if (GRAD) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+                for (int dt = 0; dt < NDT; ++dt) O[dt] *= alpha;
             }
             run_m = mn;
         }
         float ls = 0.f;
+        bf16x8 ph, pl;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sa[r] = __builtin_amdgcn_exp2f(sa[r] - run_m); ls += sa[r]; }
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sa[u][r] - run_m);
+                ls += pv;
+                const __bf16 hh = (__bf16)pv;
+                ph[4 * u + r] = hh;
+                pl[4 * u + r] = (__bf16)(pv - (float)hh);
+            }
         run_l += ls;
         if (GRAD) {
-            // ---- O^T[d, f] += sum_g G[g, d] P[f, g]: B operand of MFMA t = accumulator elements 8 t .. 8 t + 7 as they lie
-            bf16x8 ph[2], pl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const __bf16 hh = (__bf16)sa[8 * t + j];
-                    ph[t][j] = hh;
-                    pl[t][j] = (__bf16)(sa[8 * t + j] - (float)hh);
-                }
+            // ---- O^T[d, f] += sum_g G[g, d] P[f, g]: the B operand is the probabilities as they lie (k slot j = 4 u + r)
             const char* tb = rb + SM::ROW_BYTES;
+            // groups of 4 column tiles, term-major: consecutive MFMAs hit different accumulators
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int d4 = 0; d4 < NDT; d4 += 4) {
+                bf16x8 gh[4], gl[4];
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const int d = 32 * dt + fi;
-                    const bf16x8 gh = *reinterpret_cast<const bf16x8*>(tb + t_off(d, 2 * t + h));
-                    const bf16x8 gl = *reinterpret_cast<const bf16x8*>(tb + t_off(d, 4 + 2 * t + h));
-                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ph[t], O[dt], 0, 0, 0);
-                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ph[t], O[dt], 0, 0, 0);
-                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, pl[t], O[dt], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    const int d = 16 * (d4 + e) + fi;
+                    gh[e] = *reinterpret_cast<const bf16x8*>(tb + t_off(d, kg));
+                    gl[e] = *reinterpret_cast<const bf16x8*>(tb + t_off(d, 4 + kg));
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) O[d4 + e] = MFMA16(gh[e], ph, O[d4 + e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) O[d4 + e] = MFMA16(gl[e], ph, O[d4 + e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) O[d4 + e] = MFMA16(gh[e], pl, O[d4 + e]);
+            }
         }
         if (more) chunk_store<DP, GRAD>(lds + (buf ^ 1) * SM::BUF, M, D, g0n, stage);
         __syncthreads();
         buf ^= 1;
     }
-    // ---- split partials: (max, sum) per feature row and O^T as [d][128 rows] (128-byte contiguous runs per store)
+    // ---- split partials: (max, sum) per feature row and O as [128 rows][DP] (16-byte stores, 64 contiguous bytes per row)
+    run_l += __shfl_xor(run_l, 16, 64);
     run_l += __shfl_xor(run_l, 32, 64);
     const size_t slab = (size_t)rg * S + x;
-    if (h == 0) {
-        part_m[slab * BR + 32 * w + fi] = run_m;
-        part_l[slab * BR + 32 * w + fi] = run_l;
+    if (kg == 0) {
+        part_m[slab * BR + 16 * w + fi] = run_m;
+        part_l[slab * BR + 16 * w + fi] = run_l;
     }
     if (GRAD) {
-        float* po = part_o + slab * DP * BR + 32 * w + fi;
+        float* po = part_o + (((size_t)rg * BR + 16 * w + fi) * S + x) * DP + 4 * kg;      // [row][split][DP]: see finish kernel
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                po[(size_t)d * BR] = O[dt][r];
-            }
+        for (int dt = 0; dt < NDT; ++dt) store_wt_x4(po + 16 * dt, O[dt]);
     }
 }
 
-// Merge the S split partials of one row group: block = one output column d (blockIdx.x) x 128 rows; 32 float4 lanes x 8
-// split groups, fixed summation order => deterministic.  Emits lse (block d == 0) and the UNIT gradient of the inter term
-//   dF[f][d] = (inv_tau / Bdiv) (O[f][d] / L[f] - G[idx[f]][d]).
-__global__ __launch_bounds__(256) void cfl_bank_attn_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
-                                                                 const float* __restrict__ part_o, int S, int DP,
-                                                                 const float* __restrict__ G, const long long* __restrict__ idx,
-                                                                 int B, int M, int D, float coef, float* __restrict__ lse2,
-                                                                 float* __restrict__ dF) {
-    __shared__ f32x4 red[8][32];
-    __shared__ f32x4 red2[8][32];
-    const int d = blockIdx.x, rg = blockIdx.y;
-    const int f4 = (threadIdx.x & 31) * 4, xg = threadIdx.x >> 5;
-    const float* pm = part_m + (size_t)rg * S * BR + f4;
-    const float* pl = part_l + (size_t)rg * S * BR + f4;
-    f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int x = xg; x < S; x += 8) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(pm + (size_t)x * BR);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], m[e]);
-    }
-    red[xg][threadIdx.x & 31] = mx;
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const f32x4 o = red[g][threadIdx.x & 31];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], o[e]);
-    }
-    __syncthreads();
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, L = {0.f, 0.f, 0.f, 0.f};
-    const bool want_o = (dF != nullptr) && d < D;
-    const float* po = part_o + ((size_t)rg * S * DP + d) * BR + f4;
-#pragma unroll 4
-    for (int x = xg; x < S; x += 8) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(pm + (size_t)x * BR);
-        const f32x4 l = *reinterpret_cast<const f32x4*>(pl + (size_t)x * BR);
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (want_o) o = *reinterpret_cast<const f32x4*>(po + (size_t)x * DP * BR);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float wgt = __builtin_amdgcn_exp2f(m[e] - mx[e]);
-            L[e] = fmaf(wgt, l[e], L[e]);
-            acc[e] = fmaf(wgt, o[e], acc[e]);
-        }
-    }
-    red[xg][threadIdx.x & 31] = acc;
-    red2[xg][threadIdx.x & 31] = L;
-    __syncthreads();
-    if (xg == 0) {
-        acc = red[0][threadIdx.x]; L = red2[0][threadIdx.x];
-#pragma unroll
-        for (int g = 1; g < 8; ++g) { acc += red[g][threadIdx.x]; L += red2[g][threadIdx.x]; }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int f = rg * BR + f4 + e;
-            if (f >= B) continue;
-            if (d == 0) lse2[f] = (mx[e] + log2f(L[e])) * 0.6931471805599453f;
-            if (want_o) {
-                const long long tgt = idx[f];
-                const float gpos = (tgt >= 0 && tgt < M) ? G[tgt * D + d] : 0.f;
-                dF[(long long)f * D + d] = coef * (acc[e] / L[e] - gpos);
-            }
-        }
-    }
-}
-
-// Epilogue, one wave per feature row: exact-fp32 positive dot of the inter term, the intra / MOON term (A4) with its unit
-// gradient, per-row losses; the LAST block to finish (agent-scope release / acquire, cdna guide G16) reduces the rows in
-// fixed order and writes out[0..4] = {loss, loss_inter, loss_moon, coef_inter, coef_moon}: the combined loss of
-// ClientTrainer.py:416-419 and the factors the backward applies to the two unit gradients.
-//   mode bit 0: inter term present, bit 1: intra term present, bit 2: --loss_scale
-__global__ __launch_bounds__(256) void cfl_contrast_epilogue_kernel(const float* __restrict__ F, const float* __restrict__ Go,
-                                                                 const float* __restrict__ Gs, const float* __restrict__ Fo,
-                                                                 const long long* __restrict__ idx, int B, int M, int D, int Bdiv,
-                                                                 float inv_tau, float weight, int mode, const float* __restrict__ lse,
-                                                                 float* __restrict__ pos_out, float* __restrict__ rowbuf, int Bp,
-                                                                 float* __restrict__ dF_moon, float* __restrict__ out5,
-                                                                 int* __restrict__ sync) {
-    __shared__ float red[4];
+// Finish kernel = split merge + per-row terms + losses, ONE launch.  Block = (feature row f, quarter of the columns):
+//   * mode bit 0: merge the S split partials of row f (16 float4 lanes x 16 split groups, every load of a thread in flight at
+//     once; measured at B = 128, S = 256: 128 blocks x 1 KB granules 35.7 us, 512 x 256 B 18.3 us, 1024 x 128 B 26.6 us;
+//     fixed summation order => deterministic) -> lse[f] and the UNIT gradient of the inter term
+//       dF_inter[f][d] = (inv_tau / B) (O[f][d] / L[f] - G_other[idx[f]][d]);
+//   * the quarter-0 block of a row also does the row's exact-fp32 dots: the positive of the inter term (wave 0) and the intra /
+//     MOON term (A4) with its unit gradient (wave 1), and stores the row's loss terms;
+//   * the LAST block to finish (write-through stores + agent-scope ticket, cdna guide G16) reduces the rows in fixed order and writes
+//     out5 = {loss, loss_inter, loss_moon, coef_inter, coef_moon}: the combined loss of ClientTrainer.py:416-419 and the
+//     factors the backward applies to the two unit gradients.   mode bit 1: intra term present, bit 2: --loss_scale
+__global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                               const float* __restrict__ part_o, int S, int DP,
+                                                               const float* __restrict__ F, const float* __restrict__ Go,
+                                                               const float* __restrict__ Gs, const float* __restrict__ Fo,
+                                                               const long long* __restrict__ idx, int B, int M, int D, int Bdiv,
+                                                               float inv_tau, float weight, int mode, float* __restrict__ lse2,
+                                                               float* __restrict__ pos_out, float* __restrict__ rowbuf, int Bp,
+                                                               float* __restrict__ dF, float* __restrict__ dF_moon,
+                                                               float* __restrict__ out5, int* __restrict__ sync) {
+    __shared__ float redm[4];
+    __shared__ f32x4 red[16][16];
+    __shared__ float redl[16];
+    __shared__ float row_lse, row_pos;
     __shared__ int is_last;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b < B) {
-        const float* f = F + (long long)b * D;
-        const long long tgt = idx[b];
+    const int fl = blockIdx.x >> 2, quarter = blockIdx.x & 3, rg = blockIdx.y;
+    const int f = rg * BR + fl;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool live = f < B;
+    if (live && (mode & 1)) {
+        const float* pm = part_m + (size_t)rg * S * BR + fl;
+        const float* pl = part_l + (size_t)rg * S * BR + fl;
+        // 16 float4 lanes (one quarter of the columns) x 16 split groups.  ONE memory round trip: a thread first issues every
+        // load it will ever need (<= 16 splits: max, sum and its 16 bytes of O), then the block agrees on the reference.  The
+        // partials of one feature row are contiguous ([row][split][DP]): the four blocks of a row sweep one region.
+        const int c4 = (t & 15) * 4, xg = t >> 4;
+        const int d4 = quarter * (DP / 4) + c4;
+        const bool want_o = dF != nullptr && c4 < DP / 4;
+        const float* po = part_o + (((size_t)rg * BR + fl) * S) * DP + d4;
+        float pmv[16], plv[16];
+        f32x4 ov[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int x = xg + 16 * j;
+            const int xc = x < S ? x : S - 1;                      // unconditional loads (clamped), masked below
+            pmv[j] = pm[(size_t)xc * BR];
+            plv[j] = pl[(size_t)xc * BR];
+            ov[j] = want_o ? *reinterpret_cast<const f32x4*>(po + (size_t)xc * DP) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { if (xg + 16 * j >= S) pmv[j] = -INFINITY; mx = fmaxf(mx, pmv[j]); }
+        mx = wave_max(mx);
+        if (lane == 0) redm[wv] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float L = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float wgt = __builtin_amdgcn_exp2f(pmv[j] - mx);          // 0 for the masked splits (pmv = -inf)
+            L = fmaf(wgt, plv[j], L);
+            acc += ov[j] * wgt;
+        }
+        red[xg][t & 15] = acc;
+        if ((t & 15) == 0) redl[xg] = L;
+        __syncthreads();
+        if (xg == 0) {
+            L = redl[0];
+            acc = red[0][t];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) { acc += red[g][t]; L += redl[g]; }
+            if (quarter == 0 && t == 0) { row_lse = (mx + log2f(L)) * 0.6931471805599453f; lse2[f] = row_lse; }
+            if (want_o && d4 < D) {
+                const long long tgt = idx[f];
+                f32x4 gpos = {0.f, 0.f, 0.f, 0.f};
+                if (tgt >= 0 && tgt < M) gpos = *reinterpret_cast<const f32x4*>(Go + tgt * D + d4);
+                const float inv = 1.f / L;
+                *reinterpret_cast<f32x4*>(dF + (long long)f * D + d4) = (acc * inv - gpos) * (inv_tau / (float)B);
+            }
+        }
+    }
+    if (live && quarter == 0) {
+        const float* fr = F + (long long)f * D;
+        const long long tgt = idx[f];
         const bool ok = tgt >= 0 && tgt < M;
-        if (mode & 1) {
+        if ((mode & 1) && wv == 0) {
             float dot = 0.f;
             if (ok) {
                 const float* g = Go + tgt * D;
-                for (int k = lane; k < D; k += 64) dot = fmaf(f[k], g[k], dot);
+                for (int k = lane; k < D; k += 64) dot = fmaf(fr[k], g[k], dot);
             }
             dot = wave_sum(dot) * inv_tau;
-            if (lane == 0) { if (pos_out) pos_out[b] = dot; rowbuf[b] = lse[b] - dot; }
+            if (lane == 0) { row_pos = dot; if (pos_out) pos_out[f] = dot; }
         }
-        if (mode & 2) {
+        if ((mode & 2) && wv == 1) {
             const float* g = Gs + (ok ? tgt : 0) * D;
-            const float* o = Fo + (long long)b * D;
+            const float* o = Fo + (long long)f * D;
             float pos = 0.f, neg = 0.f;
-            for (int k = lane; k < D; k += 64) { pos = fmaf(f[k], ok ? g[k] : 0.f, pos); neg = fmaf(f[k], o[k], neg); }
+            for (int k = lane; k < D; k += 64) { pos = fmaf(fr[k], ok ? g[k] : 0.f, pos); neg = fmaf(fr[k], o[k], neg); }
             pos = wave_sum(pos); neg = wave_sum(neg);
             const float z = (neg - pos) * inv_tau;
-            if (lane == 0) rowbuf[Bp + b] = softplusf(z);
+            if (lane == 0) {
+                __hip_atomic_store(rowbuf + Bp + f, softplusf(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (dF_moon) {
                 const float c = sigmoidf(z) * inv_tau / (float)Bdiv;
-                for (int k = lane; k < D; k += 64) dF_moon[(long long)b * D + k] = c * (o[k] - (ok ? g[k] : 0.f));
+                for (int k = lane; k < D; k += 64) dF_moon[(long long)f * D + k] = c * (o[k] - (ok ? g[k] : 0.f));
             }
         }
+        __syncthreads();
+        if ((mode & 1) && t == 0) {
+            __hip_atomic_store(rowbuf + f, row_lse - row_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-    // ---- last-block election
+    // ---- last-block election.  The only data handed to the last block are the per-row loss terms, published above with
+    // write-through (sc1) atomic stores that were drained (vmcnt(0)) before this barrier and read back below with sc1
+    // atomic loads: the "sc1 stores and loads on both sides" form of the cdna guide (G16) -- no L2 write-back / invalidate
+    // fences, which cost ~7 us here with the freshly written gradient dirty in every L2.
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int t = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == (int)gridDim.x - 1);
-        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (t == 0) {
+        const int tk = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (tk == (int)(gridDim.x * gridDim.y) - 1);
     }
     __syncthreads();
     if (!is_last) return;
     float si = 0.f, sm = 0.f;
-    for (int r = threadIdx.x; r < B; r += 256) {
+    for (int r = t; r < B; r += 256) {
         if (mode & 1) si += __hip_atomic_load(rowbuf + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (mode & 2) sm += __hip_atomic_load(rowbuf + Bp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    si = block_sum_256(si, red);
-    sm = block_sum_256(sm, red);
-    if (threadIdx.x == 0) {
+    si = block_sum_256(si, redm);
+    sm = block_sum_256(sm, redm);
+    if (t == 0) {
         const float li = si / (float)B, lm = sm / (float)Bdiv;
         float loss, ci = 0.f, cm = 0.f;
         if ((mode & 3) == 3) {
@@ -450,7 +480,7 @@ static int launch_attn(const float* F, const float* G, int B, int M, int D, floa
                        hipStream_t stream) {
     using SM = Smem<DT, GRAD>;
     CFL_SET_LDS((cfl_bank_attn_kernel<DT, GRAD>), SM::TOTAL);
-    CFL_LAUNCH(K_BANK_FWD, (cfl_bank_attn_kernel<DT, GRAD>), dim3(p.S, p.RG), dim3(256), SM::TOTAL, stream, F, G, B, M, D, sc2,
+    CFL_LAUNCH(K_BANK_FWD, (cfl_bank_attn_kernel<DT, GRAD>), dim3(p.S, p.RG), dim3(512), SM::TOTAL, stream, F, G, B, M, D, sc2,
                w.part_m, w.part_l, w.part_o);
     return 0;
 }
@@ -497,13 +527,11 @@ int cfl_client_contrast_fwd(const float* F, const float* G_other, const float* G
                            : launch_attn<8, false>(F, G_other, B, M, D, sc2, p, w, stream);
         }
         if (rc) return rc;
-        CFL_LAUNCH(K_BANK_BWD_REDUCE, cfl_bank_attn_combine_kernel, dim3(want_grad ? p.DP : 1, p.RG), dim3(256), 0, stream,
-                   w.part_m, w.part_l, w.part_o, p.S, p.DP, G_other, idx, B, M, D, inv_tau / (float)B, lse,
-                   want_grad ? dF_inter : (float*)nullptr);
     }
-    CFL_LAUNCH(K_LSE_FINAL, cfl_contrast_epilogue_kernel, dim3(cfl_cdiv(B, 4)), dim3(256), 0, stream, F, G_other, G_same, F_old, idx,
-               B, M, D, (mode & 2) ? B_div : B, inv_tau, weight, mode, lse, pos, w.rowbuf, p.Bp,
-               want_grad ? dF_moon : (float*)nullptr, out5, sync);
+    CFL_LAUNCH(K_LSE_FINAL, cfl_contrast_finish_kernel, dim3(4 * BR, p.RG), dim3(256), 0, stream, w.part_m, w.part_l, w.part_o, p.S, p.DP,
+               F, G_other, G_same, F_old, idx, B, M, D, (mode & 2) ? B_div : B, inv_tau, weight, mode, lse, pos, w.rowbuf, p.Bp,
+               (want_grad && (mode & 1)) ? dF_inter : (float*)nullptr, (want_grad && (mode & 2)) ? dF_moon : (float*)nullptr, out5,
+               sync);
     return 0;
 }
 
