@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
             }
         } else if (mode & 1) { loss = li; ci = 1.f; }
         else { loss = lm; cm = 1.f; }
-        out5[0] = loss; out5[1] = li; out5[2] = lm; out5[3] = ci; out5[4] = cm;
+        out5[0] = loss; out5[1] = li; out5[2] = lm; out5[3] = ci; out5[4] = cm; out5[5] = loss;
         __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

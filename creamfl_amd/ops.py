@@ -119,9 +119,10 @@ _CONTRAST_STATE = {}
 def _contrast_state(device, ws_bytes):
     st = _CONTRAST_STATE.get(device)
     if st is None:
-        st = _CONTRAST_STATE[device] = {'sync': torch.zeros(1, dtype=torch.int32, device=device), 'ws': None}
-    if st['ws'] is None or st['ws'].numel() < ws_bytes:
+        st = _CONTRAST_STATE[device] = {'sync': torch.zeros(1, dtype=torch.int32, device=device), 'ws': None, 'n': 0}
+    if st['n'] < ws_bytes:
         st['ws'] = torch.empty(max(int(ws_bytes), 256), dtype=torch.uint8, device=device)
+        st['n'] = st['ws'].numel()
     return st
 
 
@@ -129,14 +130,28 @@ import os as _os
 _BANK_EXACT = bool(_os.environ.get('CFL_BANK_EXACT'))       # A/B switch: round-1 exact-fp32 two-pass kernels
 
 
+_BANK_PLAN = {}          # (B, M, D, need_grad) -> workspace bytes, or None when the fused path does not take the shape
+
+
+def _bank_plan(B, M, D, need):
+    key = (B, M, D, need)
+    v = _BANK_PLAN.get(key, -1)
+    if v == -1:
+        lib = _lib.load()
+        v = int(lib.cfl_bank_attn_ws_bytes(B, M, D, int(need))) if lib.cfl_bank_attn_supported(B, M, D) else None
+        _BANK_PLAN[key] = v
+    return v
+
+
 def bank_attn_supported(B, M, D):
     """True when the single-pass 3 x bf16-split kernels (csrc/bank_attn.hip) take this shape (D <= 256, D % 4 == 0)."""
-    return (not _BANK_EXACT) and bool(_lib.load().cfl_bank_attn_supported(int(B), int(M), int(D)))
+    return (not _BANK_EXACT) and _bank_plan(int(B), int(M), int(D), False) is not None
 
 
 class _ClientContrastFn(torch.autograd.Function):
-    """Fused A3 (+ A4): one pass over the bank gives the log-sum-exp and the unit gradient; one epilogue launch gives the
-    positive dots, the intra term, the means and the combined loss (csrc/bank_attn.hip)."""
+    """Fused A3 (+ A4): one pass over the bank gives the log-sum-exp and the unit gradient; one finish launch gives the
+    positive dots, the intra term, the means and the combined loss (csrc/bank_attn.hip).  Host work per call: three
+    allocations and one ctypes call (the workspace, its size and the election counter are cached per device / shape)."""
 
     @staticmethod
     def forward(ctx, F, G_other, G_same, idx, F_old, inv_tau, weight, mode, b_div):
@@ -145,43 +160,47 @@ class _ClientContrastFn(torch.autograd.Function):
         M = (G_other if (mode & 1) else G_same).shape[0]
         dev = F.device
         need = ctx.needs_input_grad[0]
-        out5 = torch.empty(5, dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)          # out5 = out[0:5]; the differentiable loss = out[5]
         aux = torch.empty(2, B, dtype=torch.float32, device=dev) if (mode & 1) else None        # lse, pos
         dFs = torch.empty(2, B, D, dtype=torch.float32, device=dev) if need else None            # inter, moon unit gradients
-        st = _contrast_state(dev, lib.cfl_bank_attn_ws_bytes(B, M, D, int(need)))
+        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need)))
+        p_out = out.data_ptr()
+        p_aux = aux.data_ptr() if aux is not None else 0
+        p_dfs = dFs.data_ptr() if need else 0
         _lib.check(lib.cfl_client_contrast_fwd(
-            _ptr(F), _ptr(G_other), _ptr(G_same), _ptr(idx), _ptr(F_old), B, M, D, b_div, inv_tau, weight, mode, int(need),
-            _ptr(out5), _ptr(aux[0]) if aux is not None else _ptr(None), _ptr(aux[1]) if aux is not None else _ptr(None),
-            _ptr(dFs[0]) if (need and (mode & 1)) else _ptr(None), _ptr(dFs[1]) if (need and (mode & 2)) else _ptr(None),
-            _ptr(st['ws']), _ptr(st['sync']), _stream(F)), 'cfl_client_contrast_fwd')
+            F.data_ptr(), G_other.data_ptr() if G_other is not None else 0, G_same.data_ptr() if G_same is not None else 0,
+            idx.data_ptr(), F_old.data_ptr() if F_old is not None else 0, B, M, D, b_div, inv_tau, weight, mode, int(need),
+            p_out, p_aux, p_aux + 4 * B if p_aux else 0, p_dfs if (need and (mode & 1)) else 0,
+            p_dfs + 4 * B * D if (need and (mode & 2)) else 0, st['ws'].data_ptr(), st['sync'].data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream), 'cfl_client_contrast_fwd')
         ctx.mode = mode
-        ctx.save_for_backward(out5, dFs if need else out5)
+        ctx.save_for_backward(out, dFs if need else out)
         ctx.has = need
-        ctx.mark_non_differentiable(out5)
+        ctx.mark_non_differentiable(out)
         if aux is not None:
             ctx.mark_non_differentiable(aux)
-        return out5[0].clone(), out5, aux
+        return out.new_empty(()).set_(out.untyped_storage(), 5, ()), out, aux
 
     @staticmethod
     def backward(ctx, gloss, _g5, _gaux):
         lib = _lib.load()
-        out5, dFs = ctx.saved_tensors
+        out, dFs = ctx.saved_tensors
         if not ctx.has:
             raise _lib.CreamflHipError('client_contrast backward without saved gradients')
         _, B, D = dFs.shape
-        g = gloss.reshape(1).to(torch.float32).contiguous()
+        g = gloss if (gloss.dtype == torch.float32 and gloss.is_contiguous()) else gloss.to(torch.float32).contiguous()
         dF = torch.empty(B, D, dtype=torch.float32, device=dFs.device)
-        _lib.check(lib.cfl_client_contrast_bwd(_ptr(dFs[0]) if (ctx.mode & 1) else _ptr(None),
-                                               _ptr(dFs[1]) if (ctx.mode & 2) else _ptr(None), _ptr(out5), _ptr(g), B, D, _ptr(dF),
-                                               _stream(dFs)), 'cfl_client_contrast_bwd')
+        p = dFs.data_ptr()
+        _lib.check(lib.cfl_client_contrast_bwd(p if (ctx.mode & 1) else 0, p + 4 * B * D if (ctx.mode & 2) else 0, out.data_ptr(),
+                                               g.data_ptr(), B, D, dF.data_ptr(), torch.cuda.current_stream(dF.device).cuda_stream),
+                   'cfl_client_contrast_bwd')
         return dF, None, None, None, None, None, None, None, None
 
 
 def client_contrast_fused(feature, global_same, global_other, d_idx, old_feature, temperature=0.5, weight=1.0, loss_scale=False,
                           use_inter=True, use_intra=True, mean_divisor=None):
-    """Rows A3 + A4 and their combination (ClientTrainer.py:386-419) in three launches (bank pass, split merge,
-    epilogue).  Returns (loss, loss_inter | None, loss_moon | None, lse | None, pos | None).  Needs
-    bank_attn_supported(B, M, D)."""
+    """Rows A3 + A4 and their combination (ClientTrainer.py:386-419) in two launches (bank pass, finish).
+    Returns (loss, loss_inter | None, loss_moon | None, lse | None, pos | None).  Needs bank_attn_supported(B, M, D)."""
     F = _f32(feature, 'feature')
     mode = (1 if use_inter else 0) | (2 if use_intra else 0) | (4 if loss_scale else 0)
     if not (mode & 3):
@@ -196,9 +215,9 @@ def client_contrast_fused(feature, global_same, global_other, d_idx, old_feature
         raise RuntimeError(f'the two global banks differ in shape: {tuple(Go.shape)} vs {tuple(Gs.shape)}')
     if Fo is not None and Fo.shape != F.shape:
         raise RuntimeError(f'shape mismatch {tuple(F.shape)} vs {tuple(Fo.shape)}')
-    loss, out5, aux = _ClientContrastFn.apply(F, Go, Gs, _idx(d_idx, F.device), Fo, 1.0 / float(temperature), float(weight), mode,
-                                             int(mean_divisor) if mean_divisor else F.shape[0])
-    return (loss, out5[1] if use_inter else None, out5[2] if use_intra else None,
+    loss, out, aux = _ClientContrastFn.apply(F, Go, Gs, _idx(d_idx, F.device), Fo, 1.0 / float(temperature), float(weight), mode,
+                                            int(mean_divisor) if mean_divisor else F.shape[0])
+    return (loss, out[1] if use_inter else None, out[2] if use_intra else None,
             aux[0] if aux is not None else None, aux[1] if aux is not None else None)
 
 

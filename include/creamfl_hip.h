@@ -103,7 +103,8 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
  * G is streamed ONCE: the same pass accumulates softmax . G, so the gradient needs no second pass and no [B, M] tensor.
  * Logits use 3 x bf16-split MFMA (hi.hi + lo.hi + hi.lo, fp32 accumulation, |error| ~ 1e-6 on unit-norm features); the
  * positive dot and the intra term are exact fp32.
- * out5 = {loss, li, lm, c_inter, c_moon}; dF_inter / dF_moon [B, D] are the UNIT gradients of li / lm (want_grad), and
+ * out5 (>= 6 floats) = {loss, li, lm, c_inter, c_moon, loss again}; dF_inter / dF_moon [B, D] are the UNIT gradients of li / lm
+ * (want_grad), and
  * cfl_client_contrast_bwd writes dF = gout * (c_inter dF_inter + c_moon dF_moon).
  * lse [B] (required with bit 0), pos [B] (optional).  ws >= cfl_bank_attn_ws_bytes; `sync` points at an int that is 0
  * before the first call (left 0).  idx outside [0, M) contributes a zero positive (as cfl_bank_lse_fwd).
