@@ -185,6 +185,13 @@ class ClientTrainer:
             self.optimizer.step()
             if is_test:
                 break
+        # printnreset (ClientTrainer.py:308-317, called at :365): log the epoch's meters, then start fresh ones.  The meters
+        # hold device scalars (no per-batch .item()); this one log line is the only host read-back of the epoch.
+        if self.losses.count:
+            self._log('Epoch: [{0}] {1}\tLoss {2:.4f} ({3:.4f})\tPrec@1 {4:.3f} ({5:.3f})\tPrec@5 {6:.3f} ({7:.3f})'.format(
+                self.local_epoch, self.dset_name, float(self.losses.val), float(self.losses.avg), float(self.top1.val),
+                float(self.top1.avg), float(self.top5.val), float(self.top5.avg)))
+        self.losses, self.top1, self.top5 = AverageMeter(), AverageMeter(), AverageMeter()
 
     def tra(self, global_img_feature, global_txt_feature, distill_index, global_train_loader):
         self._supervised_epoch()

@@ -57,3 +57,31 @@ def golden_dir():
 
 def golden_files(prefix):
     return sorted(f for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith('.npz'))
+
+
+def reference_main_namespace(**overrides):
+    """argparse.Namespace exactly as the reference's src/main.py:38-110 would hand it to MMFL: every flag with its default
+    (tests/golden/main_flags.json, extracted from main.py by tests/golden/make_golden.py), computed defaults filled the way
+    main.py computes them, plus `overrides` (sizes for a small test; build-defined extras such as cnn_type)."""
+    import argparse
+    import json
+    spec = json.load(open(os.path.join(GOLDEN, 'main_flags.json')))
+    parser = argparse.ArgumentParser()
+    for f in spec['flags']:
+        kw = {}
+        if 'action' in f:
+            kw['action'] = f['action']
+        else:
+            kw['type'] = {'int': int, 'float': float, 'str': str}[f.get('type', 'str')]
+        if 'nargs' in f:
+            kw['nargs'] = f['nargs']
+        if 'choices' in f:
+            kw['choices'] = f['choices']
+        default = f.get('default')
+        if f.get('computed'):
+            default = {'seed': 1234, 'data_root': os.path.expanduser('~/data/')}[f['dest']]
+        parser.add_argument(*f['options'], default=default, **kw)
+    ns = parser.parse_args([])
+    for k, v in overrides.items():
+        setattr(ns, k, v)
+    return ns, spec

@@ -18,6 +18,7 @@ What is imported from the reference:
       EncoderText.forward / PCME.forward run on a synthetic 7x7 feature map (the torchvision trunk is replaced by
       nn.Identity; `torchvision` / `torchtext` are import-time stubs only)                      -> tower_*.npz
   MMFL.py:346-378 (KD terms; inline, literal statement sequence with nn.MSELoss as at :296)      -> kd_*.npz
+  src/main.py:38-105  the argparse flag surface, extracted with ast (never imported)            -> main_flags.json
 Parameters of the encoder fixtures are not stored: they are regenerated from the state_dict key names by
 tests/golden/seeded.py on both sides.
 Rows A3/A4/A5 are inline loop bodies in the reference (ClientTrainer.py:369-429,
@@ -443,6 +444,46 @@ def make_kd():
                  d_out_txt=(ot.grad.numpy() if ot.grad is not None else np.zeros(shape, np.float32)))
 
 
+def make_main_flags():
+    """The flag surface of src/main.py:38-105 as DATA: every `parser.add_argument` of its `args()` function -> option
+    strings, dest, type name, action and default (ast only; main.py itself is never imported: it parses sys.argv at import
+    and pulls in apex / torchvision).  Defaults that are expressions (a random seed, a path under $HOME) are recorded as
+    null with `computed: true`."""
+    import ast
+    import json
+    src = open(os.path.join(REF, 'src', 'main.py')).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'args'][0]
+    flags = []
+    for node in ast.walk(fn):
+        if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == 'add_argument'):
+            continue
+        opts = [a.value for a in node.args if isinstance(a, ast.Constant)]
+        kw = {k.arg: k.value for k in node.keywords}
+        rec = {'options': opts, 'dest': opts[-1].lstrip('-').replace('-', '_'), 'line': node.lineno}
+        if 'type' in kw and isinstance(kw['type'], ast.Name):
+            rec['type'] = kw['type'].id
+        if 'action' in kw:
+            rec['action'] = ast.literal_eval(kw['action'])
+        if 'nargs' in kw:
+            rec['nargs'] = ast.literal_eval(kw['nargs'])
+        if 'choices' in kw:
+            rec['choices'] = ast.literal_eval(kw['choices'])
+        if 'default' in kw:
+            try:
+                rec['default'] = ast.literal_eval(kw['default'])
+            except ValueError:
+                rec['default'], rec['computed'] = None, True
+        flags.append(rec)
+    flags.sort(key=lambda r: r['line'])
+    # what main.py adds to the namespace / touches on the algorithm object after parsing (main.py:112-134)
+    extra = {'namespace_added_after_construction': ['save_dirs', 'log_dir'],
+             'algo_surface': ['create_model', 'load_dataset', 'train', 'logger', 'engine', 'best_scores', 'best_metadata'],
+             'engine_surface': ['report_scores', 'eval_prefix']}
+    with open(os.path.join(OUT, 'main_flags.json'), 'w') as f:
+        json.dump({'flags': flags, **extra}, f, indent=1, sort_keys=True)
+
+
 def main():
     assert os.path.isdir(REF), 'reference checkout not present (build container only)'
     sys.path[:0] = [REF, os.path.join(REF, 'src')]
@@ -472,6 +513,7 @@ def main():
     import src.networks.models.caption_encoder as caption_encoder
     make_tower(pcme_mod, image_encoder, caption_encoder)
     make_kd()
+    make_main_flags()
     print('golden vectors written to', OUT)
 
 

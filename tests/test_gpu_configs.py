@@ -46,12 +46,14 @@ def test_config0_round_two_image_two_text_clients_batch32(dev):
     from creamfl_amd.algorithms.MMFL import MMFL
     torch.manual_seed(20)
     M = 64
-    args = SimpleNamespace(name='/tmp/creamfl_test_cfg0', feature_dim=64, pub_data_num=M, not_bert=False, mlp_local=False,
-                           server_lr=2e-4, local_epochs=1, comm_rounds=1, num_img_clients=2, num_txt_clients=2,
-                           num_mm_clients=0, client_num_per_round=4, agg_method='con_w', contrast_local_intra=True,
-                           contrast_local_inter=True, interintra_weight=0.5, loss_scale=False, kd_weight=0.3,
-                           disable_distill=False, save_client=False, device=0, cnn_type='resnet18', bert_name='bert-mini',
-                           image_size=64, test_pairs=100, quiet=True, save_checkpoints=False)
+    # the Namespace src/main.py would build (all 41 reference flags at their defaults), overridden only in sizes, plus the
+    # build-defined extras (encoder names, synthetic data sizes)
+    from conftest import reference_main_namespace
+    args, _ = reference_main_namespace(name='/tmp/creamfl_test_cfg0', feature_dim=64, pub_data_num=M, local_epochs=1, comm_rounds=1,
+                                       num_img_clients=2, num_txt_clients=2, num_mm_clients=0, client_num_per_round=4,
+                                       contrast_local_intra=True, contrast_local_inter=True, cnn_type='resnet18',
+                                       bert_name='bert-mini', image_size=64, test_pairs=100, quiet=True, save_checkpoints=False)
+    assert args.agg_method == 'con_w' and args.kd_weight == 0.3 and args.interintra_weight == 0.5 and not args.disable_distill
     algo = MMFL(args, None)
     algo.config.dataloader.batch_size = 32
     algo.config.train.use_fp16 = False

@@ -211,3 +211,23 @@ def test_bert_mirror_matches_transformers_on_cpu():
             torch.testing.assert_close(p.grad, g_ref, rtol=1e-4, atol=1e-5 * (float(g_ref.abs().max()) + 1e-3), msg=n)
     c = mine(ids, attention_mask=mask, cls_only=True)['last_hidden_state'][:, 0]
     torch.testing.assert_close(c, a[:, 0].detach(), rtol=1e-5, atol=1e-5)
+
+
+def test_main_py_flag_surface_drops_into_mmfl():
+    """BASELINE north star: "keeping the src/algorithms client/server API surface so it drops into src/main.py unchanged".
+    Build the Namespace main.py builds (all 41 flags at their defaults), construct MMFL exactly as main.py:118 does, set the
+    two attributes main.py adds afterwards (:120-121) and check every name main.py touches (:118-134)."""
+    from conftest import reference_main_namespace
+    from creamfl_amd.algorithms.MMFL import MMFL
+    args, spec = reference_main_namespace()
+    assert len(spec['flags']) == 41 and args.pub_data_num == 50000 and args.feature_dim == 256 and args.agg_method == 'con_w'
+    assert args.kd_weight == 0.3 and args.interintra_weight == 0.5 and args.client_num_per_round == 10
+    algo = MMFL(args, None)                                   # main.py:118 (wandb object replaced by None)
+    args.save_dirs = {'logs': '/tmp/creamfl_logs'}            # main.py:120-121
+    args.log_dir = args.save_dirs['logs']
+    for name in spec['algo_surface']:
+        assert hasattr(algo, name), name
+    algo.logger.log('ok')                                     # main.py:129
+    # the config the constructor derives from the flags (MMFL.py:70-88): server ResNet-101 + BERT at feature_dim
+    assert algo.config.model.embed_dim == 256 and algo.config.model.cnn_type == 'resnet101' and not algo.config.model.not_bert
+    assert callable(algo.create_model) and callable(algo.load_dataset) and callable(algo.train)
