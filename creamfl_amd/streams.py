@@ -16,6 +16,11 @@ def get(device, name):
     s = _STREAMS.get(key)
     if s is None:
         s = _STREAMS[key] = torch.cuda.Stream(device=device)
+        # Gradients of the text tower / the weight gradients are PRODUCED on these streams on purpose and joined before
+        # anything consumes them (join_into_current): autograd's "AccumulateGrad stream mismatch" warning is expected here.
+        warn_off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if warn_off is not None:
+            warn_off(False)
     return s
 
 
