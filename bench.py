@@ -164,6 +164,11 @@ def main():
     args = ap.parse_args()
     if args.config == 3:
         args.batch = 512
+    # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block at
+    # communicator creation) are sent to stderr; the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -387,7 +392,8 @@ def main():
             'parity_unpinned': ['AdamP (adamp==0.3.0 is not vendored: checked against the paper restatement oracle/adamp.py)'],
             'hip_kernels_us_warmup_step': hip_us,
         }
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     if use_dp:
         torch.distributed.destroy_process_group()
 

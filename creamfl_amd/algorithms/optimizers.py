@@ -32,6 +32,7 @@ class AdamP(Optimizer):
                         nesterov=nesterov)
         super().__init__(params, defaults)
         self._plans = {}
+        self.grad_override = None        # {parameter: tensor to read its gradient from} (multi-GPU: dist.GradBuckets views)
 
     META_DTYPE = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64), ('p16', np.uint64),
                            ('numel', np.int64), ('inner', np.int64), ('row_base', np.int64),
@@ -216,8 +217,9 @@ class AdamP(Optimizer):
                 st['step'] += 1
             plan = self._plan(gi, params, clip_ids)
             grads = []
+            ov = self.grad_override
             for p in params:
-                g = p.grad
+                g = p.grad if ov is None else ov.get(p, p.grad)
                 if g.dtype != p.dtype or g.stride() != p.stride():
                     g2 = torch.empty_like(p, memory_format=torch.preserve_format)
                     g2.copy_(g)

@@ -131,7 +131,12 @@ class EngineBase(object):
 
     def enable_data_parallel(self, process_group=None, bucket_cap_mb=128):
         from ..dist import DataParallelContext
-        self.dp = DataParallelContext(self.model, process_group, bucket_cap_mb=bucket_cap_mb)
+        fused = isinstance(self.optimizer, AdamP)
+        self.dp = DataParallelContext(self.model, process_group, bucket_cap_mb=bucket_cap_mb, assign_grads=not fused)
+        if fused:
+            # the fused optimizer reads the averaged gradients straight from the bucket views (no per-parameter grad
+            # re-assignment on the host)
+            self.optimizer.grad_override = self.dp.reducer.grad_views()
 
     @torch.no_grad()
     def evaluate(self, val_loaders, n_crossfolds=None, **kwargs):
@@ -228,6 +233,8 @@ class TrainerEngine(EngineBase):
             images = images.contiguous(memory_format=torch.channels_last)
         loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens)
         self.optimizer.zero_grad(set_to_none=True)
+        if self.dp is not None:
+            self.dp.prepare_backward()
         if loss.is_cuda:
             from .. import ops
             if self._conv1x1_weights is None:

@@ -790,6 +790,8 @@ class _ConvSplitFn(torch.autograd.Function):
                                 weight.grad = g
                             else:
                                 weight.grad.add_(g)
+                        if streams.GRAD_READY[0] is not None:
+                            streams.GRAD_READY[0](weight)              # multi-GPU: this gradient may now be bucketed
                     streams.defer(task)
                 else:
                     main = torch.cuda.current_stream(x.device)

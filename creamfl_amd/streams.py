@@ -42,8 +42,9 @@ def join_into_current(device):
 # data-gradient GEMMs it slows exactly the kernels that ARE on the critical path.  The backward of a convolution
 # therefore only queues its weight-gradient launch; the queue is flushed onto the 'wgrad' stream when the main stream
 # enters a long HBM-bound phase (the backward of a residual BatchNorm) and at the end of the backward pass.
-# Not under DDP: a bucket may be all-reduced as soon as autograd has SEEN every gradient in it (see dist.py).
+# Multi-GPU: the deferred task reports its finished gradient to the gradient buckets itself (GRAD_READY, dist.py).
 DEFER_WGRAD = [True]
+GRAD_READY = [None]          # callback(parameter): a deferred weight gradient has been written (dist.GradBuckets.notify)
 _PENDING = []
 _PENDING_FOR = [-1]
 

@@ -47,12 +47,17 @@ def _worker_global_contrast(rank, world, path, out):
                     torch.nn.functional.normalize(self.m['t'](y), dim=-1))
 
     wrapped = Both(model)
-    dp = cdist.DataParallelContext(wrapped, bucket_cap_mb=1)
+    dp = cdist.DataParallelContext(wrapped, bucket_cap_mb=0.0002)        # ~200 bytes per bucket: several buckets, in order
     xs, ys = X[rank * 6:(rank + 1) * 6], Y[rank * 6:(rank + 1) * 6]
     fi, ft = dp.module(xs, ys)
     gi, gt = dp.gather_features(fi, ft)
     loss, _ = oracle.pair_loss_literal(gi, gt, a, b)
+    dp.prepare_backward()
     loss.backward()
+    dp.finish_backward()
+    # after finish() every gradient is a view into its (averaged) bucket, in the parameter's own layout
+    ok_views = all(p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == p.stride()
+                   for plist, views in zip(dp.reducer.buckets, dp.reducer.views) for p, v in zip(plist, views))
     grads = {n: p.grad.clone() for n, p in wrapped.named_parameters()}
     if rank == 0:
         # single-process large-batch reference
@@ -63,7 +68,7 @@ def _worker_global_contrast(rank, world, path, out):
         l2, _ = oracle.pair_loss_literal(torch.nn.functional.normalize(ri(X), dim=-1),
                                          torch.nn.functional.normalize(rt(Y), dim=-1), a2, b2)
         l2.backward()
-        ok = abs(loss.item() - l2.item()) < 1e-4 * abs(l2.item())
+        ok = abs(loss.item() - l2.item()) < 1e-4 * abs(l2.item()) and ok_views and len(dp.reducer.buckets) >= 1
         ok &= torch.allclose(grads['m.i.weight'], ri.weight.grad, rtol=1e-4, atol=1e-6)
         ok &= torch.allclose(grads['m.t.bias'], rt.bias.grad, rtol=1e-4, atol=1e-6)
         ok &= torch.allclose(a.grad, a2.grad, rtol=1e-4) and torch.allclose(b.grad, b2.grad, rtol=1e-4)

@@ -231,3 +231,35 @@ def test_main_py_flag_surface_drops_into_mmfl():
     # the config the constructor derives from the flags (MMFL.py:70-88): server ResNet-101 + BERT at feature_dim
     assert algo.config.model.embed_dim == 256 and algo.config.model.cnn_type == 'resnet101' and not algo.config.model.not_bert
     assert callable(algo.create_model) and callable(algo.load_dataset) and callable(algo.train)
+
+
+def test_grad_buckets_views_layout_and_unused_parameters():
+    """dist.GradBuckets on one process (no communication): after finish() every gradient is a view into its bucket with the
+    parameter's own strides (channels_last convolution weights included), values equal plain autograd's, a parameter that
+    received no gradient gets an all-zero slot, and a gradient reported through `notify` (the deferred weight-gradient
+    path) is bucketed like the hooked ones."""
+    import torch.nn as nn
+    from creamfl_amd.dist import GradBuckets
+    torch.manual_seed(0)
+    conv = nn.Conv2d(3, 8, 3).to(memory_format=torch.channels_last)
+    lin = nn.Linear(8, 4)
+    unused = nn.Parameter(torch.randn(5))
+    deferred = nn.Parameter(torch.randn(6, 2))
+    params = list(conv.parameters()) + list(lin.parameters()) + [unused, deferred]
+    gb = GradBuckets(params, bucket_cap_mb=0.0005)
+    assert len(gb.buckets) > 1
+    x = torch.randn(2, 3, 6, 6)
+    y = lin(conv(x).mean(dim=(2, 3))).sum()
+    want = torch.autograd.grad(y, [conv.weight, conv.bias, lin.weight, lin.bias], retain_graph=True)
+    gb.prepare()
+    y.backward()
+    deferred.grad = torch.full((6, 2), 3.0)               # what a deferred weight-gradient task does ...
+    gb.notify(deferred)                                   # ... and how it reports
+    gb.finish()
+    for p, w in zip([conv.weight, conv.bias, lin.weight, lin.bias], want):
+        assert torch.allclose(p.grad, w) and p.grad.stride() == p.stride()
+    assert conv.weight.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(unused.grad, torch.zeros(5)) and torch.equal(deferred.grad, torch.full((6, 2), 3.0))
+    for plist, views in zip(gb.buckets, gb.views):
+        for p, v in zip(plist, views):
+            assert p.grad.data_ptr() == v.data_ptr()
