@@ -77,6 +77,21 @@ def case_a3(B, M, D):
             'pairs_per_s': round(B / us * 1e6)}
 
 
+def case_pool(N=256, H=112, C=64):
+    """ResNet stem max pooling (3x3 / 2) on the bench's [N, 64, 112, 112] channels_last bf16 activation, fwd + bwd."""
+    x = torch.randn(N, C, H, H, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(N, C, H // 2, H // 2, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def step():
+        y = ops.maxpool3s2(x)
+        y.backward(gy)
+        x.grad = None
+    us, prof = timed(step)
+    byts = N * H * H * C * 2 + N * (H // 2) ** 2 * C * 3          # each way: big tensor + small tensor + 1-byte taps
+    return {'case': f'maxpool3s2 N={N} H={H} C={C}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'algorithmic_MB_each_way': round(byts / 1e6, 1)}
+
+
 def case_a5(M, D, C=1):
     g = torch.Generator(device='cuda').manual_seed(2)
     G = unit(M, D, gen=g)
@@ -297,6 +312,8 @@ def main():
         out += [case_a1(256, 512), case_a1(128, 256), case_a1(4096, 512)]
     if 'a3' in cases:
         out += [case_a3(128, 50000, 256), case_a3(256, 50000, 512), case_a3(128, 50000, 768), case_a3(32, 50000, 256)]
+    if 'pool' in cases:
+        out += [case_pool()]
     if 'a3one' in cases:
         out += [case_a3(128, 50000, 256)]
     if 'a5' in cases:
