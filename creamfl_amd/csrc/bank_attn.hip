@@ -166,6 +166,9 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __re
     const int nch = (M + GC - 1) / GC;
     const int ntiles = x < nch ? (nch - x + S - 1) / S : 0;
 
+    // a wave whose 16 feature rows all lie beyond B (small client batches) only helps staging the chunks: no MFMA work, no
+    // partial rows written for it
+    const bool wave_live = rg * BR + 16 * w < B;
     f32x4 stage[4];
     if (ntiles > 0) chunk_load<DP>(G, M, D, x * GC, stage);        // in flight while the feature fragments are fetched
 
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __re
         const int g0n = (x + (i + 1) * S) * GC;
         if (more) chunk_load<DP>(G, M, D, g0n, stage);
         const char* rb = lds + buf * SM::BUF;
+        if (wave_live) {
         // ---- logits S^T[g, f] = sum_k G[g, k] F[f, k], two 16-row tiles u; hi.hi on one accumulator, cross terms on another
         // three independent accumulator chains per tile (hi.hi, lo.hi, hi.lo): no MFMA waits for the one before it
         f32x4 sa[2], sb[2], sc[2];
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __re
                 for (int e = 0; e < 4; ++e) O[d4 + e] = MFMA16(gh[e], pl, O[d4 + e]);
             }
         }
+        }   // wave_live
         if (more) chunk_store<DP, GRAD>(lds + (buf ^ 1) * SM::BUF, M, D, g0n, stage);
         __syncthreads();
         buf ^= 1;
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __re
     run_l += __shfl_xor(run_l, 16, 64);
     run_l += __shfl_xor(run_l, 32, 64);
     const size_t slab = (size_t)rg * S + x;
+    if (!wave_live) return;
     if (kg == 0) {
         part_m[slab * BR + 16 * w + fi] = run_m;
         part_l[slab * BR + 16 * w + fi] = run_l;

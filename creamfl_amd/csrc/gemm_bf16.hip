@@ -369,6 +369,7 @@ extern "C" int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, lon
     if (variant == 0) variant = N >= 128 ? 22 : 21;
     switch (variant) {
         case 44: return launch_nt<4, 4, 1>(Ao, Bo, M, N, Cc, ldc, stream);
+        case 24: return launch_nt<2, 4, 1>(Ao, Bo, M, N, Cc, ldc, stream);      // 128 x 256: A read once when N <= 256
         case 42: return launch_nt<4, 2, 1>(Ao, Bo, M, N, Cc, ldc, stream);
         case 22: return launch_nt<2, 2, 2>(Ao, Bo, M, N, Cc, ldc, stream);
         case 21: return launch_nt<2, 1, 2>(Ao, Bo, M, N, Cc, ldc, stream);

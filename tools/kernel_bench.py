@@ -333,7 +333,7 @@ def main():
         os.environ.setdefault('MIOPEN_FIND_MODE', '2')
         for (H, Ci, Co) in [(56, 64, 64), (56, 64, 256), (56, 256, 64), (28, 128, 512), (28, 512, 128),
                             (14, 256, 1024), (14, 1024, 256), (7, 512, 2048), (7, 2048, 512)]:
-            vs = [v for v in (44, 42, 22, 21, 41) if not (v in (44, 42, 22) and Co < 128)]
+            vs = [v for v in (44, 24, 42, 22, 21, 41) if not (v in (44, 42, 22) and Co < 128) and not (v == 24 and Co < 256)]
             out.append(case_gemm16(H, Ci, Co, vs))
     if 'wgrad16' in cases:
         os.environ.setdefault('MIOPEN_FIND_MODE', '2')
