@@ -31,6 +31,8 @@ SIGNATURES = {
     'cfl_bank_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cfl_bank_lse_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
     'cfl_bank_lse_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'cfl_get_exact_gemm': (c_int, []),
+    'cfl_set_exact_gemm': (c_int, [c_int]),
     'cfl_bank_attn_supported': (c_int, [c_int, c_int, c_int]),
     'cfl_bank_attn_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'cfl_client_contrast_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int,

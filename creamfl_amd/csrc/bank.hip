@@ -15,6 +15,7 @@
 // that the stores of a wave are 128-byte contiguous); ws: part_m[S, Bp] part_l[S, Bp] (S = number
 // of bank splits, Bp = B rounded up to 128) followed by the backward's split-K slabs [KS, B, D].
 #include "common.h"
+#include "tile_x3.h"
 
 namespace {
 
@@ -37,7 +38,7 @@ static BankPlan bank_plan(int B, int M) {
 
 template <int TN>
 __global__ __launch_bounds__(256, 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B, int M, int Bp, float inv_tau,
-                                                           float* logits_t, float* part_m, float* part_l) {
+                                                           float* logits_t, float* part_m, float* part_l, int x3mode) {
     constexpr int TM = 2;
     using C = TileCfg<TM, TN, true, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, in
             }
         }
     };
-    if (glds_ok(G, F)) tile_gemm_seq_glds<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);
+    if (x3mode) x3::tile_gemm_seq<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);
+    else if (glds_ok(G, F)) tile_gemm_seq_glds<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);
     else tile_gemm_seq<TM, TN, true, true>(G, F, ntiles, tile_fn, lds, XfIdentity(), epi_fn);
     // back to natural-log units, then combine the two half-waves (different bank rows of the same feature row) ...
 #pragma unroll
@@ -192,14 +194,15 @@ struct XfSoftmax {
 // A[i = f][k = g] = logits_t[g*B + f] (K strided),  B[k = g][j = d] = G[g*D + d] (K strided)
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void cfl_bank_bwd_kernel(Opnd P, Opnd G, const float* __restrict__ lse, int B, int M, int D,
-                                                           int kper, float* slab) {
+                                                           int kper, float* slab, int x3mode) {
     using C = TileCfg<TM, TN, false, false>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row0 = blockIdx.z * C::BM, col0 = blockIdx.y * C::BN;
     const int kbeg = blockIdx.x * kper;
     const int kend = min(M, kbeg + kper);
     f32x16 acc[TM][TN];
-    tile_gemm<TM, TN, false, false>(P, G, row0, col0, kbeg, kend, lds, acc, XfSoftmax{lse});
+    if (x3mode) x3::tile_gemm<TM, TN, false, false>(P, G, row0, col0, kbeg, kend, lds, acc, XfSoftmax{lse});
+    else tile_gemm<TM, TN, false, false>(P, G, row0, col0, kbeg, kend, lds, acc, XfSoftmax{lse});
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
     float* out = slab + (size_t)blockIdx.x * B * D;
 #pragma unroll
@@ -346,15 +349,16 @@ static int launch_bank_fwd(const float* F, const float* G, int B, int M, int D, 
     Opnd Go{G, D, M, D, cfl_opnd_vec(G, D, D)};
     Opnd Fo{F, D, B, D, cfl_opnd_vec(F, D, D)};
     const dim3 grid(pl.S, cfl_cdiv(B, pl.BN));
+    const int x3mode = cfl_get_exact_gemm() ? 0 : 1;
     if (pl.TN == 1) {
         using C = TileCfg<2, 1, true, true>;
         CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<1>), grid, dim3(256), C::LDS_BYTES, stream,
-                   Go, Fo, B, M, pl.Bp, inv_tau, logits_t, w.part_m, w.part_l);
+                   Go, Fo, B, M, pl.Bp, inv_tau, logits_t, w.part_m, w.part_l, x3mode);
     } else {
         using C = TileCfg<2, 2, true, true>;
         CFL_SET_LDS((cfl_bank_fwd_kernel<2>), C::LDS_BYTES);
         CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<2>), grid, dim3(256), C::LDS_BYTES, stream,
-                   Go, Fo, B, M, pl.Bp, inv_tau, logits_t, w.part_m, w.part_l);
+                   Go, Fo, B, M, pl.Bp, inv_tau, logits_t, w.part_m, w.part_l, x3mode);
     }
     return 0;
 }
@@ -399,6 +403,7 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
     Opnd P{logits_t, B, B, M, cfl_opnd_vec(logits_t, B, B)};
     Opnd Go{G, D, D, M, cfl_opnd_vec(G, D, D)};
     int kper = 0, ks = 0;
+    const int x3mode = cfl_get_exact_gemm() ? 0 : 1;
     if (B > 64 && D > 64) {
         // 128-row feature tiles; 64-wide D tiles when 128-wide ones would leave CUs with a single workgroup
         const bool narrow = cfl_cdiv(B, 128) * cfl_cdiv(D, 128) * 128 < 512;
@@ -406,18 +411,18 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
             using C = TileCfg<2, 1, false, false>;
             ks = bwd_ksplits(B, M, D, C::BM, C::BN, &kper);
             CFL_LAUNCH(K_BANK_BWD, (cfl_bank_bwd_kernel<2, 1>), dim3(ks, cfl_cdiv(D, C::BN), cfl_cdiv(B, C::BM)), dim3(256),
-                       C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab);
+                       C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab, x3mode);
         } else {
             using C = TileCfg<2, 2, false, false>;
             ks = bwd_ksplits(B, M, D, C::BM, C::BN, &kper);
             CFL_LAUNCH(K_BANK_BWD, (cfl_bank_bwd_kernel<2, 2>), dim3(ks, cfl_cdiv(D, C::BN), cfl_cdiv(B, C::BM)), dim3(256),
-                       C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab);
+                       C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab, x3mode);
         }
     } else {
         using C = TileCfg<1, 1, false, false>;
         ks = bwd_ksplits(B, M, D, C::BM, C::BN, &kper);
         CFL_LAUNCH(K_BANK_BWD, (cfl_bank_bwd_kernel<1, 1>), dim3(ks, cfl_cdiv(D, C::BN), cfl_cdiv(B, C::BM)), dim3(256),
-                   C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab);
+                   C::LDS_BYTES, stream, P, Go, lse, B, M, D, kper, w.slab, x3mode);
     }
     const long long tot = (long long)B * D;
     CFL_LAUNCH(K_BANK_BWD_REDUCE, cfl_bank_bwd_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream,

@@ -1,10 +1,11 @@
 // gemm_probe.hip -- C = A * B^T through tile_gemm (both operands K-contiguous): the calibration point for the
 // fp32-MFMA building block (tools/kernel_bench.py --cases gemm) and a direct parity check of tile_gemm itself.
 #include "common.h"
+#include "tile_x3.h"
 
 namespace {
 template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void cfl_gemm_nt_kernel(Opnd A, Opnd B, int M, int N, float* Cout) {
+__global__ __launch_bounds__(256, 2) void cfl_gemm_nt_kernel(Opnd A, Opnd B, int M, int N, float* Cout, int x3mode) {
     using C = TileCfg<TM, TN, true, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ntc = (N + C::BN - 1) / C::BN, ntr = (M + C::BM - 1) / C::BM;
@@ -13,7 +14,8 @@ __global__ __launch_bounds__(256, 2) void cfl_gemm_nt_kernel(Opnd A, Opnd B, int
     const int row0 = ti * C::BM, col0 = tj * C::BN;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
     f32x16 acc[TM][TN];
-    if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
+    if (x3mode) x3::tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
+    else if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
     else tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -37,7 +39,7 @@ extern "C" int cfl_gemm_nt(const float* A, const float* B, int M, int N, int K, 
     using Cf = TileCfg<2, 2, true, true>;
     CFL_SET_LDS((cfl_gemm_nt_kernel<2, 2>), Cf::LDS_BYTES);
     CFL_LAUNCH(K_GEMM_PROBE, (cfl_gemm_nt_kernel<2, 2>), dim3(cfl_cdiv(M, Cf::BM) * cfl_cdiv(N, Cf::BN)), dim3(256), Cf::LDS_BYTES,
-               stream, Ao, Bo, M, N, C);
+               stream, Ao, Bo, M, N, C, cfl_get_exact_gemm() ? 0 : 1);
     return 0;
 }
 

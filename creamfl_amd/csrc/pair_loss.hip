@@ -13,6 +13,7 @@
 //   ni[N] nt[N] dd[N] rowsum[N] colsum[N] rowpart[NT*N] colpart[NT*N] part[NT*NT*4] It[D*N] Tt[D*N]
 // with NT = ceil(N / 64) (sized for the smallest tile).
 #include "common.h"
+#include "tile_x3.h"
 
 namespace {
 
@@ -68,7 +69,7 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N, const float* __restrict__ a_dev, const float* __restrict__ b_dev, float eps,
                                                            const float* __restrict__ ni, const float* __restrict__ nt,
                                                            const float* __restrict__ dd, float* coef,
-                                                           float* rowpart, float* colpart, float* part) {
+                                                           float* rowpart, float* colpart, float* part, int x3mode) {
     using C = TileCfg<TM, TN, true, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ntc = (N + C::BN - 1) / C::BN, ntr = (N + C::BM - 1) / C::BM;
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
     float* cs = lds;                                          // [BM][BN+1] coefficient tile (after the K loop)
     float pos = 0.f, neg = 0.f, da = 0.f, db = 0.f;
     f32x16 acc[TM][TN];
-    if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
+    if (x3mode) x3::tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
+    else if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
     else tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void cfl_pair_bwd_kernel(const float* __restri
                                                            const float* __restrict__ coef, const float* __restrict__ It,
                                                            const float* __restrict__ Tt, int N, int D, int vecN,
                                                            const float* __restrict__ rowsum, const float* __restrict__ colsum,
-                                                           const float* __restrict__ gout, float* dI, float* dT) {
+                                                           const float* __restrict__ gout, float* dI, float* dT, int x3mode) {
     using C = TileCfg<TM, TN, true, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ntc = (D + C::BN - 1) / C::BN, ntr = (N + C::BM - 1) / C::BM;
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(256) void cfl_pair_bwd_kernel(const float* __restri
     Opnd Ao{second ? coef + (long long)N * N : coef, N, N, N, vecN};
     Opnd Bo{second ? It : Tt, N, D, N, vecN};
     f32x16 acc[TM][TN];
-    if (glds_ok(Ao, Bo)) tile_gemm_glds<TM, TN>(Ao, Bo, row0, col0, 0, N, lds, acc);
+    if (x3mode) x3::tile_gemm<TM, TN, true, true>(Ao, Bo, row0, col0, 0, N, lds, acc, XfIdentity());
+    else if (glds_ok(Ao, Bo)) tile_gemm_glds<TM, TN>(Ao, Bo, row0, col0, 0, N, lds, acc);
     else tile_gemm<TM, TN, true, true>(Ao, Bo, row0, col0, 0, N, lds, acc, XfIdentity());
     const float* sums = second ? colsum : rowsum;
     float* out = second ? dT : dI;
@@ -239,6 +242,7 @@ int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float*
     CFL_LAUNCH(K_PAIR_PREP, cfl_pair_prep_kernel, dim3(cfl_cdiv(N, 4)), dim3(256), 0, stream, I, T, N, D, w.ni, w.nt, w.dd);
     Opnd A{I, D, N, D, cfl_opnd_vec(I, D, D)};
     Opnd B{T, D, N, D, cfl_opnd_vec(T, D, D)};
+    const int x3mode = cfl_get_exact_gemm() ? 0 : 1;      // S = I T^T on the 3 x bf16-split MFMA (positives stay exact: dd)
     // 128x128 tiles once they fill the chip, 64x64 tiles below that (latency-bound regime)
     const bool big = (long long)cfl_cdiv(N, 128) * cfl_cdiv(N, 128) >= 256;
     int ntr, ntc;
@@ -247,12 +251,12 @@ int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float*
         ntr = cfl_cdiv(N, C::BM); ntc = cfl_cdiv(N, C::BN);
         CFL_SET_LDS((cfl_pair_fwd_kernel<2, 2>), C::LDS_BYTES);
         CFL_LAUNCH(K_PAIR_FWD, (cfl_pair_fwd_kernel<2, 2>), dim3(ntr * ntc), dim3(256), C::LDS_BYTES, stream,
-                   A, B, N, a_dev, b_dev, eps, w.ni, w.nt, w.dd, coef, w.rowpart, w.colpart, w.part);
+                   A, B, N, a_dev, b_dev, eps, w.ni, w.nt, w.dd, coef, w.rowpart, w.colpart, w.part, x3mode);
     } else {
         using C = TileCfg<1, 1, true, true>;
         ntr = cfl_cdiv(N, C::BM); ntc = cfl_cdiv(N, C::BN);
         CFL_LAUNCH(K_PAIR_FWD, (cfl_pair_fwd_kernel<1, 1>), dim3(ntr * ntc), dim3(256), C::LDS_BYTES, stream,
-                   A, B, N, a_dev, b_dev, eps, w.ni, w.nt, w.dd, coef, w.rowpart, w.colpart, w.part);
+                   A, B, N, a_dev, b_dev, eps, w.ni, w.nt, w.dd, coef, w.rowpart, w.colpart, w.part, x3mode);
     }
     CFL_LAUNCH(K_PAIR_FINAL, cfl_pair_final_kernel, dim3(cfl_cdiv(N, 256)), dim3(256), 0, stream,
                w.part, ntr * ntc, w.rowpart, w.colpart, ntr, ntc, N, w.rowsum, w.colsum, out8);
@@ -265,6 +269,7 @@ int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, 
     hipStream_t stream = (hipStream_t)stream_;
     PairWs w = pair_ws(ws, N, D);
     const int vecN = (cfl_opnd_vec(coef, N, N) && cfl_vec_ok(w.it, N) && cfl_vec_ok(w.tt, N)) ? 1 : 0;
+    const int x3mode = cfl_get_exact_gemm() ? 0 : 1;
     // tile choice by workgroup count (two GEMMs share the launch, grid.z = 2): 128x128 when that alone gives >= 2
     // workgroups per CU, else 128x64, else 64x64 (latency-bound small batches)
     const long long t128 = (long long)cfl_cdiv(N, 128) * cfl_cdiv(D, 128) * 2;
@@ -273,15 +278,15 @@ int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, 
         using C = TileCfg<2, 2, true, true>;
         CFL_SET_LDS((cfl_pair_bwd_kernel<2, 2>), C::LDS_BYTES);
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<2, 2>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
-                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT);
+                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT, x3mode);
     } else if (t12864 >= 256) {
         using C = TileCfg<2, 1, true, true>;
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<2, 1>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
-                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT);
+                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT, x3mode);
     } else {
         using C = TileCfg<1, 1, true, true>;
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_kernel<1, 1>), dim3(cfl_cdiv(N, C::BM) * cfl_cdiv(D, C::BN), 1, 2), dim3(256),
-                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT);
+                   C::LDS_BYTES, stream, I, T, coef, w.it, w.tt, N, D, vecN, w.rowsum, w.colsum, gout_dev, dI, dT, x3mode);
     }
     return 0;
 }

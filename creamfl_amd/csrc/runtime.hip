@@ -1,6 +1,7 @@
 // runtime.hip -- library identity + per-kernel HIP-event profiler behind the C ABI.
 #include <mutex>
 #include <vector>
+#include <stdlib.h>
 #include "common.h"
 
 static const char* const g_kernel_names[K_NUM] = {
@@ -60,7 +61,20 @@ CflProfScope::~CflProfScope() {
     if (hipEventRecord(e1, s) == hipSuccess) g_pending.push_back({id, e0, e1});
 }
 
+static int g_exact_gemm = -1;        // -1: not read yet
+
 extern "C" {
+// Dense kernels that exist in two forms (pair loss, two-pass bank kernels, con_w log-prob, the GEMM probe):
+// 0 = 3 x bf16-split MFMA (csrc/tile_x3.h, default), 1 = exact fp32 MFMA (csrc/common.h).  Initialised from the
+// environment variable CFL_GEMM_EXACT on first use.
+int cfl_get_exact_gemm(void) {
+    if (g_exact_gemm < 0) {
+        const char* e = getenv("CFL_GEMM_EXACT");
+        g_exact_gemm = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_exact_gemm;
+}
+int cfl_set_exact_gemm(int exact) { g_exact_gemm = exact ? 1 : 0; return 0; }
 int cfl_version(void) { return 100; }
 const char* cfl_arch(void) { return "gfx950"; }
 int cfl_num_kernels(void) { return K_NUM; }

@@ -109,6 +109,12 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
  * lse [B] (required with bit 0), pos [B] (optional).  ws >= cfl_bank_attn_ws_bytes; `sync` points at an int that is 0
  * before the first call (left 0).  idx outside [0, M) contributes a zero positive (as cfl_bank_lse_fwd).
  */
+/* Precision of the dense kernels that exist in two forms (cfl_pair_loss_*, cfl_bank_lse_*, cfl_conw_logprob, cfl_gemm_nt):
+ * 0 = 3 x bf16-split MFMA with fp32 accumulation (default; dot products of unit-norm rows to ~1e-6), 1 = exact fp32 MFMA.
+ * Process-wide; initialised from the environment variable CFL_GEMM_EXACT. */
+int cfl_get_exact_gemm(void);
+int cfl_set_exact_gemm(int exact);
+
 int cfl_bank_attn_supported(int B, int M, int D);
 size_t cfl_bank_attn_ws_bytes(int B, int M, int D, int want_grad);
 int cfl_client_contrast_fwd(const float* F, const float* G_other, const float* G_same, const long long* idx, const float* F_old,

@@ -624,3 +624,71 @@ def test_f1_kd_terms_golden(dev, fname):
     _close(loss.item(), float(z['loss']), 1e-5, 0)
     _scale_close(oi.grad if oi.grad is not None else torch.zeros_like(oi), z['d_out_img'], 1e-5)
     _scale_close(ot.grad if ot.grad is not None else torch.zeros_like(ot), z['d_out_txt'], 1e-5)
+
+
+# ------------------------------------------------------------------ the 3 x bf16-split tile GEMM vs the exact fp32 one
+@pytest.mark.parametrize('m,n,k', [(128, 128, 256), (300, 200, 100), (1024, 512, 512), (65, 33, 31)])
+def test_tile_gemm_x3_and_exact_vs_fp64(dev, m, n, k):
+    """cfl_gemm_nt (C = A B^T through the tile GEMM that the pair loss, the two-pass bank kernels and con_w share) in both
+    precisions against an fp64 product: the exact-fp32 MFMA path to fp32 round-off, the 3 x bf16-split path to
+    2^-15 * sum_k |a_k b_k| (two bf16 per operand = 16 mantissa bits; the lo.lo term is dropped)."""
+    import ctypes
+    from creamfl_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(m + n + k)
+    A = torch.randn(m, k, generator=gen)
+    B = torch.randn(n, k, generator=gen)
+    want = (A.double() @ B.double().T).numpy()
+    bound = (A.abs().double() @ B.abs().double().T).numpy()
+    Ad, Bd = A.to(dev), B.to(dev)
+    C = torch.empty(m, n, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    old = lib.cfl_get_exact_gemm()
+    try:
+        for exact, eps in ((1, 2.0 ** -21), (0, 2.0 ** -15)):
+            lib.cfl_set_exact_gemm(exact)
+            _lib.check(lib.cfl_gemm_nt(Ad.data_ptr(), Bd.data_ptr(), m, n, k, C.data_ptr(), st), 'cfl_gemm_nt')
+            err = np.abs(C.cpu().numpy().astype(np.float64) - want)
+            assert np.all(err <= eps * bound + 1e-30), (exact, float((err / (bound + 1e-30)).max()))
+    finally:
+        lib.cfl_set_exact_gemm(old)
+
+
+@pytest.mark.parametrize('exact', [0, 1])
+def test_dense_kernels_in_both_precisions(dev, exact):
+    """The pair loss (A1), the two-pass bank kernels (A3 at D > 256) and con_w (A5) against their goldens / fp64 closed forms
+    with the dense core on the 3 x bf16-split MFMA (default) and on the exact fp32 MFMA (cfl_set_exact_gemm)."""
+    from creamfl_amd import _lib, ops
+    lib = _lib.load()
+    old = lib.cfl_get_exact_gemm()
+    lib.cfl_set_exact_gemm(exact)
+    try:
+        z = _load('a1_n128_d256_a15_b15.npz')
+        loss, stats, dI, dT, da, db = _run_pair(dev, torch.from_numpy(z['I']), torch.from_numpy(z['T']), float(z['a']), float(z['b']))
+        cf = oracle.pair_loss_closed_form(torch.from_numpy(z['I']), torch.from_numpy(z['T']), float(z['a']), float(z['b']))
+        g = oracle.pair_loss_grads_closed_form(torch.from_numpy(z['I']), torch.from_numpy(z['T']), float(z['a']), float(z['b']))
+        _close(loss, float(cf['loss']), 3e-5, 1e-6)
+        sc = float(np.abs(np.asarray(g['dI'])).max())
+        _close(dI, np.asarray(g['dI']), 1e-4, 2e-4 * sc)
+        # two-pass bank kernels (D = 320 > 256 keeps the single-pass kernel out of the way)
+        gen = torch.Generator().manual_seed(7)
+        G = _unit(gen, 3000, 320)
+        idx = torch.randint(0, 3000, (96,), generator=gen)
+        f = torch.nn.functional.normalize(G[idx] + 0.7 * _unit(gen, 96, 320), dim=-1)
+        fg = f.to(dev).requires_grad_(True)
+        l2, lse, pos = ops.inter_contrast(fg, G.to(dev), idx.tolist(), 0.5)
+        l2.backward()
+        c2 = oracle.client_contrast_grads_closed_form(f, G, G, idx.tolist(), f)
+        _close(l2.item(), c2['loss_inter'].item(), 2e-5, 1e-5)
+        dref = c2['d_inter'].numpy()
+        _close(fg.grad.cpu().numpy(), dref, 1e-4, 3e-5 * np.abs(dref).max())
+        # con_w
+        z5 = _load('a5_m600_d128_c4.npz')
+        vecs = [torch.from_numpy(v).to(dev) for v in z5['vecs']]
+        Gd = torch.from_numpy(z5['g_other']).to(dev)
+        lp = torch.stack([ops.conw_logprob(v, Gd) for v in vecs], 0)
+        agg, w = ops.conw_combine(vecs, lp, return_weights=True)
+        _close(lp.cpu().numpy(), z5['logprob'], 1e-5, 1e-5)
+        _close(w.cpu().numpy(), z5['weights'], 1e-4, 1e-6)
+    finally:
+        lib.cfl_set_exact_gemm(old)
