@@ -292,6 +292,10 @@ class MMFL(object):
         return loss
 
     def distill(self, round_n, img_vec, txt_vec, img_num, txt_num, distill_index):
+        # Multi-rank: the server phases are replicated, and the replicas stay identical only if their dropout draws are --
+        # but the ranks have just trained DIFFERENT clients and consumed the generators differently.  Rank 0 draws a seed,
+        # every rank re-seeds with it.
+        cdist.reseed_from_rank0(self.engine.device)
         self.engine.model.train()
         img_vec, txt_vec = self.aggregation(img_vec, txt_vec)
         self.img_vec, self.txt_vec = img_vec, txt_vec

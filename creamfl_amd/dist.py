@@ -39,9 +39,12 @@ def all_gather_cat(t, group=None):
         return t
     t = t.contiguous()
     if dist.get_backend(group) == 'gloo':
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t, group=group)
-        return torch.cat(parts, 0)
+        # test-only transport (CPU tests; two processes on one GPU in tests/test_gpu_multirank.py): gloo has no device
+        # all-gather, so device tensors take a host round trip
+        src = t.cpu() if t.is_cuda else t
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src, group=group)
+        return torch.cat(parts, 0).to(t.device)
     out = t.new_empty((world * t.shape[0],) + tuple(t.shape[1:]))
     dist.all_gather_into_tensor(out, t, group=group)
     return out
@@ -55,6 +58,18 @@ def broadcast_module(module, src=0, group=None):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src, group=group)
+
+
+def reseed_from_rank0(device=None, group=None):
+    """Give every rank the same torch generator state (host and device): rank 0 draws a seed, all ranks seed with it."""
+    rank, world = _world(group)
+    if world == 1:
+        return
+    seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+    if dist.get_backend(group) != 'gloo' and device is not None:
+        seed = seed.to(device)
+    dist.broadcast(seed, 0, group=group)
+    torch.manual_seed(int(seed.item()))
 
 
 class _GatherWithGrad(torch.autograd.Function):

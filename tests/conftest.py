@@ -40,7 +40,7 @@ def pytest_configure(config):
 # the trunk-glue tests (BatchNorm, BERT glue, pooling vs the library kernels) last -- with `-x` a glue failure must not
 # hide the parity run.
 _ORDER = ['test_oracle_golden', 'test_abi', 'test_host_logic', 'test_gpu_parity', 'test_gpu_configs', 'test_gpu_framework',
-          'test_gpu_optimizer', 'test_dist_gloo', 'test_gpu_bert', 'test_gpu_bnorm']
+          'test_gpu_optimizer', 'test_dist_gloo', 'test_gpu_multirank', 'test_gpu_bert', 'test_gpu_bnorm']
 
 
 def pytest_collection_modifyitems(session, config, items):
