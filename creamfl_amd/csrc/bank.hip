@@ -110,7 +110,13 @@ __global__ __launch_bounds__(256, 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, in
             }
         }
     };
-    if (x3mode) x3::tile_gemm_seq<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);
+    if (x3mode == 2)     // G, F are pre-split [hi | lo] images (launch_bank_fwd): direct-to-LDS staging, bf16 x 3 compute
+        tile_gemm_seq_glds_with<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn,
+                                        [](const float* sa, const float* sb, f32x16 (&acc)[TM][TN], int lane, int wr, int wc) {
+                                            x3::compute<TM, TN>(reinterpret_cast<const char*>(sa), reinterpret_cast<const char*>(sb), acc,
+                                                                lane, wr, wc);
+                                        });
+    else if (x3mode) x3::tile_gemm_seq<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);      // split while staging (registers)
     else if (glds_ok(G, F)) tile_gemm_seq_glds<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn);
     else tile_gemm_seq<TM, TN, true, true>(G, F, ntiles, tile_fn, lds, XfIdentity(), epi_fn);
     // back to natural-log units, then combine the two half-waves (different bank rows of the same feature row) ...
@@ -323,15 +329,6 @@ __global__ __launch_bounds__(256) void cfl_conw_combine_kernel(PtrPack V, const 
     if (W && lane < Cn) W[(size_t)lane * M + n] = expf(L[(size_t)lane * M + n] - mx) / den;
 }
 
-struct BankWs { float *part_m, *part_l, *slab; };
-static BankWs bank_ws(void* ws, const BankPlan& pl) {
-    BankWs w;
-    float* p = (float*)ws;
-    w.part_m = p; p += (size_t)pl.S * pl.Bp;
-    w.part_l = p; p += (size_t)pl.S * pl.Bp;
-    w.slab = p;
-    return w;
-}
 static int bwd_ksplits(int B, int M, int D, int BM, int BN, int* kper) {
     const int tiles = cfl_cdiv(B, BM) * cfl_cdiv(D, BN);
     int ks = cfl_cdiv(512, tiles);
@@ -344,12 +341,50 @@ static int bwd_ksplits(int B, int M, int D, int BM, int BN, int* kper) {
     return cfl_cdiv(M, per);
 }
 
+static size_t bank_slab_floats(int B, int M, int D) {          // split-K slabs of the two-pass backward (largest tile variant)
+    int kper;
+    int ks = bwd_ksplits(B, M, D, 128, 128, &kper);
+    const int ks2 = bwd_ksplits(B, M, D, 64, 64, &kper);
+    const int ks3 = bwd_ksplits(B, M, D, 128, 64, &kper);
+    ks = ks > ks2 ? ks : ks2;
+    return (size_t)(ks > ks3 ? ks : ks3) * B * D;
+}
+
+struct BankWs { float *part_m, *part_l, *img_g, *img_f, *slab; };
+// part_m | part_l | backward slabs [slab_floats] | pre-split image of the bank [M][Kp] | of the feature rows [B][Kp]
+static BankWs bank_ws(void* ws, const BankPlan& pl, int B, int M, int D, bool with_slab) {
+    const size_t slab_floats = with_slab ? bank_slab_floats(B, M, D) : 0;
+    BankWs w;
+    float* p = (float*)ws;
+    const size_t kp = (size_t)x3::image_kp(D);
+    w.part_m = p; p += (size_t)pl.S * pl.Bp;
+    w.part_l = p; p += (size_t)pl.S * pl.Bp;
+    w.slab = p; p += (slab_floats + 63) / 64 * 64;
+    w.img_g = p; p += (size_t)M * kp;
+    w.img_f = p;
+    return w;
+}
 static int launch_bank_fwd(const float* F, const float* G, int B, int M, int D, float inv_tau,
                            float* logits_t, const BankPlan& pl, const BankWs& w, hipStream_t stream) {
     Opnd Go{G, D, M, D, cfl_opnd_vec(G, D, D)};
     Opnd Fo{F, D, B, D, cfl_opnd_vec(F, D, D)};
     const dim3 grid(pl.S, cfl_cdiv(B, pl.BN));
-    const int x3mode = cfl_get_exact_gemm() ? 0 : 1;
+    // Pre-split images pay when the bank is re-read by many row groups (con_w: rows = M); a single client batch streams the
+    // bank once, where the extra pass over it (and its footprint in the Infinity Cache) costs more than it saves.
+    const int x3mode = cfl_get_exact_gemm() ? 0 : (B >= 1024 ? 2 : 1);
+    if (x3mode == 2) {
+        // split both operands once (a streaming pass, ~25 us per 51 MB) so that the GEMM itself stages with LDS-DMA and
+        // spends no VALU / ds_write on conversion: the bf16 x 3 core is 5x shorter per stage than the fp32 MFMA and would
+        // otherwise wait for the register staging
+        const int kp = x3::image_kp(D);
+        const long long qg = (long long)M * (kp / 4), qf = (long long)B * (kp / 4);
+        CFL_LAUNCH(K_PAIR_PREP, x3::split_image_kernel, dim3((unsigned)((qg + 255) / 256)), dim3(256), 0, stream, G, (long long)D, M, D, kp,
+                   w.img_g);
+        CFL_LAUNCH(K_PAIR_PREP, x3::split_image_kernel, dim3((unsigned)((qf + 255) / 256)), dim3(256), 0, stream, F, (long long)D, B, D, kp,
+                   w.img_f);
+        Go = Opnd{w.img_g, kp, M, kp, 1};
+        Fo = Opnd{w.img_f, kp, B, kp, 1};
+    }
     if (pl.TN == 1) {
         using C = TileCfg<2, 1, true, true>;
         CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<1>), grid, dim3(256), C::LDS_BYTES, stream,
@@ -370,13 +405,9 @@ extern "C" {
 size_t cfl_bank_ws_bytes(int B, int M, int D) {
     if (B <= 0 || M <= 0 || D <= 0) return 256;
     const BankPlan pl = bank_plan(B, M);
-    int kper;
-    int ks = bwd_ksplits(B, M, D, 128, 128, &kper);
-    const int ks2 = bwd_ksplits(B, M, D, 64, 64, &kper);
-    const int ks3 = bwd_ksplits(B, M, D, 128, 64, &kper);
-    ks = ks > ks2 ? ks : ks2;
-    const size_t slab = (size_t)(ks > ks3 ? ks : ks3) * B * D;
-    return cfl_align256((2 * (size_t)pl.S * pl.Bp + slab) * sizeof(float));
+    const size_t slab = (bank_slab_floats(B, M, D) + 63) / 64 * 64;
+    const size_t img = B >= 1024 ? ((size_t)M + B) * x3::image_kp(D) : 0;       // pre-split images: con_w-sized problems only
+    return cfl_align256((2 * (size_t)pl.S * pl.Bp + slab + img) * sizeof(float));
 }
 
 int cfl_bank_lse_fwd(const float* F, const float* G, const long long* idx, int B, int M, int D,
@@ -385,7 +416,7 @@ int cfl_bank_lse_fwd(const float* F, const float* G, const long long* idx, int B
     if (!F || !G || !idx || !lse || !pos || !ws || B <= 0 || M <= 0 || D <= 0 || !(inv_tau > 0.f)) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     const BankPlan pl = bank_plan(B, M);
-    BankWs w = bank_ws(ws, pl);
+    BankWs w = bank_ws(ws, pl, B, M, D, true);
     int rc = launch_bank_fwd(F, G, B, M, D, inv_tau, logits_t, pl, w, stream);
     if (rc) return rc;
     CFL_LAUNCH(K_LSE_FINAL, cfl_lse_final_kernel, dim3(cfl_cdiv(B, 4)), dim3(256), 0, stream,
@@ -399,7 +430,7 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
                      void* ws, void* stream_) {
     if (!logits_t || !G || !idx || !lse || !gout_dev || !dF || !ws || B <= 0 || M <= 0 || D <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    BankWs w = bank_ws(ws, bank_plan(B, M));
+    BankWs w = bank_ws(ws, bank_plan(B, M), B, M, D, true);
     Opnd P{logits_t, B, B, M, cfl_opnd_vec(logits_t, B, B)};
     Opnd Go{G, D, D, M, cfl_opnd_vec(G, D, D)};
     int kper = 0, ks = 0;
@@ -457,10 +488,10 @@ int cfl_kd_mse(const float* out, const float* agg, const long long* idx, int B, 
 size_t cfl_intra_ws_bytes(int B) { return cfl_align256((size_t)(B > 0 ? B : 1) * sizeof(float)); }
 
 size_t cfl_conw_ws_bytes(int rows, int M, int D) {
-    (void)D;
-    if (rows <= 0 || M <= 0) return 256;
+    if (rows <= 0 || M <= 0 || D <= 0) return 256;
     const BankPlan pl = bank_plan(rows, M);
-    return cfl_align256((2 * (size_t)pl.S * pl.Bp) * sizeof(float));
+    const size_t img = rows >= 1024 ? ((size_t)M + rows) * x3::image_kp(D) : 0;
+    return cfl_align256((2 * (size_t)pl.S * pl.Bp + img) * sizeof(float));
 }
 
 int cfl_conw_logprob(const float* V, const float* G, int M, int D, int row0, int rows,
@@ -468,7 +499,7 @@ int cfl_conw_logprob(const float* V, const float* G, int M, int D, int row0, int
     if (!V || !G || !out_l || !ws || M <= 0 || D <= 0 || rows <= 0 || row0 < 0 || row0 + rows > M) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     const BankPlan pl = bank_plan(rows, M);
-    BankWs w = bank_ws(ws, pl);
+    BankWs w = bank_ws(ws, pl, rows, M, D, false);
     const float* F = V + (long long)row0 * D;
     int rc = launch_bank_fwd(F, G, rows, M, D, 1.0f, nullptr, pl, w, stream);
     if (rc) return rc;

@@ -460,9 +460,11 @@ __device__ __forceinline__ bool glds_ok(const Opnd& A, const Opnd& B) {
     return A.vec && B.vec && (A.kdim % 32) == 0;
 }
 // Sequence of tiles, direct-to-LDS staging.  Same contract as tile_gemm_seq (KC/KC only, (kend-kbeg) % 32 == 0).
-template <int TM, int TN, class TileFn, class EpiFn>
-__device__ __forceinline__ void tile_gemm_seq_glds(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds,
-                                                   EpiFn epi_fn) {
+// ComputeFn(sa, sb, acc, lane, wr, wc) consumes one stage: tile_compute_swz (fp32 operands) or x3::compute on PRE-SPLIT
+// operand images (tile_x3.h: a 128-byte row block = [32 x bf16 hi | 32 x bf16 lo], the same bytes as 32 floats).
+template <int TM, int TN, class TileFn, class EpiFn, class ComputeFn>
+__device__ __forceinline__ void tile_gemm_seq_glds_with(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds,
+                                                        EpiFn epi_fn, ComputeFn compute_fn) {
     constexpr int BM = 64 * TM, BN = 64 * TN, STAGE = (BM + BN) * 32;
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -493,7 +495,7 @@ __device__ __forceinline__ void tile_gemm_seq_glds(const Opnd& A, const Opnd& B,
                 glds_stage<BM>(A, in_tile ? cur.row0 : nxt.row0, in_tile ? cur.kbeg + (kt + 1) * 32 : nxt.kbeg, da);
                 glds_stage<BN>(B, in_tile ? cur.col0 : nxt.col0, in_tile ? cur.kbeg + (kt + 1) * 32 : nxt.kbeg, da + BM * 32);
             }
-            tile_compute_swz<TM, TN>(sa, sa + BM * 32, acc, lane, wr, wc);
+            compute_fn(sa, sa + BM * 32, acc, lane, wr, wc);
             __syncthreads();                 // waits for the LDS-DMA of the next stage (vmcnt) and for all readers
             buf ^= 1;
         }
@@ -501,6 +503,14 @@ __device__ __forceinline__ void tile_gemm_seq_glds(const Opnd& A, const Opnd& B,
         cur = nxt;
     }
     __syncthreads();
+}
+template <int TM, int TN, class TileFn, class EpiFn>
+__device__ __forceinline__ void tile_gemm_seq_glds(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds,
+                                                   EpiFn epi_fn) {
+    tile_gemm_seq_glds_with<TM, TN>(A, B, ntiles, tile_fn, lds, epi_fn,
+                                    [](const float* sa, const float* sb, f32x16 (&acc)[TM][TN], int lane, int wr, int wc) {
+                                        tile_compute_swz<TM, TN>(sa, sb, acc, lane, wr, wc);
+                                    });
 }
 
 // Single tile, direct-to-LDS staging: acc = A[row0.., k] * B[col0.., k]^T over k in [kbeg, kend), (kend-kbeg) % 32 == 0.

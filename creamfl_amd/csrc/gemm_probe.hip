@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256, 2) void cfl_gemm_nt_kernel(Opnd A, Opnd B, int
     const int row0 = ti * C::BM, col0 = tj * C::BN;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
     f32x16 acc[TM][TN];
-    if (x3mode) x3::tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
+    if (x3mode) x3::tile_gemm_pipelined<TM, TN, true, true, 2>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
     else if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
     else tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
 #pragma unroll

@@ -166,15 +166,18 @@ struct Cfg {
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;        // <= TileCfg<TM, TN, *, *>::LDS_BYTES of common.h
 };
 
-// A SEQUENCE of output tiles through one software pipeline with PREFETCH DISTANCE 2: two register sets alternate, so the
-// global loads of stage s + 2 are issued before the MFMA block of stage s and only converted + written to LDS after the MFMA
-// block of stage s + 1 (with the bf16 core a stage is ~770 matrix-pipe cycles, shorter than an L2 round trip: distance 1
-// left the loads exposed).  tile_fn(i) -> TileDesc for i in [0, ntiles); epi_fn(i, acc) consumes the finished accumulators
+// A SEQUENCE of output tiles through one software pipeline.  DIST = prefetch distance in stages: 1 = the loads of stage
+// s + 1 are issued before the MFMA block of stage s and converted + written after it (one register set); 2 = two register
+// sets alternate, loads of stage s + 2 issued before the MFMA block of stage s and committed after that of stage s + 1 (a
+// bf16 stage is ~770 matrix-pipe cycles, shorter than an L2 round trip).  Measured: 2 helps the plain GEMM (4096^3: 200 ->
+// 210-232 TFLOP/s); routed through this generic cursor pipeline the kernels with register-hungry epilogues or K-strided
+// operands got slower (pair-loss forward 166 -> 241 us, bank backward 136 -> 233 us), so those use the plain loops below and
+// only the GEMM probe uses this one.  tile_fn(i) -> TileDesc for i in [0, ntiles); epi_fn(i, acc) consumes the finished accumulators
 // of tile i (must not touch `lds`).  Stages = every (tile, 32-deep K step) in order; the stage stream runs across tile
 // boundaries.  All 256 threads must call; the LDS (Cfg::LDS_BYTES) is free on return.
 struct Cursor { int i, kt, nk; TileDesc d; };
 
-template <int TM, int TN, bool A_KC, bool B_KC, class XfA, class TileFn, class EpiFn>
+template <int TM, int TN, bool A_KC, bool B_KC, int DIST, class XfA, class TileFn, class EpiFn>
 __device__ __forceinline__ void gemm_pipeline(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds_f, XfA xfa,
                                               EpiFn epi_fn) {
     using C = Cfg<TM, TN>;
@@ -208,7 +211,7 @@ __device__ __forceinline__ void gemm_pipeline(const Opnd& A, const Opnd& B, int 
     Cursor cur = open_tile(0), c1 = next(cur), c2 = next(c1);
     issue(cur, ra0, rb0);
     commit(cur, ra0, rb0, lds);
-    if (valid(c1)) issue(c1, ra1, rb1);
+    if (DIST == 2 && valid(c1)) issue(c1, ra1, rb1);
     __syncthreads();
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -218,10 +221,12 @@ __device__ __forceinline__ void gemm_pipeline(const Opnd& A, const Opnd& B, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     int buf = 0;
-    // one pipeline step: stage `cur` is in LDS buffer `buf`; `rin` holds stage c1 (in flight); `rout` is free for stage c2
+    // one pipeline step: stage `cur` is in LDS buffer `buf`.  DIST 2: `r*_in` holds stage c1 (in flight since the previous
+    // step), `r*_out` is free for stage c2.  DIST 1: one register set, stage c1 is issued and committed within the step.
     auto step = [&](StageRegs<A_KC, C::BM>& ra_in, StageRegs<B_KC, C::BN>& rb_in, StageRegs<A_KC, C::BM>& ra_out,
                     StageRegs<B_KC, C::BN>& rb_out) {
-        if (valid(c2)) issue(c2, ra_out, rb_out);
+        if (DIST == 2) { if (valid(c2)) issue(c2, ra_out, rb_out); }
+        else if (valid(c1)) issue(c1, ra_in, rb_in);
         const char* sa = lds + buf * C::STAGE_BYTES;
         compute<TM, TN>(sa, sa + C::BM * 128, acc, lane, wr, wc);
         if (valid(c1)) commit(c1, ra_in, rb_in, lds + (buf ^ 1) * C::STAGE_BYTES);
@@ -238,17 +243,21 @@ __device__ __forceinline__ void gemm_pipeline(const Opnd& A, const Opnd& B, int 
         buf ^= 1;
         cur = c1; c1 = c2; c2 = next(c2);
     };
-    while (valid(cur)) {
-        step(ra1, rb1, ra0, rb0);
-        if (!valid(cur)) break;
-        step(ra0, rb0, ra1, rb1);
+    if (DIST == 2) {
+        while (valid(cur)) {
+            step(ra1, rb1, ra0, rb0);
+            if (!valid(cur)) break;
+            step(ra0, rb0, ra1, rb1);
+        }
+    } else {
+        while (valid(cur)) step(ra0, rb0, ra0, rb0);
     }
 }
 
-// Single tile: acc = A[row0.., k] * B[col0.., k]^T over k in [kbeg, kend).  Same contract as tile_gemm of common.h.
-template <int TM, int TN, bool A_KC, bool B_KC, class XfA>
-__device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0, int col0, int kbeg, int kend, float* lds_f,
-                                          f32x16 (&acc)[TM][TN], XfA xfa) {
+// Single tile through the two-register-set pipeline (used by the GEMM probe).
+template <int TM, int TN, bool A_KC, bool B_KC, int DIST, class XfA>
+__device__ __forceinline__ void tile_gemm_pipelined(const Opnd& A, const Opnd& B, int row0, int col0, int kbeg, int kend,
+                                                    float* lds_f, f32x16 (&acc)[TM][TN], XfA xfa) {
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -256,19 +265,133 @@ __device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     if (kend <= kbeg) return;
-    gemm_pipeline<TM, TN, A_KC, B_KC>(A, B, 1, [&](int) { return TileDesc{row0, col0, kbeg, kend}; }, lds_f, xfa,
-                                      [&](int, const f32x16 (&a)[TM][TN]) {
+    gemm_pipeline<TM, TN, A_KC, B_KC, DIST>(A, B, 1, [&](int) { return TileDesc{row0, col0, kbeg, kend}; }, lds_f, xfa,
+                                            [&](int, const f32x16 (&a)[TM][TN]) {
 #pragma unroll
-                                          for (int m = 0; m < TM; ++m)
+                                                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                                              for (int n = 0; n < TN; ++n) acc[m][n] = a[m][n];
-                                      });
+                                                    for (int n = 0; n < TN; ++n) acc[m][n] = a[m][n];
+                                            });
 }
 
-// A sequence of tiles, both operands K-contiguous; contract of tile_gemm_seq of common.h.
+// Single tile: acc = A[row0.., k] * B[col0.., k]^T over k in [kbeg, kend).  Same contract as tile_gemm of common.h
+// ((kend - kbeg) % 32 == 0 unless kend == kdim; all 256 threads call; the LDS stage is free on return).  Plain loop,
+// prefetch distance 1: the form the kernels with register-hungry epilogues / K-strided operands run fastest with.
+template <int TM, int TN, bool A_KC, bool B_KC, class XfA>
+__device__ __forceinline__ void tile_gemm(const Opnd& A, const Opnd& B, int row0, int col0, int kbeg, int kend, float* lds_f,
+                                          f32x16 (&acc)[TM][TN], XfA xfa) {
+    using C = Cfg<TM, TN>;
+    char* lds = reinterpret_cast<char*>(lds_f);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int nk = (kend - kbeg + 31) / 32;
+    if (nk <= 0) return;
+    StageRegs<A_KC, C::BM> ra;
+    StageRegs<B_KC, C::BN> rb;
+    stage<A_KC, C::BM, 0>(A, row0, kbeg, ra, lds, xfa);
+    stage<B_KC, C::BN, 0>(B, col0, kbeg, rb, lds, XfIdentity());
+    stage<A_KC, C::BM, 1>(A, row0, kbeg, ra, lds, xfa);
+    stage<B_KC, C::BN, 1>(B, col0, kbeg, rb, lds + C::BM * 128, XfIdentity());
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sa = lds + (kt & 1) * C::STAGE_BYTES;
+        char* da = lds + ((kt + 1) & 1) * C::STAGE_BYTES;
+        const bool more = kt + 1 < nk;
+        const int k1 = kbeg + (kt + 1) * 32;
+        if (more) {
+            stage<A_KC, C::BM, 0>(A, row0, k1, ra, da, xfa);
+            stage<B_KC, C::BN, 0>(B, col0, k1, rb, da, XfIdentity());
+        }
+        compute<TM, TN>(sa, sa + C::BM * 128, acc, lane, wr, wc);
+        if (more) {
+            stage<A_KC, C::BM, 1>(A, row0, k1, ra, da, xfa);
+            stage<B_KC, C::BN, 1>(B, col0, k1, rb, da + C::BM * 128, XfIdentity());
+        }
+        __syncthreads();
+    }
+}
+
+// A SEQUENCE of output tiles through one software pipeline (both operands K-contiguous); contract of tile_gemm_seq.
 template <int TM, int TN, class TileFn, class EpiFn>
 __device__ __forceinline__ void tile_gemm_seq(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds_f, EpiFn epi_fn) {
-    gemm_pipeline<TM, TN, true, true>(A, B, ntiles, tile_fn, lds_f, XfIdentity(), epi_fn);
+    using C = Cfg<TM, TN>;
+    char* lds = reinterpret_cast<char*>(lds_f);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
+    if (ntiles <= 0) return;
+    StageRegs<true, C::BM> ra;
+    StageRegs<true, C::BN> rb;
+    TileDesc cur = tile_fn(0);
+    stage<true, C::BM, 0>(A, cur.row0, cur.kbeg, ra, lds, XfIdentity());
+    stage<true, C::BN, 0>(B, cur.col0, cur.kbeg, rb, lds, XfIdentity());
+    stage<true, C::BM, 1>(A, cur.row0, cur.kbeg, ra, lds, XfIdentity());
+    stage<true, C::BN, 1>(B, cur.col0, cur.kbeg, rb, lds + C::BM * 128, XfIdentity());
+    __syncthreads();
+    int buf = 0;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < ntiles; ++i) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        const int nk = (cur.kend - cur.kbeg + 31) / 32;
+        const bool has_next = i + 1 < ntiles;
+        TileDesc nxt = cur;
+        if (has_next) nxt = tile_fn(i + 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sa = lds + buf * C::STAGE_BYTES;
+            char* da = lds + (buf ^ 1) * C::STAGE_BYTES;
+            const bool in_tile = kt + 1 < nk;
+            const bool more = in_tile || has_next;
+            const int r0 = in_tile ? cur.row0 : nxt.row0, c0 = in_tile ? cur.col0 : nxt.col0;
+            const int k0 = in_tile ? cur.kbeg + (kt + 1) * 32 : nxt.kbeg;
+            if (more) {
+                stage<true, C::BM, 0>(A, r0, k0, ra, da, XfIdentity());
+                stage<true, C::BN, 0>(B, c0, k0, rb, da, XfIdentity());
+            }
+            compute<TM, TN>(sa, sa + C::BM * 128, acc, lane, wr, wc);
+            if (more) {
+                stage<true, C::BM, 1>(A, r0, k0, ra, da, XfIdentity());
+                stage<true, C::BN, 1>(B, c0, k0, rb, da + C::BM * 128, XfIdentity());
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        epi_fn(i, acc);
+        cur = nxt;
+    }
+    __syncthreads();
+}
+
+// ---- pre-split operand images ------------------------------------------------------------------------------------------------
+// image[r][kb] (128 bytes) = { bf16 hi of src[r][32 kb .. 32 kb + 31], then their bf16 lo }, kb < Kp / 32, Kp = K rounded up to
+// 32 (zero padded).  Byte-for-byte the size of the fp32 matrix with K padded: an Opnd {image as float*, ld = Kp, rows, kdim =
+// Kp, vec = 1} drives the unchanged direct-to-LDS staging of common.h, and x3::compute reads the stage.
+static inline int image_kp(int K) { return (K + 31) / 32 * 32; }
+
+static __global__ __launch_bounds__(256) void split_image_kernel(const float* __restrict__ src, long long ld, int rows, int K, int Kp,
+                                                          float* __restrict__ image) {
+    const long long quads_per_row = Kp / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads_per_row * rows) return;
+    const int r = (int)(i / quads_per_row), k = (int)(i % quads_per_row) * 4;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = (k + e < K) ? src[(long long)r * ld + k + e] : 0.f;
+        __bf16 h, l;
+        split1(x, h, l);
+        hi[e] = h; lo[e] = l;
+    }
+    char* blk = reinterpret_cast<char*>(image) + ((long long)r * Kp + (k & ~31)) * 4;
+    *reinterpret_cast<bf16x4*>(blk + (k & 31) * 2) = hi;
+    *reinterpret_cast<bf16x4*>(blk + 64 + (k & 31) * 2) = lo;
 }
 
 }  // namespace x3
