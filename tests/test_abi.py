@@ -41,7 +41,8 @@ def test_identity_calls_without_gpu():
     # workspace-size helpers are pure host arithmetic
     assert lib.cfl_pair_loss_ws_bytes(256, 512) >= 5 * 256 * 4
     assert lib.cfl_bank_ws_bytes(128, 50000, 256) > 0
-    assert lib.cfl_conw_ws_bytes(50000, 50000, 256) < 64 << 20
+    # con_w scratch = split partials + the two pre-split operand images (M * D * 4 bytes each): never the [M, M] logits (10 GB)
+    assert lib.cfl_conw_ws_bytes(50000, 50000, 256) < 3 * 50000 * 256 * 4
     assert lib.cfl_rank_ws_bytes(5000, 25000, 512) >= 5000 * 8
 
 
