@@ -67,6 +67,9 @@ SIGNATURES = {
     'cfl_pie_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'cfl_pie_pool_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'cfl_pie_pool_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    'cfl_pie_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'cfl_pie_head_fwd': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    'cfl_pie_head_bwd': (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'cfl_pie_epilogue_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
     'cfl_pie_epilogue_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_l2norm_fwd': (c_int, [_P, c_int, c_int, _P, _P, _P]),

@@ -273,16 +273,18 @@ __global__ __launch_bounds__(256) void cfl_pie_epi_bwd_kernel(const float* __res
         d_res_pre[base + k] = dr * rv * (1.f - rv);
     }
 }
-// d_ln_w[j] = sum_n go[n,j] xhat[n,j], d_ln_b[j] = sum_n go[n,j].  grid ceil(D/64); lanes = columns, waves = rows.
-__global__ __launch_bounds__(256) void cfl_pie_epi_bwd_ln_kernel(const float* __restrict__ go, const float* __restrict__ out,
-                                                                 const float* __restrict__ r, const float* __restrict__ stats,
-                                                                 int N, int D, float* d_lw, float* d_lb) {
-    __shared__ float sw[4][64], sb[4][64];
+// d_ln_w[j] = sum_n go[n,j] xhat[n,j], d_ln_b[j] = sum_n go[n,j].  grid ceil(D/64); lanes = columns, 16 waves = row phases
+// (the rows of a wave are a serial chain of dependent-latency loads: 16 waves instead of 4 quarter that chain).
+__global__ __launch_bounds__(1024) void cfl_pie_epi_bwd_ln_kernel(const float* __restrict__ go, const float* __restrict__ out,
+                                                                  const float* __restrict__ r, const float* __restrict__ stats,
+                                                                  int N, int D, float* d_lw, float* d_lb) {
+    __shared__ float sw[16][64], sb[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
     float aw = 0.f, ab = 0.f;
     if (j < D) {
-        for (int n = w; n < N; n += 4) {
+#pragma unroll 4
+        for (int n = w; n < N; n += 16) {
             const long long e = (long long)n * D + j;
             const float xh = (out[e] + r[e] - stats[n * 4 + 0]) * stats[n * 4 + 1];
             const float g = go[e];
@@ -292,8 +294,11 @@ __global__ __launch_bounds__(256) void cfl_pie_epi_bwd_ln_kernel(const float* __
     sw[w][lane] = aw; sb[w][lane] = ab;
     __syncthreads();
     if (w == 0 && j < D) {
-        d_lw[j] = sw[0][lane] + sw[1][lane] + sw[2][lane] + sw[3][lane];
-        d_lb[j] = sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a += sw[i][lane]; b += sb[i][lane]; }
+        d_lw[j] = a;
+        d_lb[j] = b;
     }
 }
 
@@ -329,7 +334,8 @@ size_t cfl_pie_ws_bytes(int N, int P, int Cd, int dh) {
     if (N <= 0 || P <= 0) return 256;
     const size_t rows = (size_t)N * P;
     const size_t nch = (rows + PIE_RC - 1) / PIE_RC;
-    size_t a = rows + nch * (size_t)(dh > 0 ? dh : 1);        // pool: scores/ds + dw2 partials
+    const size_t npart = nch > (size_t)N ? nch : (size_t)N;     // pie.hip: partials per row chunk; pie_fused.hip: per sample
+    size_t a = rows + npart * (size_t)(dh > 0 ? dh : 1);      // pool: scores/ds + dw2 partials
     size_t b = (size_t)N * (size_t)(Cd > 0 ? Cd : 1);         // epilogue: go [N, D] (call with Cd = D)
     return cfl_align256((a > b ? a : b) * sizeof(float));
 }
@@ -395,7 +401,7 @@ int cfl_pie_epilogue_bwd(const float* dy, const float* do_, const float* dres, c
     float* go = (float*)ws;
     CFL_LAUNCH(K_PIE_EPI_BWD, cfl_pie_epi_bwd_kernel, dim3(cfl_cdiv(N, 4)), dim3(256), 0, stream,
                dy, do_, dres, out, r, ln_w, ln_b, stats, N, D, flags, d_out, d_res_pre, go);
-    CFL_LAUNCH(K_PIE_EPI_BWD_LN, cfl_pie_epi_bwd_ln_kernel, dim3(cfl_cdiv(D, 64)), dim3(256), 0, stream,
+    CFL_LAUNCH(K_PIE_EPI_BWD_LN, cfl_pie_epi_bwd_ln_kernel, dim3(cfl_cdiv(D, 64)), dim3(1024), 0, stream,
                go, out, r, stats, N, D, d_ln_w, d_ln_b);
     return 0;
 }

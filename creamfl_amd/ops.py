@@ -460,19 +460,68 @@ class _PiePoolFn(torch.autograd.Function):
         return dX, dH, dw2, None, None
 
 
+class _PieHeadFn(torch.autograd.Function):
+    """Single-pass attention pooling (csrc/pie_fused.hip): X / H in the dtype they were produced in (fp32 or bf16)."""
+
+    @staticmethod
+    def forward(ctx, X, H, w2, mask, want_mean):
+        lib = _lib.load()
+        N, P, Cd = X.shape
+        dh = H.shape[2]
+        dev = X.device
+        bf16 = int(X.dtype == torch.bfloat16)
+        attn = torch.empty(N, P, dtype=torch.float32, device=dev)
+        pooled = torch.empty(N, Cd, dtype=torch.float32, device=dev)
+        xmean = torch.empty(N, Cd, dtype=torch.float32, device=dev) if want_mean else None
+        _lib.check(lib.cfl_pie_head_fwd(_ptr(X), _ptr(H), bf16, _ptr(w2), _ptr(mask), N, P, Cd, dh, _ptr(attn), _ptr(pooled),
+                                        _ptr(xmean), _stream(X)), 'cfl_pie_head_fwd')
+        ctx.save_for_backward(X, H, w2, attn)
+        ctx.want_mean = want_mean
+        ctx.mark_non_differentiable(attn)
+        if want_mean:
+            return pooled, attn, xmean
+        return pooled, attn, pooled.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, dpooled, _dattn, dxmean):
+        lib = _lib.load()
+        X, H, w2, attn = ctx.saved_tensors
+        N, P, Cd = X.shape
+        dh = H.shape[2]
+        dpooled = dpooled.contiguous().float()
+        dxm = dxmean.contiguous().float() if ctx.want_mean else None
+        dX = torch.empty_like(X)
+        dH = torch.empty_like(H)
+        dw2 = torch.empty_like(w2)
+        ws = _ws(lib.cfl_pie_ws_bytes(N, P, Cd, dh), X.device)
+        _lib.check(lib.cfl_pie_head_bwd(_ptr(X), _ptr(H), int(X.dtype == torch.bfloat16), _ptr(w2), _ptr(attn), _ptr(dpooled),
+                                        _ptr(dxm), N, P, Cd, dh, _ptr(dX), _ptr(dH), _ptr(dw2), _ptr(ws), _stream(X)),
+                   'cfl_pie_head_bwd')
+        return dX, dH, dw2, None, None
+
+
+PIE_FUSED = _os.environ.get('CFL_PIE_UNFUSED', '0') != '1'      # tests flip this to compare the two implementations
+
+
 def pie_pool(x, h, w2, pad_mask=None, want_mean=False):
     """softmax_P(w2 . tanh(h)) attention pooling of x (pie_model.py:28-40, n_head = 1).
     x [N,P,Cd], h = w_1(x) [N,P,dh], w2 [dh] or [1,dh], pad_mask [N,P] bool (True = padded).
-    Returns (pooled [N,Cd], attn [N,P], xmean [N,Cd] or empty)."""
-    X = _f32(x, 'x')
-    H = _f32(h, 'h')
+    Returns (pooled [N,Cd], attn [N,P], xmean [N,Cd] or empty).
+    fp32 or bf16 x / h (the autocast regime hands over bf16) go through the single-pass kernels in that dtype when the
+    shape allows (cfl_pie_fused_supported); anything else is converted to fp32 for the three-pass kernels of pie.hip."""
+    if not (torch.is_tensor(x) and x.is_cuda and torch.is_tensor(h) and h.is_cuda):
+        raise _lib.CreamflHipError('pie_pool: expected CUDA/HIP tensors (no CPU fallback in creamfl_amd)')
     W2 = _f32(w2, 'w2').reshape(-1)
-    if X.dim() != 3 or H.dim() != 3 or X.shape[:2] != H.shape[:2] or W2.numel() != H.shape[2]:
-        raise RuntimeError(f'pie_pool shape mismatch x{tuple(X.shape)} h{tuple(H.shape)} w2{tuple(W2.shape)}')
+    if x.dim() != 3 or h.dim() != 3 or x.shape[:2] != h.shape[:2] or W2.numel() != h.shape[2]:
+        raise RuntimeError(f'pie_pool shape mismatch x{tuple(x.shape)} h{tuple(h.shape)} w2{tuple(W2.shape)}')
     m = None
     if pad_mask is not None:
-        m = pad_mask.to(device=X.device, dtype=torch.uint8).contiguous()
-    return _PiePoolFn.apply(X, H, W2, m, bool(want_mean))
+        m = pad_mask.to(device=x.device, dtype=torch.uint8).contiguous()
+    N, P, Cd = x.shape
+    if (PIE_FUSED and x.dtype == h.dtype and x.dtype in (torch.float32, torch.bfloat16)
+            and _lib.load().cfl_pie_fused_supported(N, P, Cd, h.shape[2], int(x.dtype == torch.bfloat16))):
+        return _PieHeadFn.apply(x.contiguous(), h.contiguous(), W2, m, bool(want_mean))
+    return _PiePoolFn.apply(_f32(x, 'x'), _f32(h, 'h'), W2, m, bool(want_mean))
 
 
 class _PieEpilogueFn(torch.autograd.Function):

@@ -262,6 +262,19 @@ int cfl_pie_pool_bwd(const float* X, const float* H, const float* w2, const unsi
                      const float* attn, const float* d_pooled, const float* d_xmean,
                      int N, int P, int Cd, int dh, float* dX, float* dH, float* dw2,
                      void* ws, void* stream);
+/* Single-pass form of the two pool entry points (csrc/pie_fused.hip): X and H are read once per direction in the element
+ * type the trunk / the w_1 GEMM produced (bf16 != 0: bfloat16 -- the autocast regime -- else fp32; fp32 arithmetic either
+ * way) and dX / dH are written in that type.  Same math as cfl_pie_pool_fwd/bwd (pie_model.py:28-40,
+ * image_encoder.py:54-57); tanh through exp2/rcp (absolute error <= 3e-7).
+ *   cfl_pie_fused_supported: 1 when P <= 1024, Cd and dh multiples of the 16-byte vector (4 fp32 / 8 bf16), Cd <= 8192, dh <= 4096;
+ *   otherwise use cfl_pie_pool_fwd/bwd on fp32 copies (the GRU text head, dh = 150).
+ *   head_bwd ws: cfl_pie_ws_bytes(N, P, Cd, dh).  All tensor pointers 16-byte aligned. */
+int cfl_pie_fused_supported(int N, int P, int Cd, int dh, int bf16);
+int cfl_pie_head_fwd(const void* X, const void* H, int bf16, const float* w2, const unsigned char* mask,
+                     int N, int P, int Cd, int dh, float* attn, float* pooled, float* xmean, void* stream);
+int cfl_pie_head_bwd(const void* X, const void* H, int bf16, const float* w2, const float* attn,
+                     const float* d_pooled, const float* d_xmean, int N, int P, int Cd, int dh,
+                     void* dX, void* dH, float* dw2, void* ws, void* stream);
 int cfl_pie_epilogue_fwd(const float* out, const float* res_pre, const float* ln_w, const float* ln_b,
                          int N, int D, float ln_eps, int flags, float* y, float* o, float* r,
                          float* stats, void* stream);

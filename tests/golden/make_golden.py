@@ -80,7 +80,8 @@ def make_a1(probemb):
 
 def make_a2(pie_model, tensor_utils):
     cases = [('small', 3, 10, 64, 32, 32, False, 11), ('wide', 2, 49, 1024, 64, 64, False, 12),
-             ('gru_mask', 5, 12, 300, 256, 150, True, 13), ('r18', 3, 49, 512, 128, 256, False, 14)]
+             ('gru_mask', 5, 12, 300, 256, 150, True, 13), ('r18', 3, 49, 512, 128, 256, False, 14),
+             ('mask_vec', 4, 12, 64, 48, 40, True, 15)]      # pad mask on vector-friendly widths (single-pass kernels)
     for (tag, b, p, cd, d, dh, masked, seed) in cases:
         torch.manual_seed(seed)
         net = pie_model.PIENet(1, cd, d, dh)
@@ -495,6 +496,9 @@ def main():
     pie_model = _load_by_path('pie_model', 'src/networks/models/pie_model.py')
     # eval_coco does `from src.utils.tensor_utils import to_numpy` (importable) and tqdm
     eval_coco = _load_by_path('ref_eval_coco', 'src/algorithms/eval_coco.py')
+    if '--only-a2' in sys.argv:                               # one family (the others are not rewritten)
+        make_a2(pie_model, tensor_utils)
+        return
     make_a1(probemb)
     make_a2(pie_model, tensor_utils)
     make_a34(losses_mod)

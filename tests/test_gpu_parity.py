@@ -256,10 +256,14 @@ NAMES = ['attention__w_1__weight', 'attention__w_2__weight', 'fc__weight', 'fc__
          'layer_norm__weight', 'layer_norm__bias']
 
 
+@pytest.mark.parametrize('fused', [True, False], ids=['single_pass', 'three_pass'])
 @pytest.mark.parametrize('fname', golden_files('a2_'))
-def test_a2_pie_head_golden(dev, fname):
+def test_a2_pie_head_golden(dev, fname, fused, monkeypatch):
+    """both implementations of the attention pooling (csrc/pie_fused.hip where the widths allow, csrc/pie.hip) against the
+    reference's PIENet outputs and gradients."""
     from creamfl_amd.networks.models.pie_model import PIENet
     from creamfl_amd import ops
+    monkeypatch.setattr(ops, 'PIE_FUSED', fused)
     z = _load(fname)
     cd, d, dh = z['x'].shape[2], z['out'].shape[1], z['p_attention__w_1__weight'].shape[0]
     net = PIENet(1, cd, d, dh).to(dev)
@@ -320,6 +324,47 @@ def test_a2_fused_image_head_vs_oracle(dev, n, p, cd, dh, d):
     want = run(torch.device('cpu'), False)
     for i, (g_, w_) in enumerate(zip(got, want)):
         _close(g_, w_, 2e-3, 2e-4 * max(np.abs(w_).max(), 1e-8), f'tensor {i}')
+
+
+@pytest.mark.parametrize('n,p,cd,dh,masked', [(256, 49, 2048, 1024, False), (5, 49, 512, 256, False), (7, 12, 304, 152, True),
+                                              (3, 1000, 64, 64, True), (40, 49, 768, 384, False), (2, 5, 8, 8, False)])
+def test_a2_pool_bf16_operands_single_pass(dev, n, p, cd, dh, masked, monkeypatch):
+    """autocast regime: bf16 X / H go through the single-pass kernels unconverted; result == the fp32 three-pass kernels
+    on the same (bf16-valued) operands, dX / dH rounded to bf16 once."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(n + cd)
+    X = torch.randn(n, p, cd, generator=gen).bfloat16()
+    H = (torch.randn(n, p, dh, generator=gen) * 1.5).bfloat16()
+    w2 = torch.randn(dh, generator=gen) / dh ** 0.5
+    gp = torch.randn(n, cd, generator=gen)
+    gm = torch.randn(n, cd, generator=gen)
+    mask = None
+    if masked:
+        lens = torch.randint(1, p + 1, (n,), generator=gen)
+        mask = (torch.arange(p)[None, :] >= lens[:, None]).to(dev)
+
+    def run(fused, dtype):
+        monkeypatch.setattr(ops, 'PIE_FUSED', fused)
+        x = X.to(dev, dtype).requires_grad_(True)
+        h = H.to(dev, dtype).requires_grad_(True)
+        w = w2.to(dev).requires_grad_(True)
+        pooled, attn, xmean = ops.pie_pool(x, h, w, mask, want_mean=True)
+        ((pooled * gp.to(dev)).sum() + (xmean * gm.to(dev)).sum()).backward()
+        return [t.detach().float().cpu().numpy() for t in (pooled, attn, xmean, x.grad, h.grad, w.grad)], x.grad.dtype
+
+    assert ops._lib.load().cfl_pie_fused_supported(n, p, cd, dh, 1) == 1
+    got, gdt = run(True, torch.bfloat16)
+    assert gdt == torch.bfloat16
+    want, _ = run(False, torch.float32)
+    f32, _ = run(True, torch.float32)
+    names = ['pooled', 'attn', 'xmean', 'dX', 'dH', 'dw2']
+    for nm, g_, w_, f_ in zip(names, got, want, f32):
+        scale = max(float(np.abs(w_).max()), 1e-8)
+        _close(f_, w_, 1e-4, 2e-6 * scale, nm + ' (fp32 single pass vs three pass)')
+        if nm in ('dX', 'dH'):                               # one bf16 rounding (2^-8 relative)
+            _close(g_, w_, 4.5e-3, 1e-5 * scale, nm + ' (bf16)')
+        else:
+            _close(g_, w_, 1e-4, 2e-6 * scale, nm + ' (bf16 operands)')
 
 
 # ------------------------------------------------------------------------------------------ A6

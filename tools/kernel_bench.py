@@ -106,10 +106,10 @@ def case_a5(M, D, C=1):
             'algo_TFLOPs': round(flops / us / 1e6, 2)}
 
 
-def case_a2(N, P, Cd, dh, D):
+def case_a2(N, P, Cd, dh, D, dtype=torch.float32):
     g = torch.Generator(device='cuda').manual_seed(3)
-    X = torch.randn(N, P, Cd, generator=g, device='cuda', requires_grad=True)
-    H = torch.randn(N, P, dh, generator=g, device='cuda', requires_grad=True)
+    X = torch.randn(N, P, Cd, generator=g, device='cuda').to(dtype).requires_grad_(True)
+    H = torch.randn(N, P, dh, generator=g, device='cuda').to(dtype).requires_grad_(True)
     w2 = (torch.randn(dh, generator=g, device='cuda') / dh ** 0.5).requires_grad_(True)
     out = torch.randn(N, D, generator=g, device='cuda', requires_grad=True)
     rp = torch.randn(N, D, generator=g, device='cuda', requires_grad=True)
@@ -121,8 +121,8 @@ def case_a2(N, P, Cd, dh, D):
         y, o, r = ops.pie_epilogue(out, rp, lw, lb)
         (pooled.sum() + xm.sum() + y.sum()).backward()
     us, prof = timed(step)
-    fwd_bytes = N * P * (Cd + dh) * 4
-    return {'case': f'a2_pie_head N={N} P={P} Cd={Cd} dh={dh} D={D}', 'us_per_step': round(us, 1),
+    fwd_bytes = N * P * (Cd + dh) * X.element_size()
+    return {'case': f'a2_pie_head N={N} P={P} Cd={Cd} dh={dh} D={D} {str(dtype)[6:]}', 'us_per_step': round(us, 1),
             'kernels_us': prof, 'fwd_algo_MB': round(fwd_bytes / 1e6, 1)}
 
 
@@ -319,7 +319,7 @@ def main():
     if 'a5' in cases:
         out += [case_a5(args.conw_m, 256)]
     if 'a2' in cases:
-        out += [case_a2(256, 49, 2048, 1024, 512), case_a2(128, 49, 512, 256, 256)]
+        out += [case_a2(256, 49, 2048, 1024, 512), case_a2(256, 49, 2048, 1024, 512, torch.bfloat16), case_a2(128, 49, 512, 256, 256)]
     if 'a6' in cases:
         out += [case_a6(1000, 5000, 512), case_a6(5000, 25000, 512)]
     if 'f4' in cases:
