@@ -395,6 +395,7 @@ def main():
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()
     if use_dp:
+        torch.distributed.barrier()           # rank 0 is still writing its line (recall evaluation): tear down together
         torch.distributed.destroy_process_group()
 
 
