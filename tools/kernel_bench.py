@@ -189,8 +189,9 @@ def case_bn(N, H, C, res, relu=True):
             r.grad = None
     us, prof = timed(step, iters=10)
     E = N * H * H * C * 2                                   # bytes of one bf16 activation pass
-    passes = {'cfl_bn_stats_kernel': 1, 'cfl_bn_apply_kernel': 3 if res else 2, 'cfl_bn_bwd_reduce_kernel': 3 if relu else 2,
-              'cfl_bn_bwd_apply_kernel': (5 if res else 4) if relu else 3}
+    # bf16 passes per kernel (the ReLU mask is recomputed from x without a residual and is 1 bit / element with one)
+    passes = {'cfl_bn_stats_kernel': 1, 'cfl_bn_apply_kernel': 3 if res else 2, 'cfl_bn_bwd_reduce_kernel': 2 + (1 / 16 if res and relu else 0),
+              'cfl_bn_bwd_apply_kernel': (4 + 1 / 16 if res else 3)}
     gbps = {k: round(passes[k] * E / v / 1e3) for k, v in prof.items() if k in passes}
     return {'case': f'bn N={N} HxW={H}x{H} C={C} res={int(res)} relu={int(relu)}', 'MB_per_pass': round(E / 1e6, 1),
             'kernels_us': prof, 'kernels_GBps': gbps}
