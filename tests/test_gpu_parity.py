@@ -382,6 +382,29 @@ def test_a6_recall_golden(dev, fname):
         np.testing.assert_array_equal(np.array([sc[k] for k in keys]), want)   # == reference evaluator
 
 
+@pytest.mark.parametrize('nq,ng,d', [(130, 257, 50), (1, 1, 4), (300, 1000, 64), (129, 1, 16), (64, 4100, 33)])
+def test_a6_ragged_no_positive_duplicates(dev, nq, ng, d):
+    """tile edges (sizes off the 128 x 128 x 16 grid, D not a multiple of 4: scalar fetch), queries without any positive
+    (rank = gallery size), several positives per query scattered over tiles, exact duplicates of the best positive
+    (strict >: not counted), label values shared by far-apart gallery rows: ranks == the fp64 count oracle, exactly."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(nq * 7 + ng)
+    q = _unit(gen, nq, d)
+    g = _unit(gen, ng, d)
+    ql = torch.arange(nq) % 97
+    gl = torch.randint(0, 97, (ng,), generator=gen)
+    gl[gl == 5] = 1000                                  # queries labelled 5: no positive anywhere
+    if ng >= 8:
+        g[ng - 1] = g[0]                                # duplicated rows (also duplicates of some query's best positive)
+        g[ng // 2] = g[1]
+        gl[ng - 1] = gl[0]
+    ranks = ops.rank_count(q.to(dev), g.to(dev), ql, gl).cpu().numpy()
+    want = oracle.recall_ranks_count(q.numpy(), g.numpy(), ql.numpy(), gl.numpy())
+    assert np.array_equal(ranks.astype(np.float64), want)
+    nopos = ~np.isin(ql.numpy(), gl.numpy())
+    assert (ranks[nopos] == ng).all()
+
+
 def test_a6_coco_1k_fold_size(dev):
     """one 1K fold (1000 images x 5000 captions, D = 512): exact ranks vs the fp64 count oracle."""
     from creamfl_amd import ops
