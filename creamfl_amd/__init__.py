@@ -12,3 +12,10 @@ interface for this path (same names, arguments and errors):
 There is no CPU fallback: without the built library every op raises CreamflHipError.
 """
 __version__ = '0.1.0'
+import os as _os
+
+# The training step runs three HIP streams side by side (streams.py) and RCCL adds its own; HIP's default of 4 hardware queues
+# per process then makes them share queues and serialize (+9 % per step as soon as the RCCL process group exists; bench.py has
+# the numbers).  Only effective if the HIP runtime has not been initialised yet -- import creamfl_amd before the first device call
+# (or export the variable).
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')

@@ -28,6 +28,12 @@ def run(tag, n=10):
     torch.cuda.synchronize()
     sys.stderr.write(json.dumps({'variant': tag, 'ms_per_step': round((time.perf_counter() - t0) / n * 1e3, 2)}) + '\n')
 
+if os.environ.get('DP_FIRST'):
+    eng.enable_data_parallel()
+    run('dp from the first step')
+    run('dp from the first step (again)')
+    dist.destroy_process_group()
+    sys.exit(0)
 run('plain')
 eng.enable_data_parallel()
 run('dp (GradBuckets)')
