@@ -62,23 +62,34 @@ __global__ __launch_bounds__(256) void cfl_maxpool_bwd_kernel(const U4* __restri
         const int h = (int)(p % H);
         const int n = (int)(p / H);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // windows oh with 2*oh - 1 <= h <= 2*oh + 1
+        // windows oh with 2*oh - 1 <= h <= 2*oh + 1: at most 2 x 2.  All four (tap, gradient) pairs are requested up front
+        // (clamped addresses, masked afterwards): loads under the validity branches would serialize on their latency.
         const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;
-        for (int oh = oh0; oh <= oh1; ++oh) {
-            if (oh >= Ho) continue;
-            const unsigned int th = (unsigned int)(h - (2 * oh - 1));
-            for (int ow = ow0; ow <= ow1; ++ow) {
-                if (ow >= Wo) continue;
-                const unsigned int t = th * 3 + (unsigned int)(w - (2 * ow - 1));
-                const long long o = (((long long)n * Ho + oh) * Wo + ow) * C8 + c;
-                const B8 tp = idx[o];
-                float g[8];
-                unpack8(dy[o], g);
+        B8 tp[4];
+        U4 gv[4];
+        unsigned int want[4];
+        bool ok[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const unsigned int tk = ((k < 4 ? tp.lo : tp.hi) >> (8 * (k & 3))) & 0xffu;
-                    if (tk == t) acc[k] += g[k];
-                }
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int oh = a ? oh1 : oh0, ow = b ? ow1 : ow0;
+                ok[a * 2 + b] = oh < Ho && ow < Wo && (a == 0 || oh1 != oh0) && (b == 0 || ow1 != ow0);
+                const int ohc = oh < Ho ? oh : Ho - 1, owc = ow < Wo ? ow : Wo - 1;
+                want[a * 2 + b] = (unsigned int)(h - (2 * oh - 1)) * 3 + (unsigned int)(w - (2 * ow - 1));
+                const long long o = (((long long)n * Ho + ohc) * Wo + owc) * C8 + c;
+                tp[a * 2 + b] = idx[o];
+                gv[a * 2 + b] = dy[o];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;
+            float g[8];
+            unpack8(gv[q], g);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned int tk = ((k < 4 ? tp[q].lo : tp[q].hi) >> (8 * (k & 3))) & 0xffu;
+                if (tk == want[q]) acc[k] += g[k];
             }
         }
         dx[i] = pack8(acc);
@@ -96,7 +107,7 @@ int cfl_maxpool3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void*
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 8);
     const long long blocks = (total + 255) / 256;
-    CFL_LAUNCH(K_MAXPOOL, cfl_maxpool_fwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream,
+    CFL_LAUNCH(K_MAXPOOL, cfl_maxpool_fwd_kernel, dim3((unsigned)(blocks < (1LL << 30) ? blocks : (1LL << 30))), dim3(256), 0, stream,
                (const U4*)x, N, H, W, C / 8, Ho, Wo, (U4*)y, (B8*)idx);
     return 0;
 }
@@ -108,7 +119,8 @@ int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long total = (long long)N * H * W * (C / 8);
     const long long blocks = (total + 255) / 256;
-    CFL_LAUNCH(K_MAXPOOL, cfl_maxpool_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream,
+    // one pass per thread (a capped grid with a 1.5-trip grid-stride loop leaves a third of the machine idle in the second trip)
+    CFL_LAUNCH(K_MAXPOOL, cfl_maxpool_bwd_kernel, dim3((unsigned)(blocks < (1LL << 30) ? blocks : (1LL << 30))), dim3(256), 0, stream,
                (const U4*)dy, (const B8*)idx, N, H, W, C / 8, Ho, Wo, (U4*)dx);
     return 0;
 }
