@@ -59,13 +59,14 @@ __global__ __launch_bounds__(256) void cfl_bn_stats_kernel(const U4* __restrict_
 }
 
 // mean / invstd (+ running statistics) from the partials
-__global__ __launch_bounds__(256) void cfl_bn_final_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+constexpr int BN_FG = 64;              // partial groups of the two final kernels (1024 threads)
+__global__ __launch_bounds__(1024) void cfl_bn_final_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
                                                            int nblk, int C, long long R, float eps, float momentum,
                                                            float* mean, float* invstd, float* rmean, float* rvar) {
-    __shared__ float sa[16][16], sb[16][16];
+    __shared__ float sa[BN_FG][16], sb[BN_FG][16];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
     float a, b;
-    reduce_partials(psum, psq, nblk, C, c, grp, a, b, sa, sb);
+    reduce_partials<BN_FG>(psum, psq, nblk, C, c, grp, a, b, sa, sb);
     if (grp == 0 && c < C) {
         const float mu = a / (float)R;
         const float var = fmaxf(b / (float)R - mu * mu, 0.f);
@@ -176,12 +177,12 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
     block_col_reduce(m, db, dg, C, pdb, pdg, lds);
 }
 
-__global__ __launch_bounds__(256) void cfl_bn_bwd_final_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
+__global__ __launch_bounds__(1024) void cfl_bn_bwd_final_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
                                                                int nblk, int C, float* dbeta, float* dgamma) {
-    __shared__ float sa[16][16], sb[16][16];
+    __shared__ float sa[BN_FG][16], sb[BN_FG][16];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
     float a, b;
-    reduce_partials(pdb, pdg, nblk, C, c, grp, a, b, sa, sb);
+    reduce_partials<BN_FG>(pdb, pdg, nblk, C, c, grp, a, b, sa, sb);
     if (grp == 0 && c < C) { dbeta[c] = a; dgamma[c] = b; }
 }
 
@@ -275,7 +276,7 @@ int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const fl
     float* psq = psum + (size_t)p.nblk * C;
     const dim3 grid(p.nblk, p.gy);
     CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_kernel, grid, dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
-    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(256), 0, stream, psum, psq, p.nblk, C, R, eps,
+    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, p.nblk, C, R, eps,
                momentum, save_mean, save_invstd, running_mean, running_var);
     const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
     if (residual && relu)
@@ -326,7 +327,7 @@ int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, co
                                          save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, relu_mask)
     if (xmask) BN_REDUCE(true, true); else if (relu) BN_REDUCE(true, false); else BN_REDUCE(false, false);
 #undef BN_REDUCE
-    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(256), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
+    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
     U4 *ox = (U4*)dx, *orr = (U4*)dres;
 #define BN_APPLY(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<RES_, RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, \
                                               xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr, relu_mask)

@@ -76,27 +76,30 @@ __device__ __forceinline__ void block_col_reduce(const Map& m, const float (&a)[
     }
 }
 
-// sum the per-block partials of two [nblk, C] arrays for 16 channels: 256 threads = 16 channels x 16 partial groups
+// sum the per-block partials of two [nblk, C] arrays for 16 channels: 16 G threads = 16 channels x G partial groups.
+// The partials of a group are a chain of dependent-latency loads (L2 hits, ~0.6 us per round of 8): with G = 64 a thread
+// has nblk / 64 of them (12 at the 768 blocks of the BN kernels: 3 rounds instead of 12 with G = 16).  Fixed order.
+template <int G>
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ pa, const float* __restrict__ pb, int nblk, int C,
                                                 int c, int grp, float& a, float& b, float (*sa)[16], float (*sb)[16]) {
     a = 0.f; b = 0.f;
     if (c < C) {
         int i = grp;
-        for (; i + 48 < nblk; i += 64) {
-            const float a0 = pa[(long long)i * C + c], a1 = pa[(long long)(i + 16) * C + c];
-            const float a2 = pa[(long long)(i + 32) * C + c], a3 = pa[(long long)(i + 48) * C + c];
-            const float b0 = pb[(long long)i * C + c], b1 = pb[(long long)(i + 16) * C + c];
-            const float b2 = pb[(long long)(i + 32) * C + c], b3 = pb[(long long)(i + 48) * C + c];
+        for (; i + 3 * G < nblk; i += 4 * G) {
+            const float a0 = pa[(long long)i * C + c], a1 = pa[(long long)(i + G) * C + c];
+            const float a2 = pa[(long long)(i + 2 * G) * C + c], a3 = pa[(long long)(i + 3 * G) * C + c];
+            const float b0 = pb[(long long)i * C + c], b1 = pb[(long long)(i + G) * C + c];
+            const float b2 = pb[(long long)(i + 2 * G) * C + c], b3 = pb[(long long)(i + 3 * G) * C + c];
             a += (a0 + a1) + (a2 + a3); b += (b0 + b1) + (b2 + b3);
         }
-        for (; i < nblk; i += 16) { a += pa[(long long)i * C + c]; b += pb[(long long)i * C + c]; }
+        for (; i < nblk; i += G) { a += pa[(long long)i * C + c]; b += pb[(long long)i * C + c]; }
     }
     sa[grp][threadIdx.x & 15] = a; sb[grp][threadIdx.x & 15] = b;
     __syncthreads();
     if (grp == 0) {
         a = 0.f; b = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { a += sa[g][threadIdx.x & 15]; b += sb[g][threadIdx.x & 15]; }
+        for (int g = 0; g < G; ++g) { a += sa[g][threadIdx.x & 15]; b += sb[g][threadIdx.x & 15]; }
     }
 }
 
