@@ -326,13 +326,16 @@ def main():
         if roof is not None and args.batch == 256 and args.cnn == "resnet101" and args.dtype == "bf16":
             # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this timed run, so the value
             # measured offline at this exact shape (separate rocprofv3 --pmc passes, see the file) is reported.
-            try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')))
-                if roof['kernel'] in pmc:
-                    roof['traffic'] = pmc[roof['kernel']]['traffic_bytes']
-                    roof['traffic_source'] = 'OFFLINE: profiles/r1_pmc_traffic.json (separate rocprofv3 --pmc passes at this shape; not measured in this run)'
-            except (OSError, ValueError):
-                pass
+            for fn in ('r2_pmc_bench_traffic.json', 'r1_pmc_traffic.json'):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+                    if roof['kernel'] in pmc:
+                        roof['traffic'] = pmc[roof['kernel']]['traffic_bytes']
+                        roof['traffic_source'] = ('OFFLINE: profiles/%s (separate rocprofv3 --pmc passes over this bench step; '
+                                                  'not measured in this run)' % fn)
+                        break
+                except (OSError, ValueError):
+                    pass
         if roof is not None and not (os.environ.get('CFL_NO_TWO_STREAM') and os.environ.get('CFL_NO_SIDE_WGRAD')):
             # the text tower and the convolution weight gradients run on auxiliary HIP streams: part of these launches
             # share HBM with their kernels, so the per-launch rate is a lower bound of what the kernel reaches alone
