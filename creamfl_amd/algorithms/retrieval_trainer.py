@@ -239,8 +239,9 @@ class TrainerEngine(EngineBase):
             from .. import ops
             if self._conv1x1_weights is None:
                 self._conv1x1_weights = [m.weight for m in self.model.modules()
-                                         if isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1)]
-            ops.prepare_weight_transposes(self._conv1x1_weights)     # every data-gradient GEMM's W^T in one launch
+                                         if isinstance(m, nn.Conv2d) and m.stride == (1, 1) and m.groups == 1
+                                         and (m.kernel_size == (1, 1) or m.padding == (m.kernel_size[0] // 2,) * 2)]
+            ops.prepare_weight_transposes(self._conv1x1_weights)     # W^T / rotated W of every data gradient in one launch
             try:
                 loss.backward()
             finally:

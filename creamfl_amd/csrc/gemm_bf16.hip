@@ -169,29 +169,36 @@ __global__ __launch_bounds__(256) void cfl_transpose_bf16_kernel(const u16* __re
     }
 }
 
-// All weight transposes of a backward pass in ONE launch (66 of them at ResNet-101: as separate kernels they are 66 small
-// launches on the critical path of the backward).  meta[t] = {src, dst, R, C, first tile}; a workgroup finds its tensor by
-// a linear scan (a few dozen entries) and transposes one 64x64 tile.
-struct TrMeta { const u16* src; u16* dst; int R, C, tile0, tiles_c; };
+// All weight transposes of a backward pass in ONE launch (66 1x1 and 30 3x3 weights at ResNet-101: as separate kernels they are
+// a hundred small launches on the critical path of the backward).  meta[t] = {src, dst, R, C, first tile, tiles per row band,
+// source row stride, destination row stride}: dst[c * ldd + r] = src[r * lds + c].  A dense [R, C] matrix has lds = C,
+// ldd = R; one tap of a k x k weight stored [Co][k][k][Ci] (channels_last) is the matrix [Co, Ci] with lds = k k Ci, and its
+// transpose goes to tap (k-1-kh, k-1-kw) of the [Ci][k][k][Co] image with ldd = k k Co -- the rotated, transposed weight
+// that turns the FORWARD convolution kernel into the data gradient (ops._ConvSplitFn).  A workgroup finds its record by
+// binary search on tile0 and transposes one 64x64 tile.
+struct TrMeta { const u16* src; u16* dst; int R, C, tile0, tiles_c, lds, ldd; };
 
 __global__ __launch_bounds__(256) void cfl_transpose_multi_kernel(const TrMeta* __restrict__ meta, int ntensors) {
     __shared__ u16 tile[64][66];
-    int t = 0;
-    while (t + 1 < ntensors && (int)blockIdx.x >= meta[t + 1].tile0) ++t;
-    const TrMeta m = meta[t];
+    int lo = 0, hi = ntensors - 1;
+    while (lo < hi) {                                    // last record with tile0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= meta[mid].tile0) lo = mid; else hi = mid - 1;
+    }
+    const TrMeta m = meta[lo];
     const int local = blockIdx.x - m.tile0;
     const int r0 = (local / m.tiles_c) * 64, c0 = (local % m.tiles_c) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = r0 + ty * 16 + i, c = c0 + tx;
-        tile[ty * 16 + i][tx] = (r < m.R && c < m.C) ? m.src[(long long)r * m.C + c] : (u16)0;
+        tile[ty * 16 + i][tx] = (r < m.R && c < m.C) ? m.src[(long long)r * m.lds + c] : (u16)0;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = c0 + ty * 16 + i, r = r0 + tx;
-        if (r < m.R && c < m.C) m.dst[(long long)c * m.R + r] = tile[tx][ty * 16 + i];
+        if (r < m.R && c < m.C) m.dst[(long long)c * m.ldd + r] = tile[tx][ty * 16 + i];
     }
 }
 
@@ -407,8 +414,8 @@ extern "C" int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void
     return 0;
 }
 
-// meta: device array of ntensors records {src ptr, dst ptr, int R, int C, int tile0, int tiles_c} (32 bytes each, tile0
-// ascending, tiles of tensor t = ceil(R/64) * tiles_c with tiles_c = ceil(C/64)); total_tiles = sum of tiles.
+// meta: device array of ntensors records {src ptr, dst ptr, int R, C, tile0, tiles_c, lds, ldd} (40 bytes each, tile0
+// ascending, tiles of record t = ceil(R/64) * tiles_c with tiles_c = ceil(C/64)); total_tiles = sum of tiles.
 extern "C" int cfl_transpose_bf16_multi(const void* meta, int ntensors, int total_tiles, void* stream_) {
     if (!meta || ntensors <= 0 || total_tiles <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;

@@ -734,33 +734,54 @@ def gemm_bf16_tn(a, b, out_dtype=torch.bfloat16):
 _WT = {'key': None, 'meta': None, 'flat': None, 'views': {}, 'tiles': 0, 'n': 0, 'valid': False}
 
 
+def _rot_ok(w):
+    """k x k (odd k > 1) bf16 weight in channels_last memory ([Co][k][k][Ci]): its data gradient can run on the FORWARD
+    convolution kernel with the rotated, transposed weight."""
+    return (w.dim() == 4 and w.shape[2] == w.shape[3] and w.shape[2] > 1 and w.shape[2] % 2 == 1
+            and w.is_contiguous(memory_format=torch.channels_last))
+
+
 def prepare_weight_transposes(weights):
-    """Transpose every 1x1-convolution weight in `weights` ([Co, Ci, 1, 1] bf16) with ONE kernel launch; the data-gradient
-    GEMMs of the backward pass that follows pick the results up (otherwise each of them launches its own small
-    transpose on the critical path).  Call right before `loss.backward()`; `release_weight_transposes()` after it."""
+    """ONE kernel launch for every weight transform the data gradients of the backward pass that follows need:
+      * 1x1 weights [Co, Ci, 1, 1] -> W^T [Ci, Co] for the data-gradient GEMM (otherwise each GEMM launches its own small
+        transpose on the critical path);
+      * k x k weights (odd k, channels_last) -> W'[ci, co, kh, kw] = W[co, ci, k-1-kh, k-1-kw], with which the stride-1 data
+        gradient is the FORWARD convolution of dy (_ConvSplitFn.backward).
+    Call right before `loss.backward()`; `release_weight_transposes()` after it."""
     import numpy as np
-    ws = [w for w in weights if w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1
-          and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0]
+    ws = [w for w in weights if w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 4
+          and ((w.shape[2] == 1 and w.shape[3] == 1 and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0) or _rot_ok(w))]
     if not ws:
         return
     lib = _lib.load()
-    key = tuple((w.data_ptr(), w.shape[0], w.shape[1]) for w in ws)
+    key = tuple((w.data_ptr(), tuple(w.shape)) for w in ws)
     if key != _WT['key']:
         dev = ws[0].device
-        total = sum(w.shape[0] * w.shape[1] for w in ws)
+        total = sum(w.numel() for w in ws)
         flat = torch.empty(total, dtype=torch.bfloat16, device=dev)
-        meta = np.zeros(len(ws), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('R', '<i4'), ('C', '<i4'), ('tile0', '<i4'),
-                                                  ('tiles_c', '<i4')]))
+        rec = []
         views, off, tile0 = {}, 0, 0
-        for t, w in enumerate(ws):
-            Co, Ci = w.shape[0], w.shape[1]
-            v = flat[off:off + Co * Ci].view(Ci, Co)
-            views[w.data_ptr()] = v
+        for w in ws:
+            Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
             tc = (Ci + 63) // 64
-            meta[t] = (w.data_ptr(), v.data_ptr(), Co, Ci, tile0, tc)
-            tile0 += ((Co + 63) // 64) * tc
-            off += Co * Ci
-        _WT.update(key=key, flat=flat, views=views, tiles=tile0, n=len(ws),
+            ntile = ((Co + 63) // 64) * tc
+            if k == 1:
+                v = flat[off:off + Co * Ci].view(Ci, Co)
+                rec.append((w.data_ptr(), v.data_ptr(), Co, Ci, tile0, tc, Ci, Co))
+                tile0 += ntile
+            else:
+                v = flat[off:off + w.numel()].view(Ci, k, k, Co).permute(0, 3, 1, 2)     # [Ci, Co, k, k], channels_last
+                for kh in range(k):
+                    for kw in range(k):
+                        src = w.data_ptr() + ((k - 1 - kh) * k + (k - 1 - kw)) * Ci * 2
+                        dst = v.data_ptr() + (kh * k + kw) * Co * 2
+                        rec.append((src, dst, Co, Ci, tile0, tc, k * k * Ci, k * k * Co))
+                        tile0 += ntile
+            views[w.data_ptr()] = v
+            off += w.numel()
+        meta = np.array(rec, dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('R', '<i4'), ('C', '<i4'), ('tile0', '<i4'),
+                                             ('tiles_c', '<i4'), ('lds', '<i4'), ('ldd', '<i4')]))
+        _WT.update(key=key, flat=flat, views=views, tiles=tile0, n=len(rec),
                    meta=torch.from_numpy(meta.view(np.uint8).copy()).to(dev))
     _lib.check(lib.cfl_transpose_bf16_multi(_ptr(_WT['meta']), _WT['n'], _WT['tiles'], _stream(ws[0])), 'cfl_transpose_bf16_multi')
     _WT['valid'] = True
@@ -778,6 +799,7 @@ def conv1x1_supported(x, weight):
 
 
 _JOIN_QUEUED_FOR = [-1]
+_NO_FWD_DGRAD = _os.environ.get('CFL_NO_FWD_DGRAD', '0') == '1'      # measurement switch: MIOpen backward-data for k x k
 
 
 def _queue_stream_join(device):
@@ -862,6 +884,19 @@ class _ConvSplitFn(torch.autograd.Function):
                     wt = torch.empty(Ci, Co, dtype=torch.bfloat16, device=x.device)   # [Ci, Co]: reduction axis contiguous
                     _lib.check(_lib.load().cfl_transpose_bf16(_ptr(weight), Co, Ci, _ptr(wt), _stream(x)), 'cfl_transpose_bf16')
                 gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
+            elif (stride == 1 and padding == weight.shape[2] // 2 and weight.dtype == torch.bfloat16 and _rot_ok(weight)
+                  and not _NO_FWD_DGRAD):
+                # k x k / stride 1 / same padding: dX = conv2d(dY, W') with the rotated, transposed weight -- MIOpen's FORWARD
+                # kernels run this 1.3-1.6x faster than its backward-data kernels on every ResNet-101 shape (3x3, batch 256:
+                # 56x56x64 169 -> 134 us, 28x28x128 126 -> 97, 14x14x256 120 -> 75, 7x7x512 138 -> 104; tools/dgrad3x3_probe.py)
+                wr = _WT['views'].get(weight.data_ptr()) if _WT['valid'] else None
+                if wr is None and dy.numel() >= (1 << 22):
+                    # not prepared (client trainers): two small kernels, repaid by the faster convolution on large maps only
+                    wr = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+                if wr is not None:
+                    dx = torch.nn.functional.conv2d(dy, wr, None, 1, padding)
+                else:
+                    dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
             else:
                 dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
         return dx, dw, None, None, None, None

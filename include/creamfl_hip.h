@@ -195,8 +195,10 @@ int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb,
  * (cfl_gemm_bf16_tn_ws_bytes) and a fixed-order reduction.  N1 % 8 == N2 % 8 == 0, lda % 8 == ldb % 8 == 0. */
 /* dst[C][R] = src[R][C]^T, dense bf16 (the weight transpose the data gradient needs). */
 int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream);
-/* every weight transpose of a backward pass in one launch: meta = device array of ntensors 32-byte records
- * {const void* src; void* dst; int R; int C; int tile0; int tiles_c} (tile0 ascending; 64x64 tiles). */
+/* every weight transpose of a backward pass in one launch: meta = device array of ntensors 40-byte records
+ * {const void* src; void* dst; int R; int C; int tile0; int tiles_c; int lds; int ldd} (tile0 ascending; 64x64 tiles):
+ * dst[c * ldd + r] = src[r * lds + c].  Dense matrices: lds = C, ldd = R; the taps of a k x k channels_last weight are
+ * strided [Co, Ci] matrices (ops.prepare_weight_transposes builds the rotated, transposed weight of the data gradient). */
 int cfl_transpose_bf16_multi(const void* meta, int ntensors, int total_tiles, void* stream);
 size_t cfl_gemm_bf16_tn_ws_bytes(long long M, int N1, int N2);
 int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, long long ldb, void* C, int c_bf16, long long M, int N1, int N2,

@@ -161,6 +161,51 @@ def test_conv1x1_data_gradient_matches_miopen(n, cin, cout, h):
 
 
 
+@pytest.mark.parametrize('ci,co,k,h', [(64, 128, 3, 14), (128, 64, 3, 9), (256, 256, 3, 14), (16, 40, 5, 11), (64, 64, 3, 56)])
+def test_kxk_data_gradient_on_forward_kernel(ci, co, k, h):
+    """k x k / stride 1 / same padding: _ConvSplitFn runs the data gradient as the FORWARD convolution of dy with the rotated,
+    transposed weight (prepared in the one-launch transform, or built on the fly).  Must equal the library's backward-data
+    result up to one bf16 rounding, for Ci != Co (a missing transpose shows) and asymmetric taps (a missing rotation shows);
+    mixed with 1x1 weights in the same prepared launch; the weight gradient is untouched."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(ci + co + k)
+    w = (torch.randn(co, ci, k, k, generator=gen) * 0.05).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w1 = (torch.randn(64, 72, 1, 1, generator=gen) * 0.05).to(dev, torch.bfloat16).requires_grad_(True)
+    n = 3 if h < 56 else 24                               # the last case is above the size where the on-the-fly rotation is used
+    x = torch.randn(n, ci, h, h, generator=gen).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, co, h, h, generator=gen).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref_dx, ref_dw = torch.ops.aten.convolution_backward(gy, x, w.detach(), None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                                         [True, True, False])[:2]
+
+    def run(prepared):
+        if prepared:
+            ops.prepare_weight_transposes([w1, w])
+        try:
+            xg = x.clone().requires_grad_(True)
+            ops.conv_split(xg, w, 1, k // 2, side_wgrad=False).backward(gy)
+            dw = w.grad.clone()
+            w.grad = None
+            return xg.grad, dw
+        finally:
+            ops.release_weight_transposes()
+
+    scale = float(ref_dx.float().abs().max())
+    for prepared in (True, False):
+        dx, dw = run(prepared)
+        if prepared:                                       # the prepared image itself: W'[ci, co, kh, kw] = W[co, ci, k-1-kh, k-1-kw]
+            wr = ops._WT['views'][w.data_ptr()]
+            assert wr.shape == (ci, co, k, k) and wr.is_contiguous(memory_format=torch.channels_last)
+            assert torch.equal(wr, w.detach().flip(2, 3).transpose(0, 1))
+            assert torch.equal(ops._WT['views'][w1.data_ptr()], w1.detach().reshape(64, 72).t())
+        d = (dx.float() - ref_dx.float()).abs()
+        assert float(d.max()) <= 1.2e-2 * scale, (prepared, float(d.max()) / scale)          # one bf16 ulp near the top binade
+        assert float((d > 2e-3 * scale).float().mean()) < 0.02, prepared
+        assert torch.allclose(dw.float(), ref_dw.float(), rtol=2e-2, atol=2e-2 * float(ref_dw.float().abs().max()))
+
+
 def test_prepared_weight_transposes_match_individual_ones():
     """ops.prepare_weight_transposes: every 1x1-convolution weight transposed by ONE launch; the data gradient computed
     with the prepared W^T must equal the one computed with the per-layer transpose (bit-exact), ragged shapes included."""
