@@ -317,5 +317,5 @@ class MMFL(object):
             if not torch.is_tensor(loss):
                 continue
             eng.optimizer.zero_grad(set_to_none=True)
-            loss.backward()
+            eng.backward(loss)
             eng.optimizer_step()

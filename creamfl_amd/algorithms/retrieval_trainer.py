@@ -235,23 +235,28 @@ class TrainerEngine(EngineBase):
         self.optimizer.zero_grad(set_to_none=True)
         if self.dp is not None:
             self.dp.prepare_backward()
-        if loss.is_cuda:
-            from .. import ops
-            if self._conv1x1_weights is None:
-                self._conv1x1_weights = [m.weight for m in self.model.modules()
-                                         if isinstance(m, nn.Conv2d) and m.stride == (1, 1) and m.groups == 1
-                                         and (m.kernel_size == (1, 1) or m.padding == (m.kernel_size[0] // 2,) * 2)]
-            ops.prepare_weight_transposes(self._conv1x1_weights)     # W^T / rotated W of every data gradient in one launch
-            try:
-                loss.backward()
-            finally:
-                ops.release_weight_transposes()
-        else:
-            loss.backward()
+        self.backward(loss)
         if self.dp is not None:
             self.dp.finish_backward(list(self.criterion.parameters()))
         self.optimizer_step()
         return loss, loss_dict
+
+    def backward(self, loss):
+        """loss.backward() with the weight transforms of the trunk's data gradients (W^T of the 1x1 convolutions for the GEMM,
+        the rotated k x k weights for the forward-kernel data gradients) written by ONE launch beforehand."""
+        if not loss.is_cuda:
+            loss.backward()
+            return
+        from .. import ops
+        if self._conv1x1_weights is None:
+            self._conv1x1_weights = [m.weight for m in self.model.modules()
+                                     if isinstance(m, nn.Conv2d) and m.stride == (1, 1) and m.groups == 1
+                                     and (m.kernel_size == (1, 1) or m.padding == (m.kernel_size[0] // 2,) * 2)]
+        ops.prepare_weight_transposes(self._conv1x1_weights)
+        try:
+            loss.backward()
+        finally:
+            ops.release_weight_transposes()
 
     def optimizer_step(self):
         """clip_grad_norm_(model.parameters(), grad_clip) + optimizer.step() (:211-214); fused into the
