@@ -56,6 +56,7 @@ SIGNATURES = {
     'cfl_attn_small_fwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong, _P]),
     'cfl_attn_small_bwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong,
                                    _P, _P, _P, c_longlong, c_longlong, _P]),
+    'cfl_stem_s2d': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     'cfl_maxpool3s2_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_maxpool3s2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'cfl_sup_ws_bytes': (c_size_t, [c_int, c_int]),

@@ -96,9 +96,68 @@ __global__ __launch_bounds__(256) void cfl_maxpool_bwd_kernel(const U4* __restri
     }
 }
 
+// ---- stem space-to-depth ------------------------------------------------------------------------------------------------
+// The ResNet stem (torchvision ResNet.conv1: 7x7 / stride 2 / pad 3 on 3 channels) is the worst-shaped convolution of the trunk
+// for an implicit-GEMM kernel (3 input channels: 6-byte pixels, K = 147).  With 7 = 2 * 4 - 1 it is EXACTLY a 4x4 / stride-1
+// convolution of the space-to-depth image: y[oh, ow] = sum_{a,b in -2..1} sum_{p,q in 0..1} w[2a+p+3, 2b+q+3] x[2(oh+a)+p, 2(ow+b)+q]
+// (the tap 2a+p+3 = -1 does not exist: zero weight).  This kernel writes that image in one pass:
+//   out[n, i, j, (2p + q) * 3 + c] = x[n, 2 (i - 2) + p, 2 (j - 2) + q, c]   for 2 <= i, j < Ho + 2, zero elsewhere (the
+//   convolution's padding: two rows before, one after) and in the 4 padding channels;  out [N, Ho + 3, Wo + 3, 16] bf16.
+// One thread per output pixel: two 12-byte (bf16 images) or 24-byte (fp32 images, rounded to bf16 here) reads -- pixels
+// 2j', 2j'+1 of rows 2i', 2i'+1 --, one 32-byte write.
+template <bool F32>
+__global__ __launch_bounds__(256) void cfl_stem_s2d_kernel(const void* __restrict__ x_, int N, int H, int W, U4* __restrict__ out) {
+    const int Ho = H >> 1, Wo = W >> 1, Hp = Ho + 3, Wp = Wo + 3;
+    const long long total = (long long)N * Hp * Wp;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % Wp);
+    const long long t = i / Wp;
+    const int r = (int)(t % Hp), n = (int)(t / Hp);
+    U4 lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
+    if (r >= 2 && r < Ho + 2 && j >= 2 && j < Wo + 2) {
+        // a row contributes 6 consecutive elements (pixels 2j', 2j'+1) starting at the EVEN element index
+        // ((n H + row) W + 2 j') 3; the next row is W * 3 elements further (W even)
+        const long long e0 = (((long long)n * H + 2 * (r - 2)) * W + 2 * (j - 2)) * 3;
+        unsigned int d[6];                                    // 12 bf16: row p = 0 then row p = 1
+        if (F32) {                                            // fp32 images (the autocast regime): rounded here, no separate cast pass
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const float* x = reinterpret_cast<const float*>(x_);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f2* s = reinterpret_cast<const f2*>(x + e0 + (long long)p * W * 3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const f2 v = s[k]; d[p * 3 + k] = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16); }
+            }
+        } else {
+            const unsigned int* x = reinterpret_cast<const unsigned int*>(x_);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d[p * 3 + k] = x[((e0 + (long long)p * W * 3) >> 1) + k];
+        }
+        lo.x = d[0]; lo.y = d[1]; lo.z = d[2];                // channels 0..5  = (p=0, q=0..1, c)
+        lo.w = d[3]; hi.x = d[4]; hi.y = d[5];                // channels 6..11 = (p=1, q=0..1, c)
+    }
+    out[i * 2] = lo;
+    out[i * 2 + 1] = hi;
+}
+
 }  // namespace
 
 extern "C" {
+
+int cfl_stem_s2d(const void* x, int x_f32, int N, int H, int W, void* out, void* stream_) {
+    if (!x || !out || N <= 0 || H <= 0 || W <= 0) return CFL_EINVAL;
+    if ((H & 1) || (W & 1) || (((uintptr_t)x) & 7) || (((uintptr_t)out) & 15)) return CFL_ELIMIT;
+    const long long total = (long long)N * ((H >> 1) + 3) * ((W >> 1) + 3);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (x_f32)
+        CFL_LAUNCH(K_MAXPOOL, cfl_stem_s2d_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream_, x, N, H, W, (U4*)out);
+    else
+        CFL_LAUNCH(K_MAXPOOL, cfl_stem_s2d_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream_, x, N, H, W, (U4*)out);
+    return 0;
+}
 
 int cfl_maxpool3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void* idx, void* stream_) {
     if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CFL_EINVAL;

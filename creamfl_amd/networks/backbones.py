@@ -77,10 +77,13 @@ class TrunkConv(nn.Conv2d):
         super().__init__(cin, cout, k, stride, padding, bias=False)
 
     def forward(self, x):
-        if (torch.is_grad_enabled() and not _NO_CONV_SPLIT and x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype
+        if (torch.is_grad_enabled() and not _NO_CONV_SPLIT and x.is_cuda and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last)):
             from .. import ops
-            return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD)
+            if self.in_channels == 3 and ops.stem_conv_supported(x, self.weight, self.stride[0], self.padding[0]):
+                return ops.stem_conv(x, self.weight, side_wgrad=not _NO_SIDE_WGRAD)      # 3-channel 7x7 stem: space-to-depth form
+            if x.dtype == self.weight.dtype:
+                return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD)
         return super().forward(x)
 
 

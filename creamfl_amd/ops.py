@@ -799,6 +799,7 @@ def conv1x1_supported(x, weight):
 
 
 _JOIN_QUEUED_FOR = [-1]
+_NO_STEM_S2D = _os.environ.get('CFL_NO_STEM_S2D', '0') == '1'        # measurement switch: the stem as the library sees it
 _NO_FWD_DGRAD = _os.environ.get('CFL_NO_FWD_DGRAD', '0') == '1'      # measurement switch: MIOpen backward-data for k x k
 
 
@@ -910,6 +911,88 @@ def conv_split(x, weight, stride=1, padding=0, side_wgrad=True):
 
 def conv1x1(x, weight):
     return conv_split(x, weight, 1, 0)
+
+
+# ---- ResNet stem: 7x7 / stride 2 / pad 3 on 3 channels as a 4x4 / stride-1 convolution of the space-to-depth image -------------
+def _stem_weight_s2d(w):
+    """[Co, 3, 7, 7] -> [Co, 16, 4, 4] (channels_last): W4[co, (2p+q)*3 + c, a+2, b+2] = W[co, c, 2a+p+3, 2b+q+3], a, b in -2..1,
+    zero where the 7x7 tap does not exist (2a+p+3 = -1) and in the 4 padding channels."""
+    co = w.shape[0]
+    wp = torch.nn.functional.pad(w, (1, 0, 1, 0))                                     # tap index kh + 1 = 2 (a + 2) + p
+    v = wp.reshape(co, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 12, 4, 4)
+    return torch.nn.functional.pad(v, (0, 0, 0, 0, 0, 4)).contiguous(memory_format=torch.channels_last)
+
+
+def _stem_weight_s2d_inverse(g4, like):
+    """gradient of _stem_weight_s2d: [Co, 16, 4, 4] -> [Co, 3, 7, 7] in `like`'s memory format."""
+    co = g4.shape[0]
+    g = g4[:, :12].reshape(co, 2, 2, 3, 4, 4).permute(0, 3, 4, 1, 5, 2).reshape(co, 3, 8, 8)[:, :, 1:, 1:]
+    return g.contiguous(memory_format=torch.channels_last if like.is_contiguous(memory_format=torch.channels_last)
+                        and not like.is_contiguous() else torch.contiguous_format)
+
+
+class _StemConvFn(torch.autograd.Function):
+    """torchvision ResNet.conv1 (image_encoder.py:27-36).  MIOpen runs the problem as written at 376 us forward / 406 us weight
+    gradient (batch 256: 3-channel, 6-byte pixels, K = 147); after space-to-depth (csrc/pool.hip: cfl_stem_s2d, one pass, 16
+    channels) the same convolution is a 4x4 / stride-1 one that its kernels run in 229 / 225 us (tools/stem_probe.py).  The input
+    needs no gradient (images); the weight gradient is deferred to the auxiliary stream like every trunk convolution's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, side_wgrad):
+        lib = _lib.load()
+        N, _, H, W = x.shape
+        xs = torch.empty((N, 16, H // 2 + 3, W // 2 + 3), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        _lib.check(lib.cfl_stem_s2d(_ptr(x), int(x.dtype == torch.float32), N, H, W, _ptr(xs), _stream(x)), 'cfl_stem_s2d')
+        w4 = _stem_weight_s2d(weight.detach())
+        ctx.save_for_backward(xs, w4, weight)
+        ctx.side_wgrad = side_wgrad
+        with torch.autocast('cuda', enabled=False):
+            return torch.nn.functional.conv2d(xs, w4, None, 1, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, w4, weight = ctx.saved_tensors
+        if dy.dtype != xs.dtype:
+            dy = dy.to(xs.dtype)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        args = (dy, xs, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+
+        def wgrad():
+            return _stem_weight_s2d_inverse(torch.ops.aten.convolution_backward(*args, [False, True, False])[1], weight)
+        from . import streams
+        if ctx.side_wgrad and streams.DEFER_WGRAD[0]:
+            def task(main, side, weight=weight):
+                g = wgrad()
+                args[0].record_stream(side)
+                args[1].record_stream(side)
+                g.record_stream(main)
+                with torch.no_grad():
+                    if weight.grad is None:
+                        weight.grad = g
+                    else:
+                        weight.grad.add_(g)
+                if streams.GRAD_READY[0] is not None:
+                    streams.GRAD_READY[0](weight)
+            streams.defer(task)
+            _queue_stream_join(xs.device)
+            return None, None, None
+        return None, wgrad(), None
+
+
+def stem_conv_supported(x, weight, stride, padding):
+    """bf16 weights; bf16 images, or fp32 images under bf16 autocast (the cast autocast would do is folded into the kernel)."""
+    xok = x.dtype == torch.bfloat16 or (x.dtype == torch.float32 and torch.is_autocast_enabled('cuda')
+                                        and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+    return (x.is_cuda and x.dim() == 4 and xok and weight.dtype == torch.bfloat16 and not x.requires_grad
+            and tuple(weight.shape[1:]) == (3, 7, 7) and stride == 2 and padding == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and not _NO_STEM_S2D)
+
+
+def stem_conv(x, weight, side_wgrad=True):
+    """y = conv2d(x, weight, stride 2, padding 3) for the 3-channel 7x7 ResNet stem (see _StemConvFn)."""
+    return _StemConvFn.apply(x, weight, bool(side_wgrad))
 
 
 # --------------------------------------------------------------------------- ResNet stem max pooling (csrc/pool.hip)

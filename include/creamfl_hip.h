@@ -178,6 +178,11 @@ int cfl_attn_small_bwd(const void* q, const void* k, const void* v, long long ld
  * src/networks/resnet_client.py:19).  x [N,H,W,C] -> y [N,Ho,Wo,C], Ho = (H-1)/2+1; idx: one byte per output element
  * (the winning tap 0..8, first maximum in row-major window order, NaN wins -- torch's rule).  C % 8 == 0.
  * bwd: dx [N,H,W,C] from dy and idx, gather form (no atomics). */
+/* Stem space-to-depth: the 7x7 / stride 2 / pad 3 convolution on 3 channels (torchvision ResNet.conv1 inside
+ * image_encoder.py:27-36) is exactly a 4x4 / stride-1 convolution of out[n, i, j, (2p+q)*3 + c] = x[n, 2(i-2)+p, 2(j-2)+q, c]
+ * (zero for i, j outside [2, H/2+2) and in channels 12..15).  x [N,H,W,3] bf16 or (x_f32 != 0) fp32, rounded to bf16 here
+ * (H, W even), out [N, H/2+3, W/2+3, 16] bf16. */
+int cfl_stem_s2d(const void* x, int x_f32, int N, int H, int W, void* out, void* stream);
 int cfl_maxpool3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void* idx, void* stream);
 int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int C, void* dx, void* stream);
 

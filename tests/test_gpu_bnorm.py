@@ -206,6 +206,53 @@ def test_kxk_data_gradient_on_forward_kernel(ci, co, k, h):
         assert torch.allclose(dw.float(), ref_dw.float(), rtol=2e-2, atol=2e-2 * float(ref_dw.float().abs().max()))
 
 
+@pytest.mark.parametrize('n,h,w', [(4, 224, 224), (3, 64, 96), (2, 32, 32), (1, 2, 2)])
+def test_stem_conv_space_to_depth(n, h, w):
+    """the 3-channel 7x7 / stride 2 / pad 3 stem as a 4x4 / stride-1 convolution of the space-to-depth image (csrc/pool.hip
+    cfl_stem_s2d + ops._StemConvFn): forward and weight gradient == the library convolution on the problem as written (fp32
+    reference on the same bf16 operands), borders included; the image itself checked against a torch restatement."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.nn.functional as F
+    from creamfl_amd import ops, _lib
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(h + w)
+    x = torch.randn(n, 3, h, w, generator=gen).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(64, 3, 7, 7, generator=gen) * 0.05).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert ops.stem_conv_supported(x, wt, 2, 3)
+    # the space-to-depth image
+    xs = torch.empty((n, 16, h // 2 + 3, w // 2 + 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+    _lib.check(_lib.load().cfl_stem_s2d(x.data_ptr(), 0, n, h, w, xs.data_ptr(), torch.cuda.current_stream().cuda_stream), 'cfl_stem_s2d')
+    v = x.permute(0, 2, 3, 1).reshape(n, h // 2, 2, w // 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(n, h // 2, w // 2, 12)
+    want = F.pad(F.pad(v, (0, 4)).permute(0, 3, 1, 2), (2, 1, 2, 1))
+    assert torch.equal(xs, want)
+    # forward + weight gradient
+    y = ops.stem_conv(x, wt, side_wgrad=False)
+    gy = torch.randn(y.shape, generator=gen).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    wr = wt.detach().float().requires_grad_(True)
+    yr = F.conv2d(x.float(), wr, None, 2, 3)
+    yr.backward(gy.float())
+    assert y.shape == yr.shape
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-2, atol=1e-2 * float(yr.abs().max()))
+    np.testing.assert_allclose(wt.grad.float().cpu().numpy(), wr.grad.cpu().numpy(), rtol=2e-2, atol=1e-2 * float(wr.grad.abs().max()))
+    assert wt.grad.shape == wt.shape and wt.grad.stride() == wt.stride()
+    # fp32 images under bf16 autocast: the cast is folded into the space-to-depth kernel (same rounding as autocast's)
+    xf = x.float()
+    xs2 = torch.empty_like(xs)
+    _lib.check(_lib.load().cfl_stem_s2d(xf.data_ptr(), 1, n, h, w, xs2.data_ptr(), torch.cuda.current_stream().cuda_stream), 'cfl_stem_s2d')
+    assert torch.equal(xs2, xs)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert ops.stem_conv_supported(xf, wt, 2, 3)
+        assert torch.equal(ops.stem_conv(xf, wt, side_wgrad=False), y)
+    # deferred (auxiliary stream) path: the gradient lands in weight.grad at the end of the backward pass
+    wt.grad = None
+    y2 = ops.stem_conv(x, wt, side_wgrad=True)
+    (y2.float() * gy.float()).sum().backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(wt.grad.float().cpu().numpy(), wr.grad.cpu().numpy(), rtol=2e-2, atol=1e-2 * float(wr.grad.abs().max()))
+
+
 def test_prepared_weight_transposes_match_individual_ones():
     """ops.prepare_weight_transposes: every 1x1-convolution weight transposed by ONE launch; the data gradient computed
     with the prepared W^T must equal the one computed with the per-layer transpose (bit-exact), ragged shapes included."""
