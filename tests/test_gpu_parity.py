@@ -185,6 +185,33 @@ def test_a34_client_contrast_golden(dev, fname):
     _close(df3, cf['d_moon'].numpy(), 1e-4, 2e-5 * np.abs(cf['d_moon'].numpy()).max())
 
 
+@pytest.mark.parametrize('m,d', [(9, 32), (4097, 256), (300, 768)])
+def test_a34_duplicate_and_boundary_indices(dev, m, d):
+    """collisions in the batch's public-set indices (the same representation is the positive of several rows), the first and the
+    last bank row as positives, inter + intra terms with and without loss_scale: == the closed-form oracle."""
+    gen = torch.Generator().manual_seed(m + d)
+    g_same, g_other = _unit(gen, m, d), _unit(gen, m, d)
+    d_idx = [0, m - 1, 0, 0, m - 1, m // 2, m // 2, 1, m - 2, 0, m - 1, 3 % m]
+    f = torch.nn.functional.normalize(g_same[d_idx] + 0.8 * _unit(gen, len(d_idx), d), dim=-1)
+    f_old = torch.nn.functional.normalize(f + 0.3 * _unit(gen, len(d_idx), d), dim=-1)
+    args = (f, g_same, g_other, d_idx, f_old)
+    cf = oracle.client_contrast_grads_closed_form(*args)
+    _, li, lm, _ = _run_contrast(dev, *args, 0.5, False)
+    _close(li, cf['loss_inter'].item(), 2e-5, 1e-6)
+    _close(lm, cf['loss_moon'].item(), 2e-5, 1e-6)
+    _, _, _, di = _run_contrast(dev, *args, 1.0, False, use_intra=False)
+    _, _, _, dm = _run_contrast(dev, *args, 1.0, False, use_inter=False)
+    _close(di, cf['d_inter'].numpy(), 1e-4, 3e-5 * np.abs(cf['d_inter'].numpy()).max())
+    _close(dm, cf['d_moon'].numpy(), 1e-4, 3e-5 * np.abs(cf['d_moon'].numpy()).max())
+    # both terms with loss_scale: (loss_moon + loss_inter / (loss_inter / loss_moon).detach()) * w  (ClientTrainer.py:416-419)
+    w = 0.25
+    loss, li2, lm2, df = _run_contrast(dev, *args, w, True)
+    ratio = cf['loss_inter'].item() / cf['loss_moon'].item()
+    _close(loss, (cf['loss_moon'].item() + cf['loss_inter'].item() / ratio) * w, 1e-4, 0)
+    want = (cf['d_moon'].numpy() + cf['d_inter'].numpy() / ratio) * w
+    _close(df, want, 2e-4, 5e-5 * np.abs(want).max())
+
+
 @pytest.mark.parametrize('b,m,d', [(1, 1, 4), (3, 200, 17), (64, 4097, 256), (65, 5000, 100), (128, 50000, 256),
                                    (256, 20000, 512), (130, 3000, 768)])
 def test_a3_inter_shapes(dev, b, m, d):
