@@ -124,17 +124,111 @@ __global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const U4* __restrict_
     }
 }
 
+// ---- stem tail: BatchNorm + ReLU + 3x3 / stride 2 / pad 1 max pooling in one pass, and its backward without the pooled
+// gradient ever being scattered to memory (ResNet.bn1 / relu / maxpool inside image_encoder.py:27-36).  Unfused, the stem
+// BatchNorm writes its [N,112,112,64] output (411 MB at batch 256) only for the pool to read it once, and the pool's backward
+// writes a gradient of the same size that the two BatchNorm backward passes read once each: 2 GB of traffic per step.
+//   forward : y_pool = maxpool(bf16(relu(x * sc + sh)))  -- the taps are normalised on the fly (rounded to bf16 exactly as the
+//             stored activation would have been, so values, arg-max taps and ties are bit-identical to the unfused path)
+//   backward: the BatchNorm reduce / apply passes take dy(n,h,w,:) from pool_grad8 (gather over the <= 4 windows that cover
+//             the pixel, rounded to bf16 like the tensor the pool backward would have written) instead of loading it.
+struct __attribute__((aligned(8))) B8 { unsigned int lo, hi; };          // 8 tap indices (same record as pool.hip)
+
+__global__ __launch_bounds__(256) void cfl_bn_pool_fwd_kernel(const U4* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int N, int H, int W, int C8, int Ho,
+                                                              int Wo, U4* __restrict__ y, B8* __restrict__ idx) {
+    const long long total = (long long)N * Ho * Wo * C8;
+    const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C8);
+    long long p = i / C8;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float g = gamma[c * 8 + k] * invstd[c * 8 + k];
+        sc[k] = g;
+        sh[k] = beta[c * 8 + k] - mean[c * 8 + k] * g;
+    }
+    float best[8];
+    unsigned int tap[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; tap[k] = 0; }
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+        const int ih = 2 * oh - 1 + dh;
+        if (ih < 0 || ih >= H) continue;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+            const int iw = 2 * ow - 1 + dw;
+            if (iw < 0 || iw >= W) continue;
+            float v[8];
+            unpack8(x[(((long long)n * H + ih) * W + iw) * C8 + c], v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
+            unpack8(pack8(v), v);                                        // the bf16 the unfused path stores and re-reads
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; tap[k] = dh * 3 + dw; }
+        }
+    }
+    y[i] = pack8(best);
+    B8 t;
+    t.lo = tap[0] | (tap[1] << 8) | (tap[2] << 16) | (tap[3] << 24);
+    t.hi = tap[4] | (tap[5] << 8) | (tap[6] << 16) | (tap[7] << 24);
+    idx[i] = t;
+}
+
+// gradient of the pooling w.r.t. input pixel (n, h, w), channels 8 c .. 8 c + 7 (what cfl_maxpool_bwd_kernel writes there)
+__device__ __forceinline__ void pool_grad8(const U4* __restrict__ g, const B8* __restrict__ idx, int n, int h, int w, int c, int C8,
+                                           int Ho, int Wo, float (&d)[8]) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;
+    B8 tp[4];
+    U4 gv[4];
+    unsigned int want[4];
+    bool ok[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int oh = a ? oh1 : oh0, ow = b ? ow1 : ow0;
+            ok[a * 2 + b] = oh < Ho && ow < Wo && (a == 0 || oh1 != oh0) && (b == 0 || ow1 != ow0);
+            const int ohc = oh < Ho ? oh : Ho - 1, owc = ow < Wo ? ow : Wo - 1;
+            want[a * 2 + b] = (unsigned int)(h - (2 * oh - 1)) * 3 + (unsigned int)(w - (2 * ow - 1));
+            const long long o = (((long long)n * Ho + ohc) * Wo + owc) * C8 + c;
+            tp[a * 2 + b] = idx[o];
+            gv[a * 2 + b] = g[o];
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!ok[q]) continue;
+        float gg[8];
+        unpack8(gv[q], gg);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned int tk = ((k < 4 ? tp[q].lo : tp[q].hi) >> (8 * (k & 3))) & 0xffu;
+            if (tk == want[q]) acc[k] += gg[k];
+        }
+    }
+    unpack8(pack8(acc), d);
+}
+
 // XMASK: the ReLU mask is recomputed from x (y is not read) -- only without a residual, where y = relu(x*sc + sh) with
 // exactly the forward's sc/sh, so (x*sc + sh > 0) == (y > 0).  dy2 (may be NULL) is a second upstream gradient that is
 // added on the fly: the block output feeds the next convolution AND the next residual add, and autograd would
 // otherwise spend a separate read-read-write kernel on summing the two gradients.
-template <bool RELU, bool XMASK>
+template <bool RELU, bool XMASK, bool POOL = false>
 __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
                                                                 const U4* __restrict__ x, const U4* __restrict__ y,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 long long R, int C, int rows_per_block, float* pdb, float* pdg,
-                                                                const unsigned char* __restrict__ relu_mask) {
+                                                                const unsigned char* __restrict__ relu_mask,
+                                                                const B8* __restrict__ pidx = nullptr, int PH = 0, int PW = 0) {
     __shared__ float lds[4096];
     const Map m = make_map(C);
     float db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -152,7 +246,13 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
 #pragma unroll 2
         for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
             float d[8], f[8], o[8];
-            unpack8(dy[off], d);
+            if (POOL) {                                                  // dy = the pooling's gradient at this pixel, never stored
+                const int pw = (int)(r % PW);
+                const long long t_ = r / PW;
+                pool_grad8(dy, pidx, (int)(t_ / PH), (int)(t_ % PH), pw, m.c0 >> 3, C >> 3, (PH - 1) / 2 + 1, (PW - 1) / 2 + 1, d);
+            } else {
+                unpack8(dy[off], d);
+            }
             unpack8(x[off], f);
             unsigned mb = 0;
             if (RELU && !XMASK) {
@@ -186,14 +286,15 @@ __global__ __launch_bounds__(1024) void cfl_bn_bwd_final_kernel(const float* __r
     if (grp == 0 && c < C) { dbeta[c] = a; dgamma[c] = b; }
 }
 
-template <bool RES, bool RELU, bool XMASK>
+template <bool RES, bool RELU, bool XMASK, bool POOL = false>
 __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
                                                                const U4* __restrict__ x, const U4* __restrict__ y,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                                long long R, int C, int rows_per_block, U4* dx, U4* dres,
-                                                               const unsigned char* __restrict__ relu_mask) {
+                                                               const unsigned char* __restrict__ relu_mask,
+                                                               const B8* __restrict__ pidx = nullptr, int PH = 0, int PW = 0) {
     const Map m = make_map(C);
     if (!m.active) return;
     float mu[8], is[8], a[8], b[8], c[8], sh[8];
@@ -213,7 +314,13 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
 #pragma unroll 2
     for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
         float d[8], f[8], o[8];
-        unpack8(ld_nt(dy + off), d);
+        if (POOL) {
+            const int pw = (int)(r % PW);
+            const long long t_ = r / PW;
+            pool_grad8(dy, pidx, (int)(t_ / PH), (int)(t_ % PH), pw, m.c0 >> 3, C >> 3, (PH - 1) / 2 + 1, (PW - 1) / 2 + 1, d);
+        } else {
+            unpack8(ld_nt(dy + off), d);
+        }
         unpack8(ld_nt(x + off), f);
         unsigned mb = 0;
         if (RELU && !XMASK) {
@@ -337,6 +444,52 @@ int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, co
     else if (relu) BN_APPLY(false, true, false);
     else BN_APPLY(false, false, false);
 #undef BN_APPLY
+    return 0;
+}
+
+// Stem tail in one pass per direction (see cfl_bn_pool_fwd_kernel).  x [N,H,W,C] bf16 (C % 8 == 0, C <= 2048);
+// y_pool [N,Ho,Wo,C] bf16, idx [N*Ho*Wo*C] bytes (Ho = (H-1)/2+1); ws: cfl_bn_ws_bytes(N*H*W, C).
+int cfl_bn_pool_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int N, int H,
+                    int W, int C, float eps, float momentum, void* y_pool, void* idx, float* save_mean, float* save_invstd, void* ws,
+                    void* stream_) {
+    if (!x || !gamma || !beta || !y_pool || !idx || !save_mean || !save_invstd || !ws || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long R = (long long)N * H * W;
+    const Plan p = bn_plan(R, C);
+    float* psum = (float*)ws;
+    float* psq = psum + (size_t)p.nblk * C;
+    CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_kernel, dim3(p.nblk, p.gy), dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
+    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, p.nblk, C, R, eps,
+               momentum, save_mean, save_invstd, running_mean, running_var);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    CFL_LAUNCH(K_BN_POOL_FWD, cfl_bn_pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const U4*)x,
+               save_mean, save_invstd, gamma, beta, N, H, W, C / 8, Ho, Wo, (U4*)y_pool, (B8*)idx);
+    return 0;
+}
+
+// g_pool: gradient w.r.t. y_pool [N,Ho,Wo,C] bf16; dx [N,H,W,C] bf16 = gradient w.r.t. x; ws as above.
+int cfl_bn_pool_bwd(const void* g_pool, const void* idx, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                    const float* save_invstd, int N, int H, int W, int C, void* dx, float* dgamma, float* dbeta, void* ws, void* stream_) {
+    if (!g_pool || !idx || !x || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || N <= 0 || H <= 0 ||
+        W <= 0 || C <= 0)
+        return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long R = (long long)N * H * W;
+    const Plan p = bn_plan(R, C);
+    float* pdb = (float*)ws;
+    float* pdg = pdb + (size_t)p.nblk * C;
+    const dim3 grid(p.nblk, p.gy);
+    const U4* none = nullptr;
+    CFL_LAUNCH(K_BN_POOL_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
+               (const U4*)x, none, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, (const unsigned char*)nullptr,
+               (const B8*)idx, H, W);
+    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
+    CFL_LAUNCH(K_BN_POOL_BWD_APPLY, (cfl_bn_bwd_apply_kernel<false, true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
+               (const U4*)x, none, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, (U4*)dx, (U4*)nullptr,
+               (const unsigned char*)nullptr, (const B8*)idx, H, W);
     return 0;
 }
 

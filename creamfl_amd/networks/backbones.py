@@ -188,7 +188,15 @@ class ResNetTrunk(nn.Module):
         return nn.Sequential(*layers)
 
     def features(self, x):
-        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        x = self.conv1(x)
+        from .. import ops
+        bn = self.bn1
+        if (bn.training and bn.track_running_stats and bn.momentum is not None and bn.affine
+                and isinstance(self.maxpool, MaxPool3s2) and ops.bn_relu_maxpool_supported(x, bn.num_features)):
+            bn._nbt_pending += 1                      # BatchNorm + ReLU + max pooling in one pass per direction (stem tail)
+            x = ops.bn_relu_maxpool(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        else:
+            x = self.maxpool(bn(x, relu=True))
         return first_of(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
 
     def forward(self, x):

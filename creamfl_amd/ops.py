@@ -686,6 +686,57 @@ def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu
     return (y, y2) if two else y
 
 
+class _BnReluMaxPoolFn(torch.autograd.Function):
+    """ResNet stem tail: BatchNorm (batch statistics) + ReLU + MaxPool2d(3, 2, 1) without the normalised activation or the
+    scattered pooling gradient ever reaching memory (csrc/bnorm.hip: cfl_bn_pool_fwd / cfl_bn_pool_bwd); results are
+    bit-identical to bn_act_train(relu=True) followed by maxpool3s2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty(N * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.cfl_bn_ws_bytes(N * H * W, C), x.device)
+        _lib.check(lib.cfl_bn_pool_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), N, H, W, C, eps,
+                                       momentum, _ptr(y), _ptr(idx), _ptr(mean), _ptr(invstd), _ptr(ws), _stream(x)), 'cfl_bn_pool_fwd')
+        ctx.save_for_backward(x, idx, weight, bias, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, idx, weight, bias, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        from . import streams
+        streams.flush(x.device)                # a long HBM-bound phase: let the queued weight gradients run beside it
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(weight)
+        dbeta = torch.empty_like(weight)
+        ws = _ws(lib.cfl_bn_ws_bytes(N * H * W, C), x.device)
+        _lib.check(lib.cfl_bn_pool_bwd(_ptr(gy), _ptr(idx), _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), N, H, W, C,
+                                       _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_pool_bwd')
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+_NO_STEM_TAIL = _os.environ.get('CFL_NO_STEM_TAIL', '0') == '1'     # measurement switch: BatchNorm and pooling as two ops
+
+
+def bn_relu_maxpool_supported(x, num_features):
+    return (not _NO_STEM_TAIL and bn_act_supported(x, num_features) and num_features <= 2048 and x.shape[2] >= 2 and x.shape[3] >= 2
+            and torch.is_grad_enabled())
+
+
+def bn_relu_maxpool(x, weight, bias, running_mean, running_var, momentum, eps):
+    return _BnReluMaxPoolFn.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps))
+
+
 @torch.no_grad()
 def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, residual=None):
     """Evaluation-mode BatchNorm2d (+ residual) (+ ReLU), no autograd."""

@@ -328,6 +328,18 @@ int cfl_bn_apply(const void* x, const void* residual, const float* mean, const f
 int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,
                const float* beta, const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual,
                void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream);
+/* Stem tail (torchvision ResNet.bn1 -> relu -> maxpool(3, 2, 1) inside image_encoder.py:27-36) in one pass per direction:
+ * the normalised activation and the scattered pooling gradient (411 MB each at batch 256) are never materialised.
+ *   fwd: batch statistics of x (+ running statistics), then y_pool = maxpool(bf16(relu(bn(x)))) with the arg-max taps in idx --
+ *        bit-identical to cfl_bn_fwd followed by cfl_maxpool3s2_fwd.   x [N,H,W,C] bf16, y_pool [N,Ho,Wo,C] bf16,
+ *        idx [N*Ho*Wo*C] bytes, Ho = (H-1)/2+1;  ws: cfl_bn_ws_bytes(N*H*W, C).
+ *   bwd: given g_pool (gradient w.r.t. y_pool): dx, dgamma, dbeta -- bit-identical to cfl_maxpool3s2_bwd followed by cfl_bn_bwd. */
+int cfl_bn_pool_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int N, int H,
+                    int W, int C, float eps, float momentum, void* y_pool, void* idx, float* save_mean, float* save_invstd,
+                    void* ws, void* stream);
+int cfl_bn_pool_bwd(const void* g_pool, const void* idx, const void* x, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd, int N, int H, int W, int C, void* dx, float* dgamma,
+                    float* dbeta, void* ws, void* stream);
 
 /* ---- S1 tail: fused multi-tensor gradient clip + AdamP step ------
  * Replaces nn.utils.clip_grad_norm_(model.parameters(), 2) + AdamP.step()

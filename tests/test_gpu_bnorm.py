@@ -253,6 +253,42 @@ def test_stem_conv_space_to_depth(n, h, w):
     np.testing.assert_allclose(wt.grad.float().cpu().numpy(), wr.grad.cpu().numpy(), rtol=2e-2, atol=1e-2 * float(wr.grad.abs().max()))
 
 
+@pytest.mark.parametrize('n,c,h,w', [(4, 64, 112, 112), (3, 64, 7, 9), (2, 16, 2, 2), (5, 128, 13, 13), (2, 2048, 6, 4)])
+def test_stem_tail_fused_is_bit_identical(n, c, h, w):
+    """BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass per direction (ops.bn_relu_maxpool: the normalised activation and the
+    scattered pooling gradient never reach memory) == bn_act_train(relu=True) followed by maxpool3s2, BIT FOR BIT: pooled values,
+    running statistics, dx, dgamma, dbeta (odd sizes: windows hanging over the border; ties between equal taps)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(n * 100 + c + h)
+    x0 = torch.randn(n, c, h, w, generator=gen)
+    x0[:, :, ::3, ::2] = x0[:, :, :1, :1]                       # repeated values: ties inside windows
+    x0 = x0.to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gamma = (1 + 0.2 * torch.randn(c, generator=gen)).to(dev)
+    beta = (0.3 * torch.randn(c, generator=gen)).to(dev)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    g = torch.randn(n, c, ho, wo, generator=gen).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.bn_relu_maxpool_supported(x0, c)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        wg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        if fused:
+            y = ops.bn_relu_maxpool(x, wg, bg, rm, rv, 0.1, 1e-5)
+        else:
+            y = ops.maxpool3s2(ops.bn_act_train(x, wg, bg, rm, rv, 0.1, 1e-5, relu=True))
+        y.backward(g)
+        torch.cuda.synchronize()
+        return y.detach(), x.grad, wg.grad, bg.grad, rm, rv
+
+    a, b = run(True), run(False)
+    for name, ta, tb in zip(['y', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var'], a, b):
+        assert ta.shape == tb.shape and torch.equal(ta, tb), name
+
+
 def test_prepared_weight_transposes_match_individual_ones():
     """ops.prepare_weight_transposes: every 1x1-convolution weight transposed by ONE launch; the data gradient computed
     with the prepared W^T must equal the one computed with the per-layer transpose (bit-exact), ragged shapes included."""
