@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: image-text pairs/sec of the server contrastive step.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one process per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N ...`: WORLD_SIZE / RANK / LOCAL_RANK come from the environment and WORLD_SIZE must
+equal N), or -- plain `python bench.py --gpus N` -- this script re-executes itself under torch.distributed.run
+(`launch_command`).  `--backend gloo` is the single-GPU smoke mode of the N > 1 path: the ranks share the visible GPU(s) and
+collectives travel through host memory (tests/test_gpu_multirank.py uses the same transport); its line says so.
 
 Workload at N = 1 = BASELINE.json configs[1]: "Server-only MSCOCO contrastive training, ResNet101 +
 BERT-base, d=512, batch 256, 1 x MI355X" on MSCOCO-shaped synthetic batches resident in HBM.  One step =
@@ -146,9 +152,39 @@ def coco_1k_recall(dim, dev, seed=4321, noise=6.0):
             'normalize(image + %.1f * unit noise)' % (dim, noise), 'ranks_equal_cpu_oracle_fold0': exact}
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n_ranks, argv, port=None, python=None):
+    """The command that starts `n_ranks` ranks of this script on ONE node (one process per GPU), argv = the script's own
+    arguments, passed through unchanged.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [python or sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(n_ranks)),
+            '--master-addr', '127.0.0.1', '--master-port', str(port or free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def resolve_world(args, environ):
+    """(world, rank, local_rank, must_spawn) from --gpus and the launcher's environment.  --gpus N > 1 without a launcher
+    environment means: start the ranks ourselves; a launcher environment that disagrees with --gpus is an error (the line's
+    n_gpus must be what the caller asked for)."""
+    if 'WORLD_SIZE' not in environ:
+        return (args.gpus, 0, 0, args.gpus > 1)
+    world = int(environ['WORLD_SIZE'])
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    return (world, int(environ.get('RANK', '0')), int(environ.get('LOCAL_RANK', '0')), False)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl = RCCL over xGMI, one GPU per rank (the measurement); gloo = smoke mode of the multi-rank path '
+                         'on however many GPUs are visible (ranks share them, collectives through host memory)')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--no-alone', action='store_true', help='skip the 4 extra steps that measure the dominant kernel with the auxiliary streams off')
     ap.add_argument('--warmup', type=int, default=3)
@@ -166,29 +202,48 @@ def main():
                     help='BASELINE.json config: 1 = server step at 256 pairs per GPU (default, the metric\'s config); 3 = large-batch '
                          'global contrast, 512 pairs per GPU (N = 4096 over 8 GPUs)')
     ap.add_argument('--no-recall', action='store_true')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
     if args.config == 3:
         args.batch = 512
+    return args
+
+
+def main():
+    args = parse_args()
+    world, rank, local_rank, must_spawn = resolve_world(args, os.environ)
+    if must_spawn:
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes needs it on this driver)
+        env.setdefault('OMP_NUM_THREADS', '4')
+        raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block at
     # communicator creation) are sent to stderr; the JSON goes to the saved descriptor.
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
-    torch.cuda.set_device(local_rank)
+    n_visible = torch.cuda.device_count()
+    if args.backend == 'nccl' and world > n_visible:
+        raise SystemExit('bench.py: --gpus %d over RCCL needs %d GPUs, %d visible (use --backend gloo to smoke-run the '
+                         'multi-rank path on fewer GPUs)' % (world, world, n_visible))
+    dev_index = local_rank % n_visible
+    torch.cuda.set_device(dev_index)
     torch.backends.cudnn.benchmark = True
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', dev_index)
     use_dp = world > 1 or args.force_dp
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from creamfl_amd import _lib
     from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
@@ -264,7 +319,7 @@ def main():
         sys.stderr.write('loss per timed step: %s\n' % ' '.join('%.4f' % float(t) for t in trace))
 
     if use_dp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     ms_per_step = dt / args.steps * 1e3
@@ -396,6 +451,10 @@ def main():
                        'global_batch': args.batch * world, 'cnn': args.cnn, 'text': 'bert-base',
                        'encoder_precision': args.dtype, 'head_loss_precision': 'f32',
                        'parallelism': 'dp%d' % world, 'loss': round(loss_val, 4)},
+            'ranks': {'world_size': torch.distributed.get_world_size() if use_dp else 1,
+                      'backend': ('rccl' if args.backend == 'nccl' else 'gloo (SMOKE MODE: not a scaling measurement)') if use_dp
+                      else None, 'rccl_ranks': torch.distributed.get_world_size() if (use_dp and args.backend == 'nccl') else 0,
+                      'gpus_visible': n_visible},
             'roofline': roof, 'cpu_baseline': cpu, 'mfu': mfu, 'recall_1': recall,
             'parity_unpinned': ['AdamP (adamp==0.3.0 is not vendored: checked against the paper restatement oracle/adamp.py)'],
             'hip_kernels_us_warmup_step': hip_us,

@@ -316,6 +316,4 @@ class MMFL(object):
             loss = self.kd_terms(output, d_idx)
             if not torch.is_tensor(loss):
                 continue
-            eng.optimizer.zero_grad(set_to_none=True)
-            eng.backward(loss)
-            eng.optimizer_step()
+            eng.backward_and_step(loss)           # incl. the bucketed gradient averaging when data parallel is on

@@ -132,11 +132,36 @@ class EngineBase(object):
     def enable_data_parallel(self, process_group=None, bucket_cap_mb=128):
         from ..dist import DataParallelContext
         fused = isinstance(self.optimizer, AdamP)
+        if self.dp is not None:
+            self.dp.close()                      # a second reducer on the same parameters would reduce everything twice
         self.dp = DataParallelContext(self.model, process_group, bucket_cap_mb=bucket_cap_mb, assign_grads=not fused)
         if fused:
             # the fused optimizer reads the averaged gradients straight from the bucket views (no per-parameter grad
-            # re-assignment on the host)
+            # re-assignment on the host); `consume` makes it refuse views that no finish_backward() has filled
             self.optimizer.grad_override = self.dp.reducer.grad_views()
+            self.optimizer.grad_override_consume = self.dp.reducer.consume
+        # Replicas must agree on more than module state: with bf16 trunk weights the next step rewrites every weight from
+        # the rank's own fp32 master, so masters, moments and step counts travel too (and the criterion's scalars).
+        self.sync_replicas(group=process_group)
+
+    def disable_data_parallel(self):
+        if self.dp is not None:
+            self.dp.close()
+            self.dp = None
+        if isinstance(self.optimizer, AdamP):
+            self.optimizer.grad_override = None
+            self.optimizer.grad_override_consume = None
+
+    def backward_and_step(self, loss):
+        """zero_grad -> backward -> (multi-rank: bucketed gradient averaging) -> clip -> optimizer step: the tail every
+        server-side step shares (the contrastive step, retrieval_trainer.py:208-214, and the KD step, MMFL.py:385-391)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.dp is not None:
+            self.dp.prepare_backward()
+        self.backward(loss)
+        if self.dp is not None:
+            self.dp.finish_backward(list(self.criterion.parameters()))
+        self.optimizer_step()
 
     @torch.no_grad()
     def evaluate(self, val_loaders, n_crossfolds=None, **kwargs):
@@ -232,13 +257,7 @@ class TrainerEngine(EngineBase):
         if self.autocast_dtype is not None and images.dim() == 4:
             images = images.contiguous(memory_format=torch.channels_last)
         loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens)
-        self.optimizer.zero_grad(set_to_none=True)
-        if self.dp is not None:
-            self.dp.prepare_backward()
-        self.backward(loss)
-        if self.dp is not None:
-            self.dp.finish_backward(list(self.criterion.parameters()))
-        self.optimizer_step()
+        self.backward_and_step(loss)
         return loss, loss_dict
 
     def backward(self, loss):

@@ -152,10 +152,26 @@ class GradBuckets:
         self._next = 0
         self._main = None
         self.comm = None
+        # 'idle' -> prepare() -> 'open' -> finish() -> 'reduced' -> consume() -> 'idle'.  A backward pass that was not bracketed
+        # by prepare()/finish() leaves the bucket views holding the PREVIOUS step's averages: consume() refuses them.
+        self.state = 'idle'
+        self._no_grad = []                    # parameters that received no gradient in the current backward pass
         if params and params[0].is_cuda:
             from . import streams
             self.comm = streams.get(params[0].device, 'comm')
             streams.GRAD_READY[0] = self.notify          # deferred weight gradients report here (ops._ConvSplitFn)
+
+    def close(self):
+        """Detach this reducer from the model: remove the autograd hooks and the deferred-weight-gradient callback (a second
+        reducer on the same parameters would otherwise pack and all-reduce every bucket twice per step)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self.comm is not None:
+            from . import streams
+            if streams.GRAD_READY[0] == self.notify:
+                streams.GRAD_READY[0] = None
+        self.state = 'closed'
 
     @staticmethod
     def _physical_view(flat, p):
@@ -167,17 +183,21 @@ class GradBuckets:
 
     def prepare(self):
         """Before every backward pass."""
+        if self.state == 'closed':
+            raise RuntimeError('GradBuckets.prepare() on a closed reducer')
         self._ready = [0] * len(self.buckets)
         self._seen = set()
         self._next = 0
         self._keep = []
+        self._no_grad = []
+        self.state = 'open'
         p0 = self.buckets[0][0] if self.buckets else None
         self._main = torch.cuda.current_stream(p0.device) if (p0 is not None and p0.is_cuda) else None
 
     def notify(self, p):
         """A parameter's gradient for this step is complete (autograd hook, or a deferred weight-gradient task)."""
         bi = self.bucket_of.get(p)
-        if bi is None or p in self._seen:
+        if bi is None or p in self._seen or self.state != 'open':
             return
         self._seen.add(p)
         self._ready[bi] += 1
@@ -226,20 +246,40 @@ class GradBuckets:
             # the local gradients were produced on other streams and are read here on the communication stream: keep them
             # alive until finish() has ordered the caller's stream behind it (cheaper than record_stream per tensor)
             self._keep.append(grads)
+            # A parameter without a gradient in this backward pass (the same ones on every rank: e.g. a tower the KD phase
+            # does not reach) keeps grad None: optimizers skip it -- no weight decay, no moment decay -- exactly as in the
+            # single-process run.  Its (zero) slot still travels with the bucket.
+            self._no_grad += [p for p, g in zip(plist, grads) if g is None]
             if self.assign_grads:
-                for p, v in zip(plist, views):
-                    p.grad = v
+                for p, v, g in zip(plist, views, grads):
+                    if g is not None:
+                        p.grad = v
 
     def finish(self):
         """After the backward pass: reduce whatever is left (buckets holding parameters that got no gradient this step; the
         same ones on every rank), then make the caller's stream wait for the communication stream."""
+        if self.state != 'open':
+            raise RuntimeError('GradBuckets.finish() without prepare() before the backward pass')
         while self._next < len(self.buckets):
             if self._ready[self._next] > 0:
                 self._reduce(self._next)
+            else:
+                self._no_grad += list(self.buckets[self._next])
             self._next += 1
         if self.comm is not None:
             torch.cuda.current_stream(self.flat[0].device).wait_stream(self.comm)
         self._keep = []
+        self.state = 'reduced'
+
+    def consume(self):
+        """Called by the consumer of the bucket views (the fused optimizer) right before it reads them: the views are only
+        valid for a backward pass that ran between prepare() and finish().  Returns the parameters that got NO gradient in
+        that pass (their views hold zeros and must be skipped)."""
+        if self.state != 'reduced':
+            raise RuntimeError('gradient buckets are %s, not reduced: this backward pass was not bracketed by '
+                               'prepare_backward() / finish_backward() and the bucket views hold stale gradients' % self.state)
+        self.state = 'idle'
+        return self._no_grad
 
     def grad_views(self):
         """{parameter: its averaged gradient (bucket view)} -- valid after finish(); constant objects across steps."""
@@ -257,6 +297,9 @@ class DataParallelContext:
         self.module = model
         broadcast_module(model, 0, group)
         self.reducer = GradBuckets(list(model.parameters()), group, bucket_cap_mb, assign_grads=assign_grads)
+
+    def close(self):
+        self.reducer.close()
 
     def gather_features(self, image_features, caption_features):
         return (gather_with_grad(image_features.float(), self.group),

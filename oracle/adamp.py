@@ -7,6 +7,9 @@ third-party package that is neither vendored in the reference nor installed here
 restated from Heo et al., "AdamP: Slowing Down the Slowdown for Momentum Optimizers on Scale-invariant
 Weights" (ICLR 2021), Algorithm 2, with the package's defaults (delta = 0.1, wd_ratio = 0.1).
 PARITY UNPINNED: there is no golden vector for it; the HIP implementation is checked against this file.
+What IS known of the package beyond the paper and is restated here: its `step()` is a single loop over parameters, each
+with its own state dict {'step', 'exp_avg', 'exp_avg_sq'}, so bias corrections follow every parameter's OWN step count
+(parameters whose gradient is None are skipped and do not advance).
 The projection test is evaluated with torch.where instead of a python `if` (same arithmetic).
 """
 import math
@@ -65,17 +68,18 @@ class AdamP(Optimizer):
                 params.append(p); grads.append(p.grad); avgs.append(state['exp_avg']); sqs.append(state['exp_avg_sq'])
             if not params:
                 continue
-            step = self.state[params[0]]['step']          # all parameters of a group step together
-            bc1 = 1 - beta1 ** step
-            bc2 = 1 - beta2 ** step
+            # `state['step']` is kept PER PARAMETER (as adamp==0.3.0 does: its step() is one loop over parameters, each with
+            # its own state dict): a parameter whose gradient was None in earlier steps -- the criterion's shift /
+            # negative_scale during every KD phase (MMFL.py:385-391 back-propagates an MSE that does not reach them), a whole
+            # tower when only one kind of client exists -- lags behind, and its bias corrections use ITS count.
+            steps = [self.state[p]['step'] for p in params]
             torch._foreach_mul_(avgs, beta1)
             torch._foreach_add_(avgs, grads, alpha=1 - beta1)
             torch._foreach_mul_(sqs, beta2)
             torch._foreach_addcmul_(sqs, grads, grads, value=1 - beta2)
-            denoms = torch._foreach_sqrt(sqs)
-            torch._foreach_div_(denoms, math.sqrt(bc2))
-            torch._foreach_add_(denoms, group['eps'])
-            step_size = group['lr'] / bc1
+            denoms = list(torch._foreach_sqrt(sqs))
+            for i, st in enumerate(steps):
+                denoms[i].div_(math.sqrt(1 - beta2 ** st)).add_(group['eps'])
             if group['nesterov']:
                 perturbs = torch._foreach_mul(avgs, beta1)
                 torch._foreach_add_(perturbs, grads, alpha=1 - beta1)
@@ -90,5 +94,5 @@ class AdamP(Optimizer):
                                                            group['eps'])
                 if group['weight_decay'] > 0:
                     p.mul_(1 - group['lr'] * group['weight_decay'] * (1 if wd_mul is None else wd_mul))
-            torch._foreach_add_(params, perturbs, alpha=-step_size)
+                p.add_(perturbs[i], alpha=-group['lr'] / (1 - beta1 ** steps[i]))
         return loss

@@ -175,7 +175,120 @@ def _worker_config2_eight_clients(rank, world, path, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('worker', [_worker_global_contrast, _worker_clients_conw, _worker_config2_eight_clients])
+
+# ------------------------------------------------------------------------------ reducer life cycle
+def _worker_reducer_lifecycle(rank, world, path, out):
+    """(1) a backward pass that is NOT bracketed by prepare/finish (the round-2 KD step) must not hand the optimizer the
+    previous step's averages: consume() raises; (2) bracketed, a second backward (the KD step after a contrastive step)
+    yields the mean of the per-rank gradients; (3) a parameter without a gradient keeps grad None (no zero gradient that
+    would make an optimizer decay it); (4) close() detaches the hooks so that a second reducer does not double-reduce."""
+    _init(rank, world, path)
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({'a': torch.nn.Linear(6, 5), 'b': torch.nn.Linear(5, 3), 'unused': torch.nn.Linear(4, 4)})
+    dp = cdist.DataParallelContext(net, bucket_cap_mb=0.0001)
+    red = dp.reducer
+    gen = torch.Generator().manual_seed(10 + rank)
+    x1, x2 = torch.randn(4, 6, generator=gen), torch.randn(4, 6, generator=gen)
+    ok = True
+
+    def loss_of(x):
+        return net['b'](torch.tanh(net['a'](x))).pow(2).mean()
+
+    # step 1, bracketed
+    dp.prepare_backward()
+    loss_of(x1).backward()
+    dp.finish_backward()
+    ok &= red.state == 'reduced'
+    skipped = red.consume()
+    ok &= {id(p) for p in skipped} == {id(p) for p in net['unused'].parameters()}
+    ok &= all(p.grad is None for p in net['unused'].parameters())
+    # step 2 WITHOUT the bracket: the views still hold step 1 -> refused
+    for p in net.parameters():
+        p.grad = None
+    loss_of(x2).backward()
+    try:
+        red.consume()
+        ok = False
+    except RuntimeError:
+        pass
+    # step 2 bracketed: mean over ranks of the local gradients
+    for p in net.parameters():
+        p.grad = None
+    dp.prepare_backward()
+    loss_of(x2).backward()
+    local = net['a'].weight.grad.clone() if red.world == 1 else None
+    dp.finish_backward()
+    red.consume()
+    got = red.grad_views()[net['a'].weight].clone()
+    # reference: every rank recomputes both ranks' local gradients
+    want = torch.zeros_like(got)
+    for r in range(world):
+        g2 = torch.Generator().manual_seed(10 + r)
+        torch.randn(4, 6, generator=g2)
+        xr = torch.randn(4, 6, generator=g2)
+        (gr,) = torch.autograd.grad(loss_of(xr), net['a'].weight)
+        want += gr / world
+    ok &= torch.allclose(got, want, rtol=1e-5, atol=1e-7)
+    # close(): hooks gone; a fresh reducer on the same parameters works alone
+    n_hooks = len(red._hooks)
+    dp.close()
+    ok &= n_hooks > 0 and red._hooks == [] and red.state == 'closed'
+    dp2 = cdist.DataParallelContext(net, bucket_cap_mb=1)
+    for p in net.parameters():
+        p.grad = None
+    dp2.prepare_backward()
+    loss_of(x2).backward()
+    dp2.finish_backward()
+    ok &= red._seen == set() or red.state == 'closed'          # the closed reducer saw nothing of this pass
+    ok &= torch.allclose(dp2.reducer.grad_views()[net['a'].weight], want, rtol=1e-5, atol=1e-7)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(bool(flag.item() == 1.0))
+    dist.destroy_process_group()
+
+
+def _worker_adamp_broadcast_state(rank, world, path, out):
+    """AdamP.broadcast_state: masters, both moments and the per-parameter step counts of rank 0 reach every rank in a few
+    flat collectives, channels_last state keeps its layout (host logic: the state is fabricated, no step is taken)."""
+    from creamfl_amd.algorithms.optimizers import AdamP
+    _init(rank, world, path)
+    torch.manual_seed(100 + rank)                                 # DIFFERENT values per rank before the broadcast
+    conv = torch.nn.Conv2d(4, 6, 3).to(memory_format=torch.channels_last)
+    lin = torch.nn.Linear(5, 7)
+    scal = torch.nn.Parameter(torch.randn(1))
+    opt = AdamP(list(conv.parameters()) + list(lin.parameters()) + [scal], lr=1e-3)
+    for i, p in enumerate(opt.param_groups[0]['params']):
+        st = opt.state[p]
+        st['step'] = 3 + i + 10 * rank
+        st['exp_avg'] = torch.randn_like(p, memory_format=torch.preserve_format)
+        st['exp_avg_sq'] = torch.rand_like(p, memory_format=torch.preserve_format)
+        if p.dim() == 4:
+            st['master'] = torch.randn_like(p, memory_format=torch.preserve_format)
+    opt.broadcast_state(0)
+    ok = True
+    torch.manual_seed(100)                                        # rank 0's draws, replayed
+    conv0 = torch.nn.Conv2d(4, 6, 3).to(memory_format=torch.channels_last)
+    lin0 = torch.nn.Linear(5, 7)
+    scal0 = torch.nn.Parameter(torch.randn(1))
+    for i, (p, q) in enumerate(zip(opt.param_groups[0]['params'], list(conv0.parameters()) + list(lin0.parameters()) + [scal0])):
+        st = opt.state[p]
+        ok &= st['step'] == 3 + i
+        m = torch.randn_like(q, memory_format=torch.preserve_format)
+        v = torch.rand_like(q, memory_format=torch.preserve_format)
+        ok &= torch.equal(st['exp_avg'], m) and torch.equal(st['exp_avg_sq'], v)
+        ok &= st['exp_avg'].stride() == p.stride()
+        if p.dim() == 4:
+            ok &= torch.equal(st['master'], torch.randn_like(q, memory_format=torch.preserve_format))
+            ok &= st['master'].is_contiguous(memory_format=torch.channels_last)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(bool(flag.item() == 1.0))
+    dist.destroy_process_group()
+
+@pytest.mark.parametrize('worker', [_worker_global_contrast, _worker_clients_conw, _worker_config2_eight_clients,
+                                    _worker_reducer_lifecycle, _worker_adamp_broadcast_state])
 def test_two_rank_gloo(worker):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()

@@ -41,6 +41,17 @@ def _small_engine(dev, dim=64):
     return eng
 
 
+def _kd_loss(eng, b, sl):
+    """kd_weight * MSE(image features, agg[d_idx]) + the same for captions on rows `sl` of batch b (MMFL.kd_terms)."""
+    from creamfl_amd import ops
+    g = torch.Generator().manual_seed(99)
+    agg_i = torch.nn.functional.normalize(torch.randn(40, 64, generator=g), dim=-1).to(b[0].device)
+    agg_t = torch.nn.functional.normalize(torch.randn(40, 64, generator=g), dim=-1).to(b[0].device)
+    d_idx = torch.randperm(40, generator=g)[:16].to(b[0].device)[sl]
+    out = eng.model(b[0][sl], b[1][sl], None, b[3][sl])
+    return ops.kd_mse(out['image_features'], agg_i, d_idx, 0.7) + ops.kd_mse(out['caption_features'], agg_t, d_idx, 0.7)
+
+
 def _global_contrast_worker(rank, world, path, outdir):
     import torch.distributed as dist
     from creamfl_amd.utils.synthetic import coco_batch
@@ -57,10 +68,30 @@ def _global_contrast_worker(rank, world, path, outdir):
     keys = ['img_enc.fc.weight', 'img_enc.cnn.conv1.weight', 'img_enc.cnn.layer3.0.conv1.weight', 'linear.weight',
             'txt_enc.encoder.layer.0.attention.self.query.weight' if 'txt_enc.encoder.layer.0.attention.self.query.weight' in named
             else [k for k in named if k.startswith('txt_enc') and k.endswith('weight')][3]]
+    rec = {'loss': loss.detach().cpu(), 'n_buckets': len(eng.dp.reducer.buckets),
+           'grads': {k: views[named[k]].detach().float().cpu() for k in keys},
+           'weights': {k: named[k].detach().float().cpu() for k in keys}}
+    # ... followed by a KD step (MMFL.py:346-391) through the same reducer -- ADVICE r2 (high): the round-2 distill loop
+    # back-propagated without prepare/finish and the fused optimizer applied the CONTRASTIVE step's stale averages.
+    kd_loss = _kd_loss(eng, b, sl)
+    crit_steps = [eng.optimizer.state[p]['step'] for p in eng.criterion.parameters()]
+    eng.backward_and_step(kd_loss)
+    torch.cuda.synchronize()
+    rec['kd_weights'] = {k: named[k].detach().float().cpu() for k in keys}
+    rec['kd_grads'] = {k: views[named[k]].detach().float().cpu() for k in keys}      # the fused step leaves the averages intact
+    # the criterion's scalars got no gradient in the KD step: their step counts lag (per-parameter `step`)
+    rec['crit_steps'] = (crit_steps, [eng.optimizer.state[p]['step'] for p in eng.criterion.parameters()],
+                         eng.optimizer.state[named[keys[0]]]['step'])
+    # and a backward pass that bypasses the reducer must be refused, not silently fed stale averages
+    eng.optimizer.zero_grad(set_to_none=True)
+    eng.backward(_kd_loss(eng, b, sl))
+    try:
+        eng.optimizer_step()
+        rec['stale_refused'] = False
+    except RuntimeError:
+        rec['stale_refused'] = True
     if rank == 0:
-        torch.save({'loss': loss.detach().cpu(), 'n_buckets': len(eng.dp.reducer.buckets),
-                    'grads': {k: views[named[k]].detach().float().cpu() for k in keys},
-                    'weights': {k: named[k].detach().float().cpu() for k in keys}}, os.path.join(outdir, 'dp.pt'))
+        torch.save(rec, os.path.join(outdir, 'dp.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -104,6 +135,24 @@ def test_two_rank_global_contrast_matches_single_process():
     for k, w in got['weights'].items():
         ref = named[k].detach().float().cpu()
         np.testing.assert_allclose(w.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+    # the KD step after it: mean-MSE over each rank's half, averaged by the reducer == mean-MSE over the whole batch.
+    # Compared as UPDATES (weights after - weights before the KD step): a stale-gradient bug replays the contrastive
+    # step's direction, which is uncorrelated with the KD direction.
+    before = {k: named[k].detach().float().cpu() for k in got['weights']}
+    eng.backward_and_step(_kd_loss(eng, b, slice(0, 16)))
+    torch.cuda.synchronize()
+    for k, g in got['kd_grads'].items():
+        ref = named[k].grad.detach().float().cpu()
+        np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=5e-3, atol=1e-3 * float(ref.abs().max()), err_msg='KD grad ' + k)
+    for k, w in got['kd_weights'].items():
+        ref_upd = (named[k].detach().float().cpu() - before[k]).numpy().ravel()
+        got_upd = (w - got['weights'][k]).numpy().ravel()
+        cos = float(np.dot(ref_upd, got_upd) / (np.linalg.norm(ref_upd) * np.linalg.norm(got_upd) + 1e-30))
+        assert cos > 0.99, (k, cos)
+        np.testing.assert_allclose(w.numpy(), named[k].detach().float().cpu().numpy(), rtol=1e-4, atol=6e-5, err_msg=k)
+    before_steps, after_steps, trunk_steps = got['crit_steps']
+    assert before_steps == after_steps == [1, 1] and trunk_steps == 2
+    assert got['stale_refused'] is True
 
 
 def _round_args():

@@ -131,3 +131,99 @@ def test_fused_adamp_async_uploads_do_not_race():
     got = run(False)
     for a, b in zip(ref, got):
         np.testing.assert_array_equal(a, b)
+
+
+def test_fused_adamp_per_parameter_steps_lagging_gradients():
+    """parameters whose gradient is None in some steps keep their own step count (adamp==0.3.0 keeps
+    `state['step']` per parameter) -- the `tsteps` branch of optimizers.AdamP.step / CflTensorMeta.step in csrc/adamp.hip.
+    Schedule: the two trailing scalars (the criterion's shift / negative_scale) and one matrix get a gradient only on some
+    steps, exactly what every KD phase does to the criterion's scalars; the oracle uses per-parameter counts too."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from oracle.adamp import AdamP as OracleAdamP
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(11)
+    init = _make_params(gen)
+    cpu = [torch.nn.Parameter(t.clone()) for t in init]
+    gpu = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    n = len(init)
+    # two groups, like the engine's single group + a second one, so that group-local uniformity is exercised as well
+    ocpu = OracleAdamP([{'params': cpu[:4]}, {'params': cpu[4:]}], lr=1e-2, weight_decay=0.01)
+    ogpu = AdamP([{'params': gpu[:4]}, {'params': gpu[4:]}], lr=1e-2, weight_decay=0.01)
+    lag = {n - 1: [1, 0, 0, 1, 0, 1], n - 2: [1, 0, 0, 1, 0, 1], 4: [1, 1, 0, 1, 0, 0], 1: [0, 1, 1, 1, 0, 1]}
+    for it in range(6):
+        grads = [torch.randn(t.shape, generator=gen) for t in init]
+        for k, (p, q, g) in enumerate(zip(cpu, gpu, grads)):
+            on = lag.get(k, [1] * 6)[it]
+            p.grad = g.clone() if on else None
+            q.grad = g.to(dev) if on else None
+        clip_cpu = [p for p in cpu[:n - 2]]
+        norm = torch.nn.utils.clip_grad_norm_([p for p in clip_cpu if p.grad is not None], 2.0)
+        ocpu.step()
+        ogpu.step(clip=(gpu[:n - 2], 2.0))
+        np.testing.assert_allclose(ogpu.last_grad_norm.item(), norm.item(), rtol=1e-5)
+        for k, (p, q) in enumerate(zip(cpu, gpu)):
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().numpy(), rtol=2e-4, atol=2e-6,
+                                       err_msg=f'step {it} tensor {k} {tuple(p.shape)}')
+    for k, (p, q) in enumerate(zip(cpu, gpu)):
+        want = sum(lag.get(k, [1] * 6))
+        assert ogpu.state[q]['step'] == want == ocpu.state[p]['step'], (k, ogpu.state[q]['step'], want)
+
+
+def test_fused_adamp_checkpoint_round_trip_is_bit_exact():
+    """save -> load -> one step == continuing without the reload, bit for bit, with bf16 trunk weights + fp32
+    masters (AdamP.load_state_dict / master_state_dict / load_model_weights / refresh_masters)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import copy
+    import io
+    from creamfl_amd.algorithms.optimizers import AdamP
+    dev = torch.device('cuda:0')
+
+    def build():
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Flatten(), torch.nn.Linear(16 * 36, 24),
+                                  torch.nn.LayerNorm(24)).to(dev).to(memory_format=torch.channels_last)
+        opt = AdamP(list(net.parameters()), lr=1e-2, weight_decay=0.01)
+        for mod in (net[0], net[2]):
+            opt.make_master(mod.weight)
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+        return net, opt
+
+    def grads_for(net, it):
+        g = torch.Generator().manual_seed(100 + it)
+        for p in net.parameters():
+            p.grad = torch.randn(p.shape, generator=g).to(dev).to(p.dtype).contiguous(
+                memory_format=torch.channels_last if p.dim() == 4 else torch.contiguous_format)
+
+    net_a, opt_a = build()
+    for it in range(2):
+        grads_for(net_a, it)
+        opt_a.step(clip=(list(net_a.parameters()), 2.0))
+    buf = io.BytesIO()
+    torch.save({'model': opt_a.master_state_dict(net_a), 'optimizer': opt_a.state_dict()}, buf)
+    # A continues
+    grads_for(net_a, 2)
+    opt_a.step(clip=(list(net_a.parameters()), 2.0))
+    # B is rebuilt from the checkpoint (through the CPU, like retrieval_trainer.load_models) and takes the same step
+    buf.seek(0)
+    ck = torch.load(buf, map_location='cpu')
+    assert ck['model']['0.weight'].dtype == torch.float32            # checkpoints hold the masters
+    net_b, opt_b = build()
+    opt_b.load_state_dict(ck['optimizer'])
+    net_b.load_state_dict(ck['model'])                               # casts the fp32 master into the bf16 weight
+    named = dict(net_b.named_parameters())
+    opt_b.refresh_masters({named[k]: v.to(dev) for k, v in ck['model'].items() if named[k].dtype == torch.bfloat16})
+    for p in (net_b[0].weight, net_b[2].weight):
+        st = opt_b.state[p]
+        assert st['master'].dtype == st['exp_avg'].dtype == torch.float32 and st['exp_avg'].stride() == p.stride()
+    grads_for(net_b, 2)
+    opt_b.step(clip=(list(net_b.parameters()), 2.0))
+    torch.cuda.synchronize()
+    for (k, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        assert torch.equal(pa.detach(), pb.detach()), k
+        for key in ('master', 'exp_avg', 'exp_avg_sq'):
+            if key in opt_a.state[pa]:
+                assert torch.equal(opt_a.state[pa][key], opt_b.state[pb][key]), (k, key)
+        assert opt_a.state[pa]['step'] == opt_b.state[pb]['step'] == 3

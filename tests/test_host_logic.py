@@ -103,6 +103,51 @@ def test_adamp_oracle_matches_literal_algorithm():
             np.testing.assert_allclose(q.detach().numpy(), p, rtol=1e-9, atol=1e-12)
 
 
+def test_adamp_oracle_per_parameter_step_counts():
+    """adamp==0.3.0 keeps `state['step']` per parameter: one whose gradient is None in some steps (the criterion's scalars in
+    every KD phase) lags behind and is bias-corrected with ITS OWN count.  The oracle against the literal per-parameter
+    transcription on a schedule where two of four parameters skip steps."""
+    from oracle.adamp import AdamP
+    rng = np.random.default_rng(1)
+    shapes = [(6, 4, 3, 3), (1,), (5, 40), (7,)]
+    ps = [rng.standard_normal(s) * 0.1 for s in shapes]
+    tp = [torch.nn.Parameter(torch.tensor(p, dtype=torch.float64)) for p in ps]
+    opt = AdamP(tp, lr=1e-2, weight_decay=0.01)
+    sts = [{'t': 0, 'm': np.zeros(s), 'v': np.zeros(s)} for s in shapes]
+    present = [[1, 1, 1, 1], [1, 0, 1, 0], [1, 0, 0, 1], [1, 1, 1, 1], [1, 0, 1, 1]]      # rows = steps, 0 = grad None
+    for mask in present:
+        gs = [rng.standard_normal(s) for s in shapes]
+        for q, g, on in zip(tp, gs, mask):
+            q.grad = torch.tensor(g, dtype=torch.float64) if on else None
+        opt.step()
+        ps = [_literal_adamp_step(p, g, st, 1e-2, wd=0.01) if on else p for p, g, st, on in zip(ps, gs, sts, mask)]
+        for q, p in zip(tp, ps):
+            np.testing.assert_allclose(q.detach().numpy(), p, rtol=1e-9, atol=1e-12)
+    assert [opt.state[q]['step'] for q in tp] == [5, 2, 4, 4] == [st['t'] for st in sts]
+
+
+def test_adamp_load_state_without_master_into_bf16_model():
+    """an optimizer state with moments but no master (a checkpoint taken from an fp32 model) loaded into a model
+    whose trunk weights are bf16 must come out with an fp32 master (KeyError in `_plan` before), moments fp32."""
+    from creamfl_amd.algorithms.optimizers import AdamP
+    w32 = torch.nn.Parameter(torch.randn(8, 4))
+    src = AdamP([w32], lr=1e-3)
+    src.state[w32].update(step=3, exp_avg=torch.randn(8, 4), exp_avg_sq=torch.rand(8, 4))
+    sd = src.state_dict()
+    w16 = torch.nn.Parameter(torch.randn(8, 4).to(torch.bfloat16))
+    dst = AdamP([w16], lr=1e-3)
+    dst.load_state_dict(sd)
+    st = dst.state[w16]
+    assert st['step'] == 3 and st['exp_avg'].dtype == torch.float32 and st['exp_avg_sq'].dtype == torch.float32
+    assert torch.equal(st['exp_avg'], src.state[w32]['exp_avg'])
+    assert st['master'].dtype == torch.float32 and torch.equal(st['master'], w16.detach().float())
+    # refresh_masters creates a missing master too, preferring full-precision values when it is given them
+    del st['master']
+    full = torch.randn(8, 4)
+    dst.refresh_masters({w16: full})
+    assert torch.equal(dst.state[w16]['master'], full)
+
+
 def test_bert_cls_only_equals_full_forward_on_cpu():
     """`cls_only=True` evaluates the last layer for [CLS] only: same values and parameter gradients for everything PCME
     consumes (it reads [:, 0, :] only, src/networks/models/pcme.py:44)."""
@@ -236,8 +281,9 @@ def test_main_py_flag_surface_drops_into_mmfl():
 def test_grad_buckets_views_layout_and_unused_parameters():
     """dist.GradBuckets on one process (no communication): after finish() every gradient is a view into its bucket with the
     parameter's own strides (channels_last convolution weights included), values equal plain autograd's, a parameter that
-    received no gradient gets an all-zero slot, and a gradient reported through `notify` (the deferred weight-gradient
-    path) is bucketed like the hooked ones."""
+    received no gradient keeps `grad None` (optimizers must skip it as the single-process run does; its slot travels as
+    zeros and consume() names it), and a gradient reported through `notify` (the deferred weight-gradient path) is bucketed
+    like the hooked ones."""
     import torch.nn as nn
     from creamfl_amd.dist import GradBuckets
     torch.manual_seed(0)
@@ -259,7 +305,9 @@ def test_grad_buckets_views_layout_and_unused_parameters():
     for p, w in zip([conv.weight, conv.bias, lin.weight, lin.bias], want):
         assert torch.allclose(p.grad, w) and p.grad.stride() == p.stride()
     assert conv.weight.grad.is_contiguous(memory_format=torch.channels_last)
-    assert torch.equal(unused.grad, torch.zeros(5)) and torch.equal(deferred.grad, torch.full((6, 2), 3.0))
+    assert unused.grad is None and torch.equal(gb.grad_views()[unused], torch.zeros(5))
+    assert torch.equal(deferred.grad, torch.full((6, 2), 3.0))
+    assert [id(p) for p in gb.consume()] == [id(unused)]
     for plist, views in zip(gb.buckets, gb.views):
         for p, v in zip(plist, views):
-            assert p.grad.data_ptr() == v.data_ptr()
+            assert p is unused or p.grad.data_ptr() == v.data_ptr()
