@@ -38,6 +38,12 @@ SIGNATURES = {
     'cfl_client_contrast_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int,
                                         _P, _P, _P, _P, _P, _P, _P, _P]),
     'cfl_client_contrast_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
+    'cfl_bank_image_bytes': (c_size_t, [c_int, c_int]),
+    'cfl_bank_image_build': (c_int, [_P, c_int, c_int, _P, _P]),
+    'cfl_bank_gsplit_supported': (c_int, [c_int, c_int, c_int]),
+    'cfl_bank_gsplit_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'cfl_client_contrast_img_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int,
+                                            _P, _P, _P, _P, _P, _P, _P, _P]),
     'cfl_intra_ws_bytes': (c_size_t, [c_int]),
     'cfl_intra_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_kd_mse': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),

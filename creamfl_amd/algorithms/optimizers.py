@@ -232,6 +232,7 @@ class AdamP(Optimizer):
         self.last_grad_norm = None
         if self.grad_override is not None and self.grad_override_consume is not None:
             self.grad_override_consume()
+        work = []
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group['params'] if p.grad is not None]
             if not params:
@@ -270,13 +271,25 @@ class AdamP(Optimizer):
                 plan['gptrs'] = gptrs
             stream = ctypes.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
             n_items = plan['items'].shape[0]
-            clip_ptr = ctypes.c_void_p(0)
-            if clip_ids and max_norm > 0:
+            clipped = bool(clip_ids and max_norm > 0 and any(id(p) in clip_ids for p in params))
+            if clipped:
                 _lib.check(lib.cfl_grad_clip_coef(plan['meta_dev'].data_ptr(), plan['items'].data_ptr(), n_items, max_norm,
                                                   plan['partial'].data_ptr(), plan['clip'].data_ptr(), stream),
                            'cfl_grad_clip_coef')
-                clip_ptr = ctypes.c_void_p(plan['clip'].data_ptr())
-                self.last_grad_norm = plan['clip'][0]
+            work.append((group, params, plan, grads, steps, stream, n_items, clipped))
+        clipped_plans = [w[2] for w in work if w[7]]
+        if len(clipped_plans) > 1:
+            # clip_grad_norm_ is ONE norm over every clipped parameter, whatever group it sits in: combine the groups' norms
+            # on the device (still no host synchronisation) and hand every group the same coefficient
+            total = torch.stack([pl['clip'][0] for pl in clipped_plans]).square().sum().sqrt()
+            coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
+            both = torch.stack([total, coef])
+            for pl in clipped_plans:
+                pl['clip'].copy_(both)
+        if clipped_plans:
+            self.last_grad_norm = clipped_plans[0]['clip'][0]
+        for group, params, plan, grads, steps, stream, n_items, clipped in work:
+            clip_ptr = ctypes.c_void_p(plan['clip'].data_ptr()) if clipped else ctypes.c_void_p(0)
             beta1, beta2 = group['betas']
             _lib.check(lib.cfl_adamp_step(plan['meta_dev'].data_ptr(), len(params), plan['items'].data_ptr(), n_items,
                                           plan['matrix_ids'].data_ptr(), plan['n_matrix'], plan['rowstats'].data_ptr(),
@@ -284,7 +297,7 @@ class AdamP(Optimizer):
                                           float(group['eps']), float(group['weight_decay']), float(group['delta']),
                                           float(group['wd_ratio']), int(bool(group['nesterov'])),
                                           max(steps), clip_ptr, stream), 'cfl_adamp_step')
-            del grads
+        del work
         return loss
 
 

@@ -27,6 +27,7 @@
 //
 // Workspace layout (floats): part_m[RG][S][128] part_l[RG][S][128] rowbuf[2][Bp] part_o[RG][128][S][DP]; `sync` is a
 // caller-owned int that must be 0 before the first call and is left 0 (last-block election of the epilogue kernel).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __re
 //   * the LAST block to finish (write-through stores + agent-scope ticket, cdna guide G16) reduces the rows in fixed order and writes
 //     out5 = {loss, loss_inter, loss_moon, coef_inter, coef_moon}: the combined loss of ClientTrainer.py:416-419 and the
 //     factors the backward applies to the two unit gradients.   mode bit 1: intra term present, bit 2: --loss_scale
+template <int NJ>      // a thread merges the splits xg + 16 j, j < NJ (S <= 16 NJ)
 __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
                                                                const float* __restrict__ part_o, int S, int DP,
                                                                const float* __restrict__ F, const float* __restrict__ Go,
@@ -331,7 +333,8 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
     __shared__ float redl[16];
     __shared__ float row_lse, row_pos;
     __shared__ int is_last;
-    const int fl = blockIdx.x >> 2, quarter = blockIdx.x & 3, rg = blockIdx.y;
+    const int ncb = DP / 64;                        // blocks per row: 64 columns (16 lanes x 4) each
+    const int fl = blockIdx.x / ncb, quarter = blockIdx.x % ncb, rg = blockIdx.y;
     const int f = rg * BR + fl;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool live = f < B;
@@ -342,13 +345,13 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
         // load it will ever need (<= 16 splits: max, sum and its 16 bytes of O), then the block agrees on the reference.  The
         // partials of one feature row are contiguous ([row][split][DP]): the four blocks of a row sweep one region.
         const int c4 = (t & 15) * 4, xg = t >> 4;
-        const int d4 = quarter * (DP / 4) + c4;
-        const bool want_o = dF != nullptr && c4 < DP / 4;
+        const int d4 = quarter * 64 + c4;
+        const bool want_o = dF != nullptr;
         const float* po = part_o + (((size_t)rg * BR + fl) * S) * DP + d4;
-        float pmv[16], plv[16];
-        f32x4 ov[16];
+        float pmv[NJ], plv[NJ];
+        f32x4 ov[NJ];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int x = xg + 16 * j;
             const int xc = x < S ? x : S - 1;                      // unconditional loads (clamped), masked below
             pmv[j] = pm[(size_t)xc * BR];
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { if (xg + 16 * j >= S) pmv[j] = -INFINITY; mx = fmaxf(mx, pmv[j]); }
+        for (int j = 0; j < NJ; ++j) { if (xg + 16 * j >= S) pmv[j] = -INFINITY; mx = fmaxf(mx, pmv[j]); }
         mx = wave_max(mx);
         if (lane == 0) redm[wv] = mx;
         __syncthreads();
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         float L = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const float wgt = __builtin_amdgcn_exp2f(pmv[j] - mx);          // 0 for the masked splits (pmv = -inf)
             L = fmaf(wgt, plv[j], L);
             acc += ov[j] * wgt;
@@ -427,10 +430,14 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
     // write-through (sc1) atomic stores that were drained (vmcnt(0)) before this barrier and read back below with sc1
     // atomic loads: the "sc1 stores and loads on both sides" form of the cdna guide (G16) -- no L2 write-back / invalidate
     // fences, which cost ~7 us here with the freshly written gradient dirty in every L2.
+    // Only the blocks that publish row terms (column block 0 of every row) take a ticket: one counter serialises its
+    // arrivals at ~12 ns each (cdna guide, "fanin"), and with every (row, column block) voting that was 512 tickets = 6 us
+    // at D = 256 and 2048 = 25 us at D = 512 / B = 256 -- most of this kernel's time.
+    if (quarter != 0) return;
     __syncthreads();
     if (t == 0) {
         const int tk = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (tk == (int)(gridDim.x * gridDim.y) - 1);
+        is_last = (tk == (int)((gridDim.x / ncb) * gridDim.y) - 1);
     }
     __syncthreads();
     if (!is_last) return;
@@ -479,6 +486,38 @@ static AttnWs attn_ws(void* ws, const AttnPlan& p) {
     w.rowbuf = q; q += (size_t)2 * p.Bp;
     w.part_o = q;
     return w;
+}
+
+#include "bank_gsplit.h"
+
+template <int DT, int NGG, int NWAVE, int NDS, int LA, bool GRAD>
+static int launch_stream(const float* F, const void* img, int B, int M, int D, float sc2, const gs::GsPlan& p, const AttnWs& w,
+                         hipStream_t stream) {
+    using SM = gs::StSmem<DT, NGG, NWAVE, NDS>;
+    CFL_SET_LDS((gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD>), SM::TOTAL);
+    CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD>), dim3(p.S * p.RG), dim3(64 * NWAVE), SM::TOTAL, stream,
+               F, (const char*)img, B, M, D, sc2, p.S, p.RG, w.part_m, w.part_l, w.part_o);
+    return 0;
+}
+
+// the finish launch both bank passes share; S = number of splits of the partials
+static int launch_finish(const AttnWs& w, int S, int DP, int RGF, int Bp, const float* F, const float* G_other, const float* G_same,
+                         const float* F_old, const long long* idx, int B, int M, int D, int B_div, float inv_tau, float weight,
+                         int mode, int want_grad, float* out5, float* lse, float* pos, float* dF_inter, float* dF_moon, int* sync,
+                         hipStream_t stream) {
+    float* dfi = (want_grad && (mode & 1)) ? dF_inter : (float*)nullptr;
+    float* dfm = (want_grad && (mode & 2)) ? dF_moon : (float*)nullptr;
+    const int bd = (mode & 2) ? B_div : B;
+#define CFL_FINISH(NJ)                                                                                                              \
+    CFL_LAUNCH(K_LSE_FINAL, cfl_contrast_finish_kernel<NJ>, dim3((DP / 64) * BR, RGF), dim3(256), 0, stream, w.part_m, w.part_l, w.part_o, S, DP, F, \
+               G_other, G_same, F_old, idx, B, M, D, bd, inv_tau, weight, mode, lse, pos, w.rowbuf, Bp, dfi, dfm, out5, sync)
+    if (S <= 16) { CFL_FINISH(1); }
+    else if (S <= 32) { CFL_FINISH(2); }
+    else if (S <= 64) { CFL_FINISH(4); }
+    else if (S <= 128) { CFL_FINISH(8); }
+    else { CFL_FINISH(16); }
+#undef CFL_FINISH
+    return 0;
 }
 
 template <int DT, bool GRAD>
@@ -534,11 +573,69 @@ int cfl_client_contrast_fwd(const float* F, const float* G_other, const float* G
         }
         if (rc) return rc;
     }
-    CFL_LAUNCH(K_LSE_FINAL, cfl_contrast_finish_kernel, dim3(4 * BR, p.RG), dim3(256), 0, stream, w.part_m, w.part_l, w.part_o, p.S, p.DP,
-               F, G_other, G_same, F_old, idx, B, M, D, (mode & 2) ? B_div : B, inv_tau, weight, mode, lse, pos, w.rowbuf, p.Bp,
-               (want_grad && (mode & 1)) ? dF_inter : (float*)nullptr, (want_grad && (mode & 2)) ? dF_moon : (float*)nullptr, out5,
-               sync);
+    return launch_finish(w, p.S, p.DP, p.RG, p.Bp, F, G_other, G_same, F_old, idx, B, M, D, B_div, inv_tau, weight, mode, want_grad, out5,
+                         lse, pos, dF_inter, dF_moon, sync, stream);
+}
+
+// ---- round 3: the same step on a pre-split bank image (bank_gsplit.h) ---------------------------------------------------
+size_t cfl_bank_image_bytes(int M, int D) {
+    if (M <= 0 || D <= 0) return 0;
+    return cfl_align256(gs::img_bytes(M, D));
+}
+
+int cfl_bank_image_build(const float* G, int M, int D, void* image, void* stream_) {
+    if (!G || !image || M <= 0 || D <= 0) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int DP = gs::img_dp(D);
+    const long long n = (long long)cfl_cdiv(M, gs::SG) * gs::SG * (DP / 8);
+    CFL_LAUNCH(K_BANK_IMAGE, gs::cfl_bank_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, G, M, D, DP, (char*)image);
     return 0;
+}
+
+int cfl_bank_gsplit_supported(int B, int M, int D) {
+    return (B > 0 && M > 0 && D >= 4 && D <= 768 && D % 4 == 0) ? 1 : 0;
+}
+
+size_t cfl_bank_gsplit_ws_bytes(int B, int M, int D, int want_grad) {
+    if (!cfl_bank_gsplit_supported(B, M, D)) return 256;
+    const gs::GsPlan p = gs::gs_plan(B, M, D);
+    size_t n = (size_t)2 * p.RGF * p.S * BR + (size_t)2 * p.Bp;
+    if (want_grad) n += (size_t)p.Bp * p.S * p.DP;
+    return cfl_align256(n * sizeof(float));
+}
+
+int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const float* G_other, const float* G_same,
+                                const long long* idx, const float* F_old, int B, int M, int D, int B_div, float inv_tau, float weight,
+                                int mode, int want_grad, float* out5, float* lse, float* pos, float* dF_inter, float* dF_moon,
+                                void* ws, int* sync, void* stream_) {
+    if (!F || !idx || !out5 || !ws || !sync || B <= 0 || M <= 0 || D <= 0 || !(inv_tau > 0.f) || !(mode & 3)) return CFL_EINVAL;
+    if ((mode & 1) && (!G_other || !image_other || !lse)) return CFL_EINVAL;
+    if ((mode & 2) && (!G_same || !F_old || B_div <= 0)) return CFL_EINVAL;
+    if (want_grad && (((mode & 1) && !dF_inter) || ((mode & 2) && !dF_moon))) return CFL_EINVAL;
+    if (!cfl_bank_gsplit_supported(B, M, D)) return CFL_ELIMIT;
+    if ((((uintptr_t)F | (uintptr_t)G_other | (uintptr_t)image_other) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const gs::GsPlan p = gs::gs_plan(B, M, D);
+    AttnPlan q;
+    q.DT = p.DT; q.DP = p.DP; q.RG = p.RGF; q.S = p.S; q.Bp = p.Bp;
+    const AttnWs w = attn_ws(ws, q);
+    if (mode & 1) {
+        const float sc2 = inv_tau * 1.4426950408889634f;
+        int rc;
+        // <DT, streams, waves, column split, staging sets>: D <= 256: 2 feature groups x 4 slot streams, 2 waves per SIMD;
+        // D = 512: 4 column-split pairs, 2 per SIMD; D = 768: 2 column-split pairs, 1 wave per SIMD, 2 staging sets
+        if (p.DT == 24) rc = want_grad ? launch_stream<24, 1, 4, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                       : launch_stream<24, 1, 4, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        else if (p.DT == 16) rc = want_grad ? launch_stream<16, 1, 8, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                            : launch_stream<16, 1, 8, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        else if (p.DT == 8) rc = want_grad ? launch_stream<8, 4, 8, 1, 1, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                           : launch_stream<8, 4, 8, 1, 1, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        else rc = want_grad ? launch_stream<4, 4, 8, 1, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                            : launch_stream<4, 4, 8, 1, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        if (rc) return rc;
+    }
+    return launch_finish(w, p.S, p.DP, p.RGF, p.Bp, F, G_other, G_same, F_old, idx, B, M, D, B_div, inv_tau, weight, mode, want_grad,
+                         out5, lse, pos, dF_inter, dF_moon, sync, stream);
 }
 
 int cfl_client_contrast_bwd(const float* dF_inter, const float* dF_moon, const float* out5, const float* gout_dev, int B, int D,

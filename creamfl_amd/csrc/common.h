@@ -29,6 +29,7 @@ enum CflKernel {
     K_GEMM_PROBE, K_KD_MSE, K_SUP_GLUE, K_GEMM_BF16, K_BERT_DALN, K_BERT_GELU, K_ATTN_SMALL, K_MAXPOOL, K_TRANSPOSE,
     K_PIE_FWD_FUSED, K_PIE_BWD_FUSED,
     K_BN_POOL_FWD, K_BN_POOL_BWD_REDUCE, K_BN_POOL_BWD_APPLY,
+    K_BANK_IMAGE, K_BANK_STREAM,
     K_NUM
 };
 

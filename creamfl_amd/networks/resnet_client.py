@@ -1,84 +1,83 @@
-"""Client image encoder (row A2c).  Mirrors src/networks/resnet_client.py:102-250: the client ResNet with
-`scale`, the `phase == 'extract_conv_feature'` embedding path (l2-normalised, HIP kernel) and the classifier
-heads with ReLU-clamped weights.  Mode is switched by mutating `model.phase` / `model.is_train`, exactly as
-ClientTrainer does (ClientTrainer.py:372-375)."""
+"""Client image encoder (row A2c): ResNet trunk (library convolutions + the fused BatchNorm / pooling kernels of
+networks/backbones.py) -> global average -> x scale -> optional projection, then -- selected by the attributes ClientTrainer
+mutates (`phase`, `is_train`: ClientTrainer.py:372-375) -- the l2-normalised embedding (HIP kernel), the two classifier heads
+with zero-clamped weights, or the raw feature.  Behavioural contract = src/networks/resnet_client.py:102-250; parameter names
+are the reference's (its checkpoints load with strict=True; tests/golden/a2c_img_*.npz come from the reference's forward)."""
 import math
 
 import torch.nn as nn
 
 from .. import ops
 from .backbones import BasicBlock, BNAct, Bottleneck, MaxPool3s2, first_of
+from .language_model import clamped_head, local_projection_head
+
+STAGE_WIDTHS = (64, 128, 256, 512)
 
 
 class ResNet(nn.Module):
     def __init__(self, block, layers, **kwargs):
-        self.inplanes = 64
         super().__init__()
+        self.embed_dim = kwargs['embed_dim']
+        self.is_train = bool(kwargs['is_train'])
+        self.scale = int(kwargs['scale'])
+        self.phase = str(kwargs.get('phase', 'none'))
+        self.mlp_local = kwargs.get('mlp_local', False)
+        # stem
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=False)
         self.maxpool = MaxPool3s2()
-        self.layer1 = self._make_layer(block, 64, layers[0])
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        # four stages; only the first keeps the resolution
+        self.inplanes = 64
+        for i, (width, depth) in enumerate(zip(STAGE_WIDTHS, layers)):
+            setattr(self, f'layer{i + 1}', self._make_layer(block, width, depth, stride=1 if i == 0 else 2))
         self.avg_pool = nn.AdaptiveAvgPool2d((1, 1))
-        self.embed_dim = kwargs['embed_dim']
-        feat = 512 * block.expansion
-        if kwargs['embed_dim'] != 512 or feat != 512:
-            self.linear = nn.Linear(feat, self.embed_dim)
+        trunk_dim = STAGE_WIDTHS[-1] * block.expansion
+        if not (self.embed_dim == 512 and trunk_dim == 512):       # the reference skips the projection only for 512 -> 512
+            self.linear = nn.Linear(trunk_dim, self.embed_dim)
         self.class_fc_2 = nn.Linear(self.embed_dim, kwargs['num_class'])
         self.class_fc_22 = nn.Linear(self.embed_dim, 80)
-        self.is_train = bool(kwargs['is_train'])
-        self.scale = int(kwargs['scale'])
-        self.phase = str(kwargs['phase']) if 'phase' in kwargs.keys() else 'none'
-        self.mlp_local = kwargs['mlp_local'] if 'mlp_local' in kwargs.keys() else False
         if self.mlp_local:
-            self.head_proj = nn.Sequential(nn.Linear(512, 512), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
-                                           nn.Linear(512, 512))
+            self.head_proj = local_projection_head()
+        self.reset_trunk()
+
+    def reset_trunk(self):
+        """He-normal convolutions (fan-out), unit BatchNorm scale, zero BatchNorm shift (resnet_client.py:139-145)."""
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
-                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-                m.weight.data.normal_(0, math.sqrt(2. / n))
+                m.weight.data.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
 
     def _make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                BNAct(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for i in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
+        out_planes = planes * block.expansion
+        shortcut = None
+        if stride != 1 or self.inplanes != out_planes:
+            shortcut = nn.Sequential(nn.Conv2d(self.inplanes, out_planes, kernel_size=1, stride=stride, bias=False),
+                                     BNAct(out_planes))
+        stage = [block(self.inplanes, planes, stride, shortcut)] + [block(out_planes, planes) for _ in range(blocks - 1)]
+        self.inplanes = out_planes
+        return nn.Sequential(*stage)
 
     def extract_conv_feature(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        return first_of(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
+        for i in range(1, 5):
+            x = getattr(self, f'layer{i}')(x)
+        return first_of(x)
 
     def forward(self, x):
-        x = self.extract_conv_feature(x)
-        avg_x = self.avg_pool(x)
-        x = avg_x.view(avg_x.size(0), -1)
-        x = x * self.scale
+        feat = self.avg_pool(self.extract_conv_feature(x)).flatten(1) * self.scale
         if hasattr(self, 'linear'):
-            x = self.linear(x)
+            feat = self.linear(feat)
         if self.phase == 'extract_conv_feature':
-            if self.mlp_local:
-                x = self.head_proj(x)
-                x = ops.l2_normalize(x)
-            return ops.l2_normalize(x)
-        if self.is_train:
-            fc_weight_relu = self.relu(self.class_fc_2.weight)
-            self.class_fc_2.weight.data = fc_weight_relu
-            fc_weight_relu2 = self.relu(self.class_fc_22.weight)
-            self.class_fc_22.weight.data = fc_weight_relu2
-            return self.class_fc_2(x), self.class_fc_22(x), fc_weight_relu, fc_weight_relu2
-        return x
+            # (with --mlp_local the reference normalises twice, resnet_client.py:186-190; the second pass is kept)
+            return ops.l2_normalize(ops.l2_normalize(self.head_proj(feat)) if self.mlp_local else feat)
+        if not self.is_train:
+            return feat
+        logits, w = clamped_head(self.class_fc_2, feat)
+        logits2, w2 = clamped_head(self.class_fc_22, feat)
+        return logits, logits2, w, w2
 
 
 def resnet10_client(pretrained=False, **kwargs):

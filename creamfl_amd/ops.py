@@ -128,24 +128,64 @@ def _contrast_state(device, ws_bytes):
 
 import os as _os
 _BANK_EXACT = bool(_os.environ.get('CFL_BANK_EXACT'))       # A/B switch: round-1 exact-fp32 two-pass kernels
+_BANK_NOIMG = bool(_os.environ.get('CFL_BANK_NOIMG'))       # A/B switch: round-2 bank pass (fp32 bank, 128-row groups)
+
+# Pre-split bank images (csrc/bank_gsplit.h).  The global banks are frozen while a client trains (ClientTrainer.py:369-372:
+# one pair of global feature tensors per round, hundreds of steps against them), so the fp32 -> (bf16 hi, bf16 lo) image is
+# built once per bank VERSION: an entry is reused while the same storage (kept alive by the entry, so its address cannot be
+# handed to another tensor) still carries the version counter it was built from.
+_BANK_IMAGES = {}            # (data_ptr, M, D) -> [source tensor, version, image, last-use tick]
+_BANK_IMAGES_MAX = 6
+_bank_tick = [0]
+BANK_IMAGE_BUILDS = [0]      # how many images were built (tests / benches read it)
+
+
+def bank_image(G):
+    """The pre-split image of a [M, D] fp32 bank (device tensor of cfl_bank_image_bytes bytes), cached per bank version."""
+    lib = _lib.load()
+    M, D = G.shape
+    key = (G.data_ptr(), M, D)
+    _bank_tick[0] += 1
+    ent = _BANK_IMAGES.get(key)
+    if ent is not None and ent[1] == G._version:
+        ent[3] = _bank_tick[0]
+        return ent[2]
+    img = ent[2] if ent is not None else torch.empty(int(lib.cfl_bank_image_bytes(M, D)), dtype=torch.uint8, device=G.device)
+    _lib.check(lib.cfl_bank_image_build(G.data_ptr(), M, D, img.data_ptr(), torch.cuda.current_stream(G.device).cuda_stream),
+               'cfl_bank_image_build')
+    BANK_IMAGE_BUILDS[0] += 1
+    _BANK_IMAGES[key] = [G, G._version, img, _bank_tick[0]]
+    if len(_BANK_IMAGES) > _BANK_IMAGES_MAX:
+        del _BANK_IMAGES[min(_BANK_IMAGES, key=lambda k: _BANK_IMAGES[k][3])]
+    return img
+
+
+def bank_image_supported(B, M, D):
+    return (not _BANK_EXACT) and (not _BANK_NOIMG) and bool(_lib.load().cfl_bank_gsplit_supported(int(B), int(M), int(D)))
 
 
 _BANK_PLAN = {}          # (B, M, D, need_grad) -> workspace bytes, or None when the fused path does not take the shape
 
 
-def _bank_plan(B, M, D, need):
-    key = (B, M, D, need)
+def _bank_plan(B, M, D, need, img=False):
+    key = (B, M, D, need, img)
     v = _BANK_PLAN.get(key, -1)
     if v == -1:
         lib = _lib.load()
-        v = int(lib.cfl_bank_attn_ws_bytes(B, M, D, int(need))) if lib.cfl_bank_attn_supported(B, M, D) else None
+        if img:
+            v = int(lib.cfl_bank_gsplit_ws_bytes(B, M, D, int(need))) if lib.cfl_bank_gsplit_supported(B, M, D) else None
+        else:
+            v = int(lib.cfl_bank_attn_ws_bytes(B, M, D, int(need))) if lib.cfl_bank_attn_supported(B, M, D) else None
         _BANK_PLAN[key] = v
     return v
 
 
 def bank_attn_supported(B, M, D):
-    """True when the single-pass 3 x bf16-split kernels (csrc/bank_attn.hip) take this shape (D <= 256, D % 4 == 0)."""
-    return (not _BANK_EXACT) and _bank_plan(int(B), int(M), int(D), False) is not None
+    """True when the single-pass 3 x bf16-split kernels take this shape: D <= 768 on a pre-split bank image
+    (csrc/bank_gsplit.h), D <= 256 on the fp32 bank (csrc/bank_attn.hip, CFL_BANK_NOIMG=1); D % 4 == 0."""
+    if _BANK_EXACT:
+        return False
+    return bank_image_supported(B, M, D) or _bank_plan(int(B), int(M), int(D), False) is not None
 
 
 class _ClientContrastFn(torch.autograd.Function):
@@ -163,16 +203,27 @@ class _ClientContrastFn(torch.autograd.Function):
         out = torch.empty(8, dtype=torch.float32, device=dev)          # out5 = out[0:5]; the differentiable loss = out[5]
         aux = torch.empty(2, B, dtype=torch.float32, device=dev) if (mode & 1) else None        # lse, pos
         dFs = torch.empty(2, B, D, dtype=torch.float32, device=dev) if need else None            # inter, moon unit gradients
-        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need)))
+        # image path: whenever the inter term streams the bank; beyond D = 256 it is the only single-pass path (its finish
+        # launch also serves the intra-only mode)
+        use_img = bank_image_supported(B, M, D) and (bool(mode & 1) or D > 256)
+        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need), use_img))
         p_out = out.data_ptr()
         p_aux = aux.data_ptr() if aux is not None else 0
         p_dfs = dFs.data_ptr() if need else 0
-        _lib.check(lib.cfl_client_contrast_fwd(
-            F.data_ptr(), G_other.data_ptr() if G_other is not None else 0, G_same.data_ptr() if G_same is not None else 0,
-            idx.data_ptr(), F_old.data_ptr() if F_old is not None else 0, B, M, D, b_div, inv_tau, weight, mode, int(need),
-            p_out, p_aux, p_aux + 4 * B if p_aux else 0, p_dfs if (need and (mode & 1)) else 0,
-            p_dfs + 4 * B * D if (need and (mode & 2)) else 0, st['ws'].data_ptr(), st['sync'].data_ptr(),
-            torch.cuda.current_stream(dev).cuda_stream), 'cfl_client_contrast_fwd')
+        tail = (B, M, D, b_div, inv_tau, weight, mode, int(need),
+                p_out, p_aux, p_aux + 4 * B if p_aux else 0, p_dfs if (need and (mode & 1)) else 0,
+                p_dfs + 4 * B * D if (need and (mode & 2)) else 0, st['ws'].data_ptr(), st['sync'].data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream)
+        p_same = G_same.data_ptr() if G_same is not None else 0
+        p_old = F_old.data_ptr() if F_old is not None else 0
+        if use_img:
+            # bank pass on the pre-split image of G_other (built once per bank version), 32-row groups (csrc/bank_gsplit.h)
+            _lib.check(lib.cfl_client_contrast_img_fwd(F.data_ptr(), bank_image(G_other).data_ptr() if (mode & 1) else 0,
+                                                       G_other.data_ptr() if G_other is not None else 0, p_same,
+                                                       idx.data_ptr(), p_old, *tail), 'cfl_client_contrast_img_fwd')
+        else:
+            _lib.check(lib.cfl_client_contrast_fwd(F.data_ptr(), G_other.data_ptr() if G_other is not None else 0, p_same,
+                                                   idx.data_ptr(), p_old, *tail), 'cfl_client_contrast_fwd')
         ctx.mode = mode
         ctx.save_for_backward(out, dFs if need else out)
         ctx.has = need

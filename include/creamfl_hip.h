@@ -124,6 +124,25 @@ int cfl_client_contrast_fwd(const float* F, const float* G_other, const float* G
 int cfl_client_contrast_bwd(const float* dF_inter, const float* dF_moon, const float* out5, const float* gout_dev, int B, int D,
                             float* dF, void* stream);
 
+/* ---- A3 + A4 on a PRE-SPLIT bank image (round 3, csrc/bank_gsplit.h) -----------------------
+ * The global bank is frozen while a client trains (ClientTrainer.py:369-372 takes the global features once per round and
+ * every step of the round contrasts against them, :386-419), so its fp32 -> (bf16 hi, bf16 lo) split is done ONCE:
+ *   cfl_bank_image_build(G [M, D] fp32) -> image of cfl_bank_image_bytes(M, D) bytes (= the fp32 bank's size, rows padded to 16
+ *   and columns to 128 / 256): 16-row slots, [plane][row][column] bf16, 16-byte pieces XOR-swizzled -- the LDS image itself.
+ * cfl_client_contrast_img_fwd = cfl_client_contrast_fwd with the bank pass running on that image (same outputs, same finish
+ * launch, same cfl_client_contrast_bwd): 32 feature rows per workgroup, so a client batch of 128 needs 64 bank splits instead
+ * of 256 and writes a quarter of the split partials.  G_other (fp32) is still needed for the exact positive rows G_other[idx].
+ * D <= 256, D % 4 == 0 (cfl_bank_gsplit_supported); ws >= cfl_bank_gsplit_ws_bytes.
+ */
+size_t cfl_bank_image_bytes(int M, int D);
+int cfl_bank_image_build(const float* G, int M, int D, void* image, void* stream);
+int cfl_bank_gsplit_supported(int B, int M, int D);
+size_t cfl_bank_gsplit_ws_bytes(int B, int M, int D, int want_grad);
+int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const float* G_other, const float* G_same,
+                                const long long* idx, const float* F_old, int B, int M, int D, int B_div, float inv_tau,
+                                float weight, int mode, int want_grad, float* out5, float* lse, float* pos, float* dF_inter,
+                                float* dF_moon, void* ws, int* sync, void* stream);
+
 size_t cfl_intra_ws_bytes(int B);
 int cfl_intra_fwd(const float* F, const float* Gsame, const long long* idx, const float* Fold,
                   int B, int D, int M, int B_div, float inv_tau, float* loss, float* dF_unit, void* ws,

@@ -185,6 +185,64 @@ def test_a34_client_contrast_golden(dev, fname):
     _close(df3, cf['d_moon'].numpy(), 1e-4, 2e-5 * np.abs(cf['d_moon'].numpy()).max())
 
 
+def test_a34_image_cache_follows_the_bank(dev):
+    """The pre-split bank image (csrc/bank_gsplit.h) is built once per bank VERSION: repeated steps against the same bank reuse
+    it, an in-place update of the bank (a new round's global features written into the same storage) rebuilds it, and the
+    result after the update is the oracle's for the NEW bank -- never a stale image."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(77)
+    m, d, b = 2000, 128, 40
+    G = _unit(gen, m, d).to(dev)
+    Gs = _unit(gen, m, d).to(dev)
+    idx = torch.randint(0, m, (b,), generator=gen).tolist()
+    f = _unit(gen, b, d)
+    fo = _unit(gen, b, d)
+
+    def run():
+        fg = f.to(dev).requires_grad_(True)
+        loss, li, lm, _, _ = ops.client_contrast_fused(fg, Gs, G, idx, fo.to(dev), 0.5, weight=0.5)
+        loss.backward()
+        return loss.item(), fg.grad.cpu().numpy()
+
+    n0 = ops.BANK_IMAGE_BUILDS[0]
+    l1, g1 = run()
+    l2, g2 = run()
+    assert ops.BANK_IMAGE_BUILDS[0] == n0 + 1, 'second step on the same bank must reuse the image'
+    assert l1 == l2 and np.array_equal(g1, g2)
+    cf = oracle.client_contrast_grads_closed_form(f, Gs.cpu(), G.cpu(), idx, fo)
+    want = (cf['loss_moon'].item() + cf['loss_inter'].item()) * 0.5
+    _close(l1, want, 2e-5, 0)
+    with torch.no_grad():
+        G.copy_(_unit(gen, m, d).to(dev))                     # in-place: same storage, new version
+    l3, g3 = run()
+    assert ops.BANK_IMAGE_BUILDS[0] == n0 + 2, 'an in-place update of the bank must rebuild the image'
+    cf = oracle.client_contrast_grads_closed_form(f, Gs.cpu(), G.cpu(), idx, fo)
+    want3 = (cf['loss_moon'].item() + cf['loss_inter'].item()) * 0.5
+    _close(l3, want3, 2e-5, 0)
+    assert abs(l3 - l1) > 1e-3 * abs(l1)
+    wg = (cf['d_moon'].numpy() + cf['d_inter'].numpy()) * 0.5
+    _close(g3, wg, 1e-4, 3e-5 * np.abs(wg).max())
+
+
+@pytest.mark.parametrize('b,m,d', [(128, 50000, 256), (96, 7001, 512), (40, 3000, 768), (33, 1500, 64)])
+def test_a34_image_path_equals_fp32_bank_path(dev, b, m, d, monkeypatch):
+    """Same step through the round-3 bank pass (pre-split image, 16-row slots; column-split wave pairs beyond D = 256) and
+    through the previous paths (fp32 bank, 128-row groups for D <= 256; exact-fp32 two-pass kernels beyond): same loss terms
+    and gradients within the 3 x bf16-split error (both are separately compared with the oracle elsewhere)."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(b + m + d)
+    G, Gs = _unit(gen, m, d), _unit(gen, m, d)
+    idx = torch.randint(0, m, (b,), generator=gen).tolist()
+    f = torch.nn.functional.normalize(Gs[idx] + 0.9 * _unit(gen, b, d), dim=-1)
+    fo = torch.nn.functional.normalize(f + 0.4 * _unit(gen, b, d), dim=-1)
+    got = _run_contrast(dev, f, Gs, G, idx, fo, 0.5, True)
+    monkeypatch.setattr(ops, '_BANK_NOIMG', True)
+    ref = _run_contrast(dev, f, Gs, G, idx, fo, 0.5, True)
+    for a, r in zip(got[:3], ref[:3]):
+        _close(a, r, 2e-5, 0)
+    _close(got[3], ref[3], 1e-4, 3e-5 * np.abs(ref[3]).max())
+
+
 @pytest.mark.parametrize('m,d', [(9, 32), (4097, 256), (300, 768)])
 def test_a34_duplicate_and_boundary_indices(dev, m, d):
     """collisions in the batch's public-set indices (the same representation is the positive of several rows), the first and the
