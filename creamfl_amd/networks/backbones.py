@@ -242,10 +242,29 @@ class ViTTrunk(nn.Module):
         self.ln = nn.LayerNorm(dim, eps=1e-6)
         self.out_dim = dim
 
+    def patch_embed(self, x):
+        """The patch projection -- a convolution whose stride equals its kernel -- as ONE GEMM over non-overlapping patches:
+        [N * P, p * p * 3] x [p * p * 3, D].  As a convolution MIOpen has no tuned kernel for 16 x 16 / stride 16 on 3
+        channels in NHWC bf16 and falls back to `naive_conv_*`: 22.6 ms forward + 12.2 ms weight gradient per step at
+        batch 64 -- half of the configs[4] server step (rocprofv3, profiles/r3_config4_*).  Patches are taken in (kh, kw,
+        c) order, the memory order of a channels_last image and of the channels_last weight, so both reshapes are cheap;
+        `conv_proj` keeps its torchvision parameter names and shapes."""
+        n, c, H, W = x.shape
+        p = self.patch
+        if H % p or W % p:
+            return self.conv_proj(x).flatten(2).transpose(1, 2)
+        h, w = H // p, W // p
+        xp = x.permute(0, 2, 3, 1).reshape(n, h, p, w, p, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h * w, p * p * c)
+        wm = self.conv_proj.weight.permute(0, 2, 3, 1).reshape(self.conv_proj.out_channels, p * p * c)
+        return F.linear(xp, wm, self.conv_proj.bias), h, w
+
     def features(self, x):
-        t = self.conv_proj(x)                                    # [N, D, h, w]
-        n, d, h, w = t.shape
-        t = t.flatten(2).transpose(1, 2)                         # [N, P, D]
+        t = self.patch_embed(x)                                  # [N, P, D]
+        if isinstance(t, tuple):
+            t, h, w = t
+        else:
+            h, w = x.shape[2] // self.patch, x.shape[3] // self.patch
+        n, _, d = t.shape
         pos = self.pos_embedding
         if pos.shape[1] != h * w:                                # other resolutions: bilinear resize of the grid
             g = int(pos.shape[1] ** 0.5)

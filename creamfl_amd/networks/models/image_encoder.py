@@ -35,15 +35,18 @@ class EncoderImage(nn.Module):
         nn.init.xavier_uniform_(self.fc.weight)
         nn.init.constant_(self.fc.bias, 0.0)
 
-    def forward(self, images):
-        fmap = self.cnn.features(images)                                   # [N, Cd, h, w]
+    def head(self, fmap):
+        """Everything after the trunk: avgpool + fc, PIE attention pooling over the positions, sigmoid / residual / LayerNorm,
+        (head_proj), l2-normalise (image_encoder.py:55-67) on a [N, Cd, h, w] map.  Returns (embedding, attention, residual)."""
         n, cd, h, w = fmap.shape
         x = fmap.permute(0, 2, 3, 1).reshape(n, h * w, cd)                 # [N, 49, Cd]; a view under channels_last
-        output = {}
         if not self.mlp_local:
             out, _, attn, residual = self.pie_net.forward_fused(None, x, None, l2norm=True, out_from_mean=self.fc)
         else:
             _, o, attn, residual = self.pie_net.forward_fused(None, x, None, l2norm=False, out_from_mean=self.fc)
             out = ops.l2_normalize(self.head_proj(o))
-        output['embedding'] = out
-        return output
+        return out, attn, residual
+
+    def forward(self, images):
+        out, _, _ = self.head(self.cnn.features(images))                   # trunk: [N, Cd, h, w]
+        return {'embedding': out}

@@ -123,6 +123,64 @@ def test_config1_server_step_r101_bertbase_d512_b256(dev):
     assert all(torch.isfinite(p).all() for p in eng.model.parameters())
 
 
+# ------------------------------------------------------------------------------------------------ configs[4], encoders
+def test_config4_full_size_vit_b16_bert_large_d768(dev):
+    """BASELINE.json configs[4] at its OWN encoder sizes: ViT-B/16 (12 x 768, 12 heads) + BERT-large (24 x 1024, 16 heads),
+    d = 768, batch 64, bf16 trunks: two server steps -- finite, the returned loss re-derived by the fp64 oracle from the
+    features the step fed to the criterion (1e-4), weights moved -- then a client-style inter + intra step (weight 0.5)
+    against a 50 000-row bank on those features (the round-3 column-split bank kernel, D = 768)."""
+    from creamfl_amd.algorithms.contrast import client_contrast_loss
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import coco_batch
+    torch.manual_seed(41)
+    cfg = default_config(embed_dim=768, cnn_type='vit_b_16', not_bert=False)
+    cfg.model.bert_name = 'bert-large-uncased'
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    eng.model.train()
+    n_img = sum(p.numel() for p in eng.model.img_enc.parameters())
+    n_txt = sum(p.numel() for p in eng.model.txt_enc.parameters())
+    assert 80e6 < n_img < 100e6 and 320e6 < n_txt < 350e6, (n_img, n_txt)        # ViT-B/16 ~86 M, BERT-large ~335 M
+    seen = []
+    crit_forward = eng.criterion.forward
+
+    def spy(image_features, caption_features, *a, **k):
+        seen.append((image_features.detach().float().cpu(), caption_features.detach().float().cpu(),
+                     float(eng.criterion.negative_scale.detach()), float(eng.criterion.shift.detach())))
+        return crit_forward(image_features, caption_features, *a, **k)
+
+    eng.criterion.forward = spy
+    b = coco_batch(64, dev, seed=42, bert=True)
+    w0 = eng.model.linear.weight.detach().float().clone()
+    for step in range(2):
+        loss, ld = eng.train_step(b[0], b[1], b[2], b[3])
+        assert torch.isfinite(loss)
+        I, T, a, s = seen[-1]
+        assert I.shape == (64, 768) and T.shape == (64, 768)
+        cf = oracle.pair_loss_closed_form(I, T, a, s)
+        _close(loss.item(), float(cf['loss']), 1e-4, 0, f'step {step}')
+    assert float((eng.model.linear.weight.detach().float() - w0).abs().max()) > 0
+    assert all(torch.isfinite(p).all() for p in eng.model.parameters())
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        out = eng.model(b[0].contiguous(memory_format=torch.channels_last), b[1], b[2], b[3])
+    f = out['image_features'].detach().clone().requires_grad_(True)
+    gen = torch.Generator().manual_seed(43)
+    G = torch.nn.functional.normalize(torch.randn(50000, 768, generator=gen), dim=-1).to(dev)
+    Gs = torch.nn.functional.normalize(torch.randn(50000, 768, generator=gen), dim=-1).to(dev)
+    idx = torch.randperm(50000, generator=gen)[:64].tolist()
+    fo = out['caption_features'].detach()
+    loss, li, lm = client_contrast_loss(f, Gs, G, idx, fo, interintra_weight=0.5)
+    loss.backward()
+    cf = oracle.client_contrast_grads_closed_form(f.detach().cpu(), Gs.cpu(), G.cpu(), idx, fo.cpu())
+    _close(li.item(), cf['loss_inter'].item(), 1e-4, 0)
+    _close(lm.item(), cf['loss_moon'].item(), 1e-4, 0)
+    want = (cf['d_moon'].numpy() + cf['d_inter'].numpy()) * 0.5
+    _close(f.grad.cpu().numpy(), want, 1e-3, 1e-4 * np.abs(want).max())
+
+
 # ------------------------------------------------------------------------------------------------ configs[2]
 def test_config2_conw_eight_clients_public_set_50000(dev):
     """con_w at the reference's hard-coded public-set size (MMFL.py:302: 50 000 rows), d = 256, C = 8 client

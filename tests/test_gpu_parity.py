@@ -502,6 +502,22 @@ def test_a6_coco_1k_fold_size(dev):
         assert np.array_equal(ranks.astype(np.float64), oracle.recall_ranks_count(q.numpy(), g.numpy(), ql, gl))
 
 
+def test_a6_coco_5k_protocol_size(dev):
+    """The 5K protocol of the evaluator (eval_coco.py:392-448: 5000 images x 25 000 captions, no folds) at the server
+    dimension d = 512, both directions: every rank equal to the fp64 count oracle (chunked on the host).  Synthetic
+    features with a noise level that spreads the ranks over a wide range (R@1 well below 100)."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(55)
+    img = _unit(gen, 5000, 512)
+    cap = torch.nn.functional.normalize(img.repeat_interleave(5, 0) + 8.0 * _unit(gen, 25000, 512), dim=-1)
+    icls, ccls = np.arange(5000), np.arange(25000) // 5
+    for (q, g, ql, gl) in [(img, cap, icls, ccls), (cap, img, ccls, icls)]:
+        ranks = ops.rank_count(q.to(dev), g.to(dev), ql, gl).cpu().numpy().astype(np.float64)
+        want = oracle.recall_ranks_count(q.numpy(), g.numpy(), ql, gl, block=500)
+        assert np.array_equal(ranks, want), int((ranks != want).sum())
+        assert 1.0 < 100.0 * float((want < 1).mean()) < 99.0         # a non-trivial ranking
+
+
 # ------------------------------------------------------------------------------------------ KD term (8f-1)
 @pytest.mark.parametrize('b,m,d,w', [(1, 3, 4, 1.0), (37, 500, 100, 0.3), (128, 50000, 256, 0.3), (256, 1000, 512, 2.0)])
 def test_kd_mse_matches_torch(dev, b, m, d, w):

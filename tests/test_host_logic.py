@@ -311,3 +311,26 @@ def test_grad_buckets_views_layout_and_unused_parameters():
     for plist, views in zip(gb.buckets, gb.views):
         for p, v in zip(plist, views):
             assert p is unused or p.grad.data_ptr() == v.data_ptr()
+
+
+def test_vit_patch_embedding_gemm_equals_the_convolution():
+    """ViTTrunk.patch_embed (one GEMM over non-overlapping patches) == conv2d(kernel = stride = 16) on the same parameters:
+    values and the gradients of the image, the weight and the bias; NCHW and channels_last inputs / weights."""
+    from creamfl_amd.networks.backbones import ViTTrunk
+    torch.manual_seed(0)
+    m = ViTTrunk(dim=48, depth=1, heads=3, mlp_dim=96, patch=16, img=64).double()
+    x = torch.randn(3, 3, 64, 64, dtype=torch.float64)
+    for cl in (False, True):
+        xi = (x.contiguous(memory_format=torch.channels_last) if cl else x).clone().requires_grad_(True)
+        if cl:
+            m.conv_proj.to(memory_format=torch.channels_last)
+        m.zero_grad(set_to_none=True)
+        t, h, w = m.patch_embed(xi)
+        ref = m.conv_proj(xi).flatten(2).transpose(1, 2)
+        assert (h, w) == (4, 4) and t.shape == ref.shape == (3, 16, 48)
+        np.testing.assert_allclose(t.detach().numpy(), ref.detach().numpy(), rtol=1e-12, atol=1e-12)
+        g = torch.randn_like(ref)
+        gx, gw, gb = torch.autograd.grad((t * g).sum(), [xi, m.conv_proj.weight, m.conv_proj.bias])
+        rx, rw, rb = torch.autograd.grad((ref * g).sum(), [xi, m.conv_proj.weight, m.conv_proj.bias])
+        for a, b in ((gx, rx), (gw, rw), (gb, rb)):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-10, atol=1e-12)

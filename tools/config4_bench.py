@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] at full encoder size on ONE GPU: ViT-B/16 + BERT-large PCME, d = 768, batch 64 per GPU, bf16 trunks.
+Times the server contrastive step (forward -> pair loss -> backward -> clip -> AdamP) and the client-style inter + intra step
+against a 50 000-row bank (the D = 768 bank kernel).  One JSON line; run under `rocprofv3 --kernel-trace --stats` for the
+per-kernel table kept in profiles/."""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault('MIOPEN_FIND_MODE', '2')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    args = ap.parse_args()
+    from creamfl_amd import _lib
+    from creamfl_amd.algorithms.contrast import client_contrast_loss
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import coco_batch
+    _lib.load()
+    dev = torch.device('cuda', 0)
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(41)
+    cfg = default_config(embed_dim=768, cnn_type='vit_b_16', not_bert=False)
+    cfg.model.bert_name = 'bert-large-uncased'
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    eng.model.train()
+    b = coco_batch(args.batch, dev, seed=42, bert=True)
+    images = b[0].contiguous(memory_format=torch.channels_last)
+
+    def step():
+        return eng.train_step(images, b[1], b[2], b[3])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    # the client side of configs[4]: inter + intra contrast, weight 0.5, against a 50 000 x 768 bank
+    gen = torch.Generator().manual_seed(43)
+    G = torch.nn.functional.normalize(torch.randn(50000, 768, generator=gen), dim=-1).to(dev)
+    Gs = torch.nn.functional.normalize(torch.randn(50000, 768, generator=gen), dim=-1).to(dev)
+    idx = torch.randperm(50000, generator=gen)[:args.batch].to(dev)
+    f = torch.nn.functional.normalize(torch.randn(args.batch, 768, generator=gen), dim=-1).to(dev).requires_grad_(True)
+    fo = torch.nn.functional.normalize(torch.randn(args.batch, 768, generator=gen), dim=-1).to(dev)
+
+    def cstep():
+        l, _, _ = client_contrast_loss(f, Gs, G, idx, fo, interintra_weight=0.5)
+        l.backward()
+
+    for _ in range(5):
+        cstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        cstep()
+    torch.cuda.synchronize()
+    cus = (time.perf_counter() - t0) / 50 * 1e6
+    n_params = sum(p.numel() for p in eng.model.parameters())
+    print(json.dumps({'config': 'BASELINE configs[4]: ViT-B/16 + BERT-large, d=768, batch %d, bf16 trunks' % args.batch,
+                      'server_step_ms': round(ms, 2), 'pairs_per_s': round(args.batch / ms * 1e3, 1),
+                      'loss': round(float(loss), 4), 'params_M': round(n_params / 1e6, 1),
+                      'client_contrast_step_us_wall': round(cus, 1)}))
+
+
+if __name__ == '__main__':
+    main()
