@@ -380,17 +380,28 @@ def main():
                         'share_of_step_ms': round(ms / args.steps, 3)}
         if roof is not None and args.batch == 256 and args.cnn == "resnet101" and args.dtype == "bf16":
             # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this timed run, so the value
-            # measured offline at this exact shape (separate rocprofv3 --pmc passes, see the file) is reported.
-            for fn in ('r2_pmc_bench_traffic.json', 'r1_pmc_traffic.json'):
+            # measured offline at this exact shape (separate rocprofv3 --pmc passes, see the file) is reported -- but only if
+            # that profile saw the SAME number of launches per step as this run (a file taken before a fusion changed the
+            # launch count describes another kernel mix: round 2 paired 104-launch traffic with 103-launch algorithmic bytes).
+            roof['traffic_source'] = 'none: no offline PMC profile matches this run (traffic = null)'
+            per_step = roof['launches'] / float(args.steps)
+            for fn in ('r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
-                    if roof['kernel'] in pmc:
-                        roof['traffic'] = pmc[roof['kernel']]['traffic_bytes']
-                        roof['traffic_source'] = ('OFFLINE: profiles/%s (separate rocprofv3 --pmc passes over this bench step; '
-                                                  'not measured in this run)' % fn)
-                        break
                 except (OSError, ValueError):
-                    pass
+                    continue
+                ent = pmc.get(roof['kernel'])
+                if not ent:
+                    continue
+                lps = ent.get('launches_per_step')
+                if lps is None or abs(lps - per_step) > 1e-6:
+                    roof['traffic_source'] = ('none: profiles/%s was taken at %s launches of this kernel per step, this run has %g '
+                                              '(traffic = null)' % (fn, lps, per_step))
+                    continue
+                roof['traffic'] = ent['traffic_bytes']
+                roof['traffic_source'] = ('OFFLINE: profiles/%s (separate rocprofv3 --pmc passes over this bench step, %g launches '
+                                          'per step as here; not measured in this run)' % (fn, per_step))
+                break
         if roof is not None and not (os.environ.get('CFL_NO_TWO_STREAM') and os.environ.get('CFL_NO_SIDE_WGRAD')):
             # the text tower and the convolution weight gradients run on auxiliary HIP streams: part of these launches
             # share HBM with their kernels, so the per-launch rate is a lower bound of what the kernel reaches alone

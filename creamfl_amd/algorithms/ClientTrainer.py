@@ -258,26 +258,37 @@ class ClientTrainer:
         """Which representations generate_logits returns (host knowledge used by dist.client_plan)."""
         return ('img',) if self.dset_name in IMAGE_SETS else ('txt',)
 
-    def generate_logits(self, dataloader):
-        vec, idx = self.extract_pub_feature(dataloader)
-        if self.dset_name in IMAGE_SETS:
-            return {'img': vec, 'txt': None}, idx
-        elif self.dset_name in TEXT_SETS:
-            return {'img': None, 'txt': vec}, idx
-        assert False
+    def generate_logits(self, dataloader, out=None):
+        """ClientTrainer.py:622-629.  `out` = {'img' | 'txt': [M, D] tensor} (section 8f-3): the representations are written
+        straight into it -- the rank's slice of the round's all-gather buffer, possibly bf16 -- instead of being concatenated
+        into a fresh tensor; the returned dict then holds that very tensor."""
+        key = 'img' if self.dset_name in IMAGE_SETS else ('txt' if self.dset_name in TEXT_SETS else None)
+        assert key is not None
+        vec, idx = self.extract_pub_feature(dataloader, out=None if out is None else out[key])
+        return {'img': vec if key == 'img' else None, 'txt': vec if key == 'txt' else None}, idx
 
-    def extract_pub_feature(self, dataloader):
+    def extract_pub_feature(self, dataloader, out=None):
         """ClientTrainer.py:631-664, device-resident."""
         self.model.to(self.gpuid)
         self.model.phase = 'extract_conv_feature'
         self.model.is_train = False
         was_training = self.model.training
-        feature, distill_index = [], []
+        feature, distill_index, off = [], [], 0
         with torch.no_grad():
             for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(dataloader):
-                feature.append(self._features(self.model, images, captions, caption_lens).detach().float())
+                f = self._features(self.model, images, captions, caption_lens).detach()
+                if out is None:
+                    feature.append(f.float())
+                else:
+                    out[off:off + f.shape[0]].copy_(f)           # converts to the buffer's dtype (bf16 wire) on the way
+                    off += f.shape[0]
                 distill_index.extend(index)
-        feature = torch.cat(feature, dim=0)
+        if out is None:
+            feature = torch.cat(feature, dim=0)
+        else:
+            if off != out.shape[0]:
+                raise RuntimeError(f'public set yielded {off} rows, the representation buffer has {out.shape[0]}')
+            feature = out
         self.model.phase = 'None'
         self.model.is_train = True
         self.model.train(was_training)

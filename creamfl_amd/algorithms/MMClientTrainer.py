@@ -89,20 +89,30 @@ class MMClientTrainer(EngineBase):
 
     modalities = ('img', 'txt')          # generate_logits returns both representations (dist.client_plan)
 
-    def generate_logits(self, dataloader):
+    def generate_logits(self, dataloader, out=None):
+        """MMClientTrainer.py:326-359.  `out` = {'img': [M, D], 'txt': [M, D]}: write the representations straight into these
+        (the rank's slices of the round's all-gather buffer, section 8f-3) instead of concatenating fresh tensors."""
         self.model.to(self.device)
         was_training = self.model.training
         self.model.eval()
-        img_vec, txt_vec, distill_index = [], [], []
+        img_vec, txt_vec, distill_index, off = [], [], [], 0
+        D = self.args.feature_dim
         with torch.no_grad():
             for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(dataloader):
                 output = self._forward(self.model, images.to(self.device), captions.to(self.device), captions_word,
                                        caption_lens.to(self.device))
-                img_vec.append(output['image_features'].float())
-                txt_vec.append(output['caption_features'].float())
+                fi, ft = output['image_features'].view(-1, D), output['caption_features'].view(-1, D)
+                if out is None:
+                    img_vec.append(fi.float())
+                    txt_vec.append(ft.float())
+                else:
+                    out['img'][off:off + fi.shape[0]].copy_(fi)
+                    out['txt'][off:off + ft.shape[0]].copy_(ft)
+                    off += fi.shape[0]
                 distill_index.extend(index)
                 if is_test and idx == 1:
                     break
         self.model.train(was_training)
-        D = self.args.feature_dim
+        if out is not None:
+            return {'img': out['img'], 'txt': out['txt']}, distill_index
         return {'img': torch.cat(img_vec, dim=0).view(-1, D), 'txt': torch.cat(txt_vec, dim=0).view(-1, D)}, distill_index

@@ -188,7 +188,15 @@ class MMFL(object):
     def train(self, round_n):
         self.cur_epoch = round_n
         self.cur_trainers = self.total_local_trainers
-        # multi-rank: the server phases are replicated on every rank; re-synchronise the replicas each round
+        # multi-rank: the server phases (global contrastive training, KD) run DATA-PARALLEL by default -- every rank encodes 1/W
+        # of each public batch, features are all-gathered for the full-batch loss, encoder gradients are bucket-averaged
+        # (dist.GradBuckets): the 391-step global train and the KD loop cost 1/W instead of being repeated W times.  As with any
+        # data-parallel BatchNorm model the batch statistics are per shard; `--server_dp 0` keeps the replicated form (every
+        # rank does the whole batch: bit-for-bit the single-process round).  Replicas are re-synchronised each round.
+        if cdist._world()[1] > 1 and int(getattr(self.args, 'server_dp', 1)):
+            if self.engine.dp is None:
+                self.engine.enable_data_parallel()
+            self.engine.shard_batches = True
         self.engine.sync_replicas()
         if not is_test:
             self.logger.log(f"Round {round_n + 1}!")
@@ -201,23 +209,37 @@ class MMFL(object):
 
         rank, world = cdist._world()
         my_trainers = cdist.shard_clients(self.cur_trainers, rank, world)
+        gather = None
+        if world > 1:
+            # (8f-3) one pre-allocated [W, K, M, D] buffer per run: the clients write their representations into this rank's
+            # slices, ONE all-gather moves them (optionally as bf16: --rep_wire bf16)
+            M, D = self.args.pub_data_num, self.args.feature_dim
+            wire = torch.bfloat16 if getattr(self.args, 'rep_wire', 'fp32') == 'bf16' else torch.float32
+            plan = cdist.client_plan(self.cur_trainers, world)
+            gather = getattr(self, '_rep_gather', None)
+            if gather is None or not gather.matches(plan, M, D, wire):
+                gather = self._rep_gather = cdist.RepGatherBuffer(plan, M, D, self.engine.device, wire)
+            else:
+                gather.rebind(plan)
         local_reps = []
-        for trainer in my_trainers:
+        for slot, trainer in enumerate(my_trainers):
             self.logger.log(f"Training Client {trainer.client_idx}!")
             trainer.cur_epoch = round_n
             trainer.run(self.global_img_feature, self.global_txt_feature, self.distill_index,
                         self._dataloaders[self._pub_key(False)])
             self.logger.log("Generate Local Representations")
-            _vec, i = trainer.generate_logits(self.dataloaders_global[self._pub_key(True)])
+            if gather is not None:
+                _vec, i = trainer.generate_logits(self.dataloaders_global[self._pub_key(True)], out=gather.out_views(slot))
+            else:
+                _vec, i = trainer.generate_logits(self.dataloaders_global[self._pub_key(True)])
             if self.distill_index is None:
                 self.distill_index = i
             else:
                 assert i == self.distill_index
             local_reps.append(_vec)
-        if world > 1:
-            M, D = self.args.pub_data_num, self.args.feature_dim
-            img_vec, txt_vec = cdist.allgather_client_reps(local_reps, cdist.client_plan(self.cur_trainers, world), M, D,
-                                                           self.engine.device)
+        if gather is not None:
+            gather.gather()
+            img_vec, txt_vec = gather.blocks()
         else:
             img_vec = [v['img'] for v in local_reps if v['img'] is not None]
             txt_vec = [v['txt'] for v in local_reps if v['txt'] is not None]
@@ -307,10 +329,16 @@ class MMFL(object):
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(
                 self.dataloaders_global[self._pub_key(False)]):
             images = images.to(eng.device)
+            captions, caption_lens = captions.to(eng.device), caption_lens.to(eng.device)
+            sh = eng.batch_shard(images.shape[0])
+            if sh is not None:        # data-parallel KD: mean-MSE over this rank's rows; the bucket average over ranks = full mean
+                r0, r1 = sh
+                images, captions, caption_lens, index = images[r0:r1], captions[r0:r1], caption_lens[r0:r1], index[r0:r1]
+                captions_word = captions_word[r0:r1] if captions_word is not None else None
             if eng.autocast_dtype is not None:
                 images = images.contiguous(memory_format=torch.channels_last)
             with torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
-                output = model(images, captions.to(eng.device), captions_word, caption_lens.to(eng.device))
+                output = model(images, captions, captions_word, caption_lens)
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
             loss = self.kd_terms(output, d_idx)

@@ -45,6 +45,7 @@ class EngineBase(object):
         self.partition_train_distill = partition_train_distill
         self.autocast_dtype = None
         self.dp = None                       # creamfl_amd.dist.DataParallelContext when enabled
+        self.shard_batches = False           # multi-rank: train() / the KD loop give every rank 1/W of each batch (MMFL --server_dp)
         self._conv1x1_weights = None         # weights whose transposes are prepared in one launch before backward
 
     def create(self, config, word2idx, evaluator, mlp_local):
@@ -241,22 +242,33 @@ class EngineBase(object):
 
 class TrainerEngine(EngineBase):
 
-    def forward_loss(self, images, captions, captions_word, caption_lens):
+    def batch_shard(self, n):
+        """(r0, r1): this rank's rows of an n-row server batch when the server phases run data-parallel, or None when the
+        batch stays whole on every rank (single process, sharding off, or n not divisible by the world size -- the
+        collectives move equal blocks; such a batch is simply processed replicated, which gives the same update)."""
+        if self.dp is None or not self.shard_batches or self.dp.world == 1 or n % self.dp.world:
+            return None
+        per = n // self.dp.world
+        return self.dp.rank * per, (self.dp.rank + 1) * per
+
+    def forward_loss(self, images, captions, captions_word, caption_lens, gather=True):
         model = self.dp.module if self.dp is not None else self.model
         with torch.autocast('cuda', dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
             output = model(images, captions, captions_word, caption_lens)
-        if self.dp is not None:
+        if self.dp is not None and gather:
             output = dict(output)
             output['image_features'], output['caption_features'] = self.dp.gather_features(
                 output['image_features'], output['caption_features'])
         loss, loss_dict = self.criterion(**output)
         return loss, loss_dict
 
-    def train_step(self, images, captions, captions_word, caption_lens):
-        """One server contrastive step (retrieval_trainer.py:192-214)."""
+    def train_step(self, images, captions, captions_word, caption_lens, gather=True):
+        """One server contrastive step (retrieval_trainer.py:192-214).  With data parallel on, `gather=True` means the
+        arguments are THIS RANK'S part of the global batch (features are all-gathered, bench.py / sharded server phases);
+        `gather=False` means every rank holds the whole batch (replicated step: the averaged gradients are the gradients)."""
         if self.autocast_dtype is not None and images.dim() == 4:
             images = images.contiguous(memory_format=torch.channels_last)
-        loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens)
+        loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens, gather=gather)
         self.backward_and_step(loss)
         return loss, loss_dict
 
@@ -298,7 +310,13 @@ class TrainerEngine(EngineBase):
             caption_lens = caption_lens.to(self.device, non_blocking=True)
             if idx == int(len(tr_loader) * pub_data_ratio):
                 break
-            self.train_step(images, captions, captions_word, caption_lens)
+            sh = self.batch_shard(images.shape[0])
+            if sh is not None:          # multi-rank: 1/W of the batch per rank, features all-gathered, gradients bucket-averaged
+                r0, r1 = sh
+                cw = captions_word[r0:r1] if captions_word is not None else None
+                self.train_step(images[r0:r1], captions[r0:r1], cw, caption_lens[r0:r1])
+            else:
+                self.train_step(images, captions, captions_word, caption_lens, gather=False)
 
     def report_scores(self, step, scores, metadata, prefix=''):
         report_dict = {data_key: flatten_dict(_scores, sep='_') for data_key, _scores in scores.items()}

@@ -287,8 +287,59 @@ def _worker_adamp_broadcast_state(rank, world, path, out):
         out.put(bool(flag.item() == 1.0))
     dist.destroy_process_group()
 
+
+# ------------------------------------------------------------------------------ (8f-3) one-collective representation exchange
+def _worker_rep_gather_buffer(rank, world, path, out):
+    """RepGatherBuffer: clients write their [M, D] representations into views of the rank's slice, ONE all-gather moves
+    everything, blocks come back in sampled-client order -- fp32 wire bit-exact, bf16 wire = the bf16-rounded values, and the
+    con_w weights computed from bf16-wire representations stay within 1e-3 of the fp32 ones (VERDICT r2 next #7)."""
+    _init(rank, world, path)
+    M, D = 96, 16
+    pool = [_FakeClient(1, ('img',), M, D), _FakeClient(2, ('txt',), M, D), _FakeClient(3, ('img', 'txt'), M, D),
+            _FakeClient(4, ('img',), M, D), _FakeClient(6, ('img', 'txt'), M, D)]
+    plan = cdist.client_plan(pool, world)
+    ok = True
+    gen = torch.Generator().manual_seed(3)
+    G_txt = _unit(gen, M, D)
+    weights = {}
+    for wire in (torch.float32, torch.bfloat16):
+        buf = cdist.RepGatherBuffer(plan, M, D, torch.device('cpu'), wire)
+        ok &= buf.K == max(sum(len(m) for _, m in p) for p in plan)
+        mine = cdist.shard_clients(pool)
+        for c in pool:
+            c.rounds_trained = 0
+        for slot, c in enumerate(mine):
+            views = buf.out_views(slot)
+            ok &= tuple(views) == c.modalities
+            rep = c.run_and_generate(0)
+            for k in c.modalities:                              # what generate_logits(out=...) does, batch by batch
+                views[k][:M // 2].copy_(rep[k][:M // 2])
+                views[k][M // 2:].copy_(rep[k][M // 2:])
+        buf.gather()
+        img_vecs, txt_vecs = buf.blocks()
+        want_img, want_txt = [], []
+        for c in pool:
+            for k in c.modalities:
+                g2 = torch.Generator().manual_seed(1000 * c.client_idx + 10 + (0 if k == 'img' else 1))
+                (want_img if k == 'img' else want_txt).append(_unit(g2, M, D))
+        ok &= len(img_vecs) == len(want_img) == 4 and len(txt_vecs) == len(want_txt) == 3
+        for got, want in zip(img_vecs + txt_vecs, want_img + want_txt):
+            ok &= got.dtype == torch.float32
+            ok &= torch.equal(got, want if wire == torch.float32 else want.to(torch.bfloat16).float())
+        _, w, _ = oracle.conw_aggregate(img_vecs, G_txt, literal=False)
+        weights[wire] = w
+        # the buffer is reusable with another plan of the same geometry
+        ok &= buf.matches(plan, M, D, wire) and not buf.matches(plan, M, D + 1, wire)
+    ok &= bool((weights[torch.float32] - weights[torch.bfloat16]).abs().max() < 1e-3)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(bool(flag.item() == 1.0))
+    dist.destroy_process_group()
+
+
 @pytest.mark.parametrize('worker', [_worker_global_contrast, _worker_clients_conw, _worker_config2_eight_clients,
-                                    _worker_reducer_lifecycle, _worker_adamp_broadcast_state])
+                                    _worker_reducer_lifecycle, _worker_adamp_broadcast_state, _worker_rep_gather_buffer])
 def test_two_rank_gloo(worker):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()

@@ -155,22 +155,23 @@ def test_two_rank_global_contrast_matches_single_process():
     assert got['stale_refused'] is True
 
 
-def _round_args():
+def _round_args(server_dp=0, rep_wire='fp32'):
     from conftest import reference_main_namespace
     args, _ = reference_main_namespace(name='/tmp/creamfl_test_mr', feature_dim=64, pub_data_num=64, local_epochs=1, comm_rounds=1,
                                        num_img_clients=2, num_txt_clients=2, num_mm_clients=0, client_num_per_round=4,
                                        contrast_local_intra=True, contrast_local_inter=True, cnn_type='resnet18',
-                                       bert_name='bert-mini', image_size=64, test_pairs=100, quiet=True, save_checkpoints=False)
+                                       bert_name='bert-mini', image_size=64, test_pairs=100, quiet=True, save_checkpoints=False,
+                                       server_dp=server_dp, rep_wire=rep_wire)
     return args
 
 
-def _run_round(seed=20):
+def _run_round(seed=20, server_dp=0, rep_wire='fp32'):
     import random
     from creamfl_amd.algorithms.MMFL import MMFL
     torch.manual_seed(seed)
     random.seed(seed)
     np.random.seed(seed)
-    args = _round_args()
+    args = _round_args(server_dp, rep_wire)
     algo = MMFL(args, None)
     algo.config.dataloader.batch_size = 32
     algo.config.train.use_fp16 = False
@@ -193,12 +194,12 @@ def _run_round(seed=20):
     return captured, sd, trained
 
 
-def _round_worker(rank, world, path, outdir):
+def _round_worker(rank, world, path, outdir, server_dp=0, rep_wire='fp32'):
     import sys
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     _init(rank, world, path)
-    captured, sd, trained = _run_round()
+    captured, sd, trained = _run_round(server_dp=server_dp, rep_wire=rep_wire)
     torch.save({'captured': captured, 'sd': sd, 'trained': trained}, os.path.join(outdir, f'round_{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
@@ -231,3 +232,27 @@ def test_two_rank_round_matches_single_process():
     assert all(trained.values())
     for k in ('agg_i', 'agg_t'):
         np.testing.assert_allclose(r0['captured'][k].numpy(), captured[k].numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_two_rank_round_data_parallel_server_phases():
+    """The same round with the server phases DATA-PARALLEL (MMFL --server_dp 1, the multi-rank default: every rank encodes
+    half of each public batch in the global training and in the KD loop, features all-gathered, gradients bucket-averaged)
+    and the representations exchanged through the one-collective bf16-wire buffer (--rep_wire bf16): every client still
+    trains on exactly one rank, both ranks aggregate the same 2 + 2 representations, and -- the point of averaging gradients
+    instead of replicating steps -- the two server replicas end the round IDENTICAL up to the library's atomics noise."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    with tempfile.TemporaryDirectory() as out:
+        _spawn(_round_worker, 2, out, 1, 'bf16')
+        r0 = torch.load(os.path.join(out, 'round_0.pt'))
+        r1 = torch.load(os.path.join(out, 'round_1.pt'))
+    for idx in r0['trained']:
+        assert r0['trained'][idx] == (idx % 2 == 0) and r1['trained'][idx] == (idx % 2 == 1)
+    assert r0['captured']['n_img'] == 2 and r0['captured']['n_txt'] == 2
+    for k in ('agg_i', 'agg_t'):
+        assert np.isfinite(r0['captured'][k].numpy()).all()
+        np.testing.assert_allclose(r0['captured'][k].numpy(), r1['captured'][k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    for k in r0['sd']:
+        d = np.abs(r0['sd'][k].numpy() - r1['sd'][k].numpy())
+        assert np.isfinite(r0['sd'][k].numpy()).all()
+        assert d.max() <= 2e-3 and float((d > 2e-4).mean()) <= 0.1, (k, float(d.max()))
