@@ -253,6 +253,9 @@ class TrainerEngine(EngineBase):
 
     def forward_loss(self, images, captions, captions_word, caption_lens, gather=True):
         model = self.dp.module if self.dp is not None else self.model
+        if images.is_cuda:
+            from .. import ops
+            ops.join_arm()                  # the backward of this forward runs through self.backward(): gradient joins may fuse
         with torch.autocast('cuda', dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
             output = model(images, captions, captions_word, caption_lens)
         if self.dp is not None and gather:

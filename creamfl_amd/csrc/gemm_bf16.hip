@@ -60,9 +60,30 @@ __device__ __forceinline__ void tile_compute_bf16(const float* sa, const float* 
 // Persistent workgroups: the K steps of consecutive tiles form one software pipeline (the first stage of tile t+1 is
 // in flight while tile t computes and stores), because with K = 64..1024 a tile is only 1..16 K steps long and the
 // load latency / store drain of a tile-per-workgroup launch would dominate.
-template <int TM, int TN, int OCC>
+// JOIN (round 3): the epilogue adds a second bf16 matrix and applies a 1-bit-per-element mask before the store,
+//   C = (A B^T + addp) . mask        (mask byte i covers elements 8 i .. 8 i + 7 of the dense [M, N] matrix, bit k = element k)
+// -- the gradient join of a residual block: the data gradient of the block's first 1x1 convolution (this GEMM) + the
+// gradient that arrives over the skip connection, masked by the ReLU of the BatchNorm that produced the block input.  The
+// BatchNorm backward of that layer then reads ONE pre-masked gradient instead of two gradients + the mask in both of its
+// passes, and hands the same tensor on as its residual gradient (bnorm.hip writes nothing for it): -4 bytes per element.
+__device__ __forceinline__ f32x4 join8(const f32x4 v, const f32x4 b, unsigned mb) {
+    union { f32x4 q; unsigned u[4]; } a, c, o;
+    a.q = v; c.q = b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(a.u[i] << 16) + __uint_as_float(c.u[i] << 16);
+        const float hi = __uint_as_float(a.u[i] & 0xffff0000u) + __uint_as_float(c.u[i] & 0xffff0000u);
+        const unsigned l = ((mb >> (2 * i)) & 1u) ? f2bf(lo) : 0u;
+        const unsigned h = ((mb >> (2 * i + 1)) & 1u) ? f2bf(hi) : 0u;
+        o.u[i] = l | (h << 16);
+    }
+    return o.q;
+}
+
+template <int TM, int TN, int OCC, bool JOIN>
 __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd B, int M, int N, u16* __restrict__ C, long long ldc,
-                                                                    int ntiles) {
+                                                                    int ntiles, const u16* __restrict__ addp,
+                                                                    const unsigned char* __restrict__ maskp) {
     constexpr int BM = 64 * TM, BN = 64 * TN, STAGE = (BM + BN) * 32;
     constexpr int PITCH = 64 * TN + 16;                   // bytes per band row (+16: de-phase the banks)
     constexpr int CPR = 4 * TN;                           // 16-byte chunks per band row
@@ -126,9 +147,13 @@ __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd
 #pragma unroll
                 for (int p = 0; p < 16 / RPI; ++p) {
                     const int rr = p * RPI + lane / CPR, c = lane % CPR;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(band + rr * PITCH + c * 16);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(band + rr * PITCH + c * 16);
                     const int gi = gr0 + rr, gj = gc0 + c * 8;
-                    if (gi < M && gj < N) *reinterpret_cast<f32x4*>(C + (long long)gi * ldc + gj) = v;
+                    if (gi < M && gj < N) {
+                        const long long e = (long long)gi * ldc + gj;
+                        if (JOIN) v = join8(v, *reinterpret_cast<const f32x4*>(addp + e), maskp[e >> 3]);
+                        *reinterpret_cast<f32x4*>(C + e) = v;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -138,15 +163,17 @@ __global__ __launch_bounds__(256, OCC) void cfl_gemm_bf16_nt_kernel(Opnd A, Opnd
     }
 }
 
-template <int TM, int TN, int OCC>
-int launch_nt(const Opnd& A, const Opnd& B, int M, int N, u16* C, long long ldc, hipStream_t stream) {
+template <int TM, int TN, int OCC, bool JOIN = false>
+int launch_nt(const Opnd& A, const Opnd& B, int M, int N, u16* C, long long ldc, hipStream_t stream, const u16* addp = nullptr,
+              const unsigned char* maskp = nullptr) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t LDS = (size_t)2 * (BM + BN) * 32 * sizeof(float) + (size_t)4 * 16 * (64 * TN + 16);
     const int ntc = cfl_cdiv(N, BN);
     const int ntiles = cfl_cdiv(M, BM) * ntc;
     int grid = ntiles < 256 * OCC ? ntiles : 256 * OCC;
-    CFL_SET_LDS((cfl_gemm_bf16_nt_kernel<TM, TN, OCC>), LDS);
-    CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_kernel<TM, TN, OCC>), dim3(grid), dim3(256), LDS, stream, A, B, M, N, C, ldc, ntiles);
+    CFL_SET_LDS((cfl_gemm_bf16_nt_kernel<TM, TN, OCC, JOIN>), LDS);
+    CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_kernel<TM, TN, OCC, JOIN>), dim3(grid), dim3(256), LDS, stream, A, B, M, N, C, ldc, ntiles,
+               addp, maskp);
     return 0;
 }
 
@@ -383,6 +410,18 @@ extern "C" int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, lon
         case 41: return launch_nt<4, 1, 2>(Ao, Bo, M, N, Cc, ldc, stream);
         default: return CFL_EINVAL;
     }
+}
+
+extern "C" int cfl_gemm_bf16_nt_join(const void* A, long long lda, const void* B, long long ldb, void* C, const void* add,
+                                     const unsigned char* mask, int M, int N, int K, void* stream_) {
+    if (!A || !B || !C || !add || !mask || M <= 0 || N <= 0 || K <= 0) return CFL_EINVAL;
+    if (K % 64 != 0 || N % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 ||
+        (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)add) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    Opnd Ao{(const float*)A, lda / 2, M, K / 2, 1};
+    Opnd Bo{(const float*)B, ldb / 2, N, K / 2, 1};
+    if (N >= 128) return launch_nt<2, 2, 2, true>(Ao, Bo, M, N, (u16*)C, N, stream, (const u16*)add, mask);
+    return launch_nt<2, 1, 2, true>(Ao, Bo, M, N, (u16*)C, N, stream, (const u16*)add, mask);
 }
 
 extern "C" size_t cfl_gemm_bf16_tn_ws_bytes(long long M, int N1, int N2) {

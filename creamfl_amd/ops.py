@@ -657,6 +657,37 @@ def bn_act_supported(x, num_features):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
+# ---- gradient join of a residual block fused into the 1x1 data-gradient GEMM (round 3) --------------------------------------
+# z = relu(bn3(c3) + r) feeds the next block twice: its first 1x1 convolution and its skip connection.  Backward, bn3 needs
+# g = (A + B) . mask with A = that convolution's data gradient (the hand-written GEMM) and B = the gradient arriving over the
+# skip connection (the next block's bn3 hands on its own masked gradient).  Unfused, BOTH BatchNorm backward passes read A, B
+# and the mask, and the apply pass writes g again as the residual gradient.  Fused: the GEMM epilogue reads B and the mask and
+# writes g; the BatchNorm backward reads g alone (no mask, no second gradient) and hands the same tensor on: -4 bytes per
+# element of every bn3 output with a direct skip connection (29 of ResNet-101's 33 blocks).  The pieces meet through
+# these registries, keyed by the address of z's buffer; they are only consulted inside TrainerEngine.backward
+# (prepare_ / release_weight_transposes bracket it and clear them), so client trainers and plain autograd are untouched.
+_NO_JOIN_FUSE = _os.environ.get('CFL_NO_JOIN_FUSE', '0') == '1'      # measurement switch
+JOIN = {'armed': False, 'on': False, 'mask': {}, 'consumer': set(), 'pending': {}, 'pre': set(), 'fused': 0}
+
+
+def join_arm():
+    """Called by TrainerEngine before the forward pass of a step whose backward it will run itself: from here on the fused
+    BatchNorm layers register their ReLU masks and the 1x1 convolutions themselves as consumers."""
+    JOIN['armed'] = not _NO_JOIN_FUSE
+    JOIN['mask'].clear()
+    JOIN['consumer'].clear()
+
+
+def _join_reset(on):
+    JOIN['on'] = bool(on) and JOIN['armed']
+    JOIN['pending'].clear()
+    JOIN['pre'].clear()
+    if not on:
+        JOIN['armed'] = False
+        JOIN['mask'].clear()
+        JOIN['consumer'].clear()
+
+
 # element counters of the fused BN kernels (python ints; bench.py turns them into algorithmic bytes)
 BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
 
@@ -687,6 +718,10 @@ class _BNActFn(torch.autograd.Function):
                                   _stream(x)), 'cfl_bn_fwd')
         ctx.save_for_backward(x, mask if need_mask else x, weight, bias, mean, invstd)
         ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
+        ctx.y_ptr = y.data_ptr()
+        ctx.res_ptr = residual.data_ptr() if residual is not None else 0
+        if need_mask and JOIN['armed']:
+            JOIN['mask'][ctx.y_ptr] = mask               # the consumer GEMM of y applies it (see JOIN above)
         return y, _alias(y)
 
     @staticmethod
@@ -699,13 +734,19 @@ class _BNActFn(torch.autograd.Function):
             dy, dy2 = dy2, None
         if dy is None:
             return (None,) * 9
+        # JOIN: the data-gradient GEMM of the consumer already produced g = (A + B) . mask for this layer's output
+        pre = JOIN['on'] and ctx.y_ptr in JOIN['pre']
+        if pre:
+            JOIN['pre'].discard(ctx.y_ptr)
+            if dy2 is not None:
+                raise _lib.CreamflHipError('fused gradient join: a second gradient reached a pre-joined BatchNorm output')
         if ctx.has_res:
             from . import streams
             streams.flush(x.device)          # a long HBM-bound phase starts: let the queued weight gradients run beside it
         BN_COUNTERS['bwd'] += R * C
-        if ctx.relu and ctx.has_res:
+        if ctx.relu and ctx.has_res and not pre:
             BN_COUNTERS['bwd_relu'] += R * C              # passes that read the 1-bit ReLU mask
-        if ctx.has_res:
+        if ctx.has_res and not pre:
             BN_COUNTERS['bwd_res'] += R * C
         if dy2 is not None:
             BN_COUNTERS['bwd_two'] += R * C
@@ -717,13 +758,23 @@ class _BNActFn(torch.autograd.Function):
         dy = prep(dy)
         dy2 = prep(dy2) if dy2 is not None else None
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_res else None
+        dres = dy if pre else (torch.empty_like(x) if ctx.has_res else None)      # pre-joined: g IS the residual gradient
         dgamma = torch.empty_like(weight)
         dbeta = torch.empty_like(weight)
         ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
-        _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(None), _ptr(mask) if (ctx.relu and ctx.has_res) else _ptr(None),
-                                  _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res),
-                                  _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
+        if pre:          # plain BatchNorm backward of an already masked, already summed gradient
+            _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(None), _ptr(x), _ptr(None), _ptr(None), _ptr(weight), _ptr(bias), _ptr(mean),
+                                      _ptr(invstd), R, C, 0, 0, _ptr(dx), _ptr(None), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)),
+                       'cfl_bn_bwd')
+        else:
+            _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(None), _ptr(mask) if (ctx.relu and ctx.has_res) else _ptr(None),
+                                      _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res),
+                                      _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
+        if JOIN['on'] and ctx.has_res and ctx.res_ptr in JOIN['consumer'] and ctx.res_ptr in JOIN['mask']:
+            # the skip connection's gradient goes to the data-gradient GEMM of this block's first convolution instead of to
+            # autograd (None = no contribution): that GEMM adds it and masks the sum for the BatchNorm below
+            JOIN['pending'][ctx.res_ptr] = dres
+            dres = None
         return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
@@ -806,8 +857,9 @@ def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, res
 GEMM_COUNTERS = {'flops': 0, 'bytes': 0}   # python ints; bench.py turns them into algorithmic work per launch
 
 
-def gemm_bf16_nt(a, b, out=None, variant=0):
-    """out[M, N] = a[M, K] @ b[N, K]^T, bf16 (csrc/gemm_bf16.hip: cfl_gemm_bf16_nt)."""
+def gemm_bf16_nt(a, b, out=None, variant=0, add=None, mask=None):
+    """out[M, N] = a[M, K] @ b[N, K]^T, bf16 (csrc/gemm_bf16.hip: cfl_gemm_bf16_nt).  With `add` (bf16, the dense [M, N]
+    matrix in out's memory order) and `mask` (1 bit per element, cfl_bn_fwd's packing): out = (a b^T + add) . mask."""
     lib = _lib.load()
     M, K = a.shape
     N = b.shape[0]
@@ -815,6 +867,13 @@ def gemm_bf16_nt(a, b, out=None, variant=0):
     GEMM_COUNTERS['bytes'] += 2 * (M * K + N * K + M * N)
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    if add is not None:
+        if out.stride(0) != N or add.numel() != M * N or add.dtype != torch.bfloat16 or mask.numel() * 8 != M * N:
+            raise _lib.CreamflHipError('gemm_bf16_nt(add=, mask=): dense bf16 [M, N] operands and an M N / 8 byte mask expected')
+        GEMM_COUNTERS['bytes'] += 2 * M * N + M * N // 8
+        _lib.check(lib.cfl_gemm_bf16_nt_join(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), _ptr(add), _ptr(mask), M, N, K,
+                                             _stream(a)), 'cfl_gemm_bf16_nt_join')
+        return out
     _lib.check(lib.cfl_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K, variant,
                                     _stream(a)), 'cfl_gemm_bf16_nt')
     return out
@@ -850,6 +909,7 @@ def prepare_weight_transposes(weights):
       * k x k weights (odd k, channels_last) -> W'[ci, co, kh, kw] = W[co, ci, k-1-kh, k-1-kw], with which the stride-1 data
         gradient is the FORWARD convolution of dy (_ConvSplitFn.backward).
     Call right before `loss.backward()`; `release_weight_transposes()` after it."""
+    _join_reset(True)
     import numpy as np
     ws = [w for w in weights if w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 4
           and ((w.shape[2] == 1 and w.shape[3] == 1 and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0) or _rot_ok(w))]
@@ -891,6 +951,7 @@ def prepare_weight_transposes(weights):
 
 def release_weight_transposes():
     _WT['valid'] = False
+    _join_reset(False)
 
 
 def conv1x1_supported(x, weight):
@@ -933,6 +994,8 @@ class _ConvSplitFn(torch.autograd.Function):
     def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, gemm_dgrad, side_wgrad)
+        if gemm_dgrad and ctx.needs_input_grad[0] and x.data_ptr() in JOIN['mask']:
+            JOIN['consumer'].add(x.data_ptr())           # this node's data gradient can take the gradient join of x (JOIN above)
         return torch.nn.functional.conv2d(x, weight, None, stride, padding)
 
     @staticmethod
@@ -986,7 +1049,15 @@ class _ConvSplitFn(torch.autograd.Function):
                 if wt is None:
                     wt = torch.empty(Ci, Co, dtype=torch.bfloat16, device=x.device)   # [Ci, Co]: reduction axis contiguous
                     _lib.check(_lib.load().cfl_transpose_bf16(_ptr(weight), Co, Ci, _ptr(wt), _stream(x)), 'cfl_transpose_bf16')
-                gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
+                skip = JOIN['pending'].pop(x.data_ptr(), None) if JOIN['on'] else None
+                if skip is not None:
+                    # dX = (dY W + skip gradient) . ReLU mask of the BatchNorm that produced x: pre-joined for that layer
+                    gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci),
+                                 add=skip, mask=JOIN['mask'][x.data_ptr()])
+                    JOIN['pre'].add(x.data_ptr())
+                    JOIN['fused'] += 1
+                else:
+                    gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
             elif (stride == 1 and padding == weight.shape[2] // 2 and weight.dtype == torch.bfloat16 and _rot_ok(weight)
                   and not _NO_FWD_DGRAD):
                 # k x k / stride 1 / same padding: dX = conv2d(dY, W') with the rotated, transposed weight -- MIOpen's FORWARD

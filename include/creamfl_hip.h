@@ -214,6 +214,12 @@ int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int
  * variant 0 = pick by shape; 21 / 22 / 41 / 42 / 44 select the wave tile (TM,TN) for benchmarking. */
 int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
                      int M, int N, int K, int variant, void* stream);
+/* The same GEMM with the gradient JOIN of a residual block in its epilogue (round 3): C = (A B^T + add) . mask, C / add dense
+ * [M, N] bf16, mask = 1 bit per element as cfl_bn_fwd writes it (byte i = elements 8 i .. 8 i + 7).  Used for the data gradient
+ * of a bottleneck's first 1x1 convolution (torchvision resnet.py Bottleneck.forward: out += identity; relu): the BatchNorm
+ * backward of the layer below then reads one pre-masked gradient (cfl_bn_bwd with relu = 0, has_residual = 0). */
+int cfl_gemm_bf16_nt_join(const void* A, long long lda, const void* B, long long ldb, void* C, const void* add,
+                          const unsigned char* mask, int M, int N, int K, void* stream);
 /* tn: C[N1,N2] = A[M,N1]^T * B[M,N2] (reduction along the slow axis M): the weight gradient dW[Co,Ci] = dy^T x of a 1x1
  * convolution.  C dense row-major, bf16 (c_bf16 = 1) or fp32; split-K over M with fp32 partials in ws
  * (cfl_gemm_bf16_tn_ws_bytes) and a fixed-order reduction.  N1 % 8 == N2 % 8 == 0, lda % 8 == ldb % 8 == 0. */

@@ -323,3 +323,61 @@ def test_prepared_weight_transposes_match_individual_ones():
         assert torch.equal(wt, c.weight.detach().reshape(c.weight.shape[0], -1).t())
     for ga, gb in zip(a, b):
         assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize('n,hw,planes', [(8, 14, 64), (4, 28, 64), (3, 7, 128)])
+def test_gradient_join_fused_into_the_1x1_data_gradient(n, hw, planes, monkeypatch):
+    """Round 3: the gradient join of a residual block -- skip-connection gradient + data gradient of the
+    next block's first 1x1 convolution, masked by the producing BatchNorm's ReLU -- inside the epilogue of the data-gradient
+    GEMM (cfl_gemm_bf16_nt_join), the BatchNorm backward of the layer below reading ONE pre-masked gradient.  A stack of three
+    bottleneck blocks, backward run the way TrainerEngine.backward runs it, against the same stack with the fusion off: every
+    parameter gradient and the input gradient within bf16 rounding (the fused path rounds the joined gradient to bf16 once,
+    where the unfused BatchNorm passes keep the sum in fp32), and the fusion really took place (2 of the 3 joins: the first
+    block's input is not a BatchNorm output)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    from creamfl_amd.networks.backbones import Bottleneck
+    dev = torch.device('cuda:0')
+
+    def run(fuse):
+        monkeypatch.setattr(ops, '_NO_JOIN_FUSE', not fuse)
+        torch.manual_seed(7)
+        blocks = torch.nn.Sequential(*[Bottleneck(4 * planes, planes) for _ in range(3)]).to(dev).to(torch.bfloat16)
+        blocks = blocks.to(memory_format=torch.channels_last).train()
+        for m in blocks.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.float()
+        x = torch.randn(n, 4 * planes, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        w = torch.randn(n, 4 * planes, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        fused0 = ops.JOIN['fused']
+        ops.join_arm()
+        out = blocks(x)
+        out = out[0] if isinstance(out, tuple) else out
+        loss = (out.float() * w.float()).sum()
+        ops.prepare_weight_transposes([m.weight for m in blocks.modules() if isinstance(m, torch.nn.Conv2d)])
+        try:
+            loss.backward()
+        finally:
+            ops.release_weight_transposes()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().float().cpu() for k, p in blocks.named_parameters()}
+        grads['input'] = x.grad.detach().float().cpu()
+        return grads, ops.JOIN['fused'] - fused0, out.detach().float().cpu()
+
+    ref, n_ref, out_ref = run(False)
+    got, n_got, out_got = run(True)
+    assert n_ref == 0 and n_got == 2, (n_ref, n_got)
+    assert torch.equal(out_ref, out_got)                              # the forward pass is untouched
+    assert not ops.JOIN['mask'] and not ops.JOIN['pending'] and not ops.JOIN['pre']       # nothing left behind
+    for k in ref:
+        a, b = got[k].numpy(), ref[k].numpy()
+        scale = float(np.abs(b).max())
+        assert np.isfinite(a).all(), k
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-2 * scale, err_msg=k)                # element-wise: bf16-level
+        rel = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+        if k.startswith('2.'):
+            assert np.array_equal(a, b), k            # the top block's gradients are computed before any joined gradient is consumed
+        else:
+            assert rel < 2e-2, (k, rel)               # below: one more bf16 rounding per join (measured 7e-3 at the bottom), no bias
