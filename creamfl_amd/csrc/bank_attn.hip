@@ -624,12 +624,24 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
         int rc;
         // <DT, streams, waves, column split, staging sets>: D <= 256: 2 feature groups x 4 slot streams, 2 waves per SIMD;
         // D = 512: 4 column-split pairs, 2 per SIMD; D = 768: 2 column-split pairs, 1 wave per SIMD, 2 staging sets
-        if (p.DT == 24) rc = want_grad ? launch_stream<24, 1, 4, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                       : launch_stream<24, 1, 4, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
-        else if (p.DT == 16) rc = want_grad ? launch_stream<16, 1, 8, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                            : launch_stream<16, 1, 8, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
-        else if (p.DT == 8) rc = want_grad ? launch_stream<8, 4, 8, 1, 1, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                           : launch_stream<8, 4, 8, 1, 1, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        static const int regs = getenv("CFL_BANK_REGSTAGE") ? 1 : 0;       // A/B: register-staged slots instead of LDS-DMA
+        if (p.DT == 24) {
+            if (regs) rc = want_grad ? launch_stream<24, 1, 4, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                     : launch_stream<24, 1, 4, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
+            else rc = want_grad ? launch_stream<24, 1, 4, 2, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                : launch_stream<24, 1, 4, 2, 0, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        } else if (p.DT == 16) {
+            if (regs) rc = want_grad ? launch_stream<16, 1, 8, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                     : launch_stream<16, 1, 8, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
+            else rc = want_grad ? launch_stream<16, 1, 8, 2, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                : launch_stream<16, 1, 8, 2, 0, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        }
+        else if (p.DT == 8) {
+            if (regs) rc = want_grad ? launch_stream<8, 4, 8, 1, 1, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                    : launch_stream<8, 4, 8, 1, 1, false>(F, image_other, B, M, D, sc2, p, w, stream);
+            else rc = want_grad ? launch_stream<8, 4, 8, 1, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)
+                                : launch_stream<8, 4, 8, 1, 0, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        }
         else rc = want_grad ? launch_stream<4, 4, 8, 1, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
                             : launch_stream<4, 4, 8, 1, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
         if (rc) return rc;

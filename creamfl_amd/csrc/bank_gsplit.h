@@ -152,8 +152,8 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     static_assert(NDS == 1 || (KSW % 4 == 0 && NDTW % 8 == 0), "a wave's share must start on a 256-byte window");
     constexpr int STRIDE = NSW * 1024, NPT = (64 * DP) / STRIDE;         // 16-byte loads per thread and slot
     constexpr int RB = KSW % 8 == 0 ? 8 : (KSW % 6 == 0 ? 6 : 4);        // contraction steps per read burst of the logits block
-    static_assert(KSW % RB == 0 && NDTW % (NDTW >= 8 ? 8 : 4) == 0, "bursts must tile the wave's share");
-    constexpr int GW = NDTW >= 8 ? 8 : 4;                                // column tiles per read burst of the gradient block
+    constexpr int GW = (NDTW >= 8 && LA <= 1) ? 8 : 4;                   // column tiles per read burst of the gradient block
+    static_assert(KSW % RB == 0 && NDTW % GW == 0, "bursts must tile the wave's share");
     using SM = StSmem<DT, NGG, NWAVE, NDS>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -174,15 +174,32 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     auto slot_src = [&](int it) { return sbase + (size_t)(c0 + gg + it * NGG) * SM::SLOT; };
     auto has_slot = [&](int it) { return gg + it * NGG < nmine; };
 
-    u32x4v stage[LA][NPT];
+    // LA = 0: the slots travel by LDS-DMA (global_load_lds_dwordx4: 64 x 16 B per wave instruction straight into the LDS
+    // buffer, lane-linear -- the image is stored in LDS order for exactly this): no staging registers, no ds_write (the
+    // 64 KB per iteration a workgroup pushes through ds_write_b128 occupy the LDS write path for ~800 cycles of the ~3800 an
+    // iteration takes), issued at the top of an iteration and complete at its closing barrier.
+    constexpr bool DMA = (LA == 0);
+    constexpr int NSET = DMA ? 1 : LA;
+    u32x4v stage[NSET][DMA ? 1 : NPT];
+    auto dma_slot = [&](int it, int b) {
+        const char* src = slot_src(it);
+        char* dst = sbuf + b * SM::SLOT + sw * 1024;          // this wave's 1 KB of every STRIDE-byte stripe (lane l: + 16 l)
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            __builtin_amdgcn_global_load_lds((glb_vptr)(src + j * STRIDE), (lds_vptr)(dst + j * STRIDE), 16, 0, 0);
+    };
     // prologue: slot 0 straight into buffer 0; with LA = 2 the loads of slot 1 are left in flight in set 1
-    if (has_slot(0)) {
+    if (DMA) {
+        if (has_slot(0)) dma_slot(0, 0);
+    } else {
+        if (has_slot(0)) {
 #pragma unroll
-        for (int j = 0; j < NPT; ++j) stage[0][j] = *reinterpret_cast<const u32x4v*>(slot_src(0) + j * STRIDE);
-    }
-    if (LA == 2 && has_slot(1)) {
+            for (int j = 0; j < NPT; ++j) stage[0][j] = *reinterpret_cast<const u32x4v*>(slot_src(0) + j * STRIDE);
+        }
+        if (LA == 2 && has_slot(1)) {
 #pragma unroll
-        for (int j = 0; j < NPT; ++j) stage[LA - 1][j] = *reinterpret_cast<const u32x4v*>(slot_src(1) + j * STRIDE);
+            for (int j = 0; j < NPT; ++j) stage[NSET - 1][j] = *reinterpret_cast<const u32x4v*>(slot_src(1) + j * STRIDE);
+        }
     }
     // this wave's share of its 16 feature rows: contraction steps dh KSW .. + KSW - 1
     bf16x8 fh[KSW], fl[KSW];
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
 #pragma unroll
     for (int i = 0; i < (GRAD ? NDTW : 1); ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float run_m = -INFINITY, run_l = 0.f;
-    if (has_slot(0)) {
+    if (!DMA && has_slot(0)) {
 #pragma unroll
         for (int j = 0; j < NPT; ++j) *reinterpret_cast<u32x4v*>(sbuf + j * STRIDE + toff) = stage[0][j];
     }
@@ -226,8 +243,10 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     f32x4* xs = reinterpret_cast<f32x4*>(lds + SM::BODY);        // NDS > 1: [wave][lane] partial logits
 
     // one iteration: `ld` receives the loads of slot it + LA, `wr` (holding slot it + 1) goes to the other buffer at the end
-    auto iteration = [&](int it, u32x4v (&ld)[NPT], u32x4v (&wr)[NPT]) {
-        if (has_slot(it + LA)) {
+    auto iteration = [&](int it, u32x4v (&ld)[DMA ? 1 : NPT], u32x4v (&wr)[DMA ? 1 : NPT]) {
+        if (DMA) {
+            if (has_slot(it + 1)) dma_slot(it + 1, (it + 1) & 1);
+        } else if (has_slot(it + LA)) {
 #pragma unroll
             for (int j = 0; j < NPT; ++j) ld[j] = *reinterpret_cast<const u32x4v*>(slot_src(it + LA) + j * STRIDE);
         }
@@ -316,16 +335,16 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
                 }
             }
         }
-        if (has_slot(it + 1)) {
+        if (!DMA && has_slot(it + 1)) {
             char* nb = sbuf + ((it + 1) & 1) * SM::SLOT;
 #pragma unroll
             for (int j = 0; j < NPT; ++j) *reinterpret_cast<u32x4v*>(nb + j * STRIDE + toff) = wr[j];
         }
-        __syncthreads();
+        __syncthreads();                                         // also the landing point of this iteration's LDS-DMA (vmcnt)
     };
-    for (int it = 0; it < niter; it += LA) {
-        iteration(it, stage[0], stage[LA - 1]);
-        if (LA == 2 && it + 1 < niter) iteration(it + 1, stage[LA - 1], stage[0]);
+    for (int it = 0; it < niter; it += NSET) {
+        iteration(it, stage[0], stage[NSET - 1]);
+        if (NSET == 2 && it + 1 < niter) iteration(it + 1, stage[NSET - 1], stage[0]);
     }
 
     run_l += __shfl_xor(run_l, 16, 64);
