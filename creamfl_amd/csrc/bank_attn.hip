@@ -622,28 +622,13 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
     if (mode & 1) {
         const float sc2 = inv_tau * 1.4426950408889634f;
         int rc;
-        // <DT, streams, waves, column split, staging sets>: D <= 256: 2 feature groups x 4 slot streams, 2 waves per SIMD;
-        // D = 512: 4 column-split pairs, 2 per SIMD; D = 768: 2 column-split pairs, 1 wave per SIMD, 2 staging sets
-        static const int regs = getenv("CFL_BANK_REGSTAGE") ? 1 : 0;       // A/B: register-staged slots instead of LDS-DMA
-        if (p.DT == 24) {
-            if (regs) rc = want_grad ? launch_stream<24, 1, 4, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                     : launch_stream<24, 1, 4, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
-            else rc = want_grad ? launch_stream<24, 1, 4, 2, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                : launch_stream<24, 1, 4, 2, 0, false>(F, image_other, B, M, D, sc2, p, w, stream);
-        } else if (p.DT == 16) {
-            if (regs) rc = want_grad ? launch_stream<16, 1, 8, 2, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                     : launch_stream<16, 1, 8, 2, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
-            else rc = want_grad ? launch_stream<16, 1, 8, 2, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                : launch_stream<16, 1, 8, 2, 0, false>(F, image_other, B, M, D, sc2, p, w, stream);
-        }
-        else if (p.DT == 8) {
-            if (regs) rc = want_grad ? launch_stream<8, 4, 8, 1, 1, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                    : launch_stream<8, 4, 8, 1, 1, false>(F, image_other, B, M, D, sc2, p, w, stream);
-            else rc = want_grad ? launch_stream<8, 4, 8, 1, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                                : launch_stream<8, 4, 8, 1, 0, false>(F, image_other, B, M, D, sc2, p, w, stream);
-        }
-        else rc = want_grad ? launch_stream<4, 4, 8, 1, 2, true>(F, image_other, B, M, D, sc2, p, w, stream)
-                            : launch_stream<4, 4, 8, 1, 2, false>(F, image_other, B, M, D, sc2, p, w, stream);
+        // <DT, slot streams, waves, column split, staging (0 = LDS-DMA)>: D <= 256: 2 feature groups x 4 slot streams;
+        // D = 512 / 768: 4 column-split pairs on one stream; always 8 waves, two per SIMD
+#define CFL_STREAM(DT_, NGG_, NDS_)                                                                                       \
+    (want_grad ? launch_stream<DT_, NGG_, 8, NDS_, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)                  \
+               : launch_stream<DT_, NGG_, 8, NDS_, 0, false>(F, image_other, B, M, D, sc2, p, w, stream))
+        rc = p.DT == 24 ? CFL_STREAM(24, 1, 2) : p.DT == 16 ? CFL_STREAM(16, 1, 2) : p.DT == 8 ? CFL_STREAM(8, 4, 1) : CFL_STREAM(4, 4, 1);
+#undef CFL_STREAM
         if (rc) return rc;
     }
     return launch_finish(w, p.S, p.DP, p.RGF, p.Bp, F, G_other, G_same, F_old, idx, B, M, D, B_div, inv_tau, weight, mode, want_grad,

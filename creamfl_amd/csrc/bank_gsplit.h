@@ -125,9 +125,10 @@ __device__ __forceinline__ float row_max4(float v) {
 //   * beyond D = 256 the per-wave state is cut by NDS = 2: the two waves of a PAIR share 16 feature rows, each takes half of
 //     the contraction steps of the logits (its half of F: D/8 + D/8 registers) and half of the gradient columns (D/8
 //     registers of O); the partial logits -- 4 floats per lane -- cross through LDS (one extra barrier per slot), so no MFMA
-//     is issued twice and every wave reads only its half of the slot.  D = 512: 4 pairs, two waves per SIMD, 64 rows per
-//     workgroup; D = 768: 2 pairs, one wave per SIMD (F + O = 288 registers + 2 staging sets), 32 rows per workgroup
-//     (F 192 + O 192 in ONE wave left no room for staging: the compiler spilled 166 registers into the loop, 442 us).
+//     is issued twice and every wave reads only its half of the slot.  D = 512 and 768: 4 pairs = 8 waves, two per SIMD,
+//     64 rows per workgroup (at D = 768 F + O = 192 registers per wave; with the slots arriving by LDS-DMA and read bursts
+//     of 4 the kernel fits 249 registers without spilling.  Measured on the way at D = 768, B = 128, M = 50 000: F 192 + O
+//     192 in ONE wave: 166 registers spilled into the loop, 442 us; 2 pairs with one wave per SIMD: 105 us; 4 pairs: 73 us).
 template <int DT, int NGG, int NWAVE, int NDS>
 struct StSmem {
     static constexpr int DP = 32 * DT;
@@ -151,8 +152,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     constexpr int KSW = DT / NDS, NDTW = 2 * DT / NDS;                   // contraction steps / gradient column tiles per wave
     static_assert(NDS == 1 || (KSW % 4 == 0 && NDTW % 8 == 0), "a wave's share must start on a 256-byte window");
     constexpr int STRIDE = NSW * 1024, NPT = (64 * DP) / STRIDE;         // 16-byte loads per thread and slot
-    constexpr int RB = KSW % 8 == 0 ? 8 : (KSW % 6 == 0 ? 6 : 4);        // contraction steps per read burst of the logits block
-    constexpr int GW = (NDTW >= 8 && LA <= 1) ? 8 : 4;                   // column tiles per read burst of the gradient block
+    constexpr bool TIGHT = (DT == 24 && NWAVE == 8);                     // 2 waves per SIMD at D = 768: shorter bursts
+    constexpr int RB = TIGHT ? 4 : (KSW % 8 == 0 ? 8 : (KSW % 6 == 0 ? 6 : 4));   // contraction steps per read burst of the logits block
+    constexpr int GW = (NDTW >= 8 && LA <= 1 && !TIGHT) ? 8 : 4;                   // column tiles per read burst of the gradient block
     static_assert(KSW % RB == 0 && NDTW % GW == 0, "bursts must tile the wave's share");
     using SM = StSmem<DT, NGG, NWAVE, NDS>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -420,7 +422,7 @@ static GsPlan gs_plan(int B, int M, int D) {
     p.wide = D > 256;
     p.DP = D <= 128 ? 128 : (D <= 256 ? 256 : (D <= 512 ? 512 : 768));
     p.DT = p.DP / 32;
-    p.RG = cfl_cdiv(B, p.DP == 512 ? 64 : FB);      // rows per workgroup: 32, except 64 at D = 512
+    p.RG = cfl_cdiv(B, p.wide ? 64 : FB);           // rows per workgroup: 32 at D <= 256, 64 beyond (4 column-split pairs)
     p.RGF = cfl_cdiv(B, BR);
     p.Bp = p.RGF * BR;
     int s = (256 / p.RG) & ~7;             // ~one workgroup per CU; a multiple of 8 (block id -> XCD mapping), <= 256 (finish)
