@@ -338,6 +338,29 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
     const int f = rg * BR + fl;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool live = f < B;
+    // Row terms (column block 0 of a row; wave 0: the exact positive dot of the inter term, wave 1: the intra / MOON term): their
+    // operands -- the feature row, the bank row(s) of the row's public-set index, the old feature row -- are requested HERE, ahead
+    // of the split merge, so that the index -> bank-row dependency and the merge's own loads share one stretch of memory latency
+    // (they used to run after the merge's two barriers, as loops of one load per trip: ~half of this kernel's time at D = 256).
+    constexpr int NKP = 12;                                  // D <= 768 = 12 x 64 lanes
+    float pf[NKP], pg[NKP], po[NKP];
+    const bool rowwork = live && quarter == 0;
+    const long long tgt = rowwork ? idx[f] : -1;
+    const bool ok = tgt >= 0 && tgt < M;
+    const bool w_inter = rowwork && (mode & 1) && wv == 0, w_intra = rowwork && (mode & 2) && wv == 1;
+    if (w_inter || w_intra) {
+        const float* fr = F + (long long)f * D;
+        const float* g = (w_inter ? Go : Gs) + (ok ? tgt : 0) * D;
+        const float* o = w_intra ? Fo + (long long)f * D : fr;
+#pragma unroll
+        for (int j = 0; j < NKP; ++j) {
+            const int k = lane + 64 * j;
+            const int kc = k < D ? k : 0;                        // unconditional (clamped) loads, masked here
+            pf[j] = k < D ? fr[kc] : 0.f;
+            pg[j] = (k < D && ok) ? g[kc] : 0.f;
+            po[j] = (k < D && w_intra) ? o[kc] : 0.f;
+        }
+    }
     if (live && (mode & 1)) {
         const float* pm = part_m + (size_t)rg * S * BR + fl;
         const float* pl = part_l + (size_t)rg * S * BR + fl;
@@ -392,23 +415,17 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
         }
     }
     if (live && quarter == 0) {
-        const float* fr = F + (long long)f * D;
-        const long long tgt = idx[f];
-        const bool ok = tgt >= 0 && tgt < M;
-        if ((mode & 1) && wv == 0) {
+        if (w_inter) {
             float dot = 0.f;
-            if (ok) {
-                const float* g = Go + tgt * D;
-                for (int k = lane; k < D; k += 64) dot = fmaf(fr[k], g[k], dot);
-            }
+#pragma unroll
+            for (int j = 0; j < NKP; ++j) dot = fmaf(pf[j], pg[j], dot);
             dot = wave_sum(dot) * inv_tau;
             if (lane == 0) { row_pos = dot; if (pos_out) pos_out[f] = dot; }
         }
-        if ((mode & 2) && wv == 1) {
-            const float* g = Gs + (ok ? tgt : 0) * D;
-            const float* o = Fo + (long long)f * D;
+        if (w_intra) {
             float pos = 0.f, neg = 0.f;
-            for (int k = lane; k < D; k += 64) { pos = fmaf(fr[k], ok ? g[k] : 0.f, pos); neg = fmaf(fr[k], o[k], neg); }
+#pragma unroll
+            for (int j = 0; j < NKP; ++j) { pos = fmaf(pf[j], pg[j], pos); neg = fmaf(pf[j], po[j], neg); }
             pos = wave_sum(pos); neg = wave_sum(neg);
             const float z = (neg - pos) * inv_tau;
             if (lane == 0) {
@@ -417,7 +434,11 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
             }
             if (dF_moon) {
                 const float c = sigmoidf(z) * inv_tau / (float)Bdiv;
-                for (int k = lane; k < D; k += 64) dF_moon[(long long)f * D + k] = c * (o[k] - (ok ? g[k] : 0.f));
+#pragma unroll
+                for (int j = 0; j < NKP; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < D) dF_moon[(long long)f * D + k] = c * (po[j] - pg[j]);
+                }
             }
         }
         __syncthreads();
