@@ -202,12 +202,49 @@ def parse_args(argv=None):
                     help='BASELINE.json config: 1 = server step at 256 pairs per GPU (default, the metric\'s config); 3 = large-batch '
                          'global contrast, 512 pairs per GPU (N = 4096 over 8 GPUs)')
     ap.add_argument('--no-recall', action='store_true')
+    ap.add_argument('--no-prewarm', action='store_true',
+                    help='skip the one-off child process that lets MIOpen compile / select its kernels on a fresh box')
+    ap.add_argument('--prewarm-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
     if args.config == 3:
         args.batch = 512
     return args
+
+
+def prewarm(args, local_rank):
+    """On a fresh box the FIRST process that runs this workload is 3-5 % slower than every later one, whatever its warm-up
+    count (measured: 48.9 ms per step in the first process, 46.5 / 46.3 in the second and third, with 5 or 40 warm-up steps):
+    MIOpen compiles its kernels and records its solver choices while that process runs, and the process keeps the choices it
+    made before the compiled kernels existed.  That one-off library set-up is not the step this bench measures, so it is done
+    here, once per box and shape, in a CHILD process (3 untimed steps, no JSON) before the measured process builds its model.
+    A marker file next to the seeded find-db makes later invocations skip it; --no-prewarm disables it."""
+    import subprocess
+    import tempfile
+    if args.no_prewarm or args.prewarm_child or not torch.cuda.is_available():
+        return
+    mark = os.path.join(os.environ.get('MIOPEN_USER_DB_PATH', tempfile.gettempdir()),
+                        'prewarmed_%s_%d_%d_%s' % (args.cnn, args.batch, args.dim, args.dtype))
+    if os.path.exists(mark):
+        return
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'GROUP_RANK', 'ROLE_RANK',
+              'LOCAL_WORLD_SIZE', 'ROLE_WORLD_SIZE'):
+        env.pop(k, None)
+    env['HIP_VISIBLE_DEVICES'] = env.get('HIP_VISIBLE_DEVICES', '').split(',')[local_rank] if env.get('HIP_VISIBLE_DEVICES') \
+        else str(local_rank % max(1, torch.cuda.device_count()))
+    cmd = [sys.executable, os.path.abspath(__file__), '--prewarm-child', '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch',
+           str(args.batch), '--dim', str(args.dim), '--cnn', args.cnn, '--dtype', args.dtype, '--no-cpu-baseline', '--no-recall',
+           '--no-alone']
+    t0 = time.perf_counter()
+    rc = subprocess.call(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.stderr.write('bench.py: library pre-warm child rc=%d, %.1f s\n' % (rc, time.perf_counter() - t0))
+    if rc == 0:
+        try:
+            open(mark, 'w').write('ok\n')
+        except OSError:
+            pass
 
 
 def main():
@@ -219,6 +256,7 @@ def main():
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes needs it on this driver)
         env.setdefault('OMP_NUM_THREADS', '4')
         raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
+    prewarm(args, local_rank)
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block at
     # communicator creation) are sent to stderr; the JSON goes to the saved descriptor.
     sys.stdout.flush()
@@ -309,6 +347,8 @@ def main():
         trace.append(loss.detach())              # device scalars; read after the timed region
     fence()
     dt = time.perf_counter() - t0
+    if args.prewarm_child:
+        return
     _lib.prof_enable(False)
     _lib.prof_select(None)
     prof = _lib.prof_query()
