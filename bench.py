@@ -202,6 +202,7 @@ def parse_args(argv=None):
                     help='BASELINE.json config: 1 = server step at 256 pairs per GPU (default, the metric\'s config); 3 = large-batch '
                          'global contrast, 512 pairs per GPU (N = 4096 over 8 GPUs)')
     ap.add_argument('--no-recall', action='store_true')
+    ap.add_argument('--no-mfu', action='store_true', help='skip the FLOP-counting forward pass (profiling runs: every launch then belongs to a step)')
     ap.add_argument('--no-prewarm', action='store_true',
                     help='skip the one-off child process that lets MIOpen compile / select its kernels on a fresh box')
     ap.add_argument('--prewarm-child', action='store_true', help=argparse.SUPPRESS)
@@ -314,7 +315,7 @@ def main():
         torch.cuda.synchronize()
 
     from creamfl_amd import ops as _ops
-    fwd_flops = forward_flops(eng, images, captions, words, lens)
+    fwd_flops = 0 if args.no_mfu else forward_flops(eng, images, captions, words, lens)
     # Warm-up.  Its last step is event-timed for EVERY hand-written kernel: that gives the per-kernel table and
     # tells which kernel dominates.  In the timed region only that one kernel is bracketed by HIP events (two
     # hipEventRecords per launch of all ~650 hand-written launches per step cost ~5 ms of host time per step).
@@ -434,7 +435,7 @@ def main():
                 if not ent:
                     continue
                 lps = ent.get('launches_per_step')
-                if lps is None or abs(lps - per_step) > 1e-6:
+                if lps is None or abs(lps - per_step) >= 0.5:        # (the profiler may miss one launch of a run)
                     roof['traffic_source'] = ('none: profiles/%s was taken at %s launches of this kernel per step, this run has %g '
                                               '(traffic = null)' % (fn, lps, per_step))
                     continue
@@ -487,7 +488,7 @@ def main():
         # model-FLOPs utilisation of the step: forward + backward = 3 x forward model FLOPs per step and GPU
         mfma_peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else F32_MFMA_PEAK_TFLOPS
         step_tflop = 3.0 * fwd_flops / 1e12
-        mfu = {'model_tflop_per_step_per_gpu': round(step_tflop, 3), 'gflop_per_pair': round(3.0 * fwd_flops / args.batch / 1e9, 2),
+        mfu = None if args.no_mfu else {'model_tflop_per_step_per_gpu': round(step_tflop, 3), 'gflop_per_pair': round(3.0 * fwd_flops / args.batch / 1e9, 2),
                'achieved_tflops_per_gpu': round(step_tflop / (ms_per_step * 1e-3), 1), 'peak_tflops': mfma_peak,
                'mfu': round(step_tflop / (ms_per_step * 1e-3) / mfma_peak, 4),
                'how': '3 x forward FLOPs (conv / linear modules by hooks + PIE w_1 + BERT QK^T, PV) / step time / dense MFMA peak'}

@@ -27,4 +27,24 @@ for k, v in sorted(out.items()):
               'traffic_bytes': int(2 * fk * 1024 + wk * 1024)}
     if STEPS:
         res[k]['launches_per_step'] = round((f[0] or w[0]) / STEPS, 3)
+# launch-weighted aggregate per base name (the library profiler -- and bench.py's roofline -- know a kernel by its base name,
+# rocprofv3 by template instance)
+groups = {}
+for k, v in list(res.items()):
+    if k.startswith('_') or '<' not in k:
+        continue
+    base = k.split('<')[0].split('::')[-1]
+    targs = [a.strip() for a in k[k.index('<') + 1:k.rindex('>')].split(',')]
+    if base in ('cfl_bn_bwd_apply_kernel', 'cfl_bn_bwd_reduce_kernel') and len(targs) >= (4 if 'apply' in base else 3) and targs[-1] == 'true':
+        base = base.replace('cfl_bn_', 'cfl_bn_pool_')       # the stem-tail instance runs under its own profiler id
+    groups.setdefault(base, []).append(v)
+for base, vs in groups.items():
+    if base in res:
+        continue
+    n = sum(v['launches'] for v in vs)
+    agg = {'launches': n, 'traffic_bytes': int(sum(v['traffic_bytes'] * v['launches'] for v in vs) / max(n, 1)),
+           'note': 'launch-weighted average over the template instances above'}
+    if STEPS:
+        agg['launches_per_step'] = round(n / STEPS, 3)
+    res[base] = agg
 print(json.dumps(res, indent=1))

@@ -21,7 +21,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-recall --no-alone >
 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-recall > $OUT/${TAG}_bench_gloo2_line.json 2> $OUT/gloo2.err
 python tools/kernel_bench.py --cases a1,a3,a5,a2,a6,f4,pool,gemm16,opt > $OUT/${TAG}_kernel_bench.jsonl 2> $OUT/kb.err
 python tools/config4_bench.py > $OUT/${TAG}_config4_line.json 2> $OUT/c4.err
-PMC_STEPS=3 bash tools/pmc_run.sh bench python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall --no-alone > /dev/null 2>&1
+PMC_STEPS=3 bash tools/pmc_run.sh bench python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall --no-alone --no-mfu --no-prewarm > /dev/null 2>&1
 cp $ROOT/gpurun_out/pmc_bench/summary.json $OUT/${TAG}_pmc_bench_traffic.json
 bash tools/pmc_run.sh a3 python $ROOT/tools/kernel_bench.py --cases a3one > /dev/null 2>&1
 cp $ROOT/gpurun_out/pmc_a3/summary.json $OUT/${TAG}_pmc_a3.json
@@ -37,7 +37,7 @@ w.writerow(['Name', 'Calls', 'AverageNs', 'MinNs', 'MaxNs'])
 for r in rows:
     w.writerow([r['Name'].split('(float')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''), r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs']])
 PY
-rocprofv3 --kernel-trace -d $OUT/trace_bench -o bench --output-format csv -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-recall --no-alone > $OUT/trace_bench.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/trace_bench -o bench --output-format csv -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-recall --no-alone --no-prewarm > $OUT/trace_bench.log 2>&1
 python3 $ROOT/tools/trace_stats.py $(ls $OUT/trace_bench/*kernel_trace.csv $OUT/trace_bench/*/*kernel_trace.csv 2>/dev/null | head -1) > $OUT/${TAG}_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d $OUT/trace_c4 -o c4 --output-format csv -- python $ROOT/tools/config4_bench.py --steps 5 --warmup 2 > $OUT/trace_c4.log 2>&1
 python3 - $OUT/trace_c4/c4_kernel_stats.csv > $OUT/${TAG}_config4_kernel_stats.csv <<'PY'
