@@ -6,7 +6,8 @@
 #   <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace of a short bench run, timed steps only (tools/trace_stats.py)
 #   <tag>_pmc_bench_traffic.json     HBM traffic per hand-written kernel of the bench step (separate --pmc passes, launches_per_step)
 #   <tag>_kernel_bench.jsonl         tools/kernel_bench.py at the SURVEY 8(d) shapes
-#   <tag>_a3_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the client contrast step at D = 256 / 512 / 768
+#   <tag>_a3one_kernel_stats.csv     rocprofv3 --kernel-trace --stats of the client contrast step, B = 128, M = 50 000, D = 256 (+ the round-2 path, same box)
+#   <tag>_a3_kernel_stats.csv        the same at D = 256 / 512 / 768 (kernel instances tell the shapes apart)
 #   <tag>_pmc_a3.json                HBM traffic of the bank pass / finish kernel (B = 128, M = 50 000, D = 256)
 #   <tag>_sq_a3.json                 SQ / LDS / MFMA counters of the same
 #   <tag>_config4_line.json, <tag>_config4_kernel_stats.csv   BASELINE configs[4] at full encoder size (tools/config4_bench.py)
@@ -28,6 +29,19 @@ cp $ROOT/gpurun_out/pmc_a3/summary.json $OUT/${TAG}_pmc_a3.json
 bash tools/pmc_sq.sh a3 python $ROOT/tools/kernel_bench.py --cases a3one > $OUT/${TAG}_sq_a3.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/trace_a3 $OUT/trace_bench $OUT/trace_c4
+cat > $OUT/pick.py <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'cfl_' in r['Name']]
+w = csv.writer(sys.stdout)
+w.writerow(['Name', 'Calls', 'AverageNs', 'MinNs', 'MaxNs'])
+for r in rows:
+    w.writerow([r['Name'].split('(float')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''), r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs']])
+PY
+rocprofv3 --kernel-trace --stats -d $OUT/trace_a3one -o a3 --output-format csv -- python $ROOT/tools/kernel_bench.py --cases a3one > $OUT/trace_a3one.log 2>&1
+python3 $OUT/pick.py $OUT/trace_a3one/a3_kernel_stats.csv > $OUT/${TAG}_a3one_kernel_stats.csv
+CFL_BANK_NOIMG=1 rocprofv3 --kernel-trace --stats -d $OUT/trace_a3old -o a3 --output-format csv -- python $ROOT/tools/kernel_bench.py --cases a3one > $OUT/trace_a3old.log 2>&1
+python3 $OUT/pick.py $OUT/trace_a3old/a3_kernel_stats.csv > $OUT/${TAG}_a3one_round2_path_kernel_stats.csv
+rm -rf $OUT/trace_a3one $OUT/trace_a3old
 rocprofv3 --kernel-trace --stats -d $OUT/trace_a3 -o a3 --output-format csv -- python $ROOT/tools/kernel_bench.py --cases a3 > $OUT/trace_a3.log 2>&1
 python3 - $OUT/trace_a3/a3_kernel_stats.csv > $OUT/${TAG}_a3_kernel_stats.csv <<'PY'
 import csv, sys
