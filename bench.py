@@ -206,6 +206,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-prewarm', action='store_true',
                     help='skip the one-off child process that lets MIOpen compile / select its kernels on a fresh box')
     ap.add_argument('--prewarm-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--watchdog', type=int, default=-1,
+                    help='seconds after which a run that has not printed its line dumps every thread\'s stack and exits (a hung '
+                         'collective must not eat the node: default 900 with more than one rank, off with one; 0 = off)')
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
@@ -229,23 +232,29 @@ def prewarm(args, local_rank):
                         'prewarmed_%s_%d_%d_%s' % (args.cnn, args.batch, args.dim, args.dtype))
     if os.path.exists(mark):
         return
+    if local_rank != 0:
+        # one child per node is enough (the compiled kernels and the find-db are shared through MIOPEN_USER_DB_PATH): the other
+        # ranks wait for rank 0's marker, bounded -- a failed child must not hold the job
+        t0 = time.perf_counter()
+        while not os.path.exists(mark) and not os.path.exists(mark + '.failed') and time.perf_counter() - t0 < 400:
+            time.sleep(1.0)
+        return
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'GROUP_RANK', 'ROLE_RANK',
               'LOCAL_WORLD_SIZE', 'ROLE_WORLD_SIZE'):
         env.pop(k, None)
-    env['HIP_VISIBLE_DEVICES'] = env.get('HIP_VISIBLE_DEVICES', '').split(',')[local_rank] if env.get('HIP_VISIBLE_DEVICES') \
-        else str(local_rank % max(1, torch.cuda.device_count()))
+    vis = [v for v in env.get('HIP_VISIBLE_DEVICES', '').split(',') if v != '']
+    env['HIP_VISIBLE_DEVICES'] = vis[0] if vis else '0'
     cmd = [sys.executable, os.path.abspath(__file__), '--prewarm-child', '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch',
            str(args.batch), '--dim', str(args.dim), '--cnn', args.cnn, '--dtype', args.dtype, '--no-cpu-baseline', '--no-recall',
            '--no-alone']
     t0 = time.perf_counter()
     rc = subprocess.call(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     sys.stderr.write('bench.py: library pre-warm child rc=%d, %.1f s\n' % (rc, time.perf_counter() - t0))
-    if rc == 0:
-        try:
-            open(mark, 'w').write('ok\n')
-        except OSError:
-            pass
+    try:
+        open(mark if rc == 0 else mark + '.failed', 'w').write('ok\n' if rc == 0 else 'rc=%d\n' % rc)
+    except OSError:
+        pass
 
 
 def main():
@@ -257,6 +266,10 @@ def main():
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes needs it on this driver)
         env.setdefault('OMP_NUM_THREADS', '4')
         raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
+    wd = args.watchdog if args.watchdog >= 0 else (900 if world > 1 else 0)
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     prewarm(args, local_rank)
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block at
     # communicator creation) are sent to stderr; the JSON goes to the saved descriptor.
@@ -279,10 +292,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
+        import datetime
+        limit = datetime.timedelta(seconds=300)              # a collective that waits longer than this is a bug, not a straggler
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+            dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=limit)
 
     from creamfl_amd import _lib
     from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
@@ -516,6 +531,8 @@ def main():
     if use_dp:
         torch.distributed.barrier()           # rank 0 is still writing its line (recall evaluation): tear down together
         torch.distributed.destroy_process_group()
+    if wd > 0:
+        faulthandler.cancel_dump_traceback_later()
 
 
 def usable_cores():

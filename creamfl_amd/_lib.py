@@ -49,6 +49,7 @@ SIGNATURES = {
     'cfl_kd_mse': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_gemm_bf16_nt': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, _P]),
     'cfl_gemm_bf16_nt_join': (c_int, [_P, c_longlong, _P, c_longlong, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'cfl_gemm_bf16_bres_min_m': (c_int, [c_int]),
     'cfl_transpose_bf16': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_transpose_bf16_multi': (c_int, [_P, c_int, c_int, _P]),
     'cfl_gemm_bf16_tn_ws_bytes': (c_size_t, [c_longlong, c_int, c_int]),

@@ -177,6 +177,201 @@ int launch_nt(const Opnd& A, const Opnd& B, int M, int N, u16* C, long long ldc,
     return 0;
 }
 
+// ---- NT with the B tile RESIDENT in LDS (round 3) ---------------------------------------------------------------------------
+// The data gradients of the 1x1 convolutions are HBM-bound GEMMs (K, N <= 2048: below the ridge point), and the tile kernel
+// above reaches 2-3 TB/s on them: a workgroup has ONE K step (32 KB) in flight between two barriers, i.e. <= 64 KB per CU,
+// which at the loaded HBM latency is worth 3-4 TB/s at best.  This kernel is built around bytes in flight instead:
+//   * a workgroup (8 waves, one per CU) owns ONE column tile of B (the weight: BN = 64 / 128 columns x all of K <= 1024, 64-128
+//     KB) for its whole life -- staged once by LDS-DMA into the swizzled image frag reads want, then only read: the main loop
+//     has NO barrier;
+//   * every wave streams its own 32-row tiles of A straight from global memory into registers in MFMA operand layout (a lane
+//     holds 64 contiguous bytes of its row per 64-deep K step; the k order inside a K step is permuted identically on the B side)
+//     through a ring of R = 4 / 8 K steps: 16-32 KB in flight per wave, 128-256 KB per CU, waves drift freely;
+//   * the MFMA takes B as its first operand, so a lane holds 4 consecutive columns of one C row per accumulator quad: the wave
+//     transposes through its private LDS band with 8-byte writes / 16-byte reads and stores whole row segments;
+//   * JOIN operands (skip gradient + ReLU mask bits of the tile) are requested when the tile starts, not in the epilogue.
+// Block b runs on XCD b % 8: the column tiles of one row range are consecutive blocks OF ONE XCD, so A comes from HBM once per
+// row range and from that XCD's L2 for the other column tiles.
+template <int NK, int TN, int R, bool JOIN>
+__global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16* __restrict__ A, long long lda, const u16* __restrict__ B,
+                                                                       long long ldb, int M, int N, u16* __restrict__ C, long long ldc,
+                                                                       const u16* __restrict__ addp,
+                                                                       const unsigned char* __restrict__ maskp, int ntc) {
+    constexpr int BN = 32 * TN;
+    constexpr int NB = NK >= 16 ? 1 : TN;               // 32-column tiles per epilogue pass (LDS budget)
+    constexpr int PITCH = NB * 64 + 16;                 // bytes per band row
+    constexpr int CPR = NB * 4;                         // 16-byte pieces per band row
+    constexpr int RPI = 64 / CPR;                       // rows per read instruction
+    constexpr int NRI = 32 / RPI;                       // read instructions per pass
+    constexpr int U = NK > R ? NK : R;                  // units per trip of the main loop (slot and K step of a unit are static)
+    constexpr int NJ = JOIN ? TN * 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const sb = reinterpret_cast<char*>(lds);      // B image: NK stages of [BN rows][128 bytes], 16-byte slots XOR-swizzled
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const band = sb + NK * BN * 128 + wid * (32 * PITCH);
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int ct = jb % ntc, grp = jb / ntc, gpx = 32 / ntc;
+    const int col0 = ct * BN;
+    {
+        constexpr int NG = NK * BN / 8;                 // 8-row groups (1 KB each)
+        for (int g = wid; g < NG; g += 8) {
+            const int s = g / (BN / 8), rr = (g % (BN / 8)) * 8 + (lane >> 3);
+            const int q = (lane & 7) ^ ((rr >> 1) & 7);
+            int rg = col0 + rr;
+            rg = rg < N ? rg : N - 1;
+            const u16* src = B + (long long)rg * ldb + s * 64 + q * 8;
+            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(sb + g * 1024), 16, 0, 0);
+        }
+    }
+    __syncthreads();
+    const int T32 = (M + 31) >> 5;
+    const int NR = 8 * gpx, rid = xcd * gpx + grp;
+    const int t_lo = (int)((long long)rid * T32 / NR), t_hi = (int)((long long)(rid + 1) * T32 / NR);
+    const int n_my = (t_hi - t_lo - wid + 7) >> 3;     // 32-row tiles of this wave: t_lo + wid + 8 i
+    if (n_my <= 0) return;
+    const int r = lane & 31, h = lane >> 5;
+    const int total = n_my * NK;
+
+    f32x4 ar[R][4];
+    auto load_unit = [&](f32x4 (&dst)[4], int tt, int s) {
+        tt = tt < n_my ? tt : n_my - 1;
+        int row = (t_lo + wid + 8 * tt) * 32 + r;
+        row = row < M ? row : M - 1;
+        const u16* p = A + (long long)row * lda + s * 64 + h * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4*>(p + 8 * j);
+    };
+#pragma unroll
+    for (int i = 0; i < R; ++i) load_unit(ar[i], i / NK, i % NK);
+
+    f32x16 acc[TN];
+    f32x4 jadd[NJ];
+    unsigned jm[NJ];
+    // B fragment of 32-column tile n, K step s, sub-step kk: lane (c = lane & 31, h) reads 16-byte piece 4 h + kk of row n 32 + c
+    const int bsw = (r >> 1) & 7;
+    const char* const brow = sb + r * 128;
+    for (int base = 0; base < total; base += U) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int slot = i % R, s = i % NK;
+            const int tt = base / NK + i / NK;
+            if (s == 0) {
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[n][q] = 0.f;
+                if (JOIN) {
+                    const int tc = tt < n_my ? tt : n_my - 1;
+                    const int row0 = (t_lo + wid + 8 * tc) * 32;
+#pragma unroll
+                    for (int bp = 0; bp < TN / NB; ++bp)
+#pragma unroll
+                        for (int q = 0; q < NRI; ++q) {
+                            int gi = row0 + q * RPI + lane / CPR;
+                            gi = gi < M ? gi : M - 1;
+                            const long long e = (long long)gi * ldc + col0 + bp * NB * 32 + (lane % CPR) * 8;
+                            jadd[bp * NRI + q] = *reinterpret_cast<const f32x4*>(addp + e);
+                            jm[bp * NRI + q] = maskp[e >> 3];
+                        }
+                }
+            }
+            f32x4 fb[2][TN];
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                fb[0][n] = *reinterpret_cast<const f32x4*>(brow + s * (BN * 128) + n * 4096 + (((4 * h + 0) ^ bsw) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 3) {
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        fb[(kk + 1) & 1][n] =
+                            *reinterpret_cast<const f32x4*>(brow + s * (BN * 128) + n * 4096 + (((4 * h + kk + 1) ^ bsw) << 4));
+                }
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[kk & 1][n]),
+                                                                     __builtin_bit_cast(bf16x8, ar[slot][kk]), acc[n], 0, 0, 0);
+            }
+            load_unit(ar[slot], base / NK + (i + R) / NK, (i + R) % NK);
+            if (s == NK - 1 && tt < n_my) {
+                const int row0 = (t_lo + wid + 8 * tt) * 32;
+#pragma unroll
+                for (int bp = 0; bp < TN / NB; ++bp) {
+#pragma unroll
+                    for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& a = acc[bp * NB + nn];
+                            uint2 o;
+                            o.x = (unsigned)f2bf(a[4 * g + 0]) | ((unsigned)f2bf(a[4 * g + 1]) << 16);
+                            o.y = (unsigned)f2bf(a[4 * g + 2]) | ((unsigned)f2bf(a[4 * g + 3]) << 16);
+                            *reinterpret_cast<uint2*>(band + r * PITCH + (nn * 32 + 8 * g + 4 * h) * 2) = o;
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int q = 0; q < NRI; ++q) {
+                        const int rr = q * RPI + lane / CPR, c = lane % CPR;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(band + rr * PITCH + c * 16);
+                        const int gi = row0 + rr;
+                        if (gi < M) {
+                            const long long e = (long long)gi * ldc + col0 + bp * NB * 32 + c * 8;
+                            if (JOIN) v = join8(v, jadd[bp * NRI + q], jm[bp * NRI + q]);
+                            *reinterpret_cast<f32x4*>(C + e) = v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+    }
+}
+
+template <int NK, int TN, int R, bool JOIN>
+int launch_bres(const u16* A, long long lda, const u16* B, long long ldb, int M, int N, u16* C, long long ldc, const u16* addp,
+                const unsigned char* maskp, hipStream_t stream) {
+    constexpr int BN = 32 * TN, NB = NK >= 16 ? 1 : TN;
+    constexpr size_t LDS = (size_t)NK * BN * 128 + (size_t)8 * 32 * (NB * 64 + 16);
+    CFL_SET_LDS((cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, JOIN>), LDS);
+    CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, JOIN>), dim3(256), dim3(512), LDS, stream, A, lda, B, ldb, M, N, C, ldc,
+               addp, maskp, N / BN);
+    return 0;
+}
+
+// 0 when the B-resident kernel does not take the shape (the tile kernel does), else 1 after the launch
+template <bool JOIN>
+int try_bres(const u16* A, long long lda, const u16* B, long long ldb, int M, int N, int K, u16* C, long long ldc, const u16* addp,
+             const unsigned char* maskp, hipStream_t stream) {
+    static const bool off = getenv("CFL_GEMM_NO_BRES") != nullptr;
+    if (off || N % 64 != 0) return 0;
+    const bool wide = (N % 128 == 0) && K <= 256;
+    const int ntc = N / (wide ? 128 : 64);
+    if (ntc > 32 || (32 % ntc) != 0) return 0;
+    // ring depth: 8 K steps where the registers allow it (256 per wave at 8 waves per CU), else 4
+#define CFL_BRES(NK_, TN_)                                                                                                  \
+    launch_bres<NK_, TN_, (JOIN || (NK_ <= 2 && TN_ == 4) || (NK_ == 4 && TN_ == 2)) ? 4 : 8, JOIN>(A, lda, B, ldb, M, N, C, ldc, addp, \
+                                                                                                   maskp, stream)
+    int rc;
+    switch (K) {
+        case 64: rc = wide ? CFL_BRES(1, 4) : CFL_BRES(1, 2); break;
+        case 128: rc = wide ? CFL_BRES(2, 4) : CFL_BRES(2, 2); break;
+        case 256: rc = wide ? CFL_BRES(4, 4) : CFL_BRES(4, 2); break;
+        case 512: rc = CFL_BRES(8, 2); break;
+        case 1024: rc = CFL_BRES(16, 2); break;
+        default: return 0;
+    }
+    return rc < 0 ? rc : 1;
+#undef CFL_BRES
+}
+
+inline int& bres_min_m() {
+    static int v = getenv("CFL_GEMM_BRES_MIN_M") ? atoi(getenv("CFL_GEMM_BRES_MIN_M")) : 32768;
+    return v;
+}
+
 // dst[C][R] = src[R][C]^T for a small bf16 matrix (the 1x1 convolution weight [Co][Ci] -> [Ci][Co] that the data
 // gradient needs K-contiguous): 64x64 tiles through LDS, 2-byte elements, coalesced on both sides.
 __global__ __launch_bounds__(256) void cfl_transpose_bf16_kernel(const u16* __restrict__ src, int R, int C, u16* __restrict__ dst) {
@@ -400,6 +595,10 @@ extern "C" int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, lon
     Opnd Ao{(const float*)A, lda / 2, M, K / 2, 1};
     Opnd Bo{(const float*)B, ldb / 2, N, K / 2, 1};
     u16* Cc = (u16*)C;
+    if (variant == 90) {     // the B-resident kernel or a refusal (probes / tests; measured: no gain without the join operands)
+        const int rc = try_bres<false>((const u16*)A, lda, (const u16*)B, ldb, M, N, K, Cc, ldc, nullptr, nullptr, stream);
+        return rc < 0 ? rc : (rc == 0 ? CFL_ELIMIT : 0);
+    }
     if (variant == 0) variant = N >= 128 ? 22 : 21;
     switch (variant) {
         case 44: return launch_nt<4, 4, 1>(Ao, Bo, M, N, Cc, ldc, stream);
@@ -412,6 +611,12 @@ extern "C" int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, lon
     }
 }
 
+extern "C" int cfl_gemm_bf16_bres_min_m(int min_m) {
+    const int old = bres_min_m();
+    if (min_m >= 0) bres_min_m() = min_m;
+    return old;
+}
+
 extern "C" int cfl_gemm_bf16_nt_join(const void* A, long long lda, const void* B, long long ldb, void* C, const void* add,
                                      const unsigned char* mask, int M, int N, int K, void* stream_) {
     if (!A || !B || !C || !add || !mask || M <= 0 || N <= 0 || K <= 0) return CFL_EINVAL;
@@ -420,6 +625,10 @@ extern "C" int cfl_gemm_bf16_nt_join(const void* A, long long lda, const void* B
     hipStream_t stream = (hipStream_t)stream_;
     Opnd Ao{(const float*)A, lda / 2, M, K / 2, 1};
     Opnd Bo{(const float*)B, ldb / 2, N, K / 2, 1};
+    if (M >= bres_min_m() && K <= 256) {     // below: too few 32-row tiles per wave (8 waves x 256 workgroups) for the streaming kernel
+        const int rc = try_bres<true>((const u16*)A, lda, (const u16*)B, ldb, M, N, K, (u16*)C, N, (const u16*)add, mask, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (N >= 128) return launch_nt<2, 2, 2, true>(Ao, Bo, M, N, (u16*)C, N, stream, (const u16*)add, mask);
     return launch_nt<2, 1, 2, true>(Ao, Bo, M, N, (u16*)C, N, stream, (const u16*)add, mask);
 }

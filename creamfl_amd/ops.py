@@ -664,10 +664,14 @@ def bn_act_supported(x, num_features):
 # and the mask, and the apply pass writes g again as the residual gradient.  Fused: the GEMM epilogue reads B and the mask and
 # writes g; the BatchNorm backward reads g alone (no mask, no second gradient) and hands the same tensor on: -4 bytes per
 # element of every bn3 output with a direct skip connection (29 of ResNet-101's 33 blocks).  The pieces meet through
-# these registries, keyed by the address of z's buffer; they are only consulted inside TrainerEngine.backward
+# these registries, keyed by a TOKEN: a serial number bn_act_train gives every output while the registries are armed and
+# attaches to the two tensor objects it returns (`_cfl_tok`); the consuming convolution and the next block's BatchNorm read it
+# off the tensor OBJECT they are handed.  (Not the buffer address: a downsample branch's output dies inside the forward pass, the
+# allocator hands its address to a later block's output, and an address key then diverts the downsample gradient -- seen as
+# BatchNorm parameters without a gradient in some steps.)  The registries are only consulted inside TrainerEngine.backward
 # (prepare_ / release_weight_transposes bracket it and clear them), so client trainers and plain autograd are untouched.
 _NO_JOIN_FUSE = _os.environ.get('CFL_NO_JOIN_FUSE', '0') == '1'      # measurement switch
-JOIN = {'armed': False, 'on': False, 'mask': {}, 'consumer': set(), 'pending': {}, 'pre': set(), 'fused': 0}
+JOIN = {'armed': False, 'on': False, 'serial': 0, 'mask': {}, 'consumer': set(), 'pending': {}, 'pre': set(), 'fused': 0}
 
 
 def join_arm():
@@ -694,7 +698,7 @@ BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, '
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, tok=0, res_tok=0):
         lib = _lib.load()
         N, C, H, W = x.shape
         R = N * H * W
@@ -718,10 +722,10 @@ class _BNActFn(torch.autograd.Function):
                                   _stream(x)), 'cfl_bn_fwd')
         ctx.save_for_backward(x, mask if need_mask else x, weight, bias, mean, invstd)
         ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
-        ctx.y_ptr = y.data_ptr()
-        ctx.res_ptr = residual.data_ptr() if residual is not None else 0
-        if need_mask and JOIN['armed']:
-            JOIN['mask'][ctx.y_ptr] = mask               # the consumer GEMM of y applies it (see JOIN above)
+        ctx.tok = tok                                     # join tokens of the output / of the residual input (0 = none)
+        ctx.res_tok = res_tok if residual is not None else 0
+        if need_mask and JOIN['armed'] and tok:
+            JOIN['mask'][tok] = mask                     # the consumer GEMM of y applies it (see JOIN above)
         return y, _alias(y)
 
     @staticmethod
@@ -733,11 +737,11 @@ class _BNActFn(torch.autograd.Function):
         if dy is None:
             dy, dy2 = dy2, None
         if dy is None:
-            return (None,) * 9
+            return (None,) * 11
         # JOIN: the data-gradient GEMM of the consumer already produced g = (A + B) . mask for this layer's output
-        pre = JOIN['on'] and ctx.y_ptr in JOIN['pre']
+        pre = bool(JOIN['on'] and ctx.tok and ctx.tok in JOIN['pre'])
         if pre:
-            JOIN['pre'].discard(ctx.y_ptr)
+            JOIN['pre'].discard(ctx.tok)
             if dy2 is not None:
                 raise _lib.CreamflHipError('fused gradient join: a second gradient reached a pre-joined BatchNorm output')
         if ctx.has_res:
@@ -770,21 +774,30 @@ class _BNActFn(torch.autograd.Function):
             _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(None), _ptr(mask) if (ctx.relu and ctx.has_res) else _ptr(None),
                                       _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res),
                                       _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
-        if JOIN['on'] and ctx.has_res and ctx.res_ptr in JOIN['consumer'] and ctx.res_ptr in JOIN['mask']:
+        if JOIN['on'] and ctx.has_res and ctx.res_tok and ctx.res_tok in JOIN['consumer'] and ctx.res_tok in JOIN['mask']:
             # the skip connection's gradient goes to the data-gradient GEMM of this block's first convolution instead of to
             # autograd (None = no contribution): that GEMM adds it and masks the sum for the BatchNorm below
-            JOIN['pending'][ctx.res_ptr] = dres
+            JOIN['pending'][ctx.res_tok] = dres
             dres = None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None, two=False):
     """Training-mode BatchNorm2d (+ residual) (+ ReLU) on a channels_last bf16 activation (csrc/bnorm.hip).
     `two=True` returns the output as two tensor objects on one buffer: give one to the next convolution and the other
     to the next residual add, and their two gradients are summed inside the fused backward (no autograd add kernel)."""
+    res_tok = getattr(residual, '_cfl_tok', 0) if residual is not None else 0
     if residual is not None and not (residual.shape == x.shape and bn_act_supported(residual, x.shape[1])):
         residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu))
+        res_tok = 0
+    tok = 0
+    if JOIN['armed']:
+        JOIN['serial'] += 1
+        tok = JOIN['serial']
+    y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), tok, res_tok)
+    if tok:
+        y._cfl_tok = tok
+        y2._cfl_tok = tok
     return (y, y2) if two else y
 
 
@@ -994,8 +1007,10 @@ class _ConvSplitFn(torch.autograd.Function):
     def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, gemm_dgrad, side_wgrad)
-        if gemm_dgrad and ctx.needs_input_grad[0] and x.data_ptr() in JOIN['mask']:
-            JOIN['consumer'].add(x.data_ptr())           # this node's data gradient can take the gradient join of x (JOIN above)
+        tok = getattr(x, '_cfl_tok', 0)
+        ctx.x_tok = tok if (gemm_dgrad and ctx.needs_input_grad[0] and tok and tok in JOIN['mask']) else 0
+        if ctx.x_tok:
+            JOIN['consumer'].add(tok)                    # this node's data gradient can take the gradient join of x (JOIN above)
         return torch.nn.functional.conv2d(x, weight, None, stride, padding)
 
     @staticmethod
@@ -1049,12 +1064,12 @@ class _ConvSplitFn(torch.autograd.Function):
                 if wt is None:
                     wt = torch.empty(Ci, Co, dtype=torch.bfloat16, device=x.device)   # [Ci, Co]: reduction axis contiguous
                     _lib.check(_lib.load().cfl_transpose_bf16(_ptr(weight), Co, Ci, _ptr(wt), _stream(x)), 'cfl_transpose_bf16')
-                skip = JOIN['pending'].pop(x.data_ptr(), None) if JOIN['on'] else None
+                skip = JOIN['pending'].pop(ctx.x_tok, None) if (JOIN['on'] and ctx.x_tok) else None
                 if skip is not None:
                     # dX = (dY W + skip gradient) . ReLU mask of the BatchNorm that produced x: pre-joined for that layer
                     gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci),
-                                 add=skip, mask=JOIN['mask'][x.data_ptr()])
-                    JOIN['pre'].add(x.data_ptr())
+                                 add=skip, mask=JOIN['mask'][ctx.x_tok])
+                    JOIN['pre'].add(ctx.x_tok)
                     JOIN['fused'] += 1
                 else:
                     gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))

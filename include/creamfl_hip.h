@@ -211,7 +211,8 @@ int cfl_maxpool3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int
  * forward A = x[M,Ci], B = w[Co,Ci]; data gradient A = dy[M,Co], B = w^T[Ci,Co].  It ties MIOpen's forward and beats
  * its backward-data kernels on every ResNet-101 shape, so the product uses it for the DATA GRADIENT (ops.conv1x1).
  * lda/ldb/ldc in elements; K % 64 == 0, N % 8 == 0, lda % 8 == ldb % 8 == ldc % 8 == 0, 16-byte aligned pointers.
- * variant 0 = pick by shape; 21 / 22 / 41 / 42 / 44 select the wave tile (TM,TN) for benchmarking. */
+ * variant 0 = pick by shape; 21 / 22 / 41 / 42 / 44 select the wave tile (TM,TN) for benchmarking; 90 = the B-resident
+ * streaming kernel (K in {64, 128, 256, 512, 1024}, N % 64 == 0, N / tile width divides 32) or CFL_ELIMIT. */
 int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
                      int M, int N, int K, int variant, void* stream);
 /* The same GEMM with the gradient JOIN of a residual block in its epilogue (round 3): C = (A B^T + add) . mask, C / add dense
@@ -220,6 +221,10 @@ int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb,
  * backward of the layer below then reads one pre-masked gradient (cfl_bn_bwd with relu = 0, has_residual = 0). */
 int cfl_gemm_bf16_nt_join(const void* A, long long lda, const void* B, long long ldb, void* C, const void* add,
                           const unsigned char* mask, int M, int N, int K, void* stream);
+/* Measurement / test knob: the join entry runs the B-resident streaming kernel (weight tile resident in LDS, A rows streamed
+ * through registers) when M >= min_m and K <= 256, the tile kernel otherwise.  Default 32768 (CFL_GEMM_BRES_MIN_M overrides it;
+ * CFL_GEMM_NO_BRES=1 disables the streaming kernel).  Returns the previous value; min_m < 0 only queries. */
+int cfl_gemm_bf16_bres_min_m(int min_m);
 /* tn: C[N1,N2] = A[M,N1]^T * B[M,N2] (reduction along the slow axis M): the weight gradient dW[Co,Ci] = dy^T x of a 1x1
  * convolution.  C dense row-major, bf16 (c_bf16 = 1) or fp32; split-K over M with fp32 partials in ws
  * (cfl_gemm_bf16_tn_ws_bytes) and a fixed-order reduction.  N1 % 8 == N2 % 8 == 0, lda % 8 == ldb % 8 == 0. */

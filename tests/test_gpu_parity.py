@@ -610,6 +610,44 @@ def test_gemm_bf16_nt_matches_torch(dev, m, n, k, variant):
     assert err <= 2 ** -8 * scale + 1e-6, (err, scale)
 
 
+@pytest.mark.parametrize('m,n,k', [(256, 64, 64), (1000, 128, 256), (50176, 1024, 256), (50176, 256, 1024), (12544, 2048, 512),
+                                   (777, 256, 128), (33, 64, 1024), (4099, 512, 256), (100000, 256, 64), (3000, 128, 512)])
+@pytest.mark.parametrize('join', [False, True])
+def test_gemm_bf16_nt_b_resident(dev, m, n, k, join):
+    """The B-resident streaming kernel (variant 90 / the join entry): the weight tile stays in LDS, every wave streams its own
+    32-row tiles of A through registers.  Plain: vs an fp32 matmul of the same bf16 inputs at one bf16 rounding of the output.
+    Join (C = (A B^T + add) . mask): vs the same formula in fp32; masked-out elements must be exact zeros.  Ragged M, every
+    (K steps, tile width) instantiation, more row ranges than tiles (m = 33)."""
+    from creamfl_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=gen)).to(torch.bfloat16).to(dev)
+    b = (torch.randn(n, k, generator=gen) * 0.1).to(torch.bfloat16).to(dev)
+    c = torch.full((m, n), float('nan'), dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = a.float() @ b.float().t()
+    if not join:
+        _lib.check(lib.cfl_gemm_bf16_nt(a.data_ptr(), k, b.data_ptr(), k, c.data_ptr(), n, m, n, k, 90, st), 'cfl_gemm_bf16_nt')
+        scale = float(ref.abs().max())
+        assert float((c.float() - ref).abs().max()) <= 2 ** -8 * scale + 1e-6
+        return
+    add = torch.randn(m, n, generator=gen).to(torch.bfloat16).to(dev)
+    bits = (torch.rand(m * n, generator=gen) < 0.6).to(dev)
+    mask = (bits.view(-1, 8).to(torch.int32) * (2 ** torch.arange(8, device=dev, dtype=torch.int32))).sum(1).to(torch.uint8)
+    old = lib.cfl_gemm_bf16_bres_min_m(0)               # every M through the streaming kernel (the product switches at 32768)
+    try:
+        _lib.check(lib.cfl_gemm_bf16_nt_join(a.data_ptr(), k, b.data_ptr(), k, c.data_ptr(), add.data_ptr(), mask.data_ptr(), m, n,
+                                             k, st), 'cfl_gemm_bf16_nt_join')
+    finally:
+        lib.cfl_gemm_bf16_bres_min_m(old)
+    keep = bits.view(m, n)
+    # the kernel rounds the product to bf16, adds the skip gradient in fp32 and rounds again
+    want = (ref.to(torch.bfloat16).float() + add.float()) * keep
+    scale = float(want.abs().max())
+    assert float((c.float() - want).abs().max()) <= 2 ** -7 * scale + 1e-6
+    assert bool((c[~keep] == 0).all())
+
+
 @pytest.mark.parametrize('m,n1,n2', [(64, 64, 64), (1000, 128, 72), (50176, 1024, 256), (12544, 512, 2048), (777, 8, 264), (200, 136, 128)])
 def test_gemm_bf16_tn_matches_torch(dev, m, n1, n2):
     """cfl_gemm_bf16_tn (C = A^T B, reduction along the slow axis, split-K) vs an fp32 matmul of the same bf16 inputs:

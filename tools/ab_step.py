@@ -1,0 +1,71 @@
+"""Same-process A/B of the bench step: one engine, one batch, the two settings of a run-time knob alternating in rounds of timed
+steps (A B A B ...), so that box, clocks, MIOpen choices and allocator state are shared -- separate `bench.py` processes on the
+pool's boxes differ by several per cent from run to run, more than most of the effects worth measuring.
+
+    python tools/ab_step.py --knob bres [--rounds 4] [--steps 10]
+
+knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming kernel (default) vs the tile kernel
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--knob', default='bres')
+    ap.add_argument('--rounds', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=256)
+    args = ap.parse_args()
+    from creamfl_amd import _lib
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import coco_batch
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(1234)
+    cfg = default_config(embed_dim=512, cnn_type='resnet101', not_bert=False)
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    eng.model.train()
+    b = coco_batch(args.batch, dev, seed=1234, bert=True)
+    images = b[0].contiguous(memory_format=torch.channels_last)
+
+    def set_knob(on):
+        if args.knob == 'bres':
+            lib.cfl_gemm_bf16_bres_min_m(32768 if on else (1 << 30))
+        else:
+            raise SystemExit('unknown knob')
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.train_step(images, b[1], b[2], b[3])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    run(8)
+    res = {'on': [], 'off': []}
+    for r in range(args.rounds):
+        for on in ((True, False) if r % 2 == 0 else (False, True)):
+            set_knob(on)
+            run(2)
+            res['on' if on else 'off'].append(round(run(args.steps), 3))
+    set_knob(True)
+    mean = {k: round(sum(v) / len(v), 3) for k, v in res.items()}
+    print(json.dumps({'knob': args.knob, 'ms_per_step': res, 'mean': mean, 'on_minus_off_ms': round(mean['on'] - mean['off'], 3)}))
+
+
+if __name__ == '__main__':
+    main()
