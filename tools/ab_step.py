@@ -5,6 +5,7 @@ pool's boxes differ by several per cent from run to run, more than most of the e
     python tools/ab_step.py --knob bres [--rounds 4] [--steps 10]
 
 knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming kernel (default) vs the tile kernel
+        join   the gradient join of the residual blocks in the data-gradient GEMM's epilogue (default) vs in the BatchNorm backward
 """
 import argparse
 import json
@@ -44,6 +45,9 @@ def main():
     def set_knob(on):
         if args.knob == 'bres':
             lib.cfl_gemm_bf16_bres_min_m(32768 if on else (1 << 30))
+        elif args.knob == 'join':
+            from creamfl_amd import ops
+            ops._NO_JOIN_FUSE = not on
         else:
             raise SystemExit('unknown knob')
 

@@ -3,6 +3,8 @@
 #   <tag>_bench_line.json            python bench.py --steps 20 --warmup 5 (the driver's command line)
 #   <tag>_bench_nojoin_line.json     the same with CFL_NO_JOIN_FUSE=1 (same-box A/B of the fused gradient join)
 #   <tag>_bench_gloo2_line.json      python bench.py --gpus 2 --backend gloo (self-launched ranks; smoke mode of the N > 1 path)
+#   <tag>_ab_join.json, <tag>_ab_bres.json   same-process A/B (tools/ab_step.py) of the gradient-join fusion / the B-resident GEMM
+#   <tag>_step_jitter.json           per-step wall times of 80 consecutive steps (tools/step_jitter.py)
 #   <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace of a short bench run, timed steps only (tools/trace_stats.py)
 #   <tag>_pmc_bench_traffic.json     HBM traffic per hand-written kernel of the bench step (separate --pmc passes, launches_per_step)
 #   <tag>_kernel_bench.jsonl         tools/kernel_bench.py at the SURVEY 8(d) shapes
@@ -19,8 +21,10 @@ cd $ROOT
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 CFL_NO_JOIN_FUSE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-recall --no-alone > $OUT/${TAG}_bench_nojoin_line.json 2>> $OUT/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-recall --no-alone > $OUT/${TAG}_bench_line_again.json 2>> $OUT/bench.err
-python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-recall > $OUT/${TAG}_bench_gloo2_line.json 2> $OUT/gloo2.err
-python tools/kernel_bench.py --cases a1,a3,a5,a2,a6,f4,pool,gemm16,opt > $OUT/${TAG}_kernel_bench.jsonl 2> $OUT/kb.err
+python tools/ab_step.py --knob join --rounds 6 > $OUT/${TAG}_ab_join.json 2>> $OUT/bench.err
+python tools/ab_step.py --knob bres --rounds 6 > $OUT/${TAG}_ab_bres.json 2>> $OUT/bench.err
+python tools/step_jitter.py 80 2>> $OUT/bench.err | tail -1 > $OUT/${TAG}_step_jitter.json
+python tools/kernel_bench.py --cases a1,a3,a5,a2,a6,f4,pool,gemm16,dgrad16,opt > $OUT/${TAG}_kernel_bench.jsonl 2> $OUT/kb.err
 python tools/config4_bench.py > $OUT/${TAG}_config4_line.json 2> $OUT/c4.err
 PMC_STEPS=3 bash tools/pmc_run.sh bench python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall --no-alone --no-mfu --no-prewarm > /dev/null 2>&1
 cp $ROOT/gpurun_out/pmc_bench/summary.json $OUT/${TAG}_pmc_bench_traffic.json
@@ -63,4 +67,7 @@ for r in rows:
     w.writerow([r['Name'][:110], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']])
 PY
 rm -rf $OUT/trace_a3 $OUT/trace_bench $OUT/trace_c4
+# last, bounded twice (its own watchdog + timeout): the self-launched 2-rank smoke run of the multi-GPU path on this one GPU
+cd $ROOT
+timeout 420 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-recall --watchdog 240 > $OUT/${TAG}_bench_gloo2_line.json 2> $OUT/gloo2.err
 ls -la $OUT
