@@ -975,6 +975,7 @@ def conv1x1_supported(x, weight):
 
 
 _JOIN_QUEUED_FOR = [-1]
+DGRAD_PLAIN_LIB = [0]        # > 0: un-joined 1x1 data gradients with Co >= this run on the library (measurement knob)
 _NO_STEM_S2D = _os.environ.get('CFL_NO_STEM_S2D', '0') == '1'        # measurement switch: the stem as the library sees it
 _NO_FWD_DGRAD = _os.environ.get('CFL_NO_FWD_DGRAD', '0') == '1'      # measurement switch: MIOpen backward-data for k x k
 
@@ -1071,6 +1072,10 @@ class _ConvSplitFn(torch.autograd.Function):
                                  add=skip, mask=JOIN['mask'][ctx.x_tok])
                     JOIN['pre'].add(ctx.x_tok)
                     JOIN['fused'] += 1
+                elif DGRAD_PLAIN_LIB[0] and Co >= DGRAD_PLAIN_LIB[0]:
+                    # measurement knob (tools/ab_step.py --knob dgradlib): the un-joined data gradient as the library's FORWARD
+                    # 1x1 convolution on the prepared W^T
+                    dx = torch.nn.functional.conv2d(dy, wt.view(Ci, Co, 1, 1))
                 else:
                     gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
             elif (stride == 1 and padding == weight.shape[2] // 2 and weight.dtype == torch.bfloat16 and _rot_ok(weight)

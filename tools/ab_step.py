@@ -45,6 +45,9 @@ def main():
     def set_knob(on):
         if args.knob == 'bres':
             lib.cfl_gemm_bf16_bres_min_m(32768 if on else (1 << 30))
+        elif args.knob.startswith('dgradlib'):
+            from creamfl_amd import ops
+            ops.DGRAD_PLAIN_LIB[0] = int(args.knob[8:] or 64) if on else 0
         elif args.knob == 'join':
             from creamfl_amd import ops
             ops._NO_JOIN_FUSE = not on
