@@ -203,7 +203,8 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
     constexpr int CPR = NB * 4;                         // 16-byte pieces per band row
     constexpr int RPI = 64 / CPR;                       // rows per read instruction
     constexpr int NRI = 32 / RPI;                       // read instructions per pass
-    constexpr int U = NK > R ? NK : R;                  // units per trip of the main loop (slot and K step of a unit are static)
+    constexpr int U0 = NK > R ? NK : R;                 // units per trip of the main loop (slot and K step of a unit are static)
+    constexpr int U = (JOIN && U0 < 2 * NK) ? 2 * NK : U0;   // JOIN: an even number of tiles per trip (static operand buffer parity)
     constexpr int NJ = JOIN ? TN * 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* const sb = reinterpret_cast<char*>(lds);      // B image: NK stages of [BN rows][128 bytes], 16-byte slots XOR-swizzled
@@ -245,8 +246,25 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
     for (int i = 0; i < R; ++i) load_unit(ar[i], i / NK, i % NK);
 
     f32x16 acc[TN];
-    f32x4 jadd[NJ];
-    unsigned jm[NJ];
+    // JOIN operands (skip gradient, mask bytes) of a tile in the read-back layout of the epilogue, double-buffered: requested one
+    // whole tile ahead, so that the epilogue never waits for them
+    f32x4 jadd[2][NJ];
+    unsigned jm[2][NJ];
+    auto load_join = [&](f32x4 (&ja)[NJ], unsigned (&jb)[NJ], int tt) {
+        const int tc = tt < n_my ? tt : n_my - 1;
+        const int row0 = (t_lo + wid + 8 * tc) * 32;
+#pragma unroll
+        for (int bp = 0; bp < TN / NB; ++bp)
+#pragma unroll
+            for (int q = 0; q < NRI; ++q) {
+                int gi = row0 + q * RPI + lane / CPR;
+                gi = gi < M ? gi : M - 1;
+                const long long e = (long long)gi * ldc + col0 + bp * NB * 32 + (lane % CPR) * 8;
+                ja[bp * NRI + q] = *reinterpret_cast<const f32x4*>(addp + e);
+                jb[bp * NRI + q] = maskp[e >> 3];
+            }
+    };
+    if (JOIN) load_join(jadd[0], jm[0], 0);
     // B fragment of 32-column tile n, K step s, sub-step kk: lane (c = lane & 31, h) reads 16-byte piece 4 h + kk of row n 32 + c
     const int bsw = (r >> 1) & 7;
     const char* const brow = sb + r * 128;
@@ -260,20 +278,7 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
                 for (int n = 0; n < TN; ++n)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[n][q] = 0.f;
-                if (JOIN) {
-                    const int tc = tt < n_my ? tt : n_my - 1;
-                    const int row0 = (t_lo + wid + 8 * tc) * 32;
-#pragma unroll
-                    for (int bp = 0; bp < TN / NB; ++bp)
-#pragma unroll
-                        for (int q = 0; q < NRI; ++q) {
-                            int gi = row0 + q * RPI + lane / CPR;
-                            gi = gi < M ? gi : M - 1;
-                            const long long e = (long long)gi * ldc + col0 + bp * NB * 32 + (lane % CPR) * 8;
-                            jadd[bp * NRI + q] = *reinterpret_cast<const f32x4*>(addp + e);
-                            jm[bp * NRI + q] = maskp[e >> 3];
-                        }
-                }
+                if (JOIN) load_join(jadd[((i / NK) + 1) & 1], jm[((i / NK) + 1) & 1], tt + 1);
             }
             f32x4 fb[2][TN];
 #pragma unroll
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
                         const int gi = row0 + rr;
                         if (gi < M) {
                             const long long e = (long long)gi * ldc + col0 + bp * NB * 32 + c * 8;
-                            if (JOIN) v = join8(v, jadd[bp * NRI + q], jm[bp * NRI + q]);
+                            if (JOIN) v = join8(v, jadd[(i / NK) & 1][bp * NRI + q], jm[(i / NK) & 1][bp * NRI + q]);
                             *reinterpret_cast<f32x4*>(C + e) = v;
                         }
                     }
@@ -352,8 +357,8 @@ int try_bres(const u16* A, long long lda, const u16* B, long long ldb, int M, in
     if (ntc > 32 || (32 % ntc) != 0) return 0;
     // ring depth: 8 K steps where the registers allow it (256 per wave at 8 waves per CU), else 4
 #define CFL_BRES(NK_, TN_)                                                                                                  \
-    launch_bres<NK_, TN_, (JOIN || (NK_ <= 2 && TN_ == 4) || (NK_ == 4 && TN_ == 2)) ? 4 : 8, JOIN>(A, lda, B, ldb, M, N, C, ldc, addp, \
-                                                                                                   maskp, stream)
+    launch_bres<NK_, TN_, (JOIN && NK_ == 2 && TN_ == 4) ? 2 : (JOIN || (NK_ <= 2 && TN_ == 4) || (NK_ == 4 && TN_ == 2)) ? 4 : 8, JOIN>( \
+        A, lda, B, ldb, M, N, C, ldc, addp, maskp, stream)
     int rc;
     switch (K) {
         case 64: rc = wide ? CFL_BRES(1, 4) : CFL_BRES(1, 2); break;
