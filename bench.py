@@ -152,6 +152,10 @@ def coco_1k_recall(dim, dev, seed=4321, noise=6.0):
             'normalize(image + %.1f * unit noise)' % (dim, noise), 'ranks_equal_cpu_oracle_fold0': exact}
 
 
+# profiler id (runtime.hip) -> kernel names the offline PMC summary aggregates under (tools/pmc_summary.py)
+PMC_ALIASES = {'cfl_gemm_bf16_kernel': ('cfl_gemm_bf16_nt_kernel', 'cfl_gemm_bf16_nt_bres_kernel')}
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -223,13 +227,16 @@ def prewarm(args, local_rank):
     MIOpen compiles its kernels and records its solver choices while that process runs, and the process keeps the choices it
     made before the compiled kernels existed.  That one-off library set-up is not the step this bench measures, so it is done
     here, once per box and shape, in a CHILD process (3 untimed steps, no JSON) before the measured process builds its model.
-    A marker file next to the seeded find-db makes later invocations skip it; --no-prewarm disables it."""
+    A marker file in the temp directory makes later invocations skip it; --no-prewarm disables it."""
     import subprocess
     import tempfile
     if args.no_prewarm or args.prewarm_child or not torch.cuda.is_available():
         return
-    mark = os.path.join(os.environ.get('MIOPEN_USER_DB_PATH', tempfile.gettempdir()),
-                        'prewarmed_%s_%d_%d_%s' % (args.cnn, args.batch, args.dim, args.dtype))
+    # ONE marker per node, whatever launched the ranks (the find-db directory is per LOCAL_RANK when a launcher set that
+    # variable before this script was imported: a marker in there would be invisible to the other ranks)
+    mark_dir = os.path.join(tempfile.gettempdir(), 'creamfl_prewarm_%d' % os.getuid())
+    os.makedirs(mark_dir, exist_ok=True)
+    mark = os.path.join(mark_dir, 'prewarmed_%s_%d_%d_%s' % (args.cnn, args.batch, args.dim, args.dtype))
     if os.path.exists(mark):
         return
     if local_rank != 0:
@@ -243,6 +250,8 @@ def prewarm(args, local_rank):
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'GROUP_RANK', 'ROLE_RANK',
               'LOCAL_WORLD_SIZE', 'ROLE_WORLD_SIZE'):
         env.pop(k, None)
+    if os.path.exists(mark + '.failed'):
+        os.remove(mark + '.failed')                    # a new attempt: the other ranks wait for its outcome
     vis = [v for v in env.get('HIP_VISIBLE_DEVICES', '').split(',') if v != '']
     env['HIP_VISIBLE_DEVICES'] = vis[0] if vis else '0'
     cmd = [sys.executable, os.path.abspath(__file__), '--prewarm-child', '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch',
@@ -447,6 +456,14 @@ def main():
                 except (OSError, ValueError):
                     continue
                 ent = pmc.get(roof['kernel'])
+                if not ent:
+                    # one profiler id can cover several kernel templates (the data-gradient GEMMs: tile kernel + B-resident
+                    # kernel): combine the profile's per-template aggregates, launch-weighted
+                    parts = [pmc[k] for k in PMC_ALIASES.get(roof['kernel'], ()) if k in pmc and pmc[k].get('launches_per_step')]
+                    if parts:
+                        n_all = sum(p['launches_per_step'] for p in parts)
+                        ent = {'launches_per_step': n_all,
+                               'traffic_bytes': int(sum(p['traffic_bytes'] * p['launches_per_step'] for p in parts) / n_all)}
                 if not ent:
                     continue
                 lps = ent.get('launches_per_step')

@@ -57,21 +57,34 @@ def test_free_port_is_bindable():
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_runs_two_ranks_end_to_end(tmp_path):
-    """`python bench.py --gpus 2 --backend gloo` as the driver would type it (no launcher environment): the script starts its
-    two ranks itself, they build the data-parallel step (process group, gradient-aware gather, GradBuckets, optimizer state
-    broadcast), run it, and rank 0 prints ONE line with n_gpus = 2.  Small encoders so that it takes a minute; both ranks
-    share the one GPU of the box, so this is the SMOKE mode of the path, not a scaling number."""
+@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+def test_bench_gpus_2_runs_two_ranks_end_to_end(launcher, tmp_path):
+    """`python bench.py --gpus 2 --backend gloo` as the driver would type it -- 'self': no launcher environment, the script
+    starts its two ranks itself; 'torchrun': the driver's documented N > 1 command line (`python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`), with the library pre-warm ON
+    (one child per node, the other rank waits for its marker: a per-rank marker would stall it for minutes).  The ranks build the
+    data-parallel step (process group, gradient-aware gather, GradBuckets, optimizer state broadcast), run it, and rank 0
+    prints ONE line with n_gpus = 2.  Small encoders so that it takes a minute; both ranks share the one GPU of the box, so
+    this is the SMOKE mode of the path, not a scaling number."""
     import json
     import subprocess
+    import time
     import torch
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
-           '--cnn', 'resnet50', '--batch', '16', '--no-cpu-baseline', '--no-recall', '--no-prewarm', '--no-alone', '--no-mfu',
-           '--watchdog', '240']
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    env['TMPDIR'] = str(tmp_path)                          # a fresh marker / find-db location: the pre-warm really runs
+    env.pop('MIOPEN_USER_DB_PATH', None)
+    args = ['--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--cnn', 'resnet50', '--batch', '16',
+            '--no-cpu-baseline', '--no-recall', '--no-alone', '--no-mfu', '--watchdog', '300']
+    script = os.path.join(ROOT, 'bench.py')
+    if launcher == 'self':
+        cmd = [sys.executable, script] + args + ['--no-prewarm']
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(bench.free_port()), script] + args
+    t0 = time.time()
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
     assert len(lines) == 1, res.stdout.decode()[-2000:]
@@ -79,3 +92,4 @@ def test_bench_gpus_2_runs_two_ranks_end_to_end(tmp_path):
     assert out['n_gpus'] == 2 and out['ranks']['world_size'] == 2 and out['ranks']['rccl_ranks'] == 0
     assert out['config']['global_batch'] == 32 and out['value'] > 0
     assert out['config']['loss'] == out['config']['loss']            # not NaN
+    assert time.time() - t0 < 330                                     # nobody sat out a marker time-out
