@@ -43,7 +43,7 @@ def _seed_miopen_user_db():
     import shutil
     import tempfile
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'creamfl_amd', 'miopen_db')
-    if 'MIOPEN_USER_DB_PATH' in os.environ or not os.path.isdir(src):
+    if ('MIOPEN_USER_DB_PATH' in os.environ and not os.environ.get('CFL_BENCH_SEEDED_DB')) or not os.path.isdir(src):
         return
     dst = os.path.join(tempfile.gettempdir(), 'creamfl_miopen_db_%d' % os.getuid(), str(os.environ.get('LOCAL_RANK', '0')))
     os.makedirs(dst, exist_ok=True)
@@ -51,6 +51,7 @@ def _seed_miopen_user_db():
         if not os.path.exists(os.path.join(dst, f)):
             shutil.copy(os.path.join(src, f), dst)
     os.environ['MIOPEN_USER_DB_PATH'] = dst
+    os.environ['CFL_BENCH_SEEDED_DB'] = '1'              # ours, not the caller's: ranks we launch seed their own directory
 
 
 _seed_miopen_user_db()
@@ -274,6 +275,8 @@ def main():
         env = dict(os.environ)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes needs it on this driver)
         env.setdefault('OMP_NUM_THREADS', '4')
+        if env.pop('CFL_BENCH_SEEDED_DB', None):
+            env.pop('MIOPEN_USER_DB_PATH', None)         # one find-db directory per LOCAL_RANK (no two processes on one text db)
         raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
     wd = args.watchdog if args.watchdog >= 0 else (900 if world > 1 else 0)
     if wd > 0:

@@ -744,8 +744,13 @@ class _BNActFn(torch.autograd.Function):
             JOIN['pre'].discard(ctx.tok)
             if dy2 is not None:
                 raise _lib.CreamflHipError('fused gradient join: a second gradient reached a pre-joined BatchNorm output')
-        if ctx.has_res:
-            from . import streams
+        from . import streams
+        if streams.FLUSH_POLICY[0] == 2:
+            streams.flush(x.device, 1)
+        elif streams.FLUSH_POLICY[0] >= 3:
+            if ctx.has_res and len(streams._PENDING) >= streams.FLUSH_POLICY[0]:
+                streams.flush(x.device)
+        elif ctx.has_res or streams.FLUSH_POLICY[0] == 1:
             streams.flush(x.device)          # a long HBM-bound phase starts: let the queued weight gradients run beside it
         BN_COUNTERS['bwd'] += R * C
         if ctx.relu and ctx.has_res and not pre:

@@ -57,15 +57,22 @@ def defer(task):
     _PENDING.append(task)
 
 
-def flush(device):
-    """Launch every queued weight gradient on the 'wgrad' stream, after everything queued so far on the current one."""
+FLUSH_POLICY = [0]           # measurement knob (tools/ab_step.py): 0 = everything at a residual BatchNorm backward (default);
+#                              1 = everything at EVERY BatchNorm backward; 2 = one queued task per BatchNorm backward;
+#                              n >= 3 = at a residual BatchNorm backward once n tasks are queued
+
+
+def flush(device, limit=None):
+    """Launch the queued weight gradients (all, or the `limit` oldest) on the 'wgrad' stream, after everything queued so far
+    on the current one."""
     if not _PENDING:
         return
     main = torch.cuda.current_stream(device)
     side = get(device, 'wgrad')
     side.wait_stream(main)
-    tasks = list(_PENDING)
-    del _PENDING[:]
+    n = len(_PENDING) if limit is None else min(limit, len(_PENDING))
+    tasks = list(_PENDING[:n])
+    del _PENDING[:n]
     with torch.cuda.stream(side):
         for t in tasks:
             t(main, side)

@@ -52,6 +52,10 @@ def main():
             from creamfl_amd import ops
             torch.cuda.synchronize()
             ops.WGRAD_TN[0] = 1 if on else 0
+        elif args.knob.startswith('flush'):
+            from creamfl_amd import streams
+            torch.cuda.synchronize()
+            streams.FLUSH_POLICY[0] = int(args.knob[5:]) if on else 0
         elif args.knob == 'join':
             from creamfl_amd import ops
             ops._NO_JOIN_FUSE = not on
