@@ -347,3 +347,45 @@ def test_training_overfits_a_fixed_batch(dev):
     # the fp32 masters and their bf16 shadows stay in sync
     p = eng.model.img_enc.cnn.layer1[0].conv1.weight
     assert torch.equal(p.detach(), eng.optimizer.state[p]['master'].to(torch.bfloat16))
+
+
+def test_every_parameter_steps_every_step(dev):
+    """Regression guard at the engine level (round 3): with the first, address-keyed version of the fused gradient join a
+    downsample branch lost its gradient in about one step in nine -- visible as parameters whose `grad` was None at the
+    optimizer step (their AdamP step count lags) and as an optimizer that keeps rebuilding its launch plan.  Twenty bf16 steps
+    of a bottleneck trunk in one allocator state: the set of parameters that step never changes, all step counts are equal,
+    and the optimizer builds its plan exactly once."""
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from creamfl_amd.utils.synthetic import coco_batch
+    torch.manual_seed(5)
+    cfg = _small_cfg(cnn='resnet50')
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    eng.model.train()
+    b = coco_batch(8, dev, seed=3, bert=True, img=64)
+    builds = [0]
+    orig = AdamP._upload_meta
+    keys = set()
+    orig_plan = AdamP._plan
+
+    def counting_plan(self, gi, params, clip_ids):
+        plan = orig_plan(self, gi, params, clip_ids)
+        keys.add((gi, plan['key']))
+        return plan
+    AdamP._plan = counting_plan
+    try:
+        nsteps = 20
+        for _ in range(nsteps):
+            eng.train_step(b[0], b[1], None, b[3])
+        torch.cuda.synchronize()
+    finally:
+        AdamP._plan = orig_plan
+    assert len(keys) == len(eng.optimizer.param_groups), 'the optimizer saw %d different parameter sets' % len(keys)
+    steps = {n: eng.optimizer.state[p]['step'] for n, p in eng.model.named_parameters() if p in eng.optimizer.state}
+    lag = {n: s for n, s in steps.items() if s != nsteps}
+    assert not lag, sorted(lag.items())[:6]
+    assert any('downsample' in n for n in steps), 'the trunk under test has no downsample branch'
+    del builds, orig
