@@ -72,11 +72,13 @@ def main():
         cstep()
     torch.cuda.synchronize()
     cus = (time.perf_counter() - t0) / 50 * 1e6
+    from creamfl_amd import ops as _ops
+    builds = _ops.BANK_IMAGE_BUILDS[0]
     n_params = sum(p.numel() for p in eng.model.parameters())
     print(json.dumps({'config': 'BASELINE configs[4]: ViT-B/16 + BERT-large, d=768, batch %d, bf16 trunks' % args.batch,
                       'server_step_ms': round(ms, 2), 'pairs_per_s': round(args.batch / ms * 1e3, 1),
                       'loss': round(float(loss), 4), 'params_M': round(n_params / 1e6, 1),
-                      'client_contrast_step_us_wall': round(cus, 1)}))
+                      'client_contrast_step_us_wall': round(cus, 1), 'bank_image_builds': builds}))
 
 
 if __name__ == '__main__':
