@@ -407,7 +407,7 @@ def main():
             """(bound, algorithmic bytes or FLOP per launch) of a hand-written kernel over the launches just profiled"""
             bc = _ops.BN_COUNTERS
             bn_bytes = {
-                'cfl_bn_stats_kernel': 2 * bc['fwd'],
+                'cfl_bn_stats_kernel': 2 * (bc['fwd'] - bc['fwd_pre']),      # (statistics the producing GEMM's epilogue took over)
                 'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'] + bc['fwd_mask'] // 8,   # + the 1-bit ReLU mask
                 # bwd reduce: read dy (+ second upstream gradient), x and the ReLU mask bits (with a residual; otherwise
                 # the mask comes from x); bwd apply: the same reads, write dx (+ the residual gradient)

@@ -50,6 +50,8 @@ SIGNATURES = {
     'cfl_gemm_bf16_nt': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, _P]),
     'cfl_gemm_bf16_nt_join': (c_int, [_P, c_longlong, _P, c_longlong, _P, _P, _P, c_int, c_int, c_int, _P]),
     'cfl_gemm_bf16_bres_min_m': (c_int, [c_int]),
+    'cfl_gemm_bf16_nt_stats_nblk': (c_int, [c_int, c_int, c_int]),
+    'cfl_gemm_bf16_nt_stats': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_int, c_int, c_int, _P, _P]),
     'cfl_transpose_bf16': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_transpose_bf16_multi': (c_int, [_P, c_int, c_int, _P]),
     'cfl_gemm_bf16_tn_ws_bytes': (c_size_t, [c_longlong, c_int, c_int]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     'cfl_rank_count': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_bn_ws_bytes': (c_size_t, [c_longlong, c_int]),
     'cfl_bn_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
+    'cfl_bn_fwd_pre': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     'cfl_bn_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, _P]),
     'cfl_bn_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_pool_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),

@@ -397,6 +397,31 @@ int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const fl
     return 0;
 }
 
+// cfl_bn_fwd without its statistics pass: psum / psq [nblk, C] were written by the producer of x (the statistics epilogue of
+// cfl_gemm_bf16_nt_stats: per-column sum / sum of squares of the stored bf16 values, one partial row per wave).
+int cfl_bn_fwd_pre(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
+                   float* save_mean, float* save_invstd, unsigned char* relu_mask, const float* psum, const float* psq, int nblk,
+                   void* stream_) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !psum || !psq || nblk <= 0 || R <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Plan p = bn_plan(R, C);
+    const dim3 grid(p.nblk, p.gy);
+    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, nblk, C, R, eps,
+               momentum, save_mean, save_invstd, running_mean, running_var);
+    const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
+    if (residual && relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else if (residual)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else if (relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    return 0;
+}
+
 int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
                  const float* beta, long long R, int C, int relu, void* y, void* stream_) {
     unsigned char* relu_mask = nullptr;

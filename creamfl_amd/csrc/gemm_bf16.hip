@@ -192,11 +192,17 @@ int launch_nt(const Opnd& A, const Opnd& B, int M, int N, u16* C, long long ldc,
 //   * JOIN operands (skip gradient + ReLU mask bits of the tile) are requested when the tile starts, not in the epilogue.
 // Block b runs on XCD b % 8: the column tiles of one row range are consecutive blocks OF ONE XCD, so A comes from HBM once per
 // row range and from that XCD's L2 for the other column tiles.
-template <int NK, int TN, int R, bool JOIN>
+// STATS (forward of a 1x1 convolution that a training-mode BatchNorm follows): per-column sum and sum of squares of the STORED
+// bf16 outputs, accumulated by every wave over its own tiles (a lane reads back the same 8 columns of every tile: 16 running
+// sums), reduced over the wave at the end and written as ONE partial row per wave, pstat[0][prow][N] / pstat[1][prow][N] with
+// prow = 8 * row range + wave -- the layout cfl_bn_final_kernel reduces (nblk = 2048 / column tiles): the BatchNorm needs no
+// statistics pass of its own.
+template <int NK, int TN, int R, bool JOIN, bool STATS = false>
 __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16* __restrict__ A, long long lda, const u16* __restrict__ B,
                                                                        long long ldb, int M, int N, u16* __restrict__ C, long long ldc,
                                                                        const u16* __restrict__ addp,
-                                                                       const unsigned char* __restrict__ maskp, int ntc) {
+                                                                       const unsigned char* __restrict__ maskp, int ntc,
+                                                                       float* __restrict__ pstat = nullptr) {
     constexpr int BN = 32 * TN;
     constexpr int NB = NK >= 16 ? 1 : TN;               // 32-column tiles per epilogue pass (LDS budget)
     constexpr int PITCH = NB * 64 + 16;                 // bytes per band row
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
     constexpr int U0 = NK > R ? NK : R;                 // units per trip of the main loop (slot and K step of a unit are static)
     constexpr int U = (JOIN && U0 < 2 * NK) ? 2 * NK : U0;   // JOIN: an even number of tiles per trip (static operand buffer parity)
     constexpr int NJ = JOIN ? TN * 2 : 1;
+    static_assert(!STATS || NB == TN, "statistics epilogue: one band pass per tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* const sb = reinterpret_cast<char*>(lds);      // B image: NK stages of [BN rows][128 bytes], 16-byte slots XOR-swizzled
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,7 +236,17 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
     const int NR = 8 * gpx, rid = xcd * gpx + grp;
     const int t_lo = (int)((long long)rid * T32 / NR), t_hi = (int)((long long)(rid + 1) * T32 / NR);
     const int n_my = (t_hi - t_lo - wid + 7) >> 3;     // 32-row tiles of this wave: t_lo + wid + 8 i
-    if (n_my <= 0) return;
+    float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n_my <= 0) {
+        if (STATS && lane < CPR) {                       // a wave without tiles still owns a (zero) partial row
+            const long long nblk = 8ll * NR;
+            float* ps = pstat + ((long long)rid * 8 + wid) * N + col0 + lane * 8;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(ps) = z; *reinterpret_cast<f32x4*>(ps + 4) = z;
+            *reinterpret_cast<f32x4*>(ps + nblk * N) = z; *reinterpret_cast<f32x4*>(ps + nblk * N + 4) = z;
+        }
+        return;
+    }
     const int r = lane & 31, h = lane >> 5;
     const int total = n_my * NK;
 
@@ -324,6 +341,16 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
                             const long long e = (long long)gi * ldc + col0 + bp * NB * 32 + c * 8;
                             if (JOIN) v = join8(v, jadd[(i / NK) & 1][bp * NRI + q], jm[(i / NK) & 1][bp * NRI + q]);
                             *reinterpret_cast<f32x4*>(C + e) = v;
+                            if (STATS) {
+                                union { f32x4 qv; unsigned u[4]; } w;
+                                w.qv = v;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const float lo = __uint_as_float(w.u[k] << 16), hi = __uint_as_float(w.u[k] & 0xffff0000u);
+                                    ssum[2 * k] += lo; ssq[2 * k] = fmaf(lo, lo, ssq[2 * k]);
+                                    ssum[2 * k + 1] += hi; ssq[2 * k + 1] = fmaf(hi, hi, ssq[2 * k + 1]);
+                                }
+                            }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -333,6 +360,41 @@ __global__ __launch_bounds__(512, 1) void cfl_gemm_bf16_nt_bres_kernel(const u16
             }
         }
     }
+    if (STATS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) {
+                ssum[k] += __shfl_xor(ssum[k], o, 64);
+                ssq[k] += __shfl_xor(ssq[k], o, 64);
+            }
+        if (lane < CPR) {
+            const long long nblk = 8ll * NR;
+            float* ps = pstat + ((long long)rid * 8 + wid) * N + col0 + lane * 8;
+            const f32x4 a0 = {ssum[0], ssum[1], ssum[2], ssum[3]}, a1 = {ssum[4], ssum[5], ssum[6], ssum[7]};
+            const f32x4 b0 = {ssq[0], ssq[1], ssq[2], ssq[3]}, b1 = {ssq[4], ssq[5], ssq[6], ssq[7]};
+            *reinterpret_cast<f32x4*>(ps) = a0; *reinterpret_cast<f32x4*>(ps + 4) = a1;
+            *reinterpret_cast<f32x4*>(ps + nblk * N) = b0; *reinterpret_cast<f32x4*>(ps + nblk * N + 4) = b1;
+        }
+    }
+}
+
+template <int NK, int TN, int R>
+int launch_bres_stats(const u16* A, long long lda, const u16* B, long long ldb, int M, int N, u16* C, float* pstat, hipStream_t stream) {
+    constexpr int BN = 32 * TN;
+    constexpr size_t LDS = (size_t)NK * BN * 128 + (size_t)8 * 32 * (TN * 64 + 16);
+    CFL_SET_LDS((cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, false, true>), LDS);
+    CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, false, true>), dim3(256), dim3(512), LDS, stream, A, lda, B, ldb, M, N, C,
+               (long long)N, nullptr, nullptr, N / BN, pstat);
+    return 0;
+}
+
+// partial rows the statistics epilogue writes per column (0: shape not taken)
+inline int bres_stats_nblk(int M, int N, int K) {
+    if (M <= 0 || N % 128 != 0 || (K != 64 && K != 128 && K != 256)) return 0;
+    const int ntc = N / 128;
+    if (ntc > 32 || (32 % ntc) != 0) return 0;
+    return 2048 / ntc;
 }
 
 template <int NK, int TN, int R, bool JOIN>
@@ -613,6 +675,22 @@ extern "C" int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, lon
         case 21: return launch_nt<2, 1, 2>(Ao, Bo, M, N, Cc, ldc, stream);
         case 41: return launch_nt<4, 1, 2>(Ao, Bo, M, N, Cc, ldc, stream);
         default: return CFL_EINVAL;
+    }
+}
+
+extern "C" int cfl_gemm_bf16_nt_stats_nblk(int M, int N, int K) { return bres_stats_nblk(M, N, K); }
+
+extern "C" int cfl_gemm_bf16_nt_stats(const void* A, long long lda, const void* B, long long ldb, void* C, int M, int N, int K,
+                                      float* pstat, void* stream_) {
+    if (!A || !B || !C || !pstat || M <= 0 || N <= 0 || K <= 0) return CFL_EINVAL;
+    if (bres_stats_nblk(M, N, K) == 0 || lda % 8 != 0 || ldb % 8 != 0 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)pstat) & 15))
+        return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const u16 *a = (const u16*)A, *b = (const u16*)B;
+    switch (K) {
+        case 64: return launch_bres_stats<1, 4, 4>(a, lda, b, ldb, M, N, (u16*)C, pstat, stream);
+        case 128: return launch_bres_stats<2, 4, 2>(a, lda, b, ldb, M, N, (u16*)C, pstat, stream);      // deeper rings spill
+        default: return launch_bres_stats<4, 4, 4>(a, lda, b, ldb, M, N, (u16*)C, pstat, stream);
     }
 }
 

@@ -73,6 +73,8 @@ class TrunkConv(nn.Conv2d):
     AccumulateGrad does) rather than returned through autograd, so `torch.autograd.grad(..., conv.weight)` sees None;
     set CFL_NO_SIDE_WGRAD=1 for the plain behaviour."""
 
+    bn_follows = False      # set by the block that owns the module: a BatchNorm consumes the output (ops.conv_split)
+
     def __init__(self, cin, cout, k, stride=1, padding=0):
         super().__init__(cin, cout, k, stride, padding, bias=False)
 
@@ -83,7 +85,8 @@ class TrunkConv(nn.Conv2d):
             if self.in_channels == 3 and ops.stem_conv_supported(x, self.weight, self.stride[0], self.padding[0]):
                 return ops.stem_conv(x, self.weight, side_wgrad=not _NO_SIDE_WGRAD)      # 3-channel 7x7 stem: space-to-depth form
             if x.dtype == self.weight.dtype:
-                return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD)
+                return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD,
+                                      bn_follows=self.bn_follows and self.training)
         return super().forward(x)
 
 
@@ -141,9 +144,13 @@ class Bottleneck(nn.Module):
         self.conv2 = TrunkConv(planes, planes, 3, stride, 1)                 # stride on the 3x3 (torchvision v1.5)
         self.bn2 = BNAct(planes)
         self.conv3 = Conv1x1(planes, planes * 4)
+        self.conv3.bn_follows = True
         self.bn3 = BNAct(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        if isinstance(downsample, nn.Sequential) and len(downsample) == 2 and isinstance(downsample[0], TrunkConv) \
+                and isinstance(downsample[1], BNAct):
+            downsample[0].bn_follows = True
         self.stride = stride
 
     def forward(self, x):

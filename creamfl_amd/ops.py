@@ -693,12 +693,13 @@ def _join_reset(on):
 
 
 # element counters of the fused BN kernels (python ints; bench.py turns them into algorithmic bytes)
-BN_COUNTERS = {'fwd': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
+BN_COUNTERS = {'fwd': 0, 'fwd_pre': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
 
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, tok=0, res_tok=0):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, tok=0, res_tok=0, pstat=None,
+                pstat_nblk=0):
         lib = _lib.load()
         N, C, H, W = x.shape
         R = N * H * W
@@ -717,9 +718,16 @@ class _BNActFn(torch.autograd.Function):
         mask = torch.empty(R * C // 8, dtype=torch.uint8, device=x.device) if need_mask else None
         if need_mask:
             BN_COUNTERS['fwd_mask'] += R * C
-        _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                  R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(mask), _ptr(ws),
-                                  _stream(x)), 'cfl_bn_fwd')
+        if pstat is not None:        # the producing GEMM left the per-column partial sums: no statistics pass
+            BN_COUNTERS['fwd_pre'] += R * C
+            _lib.check(lib.cfl_bn_fwd_pre(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                          R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(mask),
+                                          ctypes.c_void_p(pstat.data_ptr()), ctypes.c_void_p(pstat.data_ptr() + 4 * pstat_nblk * C),
+                                          pstat_nblk, _stream(x)), 'cfl_bn_fwd_pre')
+        else:
+            _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                      R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(mask), _ptr(ws),
+                                      _stream(x)), 'cfl_bn_fwd')
         ctx.save_for_backward(x, mask if need_mask else x, weight, bias, mean, invstd)
         ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
         ctx.tok = tok                                     # join tokens of the output / of the residual input (0 = none)
@@ -737,7 +745,7 @@ class _BNActFn(torch.autograd.Function):
         if dy is None:
             dy, dy2 = dy2, None
         if dy is None:
-            return (None,) * 11
+            return (None,) * 13
         # JOIN: the data-gradient GEMM of the consumer already produced g = (A + B) . mask for this layer's output
         pre = bool(JOIN['on'] and ctx.tok and ctx.tok in JOIN['pre'])
         if pre:
@@ -784,7 +792,7 @@ class _BNActFn(torch.autograd.Function):
             # autograd (None = no contribution): that GEMM adds it and masks the sum for the BatchNorm below
             JOIN['pending'][ctx.res_tok] = dres
             dres = None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None, two=False):
@@ -799,7 +807,11 @@ def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu
     if JOIN['armed']:
         JOIN['serial'] += 1
         tok = JOIN['serial']
-    y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), tok, res_tok)
+    pre = getattr(x, '_cfl_bnstats', None)
+    if pre is not None and not (CONV_STATS[0] and pre[2] == x.shape[0] * x.shape[2] * x.shape[3] and pre[3] == x.shape[1]):
+        pre = None
+    y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), tok, res_tok,
+                           pre[0] if pre is not None else None, pre[1] if pre is not None else 0)
     if tok:
         y._cfl_tok = tok
         y2._cfl_tok = tok
@@ -1028,13 +1040,24 @@ class _ConvSplitFn(torch.autograd.Function):
         overlaps the HBM-bound BN / data-gradient kernels of the layers below (streams.py).  MIOpen computes it."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad):
+    def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad, stats_nblk=0):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, gemm_dgrad, side_wgrad)
         tok = getattr(x, '_cfl_tok', 0)
         ctx.x_tok = tok if (gemm_dgrad and ctx.needs_input_grad[0] and tok and tok in JOIN['mask']) else 0
         if ctx.x_tok:
             JOIN['consumer'].add(tok)                    # this node's data gradient can take the gradient join of x (JOIN above)
+        if stats_nblk:
+            # a training-mode BatchNorm follows: the forward GEMM on the B-resident streaming kernel with that layer's batch
+            # statistics in its epilogue (csrc/gemm_bf16.hip: cfl_gemm_bf16_nt_stats); conv_split hands the partials on
+            N, Ci, H, W = x.shape
+            Co = weight.shape[0]
+            y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            pstat = torch.empty(2 * stats_nblk * Co, dtype=torch.float32, device=x.device)
+            _lib.check(_lib.load().cfl_gemm_bf16_nt_stats(_ptr(x), Ci, _ptr(weight), Ci, _ptr(y), N * H * W, Co, Ci, _ptr(pstat),
+                                                          _stream(x)), 'cfl_gemm_bf16_nt_stats')
+            _LAST_STATS[0] = (pstat, stats_nblk, N * H * W, Co)
+            return y
         return torch.nn.functional.conv2d(x, weight, None, stride, padding)
 
     @staticmethod
@@ -1125,13 +1148,27 @@ class _ConvSplitFn(torch.autograd.Function):
                     dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
             else:
                 dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
-def conv_split(x, weight, stride=1, padding=0, side_wgrad=True):
-    """Trunk convolution with the split backward of _ConvSplitFn (x: channels_last HIP tensor; weight [Co, Ci, k, k])."""
+CONV_STATS = [_os.environ.get('CFL_NO_CONV_STATS', '0') != '1']     # switch (also flipped by tools/ab_step.py --knob convstats)
+CONV_STATS_MIN_M = 32768        # below: too few 32-row tiles per wave for the streaming kernel (as for the joined data gradient)
+_LAST_STATS = [None]
+
+
+def conv_split(x, weight, stride=1, padding=0, side_wgrad=True, bn_follows=False):
+    """Trunk convolution with the split backward of _ConvSplitFn (x: channels_last HIP tensor; weight [Co, Ci, k, k]).
+    bn_follows: a training-mode BatchNorm consumes the output -- where the shape allows, the forward runs on the hand-written
+    streaming GEMM with that BatchNorm's statistics in its epilogue, and the output tensor object carries the partial sums
+    (`_cfl_bnstats`) for bn_act_train to pick up (no statistics pass over the 4-planes-wide tensor)."""
     gemm = (weight.shape[2] == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0 and conv1x1_supported(x, weight))
-    return _ConvSplitFn.apply(x, weight, int(stride), int(padding), bool(gemm), bool(side_wgrad))
+    nblk = 0
+    if bn_follows and gemm and CONV_STATS[0] and x.shape[0] * x.shape[2] * x.shape[3] >= CONV_STATS_MIN_M:
+        nblk = int(_lib.load().cfl_gemm_bf16_nt_stats_nblk(x.shape[0] * x.shape[2] * x.shape[3], weight.shape[0], weight.shape[1]))
+    y = _ConvSplitFn.apply(x, weight, int(stride), int(padding), bool(gemm), bool(side_wgrad), nblk)
+    if nblk:
+        y._cfl_bnstats, _LAST_STATS[0] = _LAST_STATS[0], None
+    return y
 
 
 def conv1x1(x, weight):

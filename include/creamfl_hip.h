@@ -221,6 +221,18 @@ int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb,
  * backward of the layer below then reads one pre-masked gradient (cfl_bn_bwd with relu = 0, has_residual = 0). */
 int cfl_gemm_bf16_nt_join(const void* A, long long lda, const void* B, long long ldb, void* C, const void* add,
                           const unsigned char* mask, int M, int N, int K, void* stream);
+/* Forward of a 1x1 convolution that a training-mode BatchNorm follows (torchvision Bottleneck conv3 -> bn3,
+ * src/networks/models/image_encoder.py:27-36): C = A B^T on the B-resident streaming kernel with the BatchNorm's batch statistics in
+ * the epilogue -- pstat[0][nblk][N] / pstat[1][nblk][N] = per-column sum / sum of squares of the STORED bf16 outputs, one partial
+ * row per wave.  cfl_gemm_bf16_nt_stats_nblk = nblk for a shape (K in {64, 128, 256}, N % 128 == 0, N / 128 divides 32), 0 when
+ * the shape is not taken.  C dense [M, N]; pstat 2 * nblk * N floats, 16-byte aligned.  cfl_bn_fwd_pre is cfl_bn_fwd without its
+ * statistics pass. */
+int cfl_gemm_bf16_nt_stats_nblk(int M, int N, int K);
+int cfl_gemm_bf16_nt_stats(const void* A, long long lda, const void* B, long long ldb, void* C, int M, int N, int K, float* pstat,
+                           void* stream);
+int cfl_bn_fwd_pre(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, long long R, int C, float eps, float momentum, int relu, void* y, float* save_mean,
+                   float* save_invstd, unsigned char* relu_mask, const float* psum, const float* psq, int nblk, void* stream);
 /* Measurement / test knob: the join entry runs the B-resident streaming kernel (weight tile resident in LDS, A rows streamed
  * through registers) when M >= min_m and K <= 256, the tile kernel otherwise.  Default 32768 (CFL_GEMM_BRES_MIN_M overrides it;
  * CFL_GEMM_NO_BRES=1 disables the streaming kernel).  Returns the previous value; min_m < 0 only queries. */

@@ -436,3 +436,56 @@ def test_gradient_join_ignores_recycled_addresses(monkeypatch):
             scale = float(ref[k].abs().max())
             assert float((got[k] - ref[k]).abs().max()) <= 3e-2 * scale + 1e-6, (it, k)
     assert ops.JOIN['fused'] - fused0 == 12 * 3                      # blocks 1..3 take the join, the downsample block cannot
+
+
+@pytest.mark.parametrize('n,hw,ci,co', [(64, 28, 128, 512), (40, 31, 64, 256), (256, 14, 256, 1024), (48, 28, 256, 128)])
+def test_bn_statistics_from_the_conv_epilogue(n, hw, ci, co):
+    """Round 3: a 1x1 convolution that a training-mode BatchNorm follows runs its forward on the B-resident streaming GEMM with
+    the BatchNorm's batch statistics in the epilogue (cfl_gemm_bf16_nt_stats -> cfl_bn_fwd_pre): no statistics pass over the
+    output.  conv -> BN(+ReLU) forward and backward against the same modules with the fusion off (library convolution +
+    cfl_bn_fwd): output, running statistics, all gradients; ragged row count (40 x 31 x 31), every K instantiation, and a shape
+    the epilogue does not take (128 output channels: falls back silently)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    from creamfl_amd.networks.backbones import Conv1x1, BNAct
+    dev = torch.device('cuda:0')
+    torch.manual_seed(n + hw + ci)
+    conv = Conv1x1(ci, co).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last).train()
+    conv.bn_follows = True
+    bn = BNAct(co).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x0 = torch.randn(n, ci, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(n, co, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(fuse):
+        ops.CONV_STATS[0] = fuse
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        for p in list(conv.parameters()) + list(bn.parameters()):
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        pre0 = ops.BN_COUNTERS['fwd_pre']
+        y = bn(conv(x), relu=True)
+        took = ops.BN_COUNTERS['fwd_pre'] - pre0
+        (y.float() * g.float()).sum().backward()
+        torch.cuda.synchronize()
+        from creamfl_amd import streams
+        streams.flush(dev)
+        streams.join_into_current(dev)
+        torch.cuda.synchronize()
+        return (y.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.float(), conv.weight.grad.float().clone(),
+                bn.weight.grad.clone(), bn.bias.grad.clone(), took)
+    try:
+        ref = run(False)
+        got = run(True)
+    finally:
+        ops.CONV_STATS[0] = True
+    assert ref[7] == 0
+    assert (got[7] > 0) == (co % 128 == 0), got[7]
+    names = ['y', 'running_mean', 'running_var', 'dx', 'dw', 'dgamma', 'dbeta']
+    for k, (a, b) in enumerate(zip(got[:7], ref[:7])):
+        scale = float(b.abs().max())
+        tol = 2e-2 if names[k] in ('y', 'dx', 'dw') else 2e-3
+        assert float((a - b).abs().max()) <= tol * scale + 1e-6, (names[k], float((a - b).abs().max()), scale)

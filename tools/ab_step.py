@@ -56,6 +56,9 @@ def main():
             from creamfl_amd import streams
             torch.cuda.synchronize()
             streams.FLUSH_POLICY[0] = int(args.knob[5:]) if on else 0
+        elif args.knob == 'convstats':
+            from creamfl_amd import ops
+            ops.CONV_STATS[0] = bool(on)
         elif args.knob == 'join':
             from creamfl_amd import ops
             ops._NO_JOIN_FUSE = not on

@@ -347,6 +347,33 @@ def main():
                             (14, 256, 1024), (14, 1024, 256), (7, 512, 2048), (7, 2048, 512)]:
             vs = [v for v in (90, 44, 24, 42, 22, 21, 41) if not (v in (44, 42, 22) and Co < 128) and not (v == 24 and Co < 256)]
             out.append(case_gemm16(H, Ci, Co, vs))
+    if 'fwdstats16' in cases:
+        # forward 1x1 convolution + the statistics pass of the BatchNorm behind it: library convolution + cfl_bn_stats vs the
+        # B-resident GEMM with the statistics in its epilogue (cfl_gemm_bf16_nt_stats)
+        import torch.nn.functional as F
+        lib = _lib.load()
+        torch.backends.cudnn.benchmark = True
+        for (H, Ci, Co) in [(56, 64, 256), (28, 128, 512), (14, 256, 1024)]:
+            M = 256 * H * H
+            g = torch.Generator(device='cuda').manual_seed(5)
+            x = torch.randn(256, Ci, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            w = (torch.randn(Co, Ci, 1, 1, generator=g, device='cuda') * 0.05).to(torch.bfloat16)
+            y = torch.empty(256, Co, H, H, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            nblk = lib.cfl_gemm_bf16_nt_stats_nblk(M, Co, Ci)
+            ps = torch.empty(2 * nblk * Co, device='cuda', dtype=torch.float32)
+            st = torch.cuda.current_stream().cuda_stream
+            us_f, prof = timed(lambda: _lib.check(lib.cfl_gemm_bf16_nt_stats(x.data_ptr(), Ci, w.data_ptr(), Ci, y.data_ptr(), M, Co, Ci,
+                                                                             ps.data_ptr(), st), 'stats'), iters=20)
+            bnw = torch.ones(Co, device='cuda'); bnb = torch.zeros(Co, device='cuda')
+            rm = torch.zeros(Co, device='cuda'); rv = torch.ones(Co, device='cuda')
+
+            def lib_path():
+                z = F.conv2d(x, w)
+                return ops.bn_act_train(z, bnw, bnb, rm, rv, 0.1, 1e-5, relu=False)
+            us_l, prof_l = timed(lib_path, iters=20)
+            out.append({'case': f'fwdstats16 {H}x{H} {Ci}->{Co}', 'gemm_stats_us': prof.get('cfl_gemm_bf16_kernel', us_f),
+                        'lib_conv_plus_bn_us_wall': round(us_l, 1), 'bn_stats_us': prof_l.get('cfl_bn_stats_kernel'),
+                        'bn_apply_us': prof_l.get('cfl_bn_apply_kernel')})
     if 'dgrad16' in cases:
         # the data gradients of the trunk's 1x1 convolutions as the step runs them: K = forward Co, N = forward Ci; conv1 of a
         # block with the gradient join in the epilogue, conv3 plain (B-resident kernel vs the tile kernel: CFL_GEMM_NO_BRES=1)
