@@ -1054,6 +1054,8 @@ class _ConvSplitFn(torch.autograd.Function):
             Co = weight.shape[0]
             y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             pstat = torch.empty(2 * stats_nblk * Co, dtype=torch.float32, device=x.device)
+            GEMM_COUNTERS['flops'] += 2 * N * H * W * Co * Ci
+            GEMM_COUNTERS['bytes'] += 2 * (N * H * W * (Ci + Co) + Co * Ci) + 8 * stats_nblk * Co
             _lib.check(_lib.load().cfl_gemm_bf16_nt_stats(_ptr(x), Ci, _ptr(weight), Ci, _ptr(y), N * H * W, Co, Ci, _ptr(pstat),
                                                           _stream(x)), 'cfl_gemm_bf16_nt_stats')
             _LAST_STATS[0] = (pstat, stats_nblk, N * H * W, Co)
