@@ -23,8 +23,9 @@ CFL_NO_JOIN_FUSE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-recall --no-alone > $OUT/${TAG}_bench_line_again.json 2>> $OUT/bench.err
 python tools/ab_step.py --knob join --rounds 6 > $OUT/${TAG}_ab_join.json 2>> $OUT/bench.err
 python tools/ab_step.py --knob bres --rounds 6 > $OUT/${TAG}_ab_bres.json 2>> $OUT/bench.err
+python tools/ab_step.py --knob convstats --rounds 6 > $OUT/${TAG}_ab_convstats.json 2>> $OUT/bench.err
 python tools/step_jitter.py 80 2>> $OUT/bench.err | tail -1 > $OUT/${TAG}_step_jitter.json
-python tools/kernel_bench.py --cases a1,a3,a5,a2,a6,f4,pool,gemm16,dgrad16,opt > $OUT/${TAG}_kernel_bench.jsonl 2> $OUT/kb.err
+python tools/kernel_bench.py --cases a1,a3,a5,a2,a6,f4,pool,gemm16,dgrad16,fwdstats16,opt > $OUT/${TAG}_kernel_bench.jsonl 2> $OUT/kb.err
 python tools/config4_bench.py > $OUT/${TAG}_config4_line.json 2> $OUT/c4.err
 PMC_STEPS=3 bash tools/pmc_run.sh bench python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall --no-alone --no-mfu --no-prewarm > /dev/null 2>&1
 cp $ROOT/gpurun_out/pmc_bench/summary.json $OUT/${TAG}_pmc_bench_traffic.json
