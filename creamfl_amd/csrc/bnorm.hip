@@ -456,13 +456,13 @@ int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, co
     const dim3 grid(p.nblk, p.gy);
     const U4 *d = (const U4*)dy, *d2 = (const U4*)dy2, *xx = (const U4*)x, *yy = (const U4*)y;
 #define BN_REDUCE(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, xx, yy, \
-                                         save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, relu_mask)
+                                         save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, relu_mask, (const B8*)nullptr, 0, 0)
     if (xmask) BN_REDUCE(true, true); else if (relu) BN_REDUCE(true, false); else BN_REDUCE(false, false);
 #undef BN_REDUCE
     CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
     U4 *ox = (U4*)dx, *orr = (U4*)dres;
 #define BN_APPLY(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<RES_, RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, \
-                                              xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr, relu_mask)
+                                              xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr, relu_mask, (const B8*)nullptr, 0, 0)
     if (xmask) BN_APPLY(false, true, true);
     else if (has_residual && relu) BN_APPLY(true, true, false);
     else if (has_residual) BN_APPLY(true, false, false);

@@ -385,7 +385,7 @@ int launch_bres_stats(const u16* A, long long lda, const u16* B, long long ldb, 
     constexpr size_t LDS = (size_t)NK * BN * 128 + (size_t)8 * 32 * (TN * 64 + 16);
     CFL_SET_LDS((cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, false, true>), LDS);
     CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, false, true>), dim3(256), dim3(512), LDS, stream, A, lda, B, ldb, M, N, C,
-               (long long)N, nullptr, nullptr, N / BN, pstat);
+               (long long)N, (const u16*)nullptr, (const unsigned char*)nullptr, N / BN, pstat);
     return 0;
 }
 
@@ -404,7 +404,7 @@ int launch_bres(const u16* A, long long lda, const u16* B, long long ldb, int M,
     constexpr size_t LDS = (size_t)NK * BN * 128 + (size_t)8 * 32 * (NB * 64 + 16);
     CFL_SET_LDS((cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, JOIN>), LDS);
     CFL_LAUNCH(K_GEMM_BF16, (cfl_gemm_bf16_nt_bres_kernel<NK, TN, R, JOIN>), dim3(256), dim3(512), LDS, stream, A, lda, B, ldb, M, N, C, ldc,
-               addp, maskp, N / BN);
+               addp, maskp, N / BN, (float*)nullptr);
     return 0;
 }
 

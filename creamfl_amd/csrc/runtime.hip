@@ -51,17 +51,16 @@ void drain_locked() {
 }
 }  // namespace
 
-CflProfScope::CflProfScope(int id_, hipStream_t s_) : id(id_), s(s_), e0(nullptr), e1(nullptr), on(false) {
-    if (!g_on || (g_only >= 0 && g_only != id)) return;
+bool cfl_prof_begin(int id, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!g_on || (g_only >= 0 && g_only != id)) return false;
     std::lock_guard<std::mutex> lk(g_mu);
-    e0 = get_event();
-    e1 = get_event();
-    on = (e0 && e1 && hipEventRecord(e0, s) == hipSuccess);
+    *e0 = get_event();
+    *e1 = get_event();
+    return *e0 && *e1;
 }
-CflProfScope::~CflProfScope() {
-    if (!on) return;
+void cfl_prof_end(int id, hipEvent_t e0, hipEvent_t e1) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (hipEventRecord(e1, s) == hipSuccess) g_pending.push_back({id, e0, e1});
+    g_pending.push_back({id, e0, e1});
 }
 
 static int g_exact_gemm = -1;        // -1: not read yet
