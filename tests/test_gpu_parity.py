@@ -899,3 +899,43 @@ def test_dense_kernels_in_both_precisions(dev, exact):
         _close(w.cpu().numpy(), z5['weights'], 1e-4, 1e-6)
     finally:
         lib.cfl_set_exact_gemm(old)
+
+
+def test_kernel_profiler_counts_and_times_launches(dev):
+    """The per-kernel profiler behind the C ABI (what bench.py's `roofline` and tools/kernel_bench.py read): a profiled launch goes
+    through hipExtLaunchKernelGGL with a start and a stop event.  Launch counts are exact, `prof_select` restricts them to one
+    kernel, the duration of a 205 MB GEMM is in the range HBM allows (not the ~zero of two back-to-back markers, not a
+    host-side interval), and results are identical with the profiler on and off."""
+    from creamfl_amd import _lib, ops
+    m, n, k = 50176, 1024, 256
+    gen = torch.Generator().manual_seed(3)
+    a = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(dev)
+    b = (torch.randn(n, k, generator=gen) * 0.1).to(torch.bfloat16).to(dev)
+    ref = ops.gemm_bf16_nt(a, b)
+    x = torch.randn(4096, 64, generator=gen).to(dev)
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_select(None)
+    _lib.prof_enable(True)
+    try:
+        outs = [ops.gemm_bf16_nt(a, b) for _ in range(5)]
+        ops.l2_normalize(x)
+        torch.cuda.synchronize()
+        q = _lib.prof_query()
+        assert q['cfl_gemm_bf16_kernel'][0] == 5
+        us = q['cfl_gemm_bf16_kernel'][1] / 5 * 1e3
+        assert 15.0 < us < 400.0, us                       # 128 MB of traffic: 16 us at the HBM peak
+        assert sum(v[0] for v in q.values()) >= 6
+        _lib.prof_reset()
+        _lib.prof_select('cfl_gemm_bf16_kernel')
+        ops.gemm_bf16_nt(a, b)
+        ops.l2_normalize(x)
+        torch.cuda.synchronize()
+        q = _lib.prof_query()
+        assert list(q) == ['cfl_gemm_bf16_kernel'] and q['cfl_gemm_bf16_kernel'][0] == 1
+    finally:
+        _lib.prof_enable(False)
+        _lib.prof_select(None)
+        _lib.prof_reset()
+    for o in outs:
+        assert torch.equal(o, ref)
