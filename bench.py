@@ -17,7 +17,7 @@ large-batch global contrast: RCCL all-gather of the per-rank features, full-batc
 all-reduce of the encoder gradients.
 
 Prints ONE JSON line (rank 0) with the contract keys plus
-  roofline      -- the dominant hand-written kernel of the step, timed with HIP events inside the timed region
+  roofline      -- the dominant hand-written kernel of the step, timed with HIP events (start / stop events of the launch) inside the timed region
   cpu_baseline  -- the oracle port of the same step timed on the host cores (N = 1 only)
 """
 import argparse
@@ -344,8 +344,8 @@ def main():
     from creamfl_amd import ops as _ops
     fwd_flops = 0 if args.no_mfu else forward_flops(eng, images, captions, words, lens)
     # Warm-up.  Its last step is event-timed for EVERY hand-written kernel: that gives the per-kernel table and
-    # tells which kernel dominates.  In the timed region only that one kernel is bracketed by HIP events (two
-    # hipEventRecords per launch of all ~650 hand-written launches per step cost ~5 ms of host time per step).
+    # tells which kernel dominates.  In the timed region only that one kernel is timed (its launches go through
+    # hipExtLaunchKernelGGL with a start / stop event: the dispatch's own timestamps, no marker packets in the stream).
     for i in range(args.warmup):
         last = (i == args.warmup - 1)
         if last:
