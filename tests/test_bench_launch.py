@@ -93,3 +93,56 @@ def test_bench_gpus_2_runs_two_ranks_end_to_end(launcher, tmp_path):
     assert out['config']['global_batch'] == 32 and out['value'] > 0
     assert out['config']['loss'] == out['config']['loss']            # not NaN
     assert time.time() - t0 < 330                                     # nobody sat out a marker time-out
+
+
+def _prewarm_env(monkeypatch, tmp_path, calls, rc=0):
+    import subprocess
+    import tempfile
+    import torch
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(tempfile, 'gettempdir', lambda: str(tmp_path))
+
+    def fake_call(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return rc
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+
+
+def test_prewarm_one_child_per_node_and_a_shared_marker(monkeypatch, tmp_path):
+    """The library pre-warm (a child process that runs 3 untimed steps on a fresh box): local rank 0 spawns it -- on ONE GPU, with
+    the launcher's environment removed so that the child is a plain single-rank run --, writes the marker where EVERY rank of the
+    node looks (not into a per-rank directory), and a second invocation skips it; the other ranks never spawn anything."""
+    calls = []
+    _prewarm_env(monkeypatch, tmp_path, calls)
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    monkeypatch.setenv('LOCAL_RANK', '0')
+    monkeypatch.setenv('MASTER_PORT', '29999')
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '4,5,6,7')
+    args = bench.parse_args(['--gpus', '8'])
+    bench.prewarm(args, 0)
+    assert len(calls) == 1
+    cmd, env = calls[0]
+    assert '--prewarm-child' in cmd and cmd[cmd.index('--gpus') + 1] == '1'
+    assert env['HIP_VISIBLE_DEVICES'] == '4'
+    assert not any(k in env for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'))
+    bench.prewarm(args, 0)                                   # marker present: no second child
+    bench.prewarm(args, 3, wait_s=0.2)                       # another rank: returns at once, spawns nothing
+    assert len(calls) == 1
+
+
+def test_prewarm_other_ranks_wait_bounded_and_see_a_failed_child(monkeypatch, tmp_path):
+    import time
+    calls = []
+    _prewarm_env(monkeypatch, tmp_path, calls, rc=3)
+    args = bench.parse_args(['--gpus', '2'])
+    t0 = time.perf_counter()
+    bench.prewarm(args, 1, wait_s=0.4)                       # no marker yet: waits, but only as long as it was told to
+    assert 0.3 < time.perf_counter() - t0 < 3.0 and not calls
+    bench.prewarm(args, 0)                                   # the child fails: a '.failed' marker, so that nobody waits for it
+    assert len(calls) == 1
+    t0 = time.perf_counter()
+    bench.prewarm(args, 1, wait_s=30.0)
+    assert time.perf_counter() - t0 < 2.0
+    bench.prewarm(args, 0)                                   # rank 0 tries again next time (and clears the stale marker first)
+    assert len(calls) == 2
