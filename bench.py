@@ -157,6 +157,38 @@ def coco_1k_recall(dim, dev, seed=4321, noise=6.0):
 PMC_ALIASES = {'cfl_gemm_bf16_kernel': ('cfl_gemm_bf16_nt_kernel', 'cfl_gemm_bf16_nt_bres_kernel')}
 
 
+def offline_traffic(kernel, per_step, profiles_dir=None):
+    """(HBM bytes per launch, provenance) of `kernel` from the offline PMC profile of this bench step under profiles/ -- quoted
+    ONLY if that profile saw the same number of launches of the kernel per step as this run (a file taken before a fusion changed
+    the launch count describes another kernel mix: round 2 paired 104-launch traffic with 103-launch algorithmic bytes); else
+    (None, reason).  One profiler id can cover several kernel templates (PMC_ALIASES): their aggregates are combined,
+    launch-weighted."""
+    profiles_dir = profiles_dir or os.path.join(ROOT, 'profiles')
+    source = 'none: no offline PMC profile matches this run (traffic = null)'
+    for fn in ('r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
+        try:
+            pmc = json.load(open(os.path.join(profiles_dir, fn)))
+        except (OSError, ValueError):
+            continue
+        ent = pmc.get(kernel)
+        if not ent:
+            parts = [pmc[k] for k in PMC_ALIASES.get(kernel, ()) if k in pmc and pmc[k].get('launches_per_step')]
+            if parts:
+                n_all = sum(p['launches_per_step'] for p in parts)
+                ent = {'launches_per_step': n_all,
+                       'traffic_bytes': int(sum(p['traffic_bytes'] * p['launches_per_step'] for p in parts) / n_all)}
+        if not ent:
+            continue
+        lps = ent.get('launches_per_step')
+        if lps is None or abs(lps - per_step) >= 0.5:            # (the profiler may miss one launch of a run)
+            source = ('none: profiles/%s was taken at %s launches of this kernel per step, this run has %g (traffic = null)'
+                      % (fn, lps, per_step))
+            continue
+        return ent['traffic_bytes'], ('OFFLINE: profiles/%s (separate rocprofv3 --pmc passes over this bench step, %g launches per '
+                                      'step as here; not measured in this run)' % (fn, per_step))
+    return None, source
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -451,33 +483,7 @@ def main():
             # measured offline at this exact shape (separate rocprofv3 --pmc passes, see the file) is reported -- but only if
             # that profile saw the SAME number of launches per step as this run (a file taken before a fusion changed the
             # launch count describes another kernel mix: round 2 paired 104-launch traffic with 103-launch algorithmic bytes).
-            roof['traffic_source'] = 'none: no offline PMC profile matches this run (traffic = null)'
-            per_step = roof['launches'] / float(args.steps)
-            for fn in ('r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
-                try:
-                    pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
-                except (OSError, ValueError):
-                    continue
-                ent = pmc.get(roof['kernel'])
-                if not ent:
-                    # one profiler id can cover several kernel templates (the data-gradient GEMMs: tile kernel + B-resident
-                    # kernel): combine the profile's per-template aggregates, launch-weighted
-                    parts = [pmc[k] for k in PMC_ALIASES.get(roof['kernel'], ()) if k in pmc and pmc[k].get('launches_per_step')]
-                    if parts:
-                        n_all = sum(p['launches_per_step'] for p in parts)
-                        ent = {'launches_per_step': n_all,
-                               'traffic_bytes': int(sum(p['traffic_bytes'] * p['launches_per_step'] for p in parts) / n_all)}
-                if not ent:
-                    continue
-                lps = ent.get('launches_per_step')
-                if lps is None or abs(lps - per_step) >= 0.5:        # (the profiler may miss one launch of a run)
-                    roof['traffic_source'] = ('none: profiles/%s was taken at %s launches of this kernel per step, this run has %g '
-                                              '(traffic = null)' % (fn, lps, per_step))
-                    continue
-                roof['traffic'] = ent['traffic_bytes']
-                roof['traffic_source'] = ('OFFLINE: profiles/%s (separate rocprofv3 --pmc passes over this bench step, %g launches '
-                                          'per step as here; not measured in this run)' % (fn, per_step))
-                break
+            roof['traffic'], roof['traffic_source'] = offline_traffic(roof['kernel'], roof['launches'] / float(args.steps))
         if roof is not None and not (os.environ.get('CFL_NO_TWO_STREAM') and os.environ.get('CFL_NO_SIDE_WGRAD')):
             # the text tower and the convolution weight gradients run on auxiliary HIP streams: part of these launches
             # share HBM with their kernels, so the per-launch rate is a lower bound of what the kernel reaches alone

@@ -146,3 +146,28 @@ def test_prewarm_other_ranks_wait_bounded_and_see_a_failed_child(monkeypatch, tm
     assert time.perf_counter() - t0 < 2.0
     bench.prewarm(args, 0)                                   # rank 0 tries again next time (and clears the stale marker first)
     assert len(calls) == 2
+
+
+def test_offline_traffic_is_quoted_only_for_the_same_launch_count(tmp_path):
+    """`roofline.traffic` comes from an offline PMC profile; it is quoted only when that profile saw the kernel as often per step
+    as the run did (VERDICT r2 #11: a stale file once paired 104-launch traffic with 103-launch algorithmic bytes)."""
+    import json
+    prof = {'cfl_bn_bwd_apply_kernel': {'launches_per_step': 103.0, 'traffic_bytes': 245000000},
+            'cfl_gemm_bf16_nt_kernel': {'launches_per_step': 40.0, 'traffic_bytes': 200000000},
+            'cfl_gemm_bf16_nt_bres_kernel': {'launches_per_step': 58.0, 'traffic_bytes': 260000000}}
+    (tmp_path / 'r3_pmc_bench_traffic.json').write_text(json.dumps(prof))
+    t, src = bench.offline_traffic('cfl_bn_bwd_apply_kernel', 103.0, str(tmp_path))
+    assert t == 245000000 and src.startswith('OFFLINE')
+    t, src = bench.offline_traffic('cfl_bn_bwd_apply_kernel', 104.0, str(tmp_path))
+    assert t is None and '103' in src
+    t, src = bench.offline_traffic('cfl_gemm_bf16_kernel', 98.0, str(tmp_path))          # one profiler id, two kernel templates
+    assert t == int((40 * 200000000 + 58 * 260000000) / 98) and src.startswith('OFFLINE')
+    t, src = bench.offline_traffic('cfl_gemm_bf16_kernel', 67.0, str(tmp_path))
+    assert t is None
+    t, src = bench.offline_traffic('cfl_pie_fwd_fused_kernel', 2.0, str(tmp_path))
+    assert t is None and src.startswith('none')
+    # the committed profile matches the committed bench line
+    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r3_bench_line.json')).read().strip().splitlines()[-1])
+    r = line['roofline']
+    t, _ = bench.offline_traffic(r['kernel'], r['launches'] / float(line['steps']))
+    assert t == r['traffic']
