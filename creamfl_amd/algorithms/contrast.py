@@ -52,7 +52,14 @@ def mm_client_contrast_loss(out_img, out_txt, global_img, global_txt, d_idx, old
     """Multi-modal client (MMClientTrainer.py:150-324): the intra CE runs over the stacked [2B, 2]
     logits (mean over 2B rows), the inter term is CE(img vs G_txt) + CE(txt vs G_img)."""
     loss_inter = loss_intra = None
+    if not (use_inter or use_intra):
+        raise ValueError('no contrast term selected')
     b = out_img.shape[0]
+    if ops.bank_attn_supported(b, global_img.shape[0], out_img.shape[1]):
+        # per modality one pass over the bank + one finish launch (A4 inside); the second finish combines both modalities
+        return ops.mm_client_contrast_fused(out_img, out_txt, global_img, global_txt, d_idx, old_img, old_txt, temperature,
+                                            weight=interintra_weight, loss_scale=loss_scale, use_inter=use_inter,
+                                            use_intra=use_intra)
     if use_intra:
         loss_intra = (ops.intra_contrast(out_img, global_img, d_idx, old_img, temperature, mean_divisor=2 * b)
                       + ops.intra_contrast(out_txt, global_txt, d_idx, old_txt, temperature, mean_divisor=2 * b))

@@ -317,7 +317,8 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __re
 //     MOON term (A4) with its unit gradient (wave 1), and stores the row's loss terms;
 //   * the LAST block to finish (write-through stores + agent-scope ticket, cdna guide G16) reduces the rows in fixed order and writes
 //     out5 = {loss, loss_inter, loss_moon, coef_inter, coef_moon}: the combined loss of ClientTrainer.py:416-419 and the
-//     factors the backward applies to the two unit gradients.   mode bit 1: intra term present, bit 2: --loss_scale
+//     factors the backward applies to the two unit gradients.   mode bit 1: intra term present, bit 2: --loss_scale,
+//     bit 3: add the li / lm out5 already holds (the other modality of a multi-modal client) before combining
 template <int NJ>      // a thread merges the splits xg + 16 j, j < NJ (S <= 16 NJ)
 __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
                                                                const float* __restrict__ part_o, int S, int DP,
@@ -470,7 +471,12 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
     si = block_sum_256(si, redm);
     sm = block_sum_256(sm, redm);
     if (t == 0) {
-        const float li = si / (float)B, lm = sm / (float)Bdiv;
+        float li = si / (float)B, lm = sm / (float)Bdiv;
+        // mode bit 3 (multi-modal client, MMClientTrainer.py:184-206): out5 still holds the OTHER modality's terms, written by
+        // the previous launch on this stream -- loss_inter = loss_1_inter + loss_2_inter, loss_intra = the CE over the stacked
+        // [2B, 2] logits = the two modalities' softplus sums over Bdiv = 2B; the combination below then runs on the totals and
+        // ONE coefficient pair serves the backward of both modalities.
+        if (mode & 8) { li += out5[1]; lm += out5[2]; }
         float loss, ci = 0.f, cm = 0.f;
         if ((mode & 3) == 3) {
             if (mode & 4) {          // (loss_moon + loss_inter / (loss_inter / loss_moon).detach()) * w

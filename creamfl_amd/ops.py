@@ -272,6 +272,87 @@ def client_contrast_fused(feature, global_same, global_other, d_idx, old_feature
             aux[0] if aux is not None else None, aux[1] if aux is not None else None)
 
 
+class _MMClientContrastFn(torch.autograd.Function):
+    """The multi-modal client's contrast step (MMClientTrainer.py:164-206, :246-264, :301-308) as two chained calls of the
+    fused uni-modal step: image rows against (G_txt bank, G_img positives), then caption rows against (G_img bank, G_txt
+    positives) with mode bit 3, whose finish launch adds the first call's terms before combining -- 2 bank passes + 2 finish
+    launches forward, ONE launch backward for both modalities (they share the coefficient pair in `out`)."""
+
+    @staticmethod
+    def forward(ctx, F_img, F_txt, G_img, G_txt, idx, Fo_img, Fo_txt, inv_tau, weight, mode):
+        lib = _lib.load()
+        B, D = F_img.shape
+        M = G_img.shape[0]
+        dev = F_img.device
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        aux = torch.empty(2, 2, B, dtype=torch.float32, device=dev) if (mode & 1) else None     # [modality][lse, pos][B]
+        dFs = torch.empty(2, 2, B, D, dtype=torch.float32, device=dev) if need else None          # [inter, moon][modality][B, D]
+        use_img = bank_image_supported(B, M, D) and (bool(mode & 1) or D > 256)
+        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need), use_img))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for k, (F, G_other, G_same, F_old) in enumerate(((F_img, G_txt, G_img, Fo_img), (F_txt, G_img, G_txt, Fo_txt))):
+            p_aux = aux.data_ptr() + 8 * B * k if aux is not None else 0
+            p_dfi = dFs.data_ptr() + 4 * B * D * k if (need and (mode & 1)) else 0
+            p_dfm = dFs.data_ptr() + 4 * B * D * (2 + k) if (need and (mode & 2)) else 0
+            tail = (B, M, D, 2 * B, inv_tau, weight, mode | (8 if k else 0), int(need), out.data_ptr(), p_aux,
+                    p_aux + 4 * B if p_aux else 0, p_dfi, p_dfm, st['ws'].data_ptr(), st['sync'].data_ptr(), stream)
+            p_other = G_other.data_ptr() if (mode & 1) else 0
+            p_same = G_same.data_ptr() if (mode & 2) else 0
+            p_old = F_old.data_ptr() if (mode & 2) else 0
+            if use_img:
+                _lib.check(lib.cfl_client_contrast_img_fwd(F.data_ptr(), bank_image(G_other).data_ptr() if (mode & 1) else 0,
+                                                           p_other, p_same, idx.data_ptr(), p_old, *tail),
+                           'cfl_client_contrast_img_fwd')
+            else:
+                _lib.check(lib.cfl_client_contrast_fwd(F.data_ptr(), p_other, p_same, idx.data_ptr(), p_old, *tail),
+                           'cfl_client_contrast_fwd')
+        ctx.mode = mode
+        ctx.save_for_backward(out, dFs if need else out)
+        ctx.has = need
+        ctx.mark_non_differentiable(out)
+        if aux is not None:
+            ctx.mark_non_differentiable(aux)
+        return out.new_empty(()).set_(out.untyped_storage(), 5, ()), out, aux
+
+    @staticmethod
+    def backward(ctx, gloss, _g5, _gaux):
+        lib = _lib.load()
+        out, dFs = ctx.saved_tensors
+        if not ctx.has:
+            raise _lib.CreamflHipError('mm_client_contrast backward without saved gradients')
+        _, _, B, D = dFs.shape
+        g = gloss if (gloss.dtype == torch.float32 and gloss.is_contiguous()) else gloss.to(torch.float32).contiguous()
+        dF = torch.empty(2, B, D, dtype=torch.float32, device=dFs.device)
+        p = dFs.data_ptr()
+        _lib.check(lib.cfl_client_contrast_bwd(p if (ctx.mode & 1) else 0, p + 8 * B * D if (ctx.mode & 2) else 0, out.data_ptr(),
+                                               g.data_ptr(), 2 * B, D, dF.data_ptr(), torch.cuda.current_stream(dF.device).cuda_stream),
+                   'cfl_client_contrast_bwd')
+        return dF[0], dF[1], None, None, None, None, None, None, None, None
+
+
+def mm_client_contrast_fused(out_img, out_txt, global_img, global_txt, d_idx, old_img=None, old_txt=None, temperature=0.5,
+                             weight=1.0, loss_scale=False, use_inter=True, use_intra=True):
+    """The multi-modal client's contrast terms and their combination (MMClientTrainer.py:164-206; intra only :246-264; inter only
+    :301-308): 4 launches forward, 1 backward.  Returns (loss, loss_inter | None, loss_intra | None).  Needs
+    bank_attn_supported(B, M, D)."""
+    Fi, Ft = _f32(out_img, 'out_img'), _f32(out_txt, 'out_txt')
+    mode = (1 if use_inter else 0) | (2 if use_intra else 0) | (4 if loss_scale else 0)
+    if not (mode & 3):
+        raise ValueError('no contrast term selected')
+    Gi, Gt = _f32(global_img.detach(), 'global_img'), _f32(global_txt.detach(), 'global_txt')
+    if Fi.dim() != 2 or Fi.shape != Ft.shape or Gi.dim() != 2 or Gi.shape != Gt.shape or Gi.shape[1] != Fi.shape[1]:
+        raise RuntimeError(f'shape mismatch {tuple(Fi.shape)} / {tuple(Ft.shape)} vs {tuple(Gi.shape)} / {tuple(Gt.shape)}')
+    Oi = Ot = None
+    if use_intra:
+        Oi, Ot = _f32(old_img.detach(), 'old_img'), _f32(old_txt.detach(), 'old_txt')
+        if Oi.shape != Fi.shape or Ot.shape != Ft.shape:
+            raise RuntimeError(f'shape mismatch {tuple(Fi.shape)} vs {tuple(Oi.shape)} / {tuple(Ot.shape)}')
+    loss, out, _ = _MMClientContrastFn.apply(Fi, Ft, Gi, Gt, _idx(d_idx, Fi.device), Oi, Ot, 1.0 / float(temperature), float(weight),
+                                            mode)
+    return loss, out[1] if use_inter else None, out[2] if use_intra else None
+
+
 class _BankInterFn(torch.autograd.Function):
     """Round-1 exact-fp32 two-pass path (v_mfma_f32_32x32x2_f32): kept for D > 256 / D % 4 != 0 and as the A/B reference
     (CFL_BANK_EXACT=1)."""

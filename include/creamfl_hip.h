@@ -100,6 +100,10 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
  *   inter:  li = mean_b [ LSE_m(inv_tau F_b.G_other_m) - inv_tau F_b.G_other_idx[b] ]          (mode bit 0)
  *   intra:  lm = (1/B_div) sum_b softplus(inv_tau (F_b.Fold_b - F_b.G_same_idx[b]))             (mode bit 1)
  *   loss = (lm + li) w | (lm + li / (li/lm)) w with mode bit 2 (--loss_scale) | li | lm
+ *   mode bit 3 (multi-modal client, MMClientTrainer.py:164-206 / :246-264 / :301-308): out5 holds on entry the terms of the
+ *   OTHER modality (the previous call on this stream, same out5); li and lm become the totals over both modalities
+ *   (loss_inter = loss_1_inter + loss_2_inter; loss_intra = CE over the stacked [2B, 2] logits, B_div = 2B in both calls)
+ *   before the combination, and out5 = {loss, li_total, lm_total, c_inter, c_moon, loss} serves the backward of both.
  * G is streamed ONCE: the same pass accumulates softmax . G, so the gradient needs no second pass and no [B, M] tensor.
  * Logits use 3 x bf16-split MFMA (hi.hi + lo.hi + hi.lo, fp32 accumulation, |error| ~ 1e-6 on unit-norm features); the
  * positive dot and the intra term are exact fp32.

@@ -7,7 +7,7 @@ Reference (inline loop bodies, not importable in isolation):
   src/algorithms/ClientTrainer.py:369-429   both terms (uni-modal client)
   src/algorithms/ClientTrainer.py:431-480   intra only
   src/algorithms/ClientTrainer.py:482-507   inter only
-  src/algorithms/MMClientTrainer.py:150-224 both terms (multi-modal client)
+  src/algorithms/MMClientTrainer.py:150-224 both terms (multi-modal client), :225-293 intra only, :294-324 inter only
 The criterion is nn.CrossEntropyLoss (src/losses/__init__.py:19, mean reduction).
 """
 import torch
@@ -67,26 +67,40 @@ def client_contrast_loss(feature, global_same, global_other, d_idx, old_feature,
 
 
 def mm_client_contrast_loss(out_img, out_txt, global_img, global_txt, d_idx,
-                            old_img, old_txt, interintra_weight=0.5, loss_scale=False,
-                            temperature=0.5):
-    """MMClientTrainer.py:150-206 (both flags): intra over the stacked [2B, 2]
-    logits, inter = CE(img vs G_txt) + CE(txt vs G_img)."""
-    idx = torch.as_tensor(d_idx, dtype=torch.long)
-    pos_i = torch.sum(out_img * global_img[idx], dim=-1).reshape(-1, 1)
-    pos_t = torch.sum(out_txt * global_txt[idx], dim=-1).reshape(-1, 1)
-    neg_i = torch.sum(out_img * old_img, dim=-1)
-    neg_t = torch.sum(out_txt * old_txt, dim=-1)
-    logits_1 = torch.cat((pos_i, neg_i.reshape(-1, 1)), dim=1)
-    logits_2 = torch.cat((pos_t, neg_t.reshape(-1, 1)), dim=1)
-    logits = torch.cat((logits_1, logits_2), dim=0) / temperature
-    labels = torch.zeros(out_img.size(0) * 2, dtype=torch.long)
-    loss_intra = F.cross_entropy(logits, labels)
-    loss_inter = (inter_contrast(out_img, global_txt, d_idx, temperature)
-                  + inter_contrast(out_txt, global_img, d_idx, temperature))
-    if not loss_scale:
-        loss = (loss_intra + loss_inter) * interintra_weight
+                            old_img=None, old_txt=None, interintra_weight=0.5, loss_scale=False,
+                            use_inter=True, use_intra=True, temperature=0.5):
+    """The three flag branches of MMClientTrainer.train_epoch:
+      both  (MMClientTrainer.py:164-206): intra = CE over the stacked [2B, 2] logits (mean over 2B rows),
+            inter = CE(img vs G_txt) + CE(txt vs G_img); (intra + inter) * w, or the --loss_scale form (:203-206)
+      intra only (:246-264): the stacked CE alone, unweighted
+      inter only (:301-308): loss_1 + loss_2, unweighted
+    Returns (loss, loss_inter | None, loss_intra | None)."""
+    loss_inter = loss_intra = None
+    if use_intra:
+        idx = torch.as_tensor(d_idx, dtype=torch.long)
+        pos_i = torch.sum(out_img * global_img[idx].type_as(out_img), dim=-1).reshape(-1, 1)
+        pos_t = torch.sum(out_txt * global_txt[idx].type_as(out_txt), dim=-1).reshape(-1, 1)
+        neg_i = torch.sum(out_img * old_img, dim=-1)
+        neg_t = torch.sum(out_txt * old_txt, dim=-1)
+        logits_1 = torch.cat((pos_i, neg_i.reshape(-1, 1)), dim=1)
+        logits_2 = torch.cat((pos_t, neg_t.reshape(-1, 1)), dim=1)
+        logits = torch.cat((logits_1, logits_2), dim=0) / temperature
+        labels = torch.zeros(out_img.size(0) * 2, dtype=torch.long)
+        loss_intra = F.cross_entropy(logits, labels)
+    if use_inter:
+        loss_inter = (inter_contrast(out_img, global_txt, d_idx, temperature)
+                      + inter_contrast(out_txt, global_img, d_idx, temperature))
+    if use_inter and use_intra:
+        if not loss_scale:
+            loss = (loss_intra + loss_inter) * interintra_weight
+        else:
+            loss = (loss_intra + loss_inter / (loss_inter / loss_intra).detach()) * interintra_weight
+    elif use_intra:
+        loss = loss_intra
+    elif use_inter:
+        loss = loss_inter
     else:
-        loss = (loss_intra + loss_inter / (loss_inter / loss_intra).detach()) * interintra_weight
+        raise ValueError('no contrast term selected')
     return loss, loss_inter, loss_intra
 
 

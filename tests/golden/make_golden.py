@@ -8,7 +8,7 @@ The reference source never ships; only inputs + outputs are stored.
 What is imported from the reference:
   src/criterions/probemb.py            MCSoftContrastiveLoss         -> a1_*.npz
   src/networks/models/pie_model.py     PIENet (by file path)          -> a2_*.npz
-  src/losses/__init__.py               create('softmax')              -> a34_*.npz
+  src/losses/__init__.py               create('softmax')              -> a34_*.npz, a34mm_*.npz (MMClientTrainer.py:164-206,:246-264,:301-308)
   src/algorithms/eval_coco.py          COCOEvaluator.evaluate_recall  -> a6_*.npz
   src/utils/tensor_utils.py            l2_normalize
   src/utils/Utils.py                   to_one_hot (+ create('softmax'))  -> f4_*.npz
@@ -156,6 +156,87 @@ def make_a34(losses_mod):
                  loss_inter=loss_inter.detach().numpy(), loss_moon=loss_moon.detach().numpy(),
                  df=im_feature.grad.numpy(), df_inter_only=f2.grad.numpy(),
                  df_intra_only=f3.grad.numpy())
+
+
+def make_a34_mm(losses_mod):
+    """Multi-modal client (MMClientTrainer.py:150-324): the literal statement sequences of the three flag branches
+    (:164-206 both, :246-264 intra only, :301-308 inter only) on CPU tensors (the reference's `.cuda()` calls dropped),
+    with the imported criterion object (`nn.CrossEntropyLoss().cuda()` at :149 is the same class
+    losses.create('softmax') returns)."""
+    criterion = losses_mod.create('softmax')
+    for (tag, b, m, d, w, scale, seed, dup) in [('b8_m64_d16', 8, 64, 16, 0.5, False, 10, False),
+                                                ('b32_m1000_d256', 32, 1000, 256, 0.5, False, 11, False),
+                                                ('b32_m1000_d256_ls', 32, 1000, 256, 0.5, True, 11, False),
+                                                ('b19_m333_d96_ls', 19, 333, 96, 0.25, True, 12, False),
+                                                ('b21_m500_d128_dup', 21, 500, 128, 0.5, False, 13, True),
+                                                ('b64_m1200_d512', 64, 1200, 512, 0.5, False, 14, False)]:
+        gen = torch.Generator().manual_seed(seed)
+        global_img_feature = _unit(gen, m, d)
+        global_txt_feature = torch.nn.functional.normalize(global_img_feature + 0.7 * _unit(gen, m, d), dim=-1)
+        perm = [int(v) for v in torch.randperm(m, generator=gen)[:b]]
+        if dup:                                     # repeated bank positions inside one batch
+            perm[3] = perm[0]
+            perm[-1] = perm[5]
+        d_idx = tuple(perm)
+        base_i = global_img_feature[list(d_idx)]
+        base_t = global_txt_feature[list(d_idx)]
+        out_img = torch.nn.functional.normalize(base_i + 0.6 * _unit(gen, b, d), dim=-1).requires_grad_(True)
+        out_txt = torch.nn.functional.normalize(base_t + 0.6 * _unit(gen, b, d), dim=-1).requires_grad_(True)
+        out_img_o = torch.nn.functional.normalize(base_i + 0.6 * _unit(gen, b, d), dim=-1)
+        out_txt_o = torch.nn.functional.normalize(base_t + 0.6 * _unit(gen, b, d), dim=-1)
+        images = out_img                              # only `images.size(0)` is used below
+        # ---- MMClientTrainer.py:164-206 (both flags) ----
+        target_img_feature = global_img_feature[d_idx, :].type_as(out_img)
+        target_txt_feature = global_txt_feature[d_idx, :].type_as(out_txt)
+        pos_i = torch.sum(out_img * target_img_feature, dim=-1)
+        pos_i = pos_i.reshape(-1, 1)
+        pos_t = torch.sum(out_txt * target_txt_feature, dim=-1)
+        pos_t = pos_t.reshape(-1, 1)
+        neg_i = torch.sum(out_img * out_img_o, dim=-1)
+        neg_t = torch.sum(out_txt * out_txt_o, dim=-1)
+        logits_1 = torch.cat((pos_i, neg_i.reshape(-1, 1)), dim=1)
+        logits_2 = torch.cat((pos_t, neg_t.reshape(-1, 1)), dim=1)
+        logits = torch.cat((logits_1, logits_2), dim=0)
+        logits /= 0.5  # temperature
+        labels = torch.zeros(images.size(0) * 2).long()
+        loss_intra = criterion(logits, labels)
+        logits_1_inter = torch.div(torch.matmul(out_img, global_txt_feature.T), 0.5)
+        logits_2_inter = torch.div(torch.matmul(out_txt, global_img_feature.T), 0.5)
+        labels_inter = torch.tensor(d_idx)
+        loss_1_inter = criterion(logits_1_inter, labels_inter)
+        loss_2_inter = criterion(logits_2_inter, labels_inter)
+        loss_inter = loss_1_inter + loss_2_inter
+        if not scale:
+            loss = (loss_intra + loss_inter) * w
+        else:
+            loss = (loss_intra + loss_inter / (loss_inter / loss_intra).detach()) * w
+        loss.backward()
+        # ---- :246-264 (intra only; unweighted) ----
+        i2 = out_img.detach().clone().requires_grad_(True)
+        t2 = out_txt.detach().clone().requires_grad_(True)
+        p_i = torch.sum(i2 * target_img_feature, dim=-1).reshape(-1, 1)
+        p_t = torch.sum(t2 * target_txt_feature, dim=-1).reshape(-1, 1)
+        n_i = torch.sum(i2 * out_img_o, dim=-1)
+        n_t = torch.sum(t2 * out_txt_o, dim=-1)
+        lg = torch.cat((torch.cat((p_i, n_i.reshape(-1, 1)), dim=1), torch.cat((p_t, n_t.reshape(-1, 1)), dim=1)), dim=0)
+        lg /= 0.5
+        loss_intra_only = criterion(lg, labels)
+        loss_intra_only.backward()
+        # ---- :301-308 (inter only; unweighted) ----
+        i3 = out_img.detach().clone().requires_grad_(True)
+        t3 = out_txt.detach().clone().requires_grad_(True)
+        l1 = criterion(torch.div(torch.matmul(i3, global_txt_feature.T), 0.5), labels_inter)
+        l2 = criterion(torch.div(torch.matmul(t3, global_img_feature.T), 0.5), labels_inter)
+        loss_inter_only = l1 + l2
+        loss_inter_only.backward()
+        np.savez(os.path.join(OUT, f'a34mm_{tag}.npz'), out_img=out_img.detach().numpy(), out_txt=out_txt.detach().numpy(),
+                 old_img=out_img_o.numpy(), old_txt=out_txt_o.numpy(), g_img=global_img_feature.numpy(),
+                 g_txt=global_txt_feature.numpy(), d_idx=np.array(d_idx, dtype=np.int64), weight=np.float32(w),
+                 loss_scale=np.bool_(scale), loss=loss.detach().numpy(), loss_inter=loss_inter.detach().numpy(),
+                 loss_intra=loss_intra.detach().numpy(), d_img=out_img.grad.numpy(), d_txt=out_txt.grad.numpy(),
+                 loss_intra_only=loss_intra_only.detach().numpy(), d_img_intra_only=i2.grad.numpy(),
+                 d_txt_intra_only=t2.grad.numpy(), loss_inter_only=loss_inter_only.detach().numpy(),
+                 d_img_inter_only=i3.grad.numpy(), d_txt_inter_only=t3.grad.numpy())
 
 
 def make_a5():
@@ -499,9 +580,13 @@ def main():
     if '--only-a2' in sys.argv:                               # one family (the others are not rewritten)
         make_a2(pie_model, tensor_utils)
         return
+    if '--only-a34mm' in sys.argv:
+        make_a34_mm(losses_mod)
+        return
     make_a1(probemb)
     make_a2(pie_model, tensor_utils)
     make_a34(losses_mod)
+    make_a34_mm(losses_mod)
     make_a5()
     make_a6(eval_coco)
     import src.utils.Utils as utils_mod

@@ -185,6 +185,93 @@ def test_a34_client_contrast_golden(dev, fname):
     _close(df3, cf['d_moon'].numpy(), 1e-4, 2e-5 * np.abs(cf['d_moon'].numpy()).max())
 
 
+def _run_mm_contrast(dev, z_or_args, w, scale, use_inter=True, use_intra=True):
+    from creamfl_amd.algorithms.contrast import mm_client_contrast_loss
+    out_img, out_txt, g_img, g_txt, d_idx, old_img, old_txt = z_or_args
+    ig, tg = out_img.to(dev).requires_grad_(True), out_txt.to(dev).requires_grad_(True)
+    loss, li, lm = mm_client_contrast_loss(ig, tg, g_img.to(dev), g_txt.to(dev), d_idx, old_img.to(dev), old_txt.to(dev),
+                                           interintra_weight=w, loss_scale=scale, use_inter=use_inter, use_intra=use_intra)
+    loss.backward()
+    return (loss.item(), None if li is None else li.item(), None if lm is None else lm.item(), ig.grad.cpu().numpy(),
+            tg.grad.cpu().numpy())
+
+
+@pytest.mark.parametrize('fname', golden_files('a34mm_'))
+def test_a34_mm_client_contrast_golden(dev, fname):
+    """The multi-modal client's contrast block (MMClientTrainer.py:164-206 both terms +- --loss_scale, :246-264 intra only,
+    :301-308 inter only) through creamfl_amd.algorithms.contrast.mm_client_contrast_loss vs the reference statement sequence
+    (a34mm_*.npz): loss terms 1e-4, both feature gradients 1e-3 of scale; duplicate indices, B not a multiple of 16."""
+    z = _load(fname)
+    args = (torch.from_numpy(z['out_img']), torch.from_numpy(z['out_txt']), torch.from_numpy(z['g_img']),
+            torch.from_numpy(z['g_txt']), [int(v) for v in z['d_idx']], torch.from_numpy(z['old_img']),
+            torch.from_numpy(z['old_txt']))
+    loss, li, lm, di, dt = _run_mm_contrast(dev, args, float(z['weight']), bool(z['loss_scale']))
+    _close(loss, float(z['loss']), 1e-4, 0)
+    _close(li, float(z['loss_inter']), 1e-4, 0)
+    _close(lm, float(z['loss_intra']), 1e-4, 0)
+    _close(di, z['d_img'], 1e-3, 1e-4 * np.abs(z['d_img']).max())
+    _close(dt, z['d_txt'], 1e-3, 1e-4 * np.abs(z['d_txt']).max())
+    loss, li, lm, di, dt = _run_mm_contrast(dev, args, 0.5, False, use_inter=False)
+    assert li is None
+    _close(loss, float(z['loss_intra_only']), 1e-4, 0)
+    _close(di, z['d_img_intra_only'], 1e-3, 1e-4 * np.abs(z['d_img_intra_only']).max())
+    _close(dt, z['d_txt_intra_only'], 1e-3, 1e-4 * np.abs(z['d_txt_intra_only']).max())
+    loss, li, lm, di, dt = _run_mm_contrast(dev, args, 0.5, False, use_intra=False)
+    assert lm is None
+    _close(loss, float(z['loss_inter_only']), 1e-4, 0)
+    _close(di, z['d_img_inter_only'], 1e-3, 1e-4 * np.abs(z['d_img_inter_only']).max())
+    _close(dt, z['d_txt_inter_only'], 1e-3, 1e-4 * np.abs(z['d_txt_inter_only']).max())
+
+
+@pytest.mark.parametrize('b,m,d,scale', [(128, 50000, 256, False), (128, 50000, 256, True), (50, 7001, 768, True),
+                                         (33, 999, 100, False), (5, 40, 18, True)])
+def test_a34_mm_client_contrast_shapes(dev, b, m, d, scale):
+    """Same block at the public-set size (M = 50 000), at d = 768 (column-split wave pairs), at a width the fused kernels do not
+    take (d % 4 != 0: the four-op fallback chain), vs the fp32 oracle restatement and the fp64 closed forms of the two
+    modalities; the fused path must be 4 forward launches + 1 backward launch."""
+    from creamfl_amd import _lib, ops
+    gen = torch.Generator().manual_seed(b + m + d)
+    g_img = _unit(gen, m, d)
+    g_txt = torch.nn.functional.normalize(g_img + 0.7 * _unit(gen, m, d), dim=-1)
+    d_idx = torch.randint(0, m, (b,), generator=gen).tolist()
+    out_img = torch.nn.functional.normalize(g_img[d_idx] + 0.8 * _unit(gen, b, d), dim=-1)
+    out_txt = torch.nn.functional.normalize(g_txt[d_idx] + 0.8 * _unit(gen, b, d), dim=-1)
+    old_img = torch.nn.functional.normalize(out_img + 0.4 * _unit(gen, b, d), dim=-1)
+    old_txt = torch.nn.functional.normalize(out_txt + 0.4 * _unit(gen, b, d), dim=-1)
+    args = (out_img, out_txt, g_img, g_txt, d_idx, old_img, old_txt)
+    w = 0.5
+    fused = ops.bank_attn_supported(b, m, d)
+    assert fused == (d % 4 == 0)
+    _run_mm_contrast(dev, args, w, scale)                         # builds the bank images (not a step launch)
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    loss, li, lm, di, dt = _run_mm_contrast(dev, args, w, scale)
+    torch.cuda.synchronize()
+    launches = {k: v[0] for k, v in _lib.prof_query().items()}
+    _lib.prof_enable(False)
+    if fused:
+        assert sum(launches.values()) == 5, launches
+    ci = oracle.client_contrast_grads_closed_form(out_img, g_img, g_txt, d_idx, old_img)
+    ct = oracle.client_contrast_grads_closed_form(out_txt, g_txt, g_img, d_idx, old_txt)
+    inter = (ci['loss_inter'] + ct['loss_inter']).item()
+    intra = ((ci['loss_moon'] + ct['loss_moon']) / 2).item()
+    ratio = inter / intra if scale else 1.0
+    _close(li, inter, 2e-5, 1e-6)
+    _close(lm, intra, 2e-5, 1e-6)
+    _close(loss, (intra + inter / ratio) * w, 1e-4, 0)
+    for got, c in ((di, ci), (dt, ct)):
+        want = (c['d_moon'].numpy() / 2 + c['d_inter'].numpy() / ratio) * w
+        _close(got, want, 2e-4, 5e-5 * np.abs(want).max())
+    if m <= 8000:
+        ig, tg = out_img.clone().requires_grad_(True), out_txt.clone().requires_grad_(True)
+        ol, oli, olm = oracle.mm_client_contrast_loss(ig, tg, g_img, g_txt, d_idx, old_img, old_txt, interintra_weight=w,
+                                                      loss_scale=scale)
+        ol.backward()
+        _close(loss, ol.item(), 1e-4, 0)
+        _close(di, ig.grad.numpy(), 1e-3, 1e-4 * np.abs(ig.grad.numpy()).max())
+        _close(dt, tg.grad.numpy(), 1e-3, 1e-4 * np.abs(tg.grad.numpy()).max())
+
+
 def test_a34_image_cache_follows_the_bank(dev):
     """The pre-split bank image (csrc/bank_gsplit.h) is built once per bank VERSION: repeated steps against the same bank reuse
     it, an in-place update of the bank (a new round's global features written into the same storage) rebuilds it, and the

@@ -116,6 +116,51 @@ def test_a34_client_contrast(fname):
     np.testing.assert_allclose(cf['d_moon'].numpy(), z['df_intra_only'], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('fname', golden_files('a34mm_'))
+def test_a34_mm_client_contrast(fname):
+    """oracle.mm_client_contrast_loss vs the literal statement sequences of MMClientTrainer.py:164-206 (both terms, with and
+    without --loss_scale), :246-264 (intra only), :301-308 (inter only) evaluated with the reference's criterion object."""
+    z = _load(fname)
+    d_idx = tuple(int(v) for v in z['d_idx'])
+    consts = (torch.from_numpy(z['g_img']), torch.from_numpy(z['g_txt']), d_idx, torch.from_numpy(z['old_img']),
+              torch.from_numpy(z['old_txt']))
+
+    def leaves():
+        return torch.from_numpy(z['out_img']).requires_grad_(True), torch.from_numpy(z['out_txt']).requires_grad_(True)
+
+    i, t = leaves()
+    loss, li, lm = oracle.mm_client_contrast_loss(i, t, *consts, interintra_weight=float(z['weight']),
+                                                  loss_scale=bool(z['loss_scale']))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z['loss']), rtol=1e-6)
+    np.testing.assert_allclose(li.item(), float(z['loss_inter']), rtol=1e-6)
+    np.testing.assert_allclose(lm.item(), float(z['loss_intra']), rtol=1e-6)
+    np.testing.assert_allclose(i.grad.numpy(), z['d_img'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(t.grad.numpy(), z['d_txt'], rtol=1e-5, atol=1e-8)
+    i, t = leaves()
+    loss, li, lm = oracle.mm_client_contrast_loss(i, t, *consts, use_inter=False)
+    assert li is None
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z['loss_intra_only']), rtol=1e-6)
+    np.testing.assert_allclose(i.grad.numpy(), z['d_img_intra_only'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(t.grad.numpy(), z['d_txt_intra_only'], rtol=1e-5, atol=1e-8)
+    i, t = leaves()
+    loss, li, lm = oracle.mm_client_contrast_loss(i, t, *consts[:3], use_intra=False)
+    assert lm is None
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z['loss_inter_only']), rtol=1e-6)
+    np.testing.assert_allclose(i.grad.numpy(), z['d_img_inter_only'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(t.grad.numpy(), z['d_txt_inter_only'], rtol=1e-5, atol=1e-8)
+    # the fp64 closed forms of the two modalities assemble the same numbers (what the GPU tests compare against)
+    g_img, g_txt, _, o_img, o_txt = consts
+    ci = oracle.client_contrast_grads_closed_form(torch.from_numpy(z['out_img']), g_img, g_txt, d_idx, o_img)
+    ct = oracle.client_contrast_grads_closed_form(torch.from_numpy(z['out_txt']), g_txt, g_img, d_idx, o_txt)
+    np.testing.assert_allclose((ci['loss_inter'] + ct['loss_inter']).item(), float(z['loss_inter']), rtol=1e-5)
+    np.testing.assert_allclose(((ci['loss_moon'] + ct['loss_moon']) / 2).item(), float(z['loss_intra']), rtol=1e-5)
+    np.testing.assert_allclose(ci['d_inter'].numpy(), z['d_img_inter_only'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(ct['d_moon'].numpy() / 2, z['d_txt_intra_only'], rtol=1e-4, atol=1e-7)
+
+
 @pytest.mark.parametrize('fname', golden_files('a5_'))
 @pytest.mark.parametrize('literal', [True, False])
 def test_a5_conw(fname, literal):
