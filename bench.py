@@ -26,40 +26,17 @@ import os
 import sys
 import time
 
-# MIOpen: pick convolution algorithms by (fast) find with workspace instead of the immediate-mode fallback;
-# must be set before the first convolution.  FIND_MODE=2 keeps the one-off search to ~10 s on a fresh box.
-os.environ.setdefault('MIOPEN_FIND_MODE', '2')
-# HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues.  The step uses three
-# concurrent streams (image tower, text tower, deferred weight gradients); once RCCL has created its own streams the three
-# no longer get a queue each and serialize: measured 48.4 -> 53.1 ms per step from `init_process_group('nccl')` alone, with no
-# collective issued -- and 48.3 ms again with 8 queues.  Read by the HIP runtime when it initialises (first device call).
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-
-
-def _seed_miopen_user_db():
-    """A fresh box has no MIOpen find-db for gfx950, and searching ResNet-101's ~150 convolution problems costs
-    ~3.5 minutes.  creamfl_amd/miopen_db holds the (text, ~50 KB) user find-db recorded on an MI355X for this
-    exact workload; it is copied to a private writable directory that MIOpen is pointed at."""
-    import shutil
-    import tempfile
-    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'creamfl_amd', 'miopen_db')
-    if ('MIOPEN_USER_DB_PATH' in os.environ and not os.environ.get('CFL_BENCH_SEEDED_DB')) or not os.path.isdir(src):
-        return
-    dst = os.path.join(tempfile.gettempdir(), 'creamfl_miopen_db_%d' % os.getuid(), str(os.environ.get('LOCAL_RANK', '0')))
-    os.makedirs(dst, exist_ok=True)
-    for f in os.listdir(src):
-        if not os.path.exists(os.path.join(dst, f)):
-            shutil.copy(os.path.join(src, f), dst)
-    os.environ['MIOPEN_USER_DB_PATH'] = dst
-    os.environ['CFL_BENCH_SEEDED_DB'] = '1'              # ours, not the caller's: ranks we launch seed their own directory
-
-
-_seed_miopen_user_db()
-
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# Library set-up = the PRODUCT's (creamfl_amd/runtime.py: MIOpen find mode 2 + the find-db / kernel cache recorded on an
+# MI355X, GPU_MAX_HW_QUEUES=8); importing the package applies the environment half before torch / HIP initialise, and
+# TrainerEngine.create() switches cudnn.benchmark on.  Nothing here that a `src/main.py` user would not get.
+from creamfl_amd import runtime as _runtime
+
+_runtime.configure_env()
+
+import torch
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s achievable)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md
@@ -232,6 +209,8 @@ def parse_args(argv=None):
                     help='encoder trunk precision (reference: apex O2 fp16); head + loss are always fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dp', action='store_true', help='exercise the multi-GPU code path even with one rank')
+    ap.add_argument('--bucket-mb', type=int, default=32,
+                    help='gradient all-reduce bucket size (MB): ~10 buckets for 310 MB of gradients, all but the last overlap backward')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=5, help='timed CPU steps (median reported)')
     ap.add_argument('--cpu-warmup', type=int, default=3)
@@ -240,8 +219,12 @@ def parse_args(argv=None):
                          'global contrast, 512 pairs per GPU (N = 4096 over 8 GPUs)')
     ap.add_argument('--no-recall', action='store_true')
     ap.add_argument('--no-mfu', action='store_true', help='skip the FLOP-counting forward pass (profiling runs: every launch then belongs to a step)')
-    ap.add_argument('--no-prewarm', action='store_true',
-                    help='skip the one-off child process that lets MIOpen compile / select its kernels on a fresh box')
+    ap.add_argument('--prewarm', action='store_true',
+                    help='let a CHILD process run 3 untimed steps first (MIOpen compiles / selects its kernels there).  Off by '
+                         'default since round 4: the product does no such thing, and with the recorded find-db + kernel cache of '
+                         'creamfl_amd/runtime.py the first process on a fresh box is within 0.5 %% of the second '
+                         '(profiles/r4_first_process.txt)')
+    ap.add_argument('--no-prewarm', action='store_true', help='(accepted for older command lines; the pre-warm is opt-in now)')
     ap.add_argument('--prewarm-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--watchdog', type=int, default=-1,
                     help='seconds after which a run that has not printed its line dumps every thread\'s stack and exits (a hung '
@@ -255,15 +238,15 @@ def parse_args(argv=None):
 
 
 def prewarm(args, local_rank, wait_s=400.0):
-    """On a fresh box the FIRST process that runs this workload is 3-5 % slower than every later one, whatever its warm-up
-    count (measured: 48.9 ms per step in the first process, 46.5 / 46.3 in the second and third, with 5 or 40 warm-up steps):
-    MIOpen compiles its kernels and records its solver choices while that process runs, and the process keeps the choices it
-    made before the compiled kernels existed.  That one-off library set-up is not the step this bench measures, so it is done
-    here, once per box and shape, in a CHILD process (3 untimed steps, no JSON) before the measured process builds its model.
-    A marker file in the temp directory makes later invocations skip it; --no-prewarm disables it."""
+    """OPT-IN (--prewarm).  Rounds 2-3 measured the FIRST process on a fresh box 3-5 % slower than every later one, whatever its
+    warm-up count (48.9 ms per step vs 46.5 / 46.3): MIOpen compiled kernels and fixed solver choices while that process ran.
+    With the find-db of the final kernel mix recorded and the compiled-kernel cache shipped (creamfl_amd/runtime.py) the effect is
+    gone -- fresh box, same lease: first 44.50 ms, second 44.28, caches wiped again 44.33 / 44.22 (profiles/r4_first_process.txt)
+    -- so the default run is now exactly what a `src/main.py` user gets.  The child (3 untimed steps, no JSON, once per box and
+    shape, a marker file makes later invocations skip it) stays available for A/B runs."""
     import subprocess
     import tempfile
-    if args.no_prewarm or args.prewarm_child or not torch.cuda.is_available():
+    if not args.prewarm or args.no_prewarm or args.prewarm_child or not torch.cuda.is_available():
         return
     # ONE marker per node, whatever launched the ranks (the find-db directory is per LOCAL_RANK when a launcher set that
     # variable before this script was imported: a marker in there would be invisible to the other ranks)
@@ -304,11 +287,9 @@ def main():
     world, rank, local_rank, must_spawn = resolve_world(args, os.environ)
     if must_spawn:
         import subprocess
-        env = dict(os.environ)
+        env = _runtime.child_env()                             # one find-db directory per LOCAL_RANK (no two processes on one text db)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes needs it on this driver)
         env.setdefault('OMP_NUM_THREADS', '4')
-        if env.pop('CFL_BENCH_SEEDED_DB', None):
-            env.pop('MIOPEN_USER_DB_PATH', None)         # one find-db directory per LOCAL_RANK (no two processes on one text db)
         raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
     wd = args.watchdog if args.watchdog >= 0 else (900 if world > 1 else 0)
     if wd > 0:
@@ -329,7 +310,6 @@ def main():
                          'multi-rank path on fewer GPUs)' % (world, world, n_visible))
     dev_index = local_rank % n_visible
     torch.cuda.set_device(dev_index)
-    torch.backends.cudnn.benchmark = True
     dev = torch.device('cuda', dev_index)
     use_dp = world > 1 or args.force_dp
     if use_dp:
@@ -357,7 +337,7 @@ def main():
     if args.dtype == 'bf16':
         eng.to_half()
     if use_dp:
-        eng.enable_data_parallel()
+        eng.enable_data_parallel(bucket_cap_mb=args.bucket_mb)
     eng.model.train()
 
     batch = coco_batch(args.batch, dev, seed=1234 + rank, bert=True)
@@ -534,6 +514,13 @@ def main():
                'mfu': round(step_tflop / (ms_per_step * 1e-3) / mfma_peak, 4),
                'how': '3 x forward FLOPs (conv / linear modules by hooks + PIE w_1 + BERT QK^T, PV) / step time / dense MFMA peak'}
 
+        comm = None
+        if use_dp:
+            # what one step puts on the wire per rank: the bucketed encoder-gradient all-reduce and the two feature all-gathers
+            comm = dict(eng.dp.reducer.comm_stats())
+            comm['bucket_mb'] = args.bucket_mb
+            comm['gather_bytes_per_step'] = 2 * args.batch * world * args.dim * 4       # image + caption features, fp32, all ranks' rows
+            comm['bucket_bytes'] = comm['bucket_bytes'][:16]
         out = {
             'metric': 'image-text pairs/sec (contrastive step)', 'value': round(value, 2), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -548,7 +535,7 @@ def main():
                       'backend': ('rccl' if args.backend == 'nccl' else 'gloo (SMOKE MODE: not a scaling measurement)') if use_dp
                       else None, 'rccl_ranks': torch.distributed.get_world_size() if (use_dp and args.backend == 'nccl') else 0,
                       'gpus_visible': n_visible},
-            'roofline': roof, 'cpu_baseline': cpu, 'mfu': mfu, 'recall_1': recall,
+            'comm': comm, 'roofline': roof, 'cpu_baseline': cpu, 'mfu': mfu, 'recall_1': recall,
             'parity_unpinned': ['AdamP (adamp==0.3.0 is not vendored: checked against the paper restatement oracle/adamp.py)'],
             'hip_kernels_us_warmup_step': hip_us,
         }

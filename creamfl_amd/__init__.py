@@ -12,10 +12,9 @@ interface for this path (same names, arguments and errors):
 There is no CPU fallback: without the built library every op raises CreamflHipError.
 """
 __version__ = '0.1.0'
-import os as _os
+# Library set-up (runtime.py): MIOpen find mode + the recorded find-db / kernel cache, 8 hardware queues for the step's three
+# streams plus RCCL's.  The environment half runs here, at import, before the HIP runtime or MIOpen can have read anything;
+# the engines call runtime.configure() (adds cudnn.benchmark) when they are built.  Every variable is a setdefault.
+from . import runtime as _runtime
 
-# The training step runs three HIP streams side by side (streams.py) and RCCL adds its own; HIP's default of 4 hardware queues
-# per process then makes them share queues and serialize (+9 % per step as soon as the RCCL process group exists; bench.py has
-# the numbers).  Only effective if the HIP runtime has not been initialised yet -- import creamfl_amd before the first device call
-# (or export the variable).
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+_runtime.configure_env()

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from .. import losses, ops
+from .. import losses, ops, runtime
 from ..networks.language_model import EncoderText
 from ..networks.resnet_client import resnet18_client
 from ..utils.Utils import to_one_hot
@@ -61,6 +61,7 @@ class ClientTrainer:
                  loss='softmax', gpuid='cuda:0', num_epochs=30, init_lr=0.0001, decay=0.1, batch_size=512,
                  imgsize=256, num_workers=4, print_freq=10, save_step=10, scale=128, pool_type='max_avg',
                  client_id=-1, wandb=None):
+        runtime.configure()                  # same library set-up as the server engine (creamfl_amd/runtime.py)
         torch.manual_seed(0)
         self.args = args
         if dataset == 'Flickr30k':

@@ -7,6 +7,7 @@ import os
 import torch
 import torch.nn as nn
 
+from ..utils.prefetch import DevicePrefetcher
 from .base import EngineBase
 from .contrast import mm_client_contrast_loss
 from .optimizers import AdamP
@@ -67,7 +68,7 @@ class MMClientTrainer(EngineBase):
         g_img, g_txt = global_img_feature.to(self.device), global_txt_feature.to(self.device)
         distill_dict = {b: a for a, b in enumerate(distill_index)}
         self.last_contrast_loss = None
-        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):
+        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(DevicePrefetcher(global_train_loader, self.device)):
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
             images, captions, caption_lens = images.to(self.device), captions.to(self.device), caption_lens.to(self.device)
@@ -114,5 +115,10 @@ class MMClientTrainer(EngineBase):
                     break
         self.model.train(was_training)
         if out is not None:
+            if off != out['img'].shape[0] or off != out['txt'].shape[0]:
+                # a short public loader (or the is_test early break) would leave stale rows of a previous round / client in the
+                # all-gather buffer, and con_w would aggregate them as if they were this client's (ClientTrainer raises too)
+                raise RuntimeError(f"public set yielded {off} rows, the representation buffers have "
+                                   f"{out['img'].shape[0]} / {out['txt'].shape[0]}")
             return {'img': out['img'], 'txt': out['txt']}, distill_index
         return {'img': torch.cat(img_vec, dim=0).view(-1, D), 'txt': torch.cat(txt_vec, dim=0).view(-1, D)}, distill_index

@@ -27,9 +27,10 @@ import torch
 import torch.nn as nn
 
 from .. import dist as cdist
-from .. import ops
+from .. import flags, ops
 from ..utils.config import default_config, parse_config
 from ..utils.logger import PythonLogger
+from ..utils.prefetch import DevicePrefetcher
 from ..utils.synthetic import SyntheticCocoLoader
 from .ClientTrainer import ClientTrainer
 from .MMClientTrainer import MMClientTrainer
@@ -171,7 +172,7 @@ class MMFL(object):
         img_feature, txt_feature, distill_index = [], [], []
         eng = self.engine
         was_training = eng.model.training
-        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(loader):
+        for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(DevicePrefetcher(loader, eng.device)):
             images = images.to(eng.device)
             if eng.autocast_dtype is not None:
                 images = images.contiguous(memory_format=torch.channels_last)
@@ -181,6 +182,7 @@ class MMFL(object):
             txt_feature.append(output['caption_features'].float())
             distill_index.extend(index)
         eng.model.train(was_training)
+        ops.invalidate_bank_images()         # last round's banks (and their pre-split images) are released with the tensors below
         self.global_img_feature = torch.cat(img_feature, dim=0)
         self.global_txt_feature = torch.cat(txt_feature, dim=0)
         self.distill_index = distill_index
@@ -188,15 +190,20 @@ class MMFL(object):
     def train(self, round_n):
         self.cur_epoch = round_n
         self.cur_trainers = self.total_local_trainers
-        # multi-rank: the server phases (global contrastive training, KD) run DATA-PARALLEL by default -- every rank encodes 1/W
-        # of each public batch, features are all-gathered for the full-batch loss, encoder gradients are bucket-averaged
-        # (dist.GradBuckets): the 391-step global train and the KD loop cost 1/W instead of being repeated W times.  As with any
-        # data-parallel BatchNorm model the batch statistics are per shard; `--server_dp 0` keeps the replicated form (every
-        # rank does the whole batch: bit-for-bit the single-process round).  Replicas are re-synchronised each round.
-        if cdist._world()[1] > 1 and int(getattr(self.args, 'server_dp', 1)):
+        # multi-rank: the server phases (global contrastive training, KD) are REPLICATED by default -- every rank does the whole
+        # public batch: bit-for-bit the single-process round, full-batch BatchNorm statistics (the reference's semantics).
+        # `--server_dp 1` (creamfl_amd/flags.py) makes them DATA-PARALLEL: every rank encodes 1/W of each public batch, features
+        # are all-gathered for the full-batch loss, encoder gradients are bucket-averaged (dist.GradBuckets) -- the 391-step
+        # global train and the KD loop cost 1/W instead of being repeated W times, at the price of per-shard BatchNorm batch
+        # statistics (as in any data-parallel BatchNorm model); the running statistics are averaged over the ranks before the
+        # evaluation and the checkpoint below.  Replicas are re-synchronised each round.
+        server_dp = cdist._world()[1] > 1 and bool(int(flags.get(self.args, 'server_dp')))
+        if server_dp:
             if self.engine.dp is None:
-                self.engine.enable_data_parallel()
+                self.engine.enable_data_parallel(bucket_cap_mb=int(flags.get(self.args, 'bucket_mb')))
             self.engine.shard_batches = True
+        elif self.engine.dp is not None:
+            self.engine.shard_batches = False
         self.engine.sync_replicas()
         if not is_test:
             self.logger.log(f"Round {round_n + 1}!")
@@ -214,7 +221,7 @@ class MMFL(object):
             # (8f-3) one pre-allocated [W, K, M, D] buffer per run: the clients write their representations into this rank's
             # slices, ONE all-gather moves them (optionally as bf16: --rep_wire bf16)
             M, D = self.args.pub_data_num, self.args.feature_dim
-            wire = torch.bfloat16 if getattr(self.args, 'rep_wire', 'fp32') == 'bf16' else torch.float32
+            wire = torch.bfloat16 if flags.get(self.args, 'rep_wire') == 'bf16' else torch.float32
             plan = cdist.client_plan(self.cur_trainers, world)
             gather = getattr(self, '_rep_gather', None)
             if gather is None or not gather.matches(plan, M, D, wire):
@@ -247,6 +254,10 @@ class MMFL(object):
         if not self.args.disable_distill:
             self.distill(round_n, img_vec, txt_vec, None, None, self.distill_index)
 
+        if server_dp:
+            # per-shard BatchNorm statistics: every rank evaluates (and rank 0 saves) the SAME model -- the mean of the ranks'
+            # running statistics, not rank 0's shard-local ones
+            self.engine.average_running_stats()
         metadata = self.engine.metadata.copy()
         metadata['cur_epoch'] = round_n + 1
         metadata['lr'] = self.engine.optimizer.param_groups[0]['lr']
@@ -327,7 +338,7 @@ class MMFL(object):
         model = eng.dp.module if eng.dp is not None else eng.model
 
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(
-                self.dataloaders_global[self._pub_key(False)]):
+                DevicePrefetcher(self.dataloaders_global[self._pub_key(False)], eng.device)):
             images = images.to(eng.device)
             captions, caption_lens = captions.to(eng.device), caption_lens.to(eng.device)
             sh = eng.batch_shard(images.shape[0])
@@ -337,11 +348,12 @@ class MMFL(object):
                 captions_word = captions_word[r0:r1] if captions_word is not None else None
             if eng.autocast_dtype is not None:
                 images = images.contiguous(memory_format=torch.channels_last)
-            with torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
-                output = model(images, captions, captions_word, caption_lens)
-            d_idx = operator.itemgetter(*index)(distill_dict)
-            d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
-            loss = self.kd_terms(output, d_idx)
-            if not torch.is_tensor(loss):
-                continue
-            eng.backward_and_step(loss)           # incl. the bucketed gradient averaging when data parallel is on
+            with ops.join_scope():                # the same backward path as the contrastive step (gradient joins fused)
+                with torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
+                    output = model(images, captions, captions_word, caption_lens)
+                d_idx = operator.itemgetter(*index)(distill_dict)
+                d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
+                loss = self.kd_terms(output, d_idx)
+                if not torch.is_tensor(loss):
+                    continue
+                eng.backward_and_step(loss)       # incl. the bucketed gradient averaging when data parallel is on

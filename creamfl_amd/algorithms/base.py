@@ -3,6 +3,7 @@ GRU text tower), MCSoftContrastiveLoss, the optimizer / scheduler and an evaluat
 Loaders are injected (`train_loader`, `val_loader`): the Flickr30k dataset classes are out of scope."""
 import torch
 
+from .. import runtime
 from ..criterions import get_criterion
 from ..networks.models import get_model
 from .eval_coco import COCOEvaluator
@@ -13,6 +14,7 @@ class EngineBase(object):
     def __init__(self, args, config, logger, client=-1, dset_name="flicker30k", device='cuda',
                  vocab_path='./datasets/vocabs/coco_vocab.pkl', mlp_local=False, word2idx=None, train_loader=None,
                  val_loader=None):
+        runtime.configure()                  # same library set-up as the server engine (creamfl_amd/runtime.py)
         self.dset_name = dset_name
         self.args = args
         self.config = config

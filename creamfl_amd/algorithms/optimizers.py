@@ -109,27 +109,60 @@ class AdamP(Optimizer):
         # Which parameters carry which state is identical on every rank (same model, same history of None gradients), so the
         # whole state travels as ONE flat fp32 tensor per device plus one int64 vector of step counts -- not ~4 small
         # broadcasts and a host sync per parameter (~2000 collectives for ResNet-101 + BERT-base).
-        held = [(p, self.state[p]) for g in self.param_groups for p in g['params'] if self.state.get(p)]
+        gloo = dist.get_backend(group) == 'gloo'
+        params = [p for g in self.param_groups for p in g['params']]
+        if not params:
+            return
+        dev = params[0].device
+        # EVERY rank joins every collective below, whatever state it holds: first rank `src` says which parameters carry which
+        # state tensors (one int per parameter), and the others create what they lack (a rank that loaded / resumed nothing
+        # yet) or drop what `src` does not have -- a rank returning early while the others broadcast would hang the job.
+        sig = torch.tensor([sum(1 << j for j, k in enumerate(self.FP32_STATE) if k in (self.state.get(p) or {})) for p in params],
+                           dtype=torch.int64)
+        sig = sig if gloo else sig.to(dev)
+        dist.broadcast(sig, src, group=group)
+        held = []
+        for p, bits in zip(params, sig.tolist()):
+            if bits == 0:
+                self.state.pop(p, None)
+                continue
+            st = self.state[p]
+            for j, k in enumerate(self.FP32_STATE):
+                if (bits >> j) & 1 and k not in st:
+                    st[k] = (p.detach().to(torch.float32, memory_format=torch.preserve_format).clone() if k == 'master'
+                             else torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format))
+                elif not (bits >> j) & 1 and k in st:
+                    del st[k]
+            held.append((p, st))
         if not held:
             return
         tensors = [st[k] for p, st in held for k in self.FP32_STATE if k in st]
         steps = torch.tensor([int(st.get('step', 0)) for p, st in held], dtype=torch.int64)
-        gloo = dist.get_backend(group) == 'gloo'
-        dev = held[0][0].device
-        def phys(t):                             # the tensor's bytes as a contiguous view (channels_last weights are NHWC runs)
-            return t if t.is_contiguous() else t.permute(0, 2, 3, 1)
+
+        def phys(t):
+            """(view to read, view to write back into or None): the tensor's bytes as one contiguous run.  channels_last 4-D
+            weights are NHWC runs; anything else non-contiguous goes through a contiguous copy and is copied back."""
+            if t.is_contiguous():
+                return t, None
+            if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+                return t.permute(0, 2, 3, 1), None
+            return t.contiguous(), t
         chunk, size = [], 0
         for t in tensors + [None]:
             if t is not None and (not chunk or size + t.numel() <= (64 << 20)):      # <= 256 MB of fp32 per collective
                 chunk.append(t)
                 size += t.numel()
                 continue
-            flat = torch.cat([phys(c).reshape(-1) for c in chunk])
-            dist.broadcast(flat, src, group=group)
-            off = 0
-            for c in chunk:
-                phys(c).copy_(flat[off:off + c.numel()].view(phys(c).shape))
-                off += c.numel()
+            if chunk:
+                views = [phys(c) for c in chunk]
+                flat = torch.cat([v.reshape(-1) for v, _ in views])
+                dist.broadcast(flat, src, group=group)
+                off = 0
+                for c, (v, back) in zip(chunk, views):
+                    v.copy_(flat[off:off + c.numel()].view(v.shape))
+                    if back is not None:
+                        back.copy_(v)
+                    off += c.numel()
             chunk, size = ([t], t.numel()) if t is not None else ([], 0)
         steps = steps if gloo else steps.to(dev)
         dist.broadcast(steps, src, group=group)

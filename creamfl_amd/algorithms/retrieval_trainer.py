@@ -14,14 +14,17 @@ MI355X specifics:
     into large-batch global contrast: per-rank features are all-gathered (creamfl_amd/dist.py) and the encoder
     gradients are summed by bucketed all-reduce overlapped with backward.
 """
+import contextlib
 import hashlib
 import json
 
 import torch
 import torch.nn as nn
 
+from .. import runtime
 from ..criterions import get_criterion
 from ..networks.models import get_model
+from ..utils.prefetch import DevicePrefetcher
 from ..utils.serialize_utils import flatten_dict
 from .optimizers import AdamP, get_lr_scheduler, get_optimizer
 
@@ -49,6 +52,7 @@ class EngineBase(object):
         self._conv1x1_weights = None         # weights whose transposes are prepared in one launch before backward
 
     def create(self, config, word2idx, evaluator, mlp_local):
+        runtime.configure()                  # MIOpen find mode / recorded find-db / cudnn.benchmark before the first convolution
         self.config = config
         self.word2idx = word2idx
         self.model = get_model(word2idx, config.model, mlp_local)
@@ -130,7 +134,19 @@ class EngineBase(object):
         if isinstance(self.optimizer, AdamP):
             self.optimizer.broadcast_state(src, group)
 
-    def enable_data_parallel(self, process_group=None, bucket_cap_mb=128):
+    def average_running_stats(self, group=None):
+        """Data-parallel server phases: BatchNorm batch statistics are per shard, so the running statistics drift apart
+        between the round-start syncs.  Average them over the ranks (one flat all-reduce) so that every rank evaluates, and
+        rank 0 checkpoints, the same model."""
+        from .. import dist as cdist
+        if cdist._world(group)[1] == 1:
+            return
+        for m in self.model.modules():
+            if hasattr(m, 'flush_num_batches_tracked'):
+                m.flush_num_batches_tracked()
+        cdist.average_buffers(self.model, group)
+
+    def enable_data_parallel(self, process_group=None, bucket_cap_mb=32):
         from ..dist import DataParallelContext
         fused = isinstance(self.optimizer, AdamP)
         if self.dp is not None:
@@ -152,17 +168,6 @@ class EngineBase(object):
         if isinstance(self.optimizer, AdamP):
             self.optimizer.grad_override = None
             self.optimizer.grad_override_consume = None
-
-    def backward_and_step(self, loss):
-        """zero_grad -> backward -> (multi-rank: bucketed gradient averaging) -> clip -> optimizer step: the tail every
-        server-side step shares (the contrastive step, retrieval_trainer.py:208-214, and the KD step, MMFL.py:385-391)."""
-        self.optimizer.zero_grad(set_to_none=True)
-        if self.dp is not None:
-            self.dp.prepare_backward()
-        self.backward(loss)
-        if self.dp is not None:
-            self.dp.finish_backward(list(self.criterion.parameters()))
-        self.optimizer_step()
 
     @torch.no_grad()
     def evaluate(self, val_loaders, n_crossfolds=None, **kwargs):
@@ -251,11 +256,19 @@ class TrainerEngine(EngineBase):
         per = n // self.dp.world
         return self.dp.rank * per, (self.dp.rank + 1) * per
 
+    def backward_and_step(self, loss):
+        """zero_grad -> backward -> (multi-rank: bucketed gradient averaging) -> clip -> optimizer step: the tail every
+        server-side step shares (the contrastive step, retrieval_trainer.py:208-214, and the KD step, MMFL.py:385-391)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.dp is not None:
+            self.dp.prepare_backward()
+        self.backward(loss)
+        if self.dp is not None:
+            self.dp.finish_backward(list(self.criterion.parameters()))
+        self.optimizer_step()
+
     def forward_loss(self, images, captions, captions_word, caption_lens, gather=True):
         model = self.dp.module if self.dp is not None else self.model
-        if images.is_cuda:
-            from .. import ops
-            ops.join_arm()                  # the backward of this forward runs through self.backward(): gradient joins may fuse
         with torch.autocast('cuda', dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
             output = model(images, captions, captions_word, caption_lens)
         if self.dp is not None and gather:
@@ -271,8 +284,12 @@ class TrainerEngine(EngineBase):
         `gather=False` means every rank holds the whole batch (replicated step: the averaged gradients are the gradients)."""
         if self.autocast_dtype is not None and images.dim() == 4:
             images = images.contiguous(memory_format=torch.channels_last)
-        loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens, gather=gather)
-        self.backward_and_step(loss)
+        from .. import ops
+        # the backward of this forward runs through self.backward(): the gradient joins of the residual blocks may fuse into the
+        # data-gradient GEMMs (ops.JOIN), armed for exactly this step
+        with (ops.join_scope() if images.is_cuda else contextlib.nullcontext()):
+            loss, loss_dict = self.forward_loss(images, captions, captions_word, caption_lens, gather=gather)
+            self.backward_and_step(loss)
         return loss, loss_dict
 
     def backward(self, loss):
@@ -307,11 +324,14 @@ class TrainerEngine(EngineBase):
         self.model.train()
         if self.logger is not None:
             self.logger.log("Global Training!")
-        for idx, (images, captions, captions_word, caption_lens, a_, b_, index) in enumerate(tr_loader):
+        n_batches = len(tr_loader)
+        # batch k+1 is pinned and copied on a side stream while batch k trains (utils/prefetch.py); the reference copies at the
+        # top of every iteration (retrieval_trainer.py:194-196)
+        for idx, (images, captions, captions_word, caption_lens, a_, b_, index) in enumerate(DevicePrefetcher(tr_loader, self.device)):
             images = images.to(self.device, non_blocking=True)
             captions = captions.to(self.device, non_blocking=True)
             caption_lens = caption_lens.to(self.device, non_blocking=True)
-            if idx == int(len(tr_loader) * pub_data_ratio):
+            if idx == int(n_batches * pub_data_ratio):
                 break
             sh = self.batch_shard(images.shape[0])
             if sh is not None:          # multi-rank: 1/W of the batch per rank, features all-gathered, gradients bucket-averaged

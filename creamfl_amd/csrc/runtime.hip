@@ -56,7 +56,12 @@ bool cfl_prof_begin(int id, hipEvent_t* e0, hipEvent_t* e1) {
     std::lock_guard<std::mutex> lk(g_mu);
     *e0 = get_event();
     *e1 = get_event();
-    return *e0 && *e1;
+    if (*e0 && *e1) return true;
+    // an incomplete pair is not used: hand the event that WAS obtained back to the pool (it used to leak)
+    if (*e0) g_pool.push_back(*e0);
+    if (*e1) g_pool.push_back(*e1);
+    *e0 = *e1 = nullptr;
+    return false;
 }
 void cfl_prof_end(int id, hipEvent_t e0, hipEvent_t e1) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -16,7 +16,8 @@ xGMI mesh.  The reference is strictly single-GPU and time-multiplexes clients on
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): the representation all-gathers are <= 51 MB per rank
 (latency/link bound, a few ms); the only bandwidth-significant collective is the encoder-gradient all-reduce
-(~620 MB fp32 for ResNet-101 + BERT-base), hence large buckets (128 MB default) and overlap with backward.
+(~620 MB fp32 / 310 MB with bf16 trunk weights for ResNet-101 + BERT-base), hence buckets of tens of MB (32 MB default) overlapped
+with backward.
 
 The collectives take the compute kernels as arguments (defaults = the HIP ops) so that the sharding logic can
 be exercised by world_size-2 gloo tests on CPU with the oracle injected (tests/test_dist_gloo.py); the
@@ -58,6 +59,31 @@ def broadcast_module(module, src=0, group=None):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src, group=group)
+
+
+def average_buffers(module, group=None):
+    """Replace every floating-point buffer of `module` (BatchNorm running statistics) by its mean over the ranks: ONE flat
+    all-reduce.  Integer buffers (batch counters) are left alone -- they advance identically on every rank."""
+    rank, world = _world(group)
+    if world == 1:
+        return
+    with torch.no_grad():
+        bufs = [b for b in module.buffers() if b.is_floating_point()]
+        if not bufs:
+            return
+        flat = torch.cat([b.detach().float().reshape(-1) for b in bufs])
+        if dist.get_backend(group) == 'gloo' and flat.is_cuda:
+            host = flat.cpu()
+            dist.all_reduce(host, group=group)
+            flat = host.to(flat.device)
+        else:
+            dist.all_reduce(flat, group=group)
+        flat /= world
+        off = 0
+        for b in bufs:
+            n = b.numel()
+            b.copy_(flat[off:off + n].view_as(b))
+            off += n
 
 
 def reseed_from_rank0(device=None, group=None):
@@ -107,9 +133,11 @@ class GradBuckets:
     <= bucket_cap_mb each, and reduced strictly in completion order on every rank.  The pack + all-reduce run on a communication stream that
     first waits for every stream a gradient may have been produced on; `finish()` makes the caller's stream wait for it.
     After `finish()` every `p.grad` is a view into its (averaged) bucket: the optimizer reads the reduced values in place.
-    RCCL: ring all-reduce over xGMI is per-link bound, hence few large buckets (128 MB default)."""
+    RCCL: ring all-reduce over xGMI is per-link bound (large messages), but the LAST bucket's all-reduce cannot overlap anything:
+    32 MB buckets (default; `bucket_cap_mb`, bench.py --bucket-mb, MMFL --bucket_mb) give ~10 buckets for the 310 MB of bf16 / fp32
+    gradients of ResNet-101 + BERT-base -- >= 8 of them overlap the backward pass, the exposed tail is ~1/10 of the bytes."""
 
-    def __init__(self, params, group=None, bucket_cap_mb=128, assign_grads=True):
+    def __init__(self, params, group=None, bucket_cap_mb=32, assign_grads=True):
         self.group = group
         self.assign_grads = assign_grads       # False: the optimizer reads the bucket views itself (grad_views)
         self._keep = []
@@ -281,6 +309,12 @@ class GradBuckets:
         self.state = 'idle'
         return self._no_grad
 
+    def comm_stats(self):
+        """What one step moves through the gradient all-reduce: bytes (sum of the bucket sizes) and the bucket sizes in reduce
+        order."""
+        sizes = [f.numel() * f.element_size() for f in self.flat]
+        return {'allreduce_bytes_per_step': int(sum(sizes)), 'buckets': len(sizes), 'bucket_bytes': sizes}
+
     def grad_views(self):
         """{parameter: its averaged gradient (bucket view)} -- valid after finish(); constant objects across steps."""
         return {p: v for plist, views in zip(self.buckets, self.views) for p, v in zip(plist, views)}
@@ -291,7 +325,7 @@ class DataParallelContext:
     are all-gathered with a gradient-aware gather, every rank evaluates the (cheap) full-batch pair loss, and the encoder
     gradients are averaged by GradBuckets while the backward pass is still running."""
 
-    def __init__(self, model, group=None, bucket_cap_mb=128, assign_grads=True):
+    def __init__(self, model, group=None, bucket_cap_mb=32, assign_grads=True):
         self.group = group
         self.rank, self.world = _world(group)
         self.module = model

@@ -1,0 +1,51 @@
+"""Build-defined command-line flags, next to the reference's own (src/main.py:38-105, which stay untouched).
+
+The reference driver builds its parser in `args()` (main.py:38-105) and hands the Namespace to `MMFL(args, wandb)`
+(main.py:112-118).  Everything this package adds is OPTIONAL and read through `flags.get(args, name)`, so the unmodified
+reference Namespace works; a driver that wants the extras on its command line adds one call:
+
+    parser = argparse.ArgumentParser()          # main.py:39
+    ...
+    from creamfl_amd.flags import add_build_flags
+    add_build_flags(parser)
+
+Defaults keep the reference's semantics: `--server_dp 0` runs the server phases (global contrastive training, KD) on the
+full batch on every rank -- bit-for-bit the single-process round, full-batch BatchNorm statistics -- and data-parallel
+server phases (per-shard BatchNorm statistics, as in any data-parallel BatchNorm model) are an opt-in speed-up.
+"""
+
+# name -> (argparse keyword arguments, what it does)
+BUILD_FLAGS = {
+    'server_dp': (dict(type=int, default=0, choices=[0, 1]),
+                  'multi-GPU: 1 = the server phases (global contrastive training, KD distillation) run data-parallel -- every '
+                  'rank encodes 1/W of each public batch, features are all-gathered for the full-batch loss, gradients are '
+                  'bucket-averaged; BatchNorm batch statistics are then per shard and the running statistics are averaged over '
+                  'the ranks before evaluation / checkpointing.  0 (default) = replicated: the reference semantics'),
+    'rep_wire': (dict(type=str, default='fp32', choices=['fp32', 'bf16']),
+                 'multi-GPU: wire format of the public-set representations in the one all-gather per round'),
+    'bucket_mb': (dict(type=int, default=32),
+                  'multi-GPU: size of a gradient all-reduce bucket in MB (overlap granularity of the encoder-gradient all-reduce)'),
+    'cnn_type': (dict(type=str, default=None), 'override the server image trunk (resnet18 / resnet50 / resnet101 / vit_b16)'),
+    'bert_name': (dict(type=str, default=None), 'override the server text trunk (bert-mini / bert-base / bert-large)'),
+    'image_size': (dict(type=int, default=224), 'side of the synthetic images when no loaders are passed'),
+    'test_pairs': (dict(type=int, default=5000), 'captions of the synthetic test set when no loaders are passed'),
+    'quiet': (dict(action='store_true'), 'no console logging'),
+    'client_graph': (dict(type=int, default=1, choices=[0, 1]),
+                     'capture the client contrast step (fixed B, M, D) in a HIP graph'),
+}
+
+
+def add_build_flags(parser):
+    """Register every build-defined flag on an argparse parser (flags the parser already has are left alone)."""
+    have = {a.dest for a in parser._actions}
+    for name, (kw, doc) in BUILD_FLAGS.items():
+        if name not in have:
+            parser.add_argument('--' + name, help=doc, **kw)
+    return parser
+
+
+def get(args, name):
+    """The value of a build-defined flag: the Namespace's, else the flag's default (the reference's own Namespace has none)."""
+    kw = BUILD_FLAGS[name][0]
+    default = kw.get('default', False if kw.get('action') == 'store_true' else None)
+    return getattr(args, name, default)

@@ -5,6 +5,7 @@ ordinary torch tensors, and raises if the HIP library is missing or an argument 
 contiguous fp32 device tensor -- there is no CPU fallback (the CPU oracle lives in oracle/ and is
 test infrastructure only).
 """
+import contextlib
 import ctypes
 from collections.abc import Mapping
 
@@ -135,13 +136,24 @@ _BANK_NOIMG = bool(_os.environ.get('CFL_BANK_NOIMG'))       # A/B switch: round-
 # built once per bank VERSION: an entry is reused while the same storage (kept alive by the entry, so its address cannot be
 # handed to another tensor) still carries the version counter it was built from.
 _BANK_IMAGES = {}            # (data_ptr, M, D) -> [source tensor, version, image, last-use tick]
-_BANK_IMAGES_MAX = 6
+_BANK_IMAGES_MAX = 4         # the two live banks of a round (image + text) and, briefly, the next round's two
 _bank_tick = [0]
 BANK_IMAGE_BUILDS = [0]      # how many images were built (tests / benches read it)
 
 
+def invalidate_bank_images():
+    """Drop every cached bank image.  MMFL calls this where it replaces global_img_feature / global_txt_feature each round
+    (MMFL.py:194-221), so that the previous round's banks and their images (2 x the bank's bytes each) are released at once.
+    Also the remedy after a write the version counter cannot see (`.data`, raw-pointer kernels): see bank_image()."""
+    _BANK_IMAGES.clear()
+
+
 def bank_image(G):
-    """The pre-split image of a [M, D] fp32 bank (device tensor of cfl_bank_image_bytes bytes), cached per bank version."""
+    """The pre-split image of a [M, D] fp32 bank (device tensor of cfl_bank_image_bytes bytes), cached per bank version.
+    An entry keeps its source tensor alive (so the address in the key cannot be handed to another tensor) -- at most
+    _BANK_IMAGES_MAX entries, and MMFL drops them all when it replaces the global features (invalidate_bank_images).
+    Validity is the tensor's autograd version counter: in-place torch operations bump it; writes through `.data` or through
+    raw-pointer kernels do not -- call invalidate_bank_images() after those."""
     lib = _lib.load()
     M, D = G.shape
     key = (G.data_ptr(), M, D)
@@ -752,15 +764,33 @@ def bn_act_supported(x, num_features):
 # BatchNorm parameters without a gradient in some steps.)  The registries are only consulted inside TrainerEngine.backward
 # (prepare_ / release_weight_transposes bracket it and clear them), so client trainers and plain autograd are untouched.
 _NO_JOIN_FUSE = _os.environ.get('CFL_NO_JOIN_FUSE', '0') == '1'      # measurement switch
-JOIN = {'armed': False, 'on': False, 'serial': 0, 'mask': {}, 'consumer': set(), 'pending': {}, 'pre': set(), 'fused': 0}
+# Structural assumption, CHECKED in the BatchNorm backward: the pre-joined output object `y` is consumed by the block's first 1x1
+# convolution ONLY (and its alias y2 by the next bn3's residual input only).  JOIN['pre'][tok] records the address of the g the
+# GEMM wrote; the BatchNorm backward requires the gradient it is handed to BE that tensor -- if anything else consumed y (a
+# feature tap, a hook, another block variant) autograd has added an UNMASKED gradient into a new tensor, and the layer raises
+# instead of back-propagating a silently wrong sum.
+JOIN = {'armed': False, 'on': False, 'serial': 0, 'mask': {}, 'consumer': set(), 'pending': {}, 'pre': {}, 'fused': 0}
 
 
 def join_arm():
-    """Called by TrainerEngine before the forward pass of a step whose backward it will run itself: from here on the fused
-    BatchNorm layers register their ReLU masks and the 1x1 convolutions themselves as consumers."""
+    """From here on the fused BatchNorm layers register their ReLU masks and the 1x1 convolutions themselves as consumers.
+    Use through `join_scope()` (TrainerEngine.train_step, the KD step): a bare call leaves the registries armed -- and the mask
+    tensors referenced -- until the next TrainerEngine.backward."""
     JOIN['armed'] = not _NO_JOIN_FUSE
     JOIN['mask'].clear()
     JOIN['consumer'].clear()
+
+
+@contextlib.contextmanager
+def join_scope():
+    """Arms the gradient-join registries for ONE step -- the forward pass and the TrainerEngine.backward inside the `with` -- and
+    disarms / empties them on the way out, exception or not: no stale armed state, no mask tensors kept alive past the step, and
+    forwards of other models in the process (client trainers, evaluation) never register anything."""
+    join_arm()
+    try:
+        yield
+    finally:
+        _join_reset(False)
 
 
 def _join_reset(on):
@@ -830,9 +860,12 @@ class _BNActFn(torch.autograd.Function):
         # JOIN: the data-gradient GEMM of the consumer already produced g = (A + B) . mask for this layer's output
         pre = bool(JOIN['on'] and ctx.tok and ctx.tok in JOIN['pre'])
         if pre:
-            JOIN['pre'].discard(ctx.tok)
-            if dy2 is not None:
-                raise _lib.CreamflHipError('fused gradient join: a second gradient reached a pre-joined BatchNorm output')
+            joined_at = JOIN['pre'].pop(ctx.tok)
+            if dy2 is not None or dy.data_ptr() != joined_at:
+                raise _lib.CreamflHipError(
+                    'fused gradient join: the output of a pre-joined BatchNorm layer was consumed by something besides the '
+                    "block's first 1x1 convolution (a second gradient, or a sum autograd built from an unmasked one, reached it); "
+                    'run this model with CFL_NO_JOIN_FUSE=1')
         from . import streams
         if streams.FLUSH_POLICY[0] == 2:
             streams.flush(x.device, 1)
@@ -1208,7 +1241,7 @@ class _ConvSplitFn(torch.autograd.Function):
                     # dX = (dY W + skip gradient) . ReLU mask of the BatchNorm that produced x: pre-joined for that layer
                     gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci),
                                  add=skip, mask=JOIN['mask'][ctx.x_tok])
-                    JOIN['pre'].add(ctx.x_tok)
+                    JOIN['pre'][ctx.x_tok] = dx.data_ptr()       # the BatchNorm backward must be handed exactly this tensor
                     JOIN['fused'] += 1
                 elif DGRAD_PLAIN_LIB[0] and Co >= DGRAD_PLAIN_LIB[0]:
                     # measurement knob (tools/ab_step.py --knob dgradlib): the un-joined data gradient as the library's FORWARD

@@ -1,0 +1,99 @@
+"""Host -> device staging of loader batches one (or two) batches ahead of the training step.
+
+The reference's loops move every batch synchronously at the top of the iteration (`images = images.to(self.device)`,
+src/algorithms/retrieval_trainer.py:192-206, MMFL.py:346-351, ClientTrainer.py:376-380): 154 MB of fp32 images per server
+batch, ~3 ms over PCIe plus -- for pageable memory -- a staging copy on the host thread that also has to enqueue the step's
+~2000 kernel launches.  `DevicePrefetcher` wraps any loader with the reference's batch-tuple contract
+(src/datasets/_dataloader.py:49-64): a daemon thread takes batches from the loader, pins the tensors that are not pinned yet,
+issues their copies on a dedicated HIP stream and hands (device batch, event) to the consumer through a bounded queue; the
+consumer's stream waits for the event (no host synchronisation anywhere).  Non-tensor items (caption strings, ids, index lists)
+pass through; batches that already live on the device pass through untouched.
+"""
+import queue
+import threading
+
+import torch
+
+_H2D = {}        # device -> copy stream.  NOT one of streams.py's auxiliary streams: the end-of-backward join and the gradient
+                 # reducer wait for those, and must not wait for the next batch's copy
+
+
+def _copy_stream(device):
+    s = _H2D.get(device)
+    if s is None:
+        s = _H2D[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+class DevicePrefetcher:
+    def __init__(self, loader, device, depth=2, pin=True):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.depth = max(1, int(depth))
+        self.pin = pin
+        self.dataset = getattr(loader, 'dataset', None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch, stream):
+        out, moved = [], False
+        with torch.cuda.stream(stream):
+            for item in batch:
+                if torch.is_tensor(item) and not item.is_cuda:
+                    src = item.pin_memory() if (self.pin and not item.is_pinned()) else item
+                    item = src.to(self.device, non_blocking=True)    # the pinned-host allocator keeps `src` alive until the copy ran
+                    moved = True
+                out.append(item)
+        ev = None
+        if moved:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return tuple(out) if isinstance(batch, tuple) else out, ev
+
+    def __iter__(self):
+        if self.device.type != 'cuda':
+            yield from self.loader
+            return
+        q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+        h2d = _copy_stream(self.device)
+
+        def put(x):
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def worker():
+            try:
+                torch.cuda.set_device(self.device)
+                for batch in self.loader:
+                    if not put(self._stage(batch, h2d)):
+                        return
+                put(None)
+            except BaseException as e:          # re-raised in the consumer
+                put(e)
+
+        th = threading.Thread(target=worker, name='creamfl-h2d', daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ev = item
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for t in batch:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)         # allocated on the copy stream, consumed on this one
+                yield batch
+        finally:
+            stop.set()                                   # an early `break` in the consumer must not leave the thread blocked

@@ -1,7 +1,5 @@
 import os
-import shutil
 import sys
-import tempfile
 
 import pytest
 
@@ -13,20 +11,13 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 def _miopen_env():
-    """Same MIOpen setup as bench.py: (fast) find mode with workspace instead of the immediate-mode fallback kernels,
-    and the find-db recorded on an MI355X (creamfl_amd/miopen_db) so that the library convolutions the trunk tests
-    compare against are the ones the bench runs.  Must happen before the first convolution."""
-    os.environ.setdefault('MIOPEN_FIND_MODE', '2')
-    os.environ.setdefault('MIOPEN_LOG_LEVEL', '1')       # the fallback warnings otherwise bury the test log
-    src = os.path.join(ROOT, 'creamfl_amd', 'miopen_db')
-    if 'MIOPEN_USER_DB_PATH' in os.environ or not os.path.isdir(src):
-        return
-    dst = os.path.join(tempfile.gettempdir(), 'creamfl_miopen_db_%d' % os.getuid(), 'tests')
-    os.makedirs(dst, exist_ok=True)
-    for f in os.listdir(src):
-        if not os.path.exists(os.path.join(dst, f)):
-            shutil.copy(os.path.join(src, f), dst)
-    os.environ['MIOPEN_USER_DB_PATH'] = dst
+    """The product's own library set-up (creamfl_amd/runtime.py: find mode 2, recorded find-db / kernel cache, cudnn.benchmark),
+    so that the library convolutions the trunk tests compare against are the ones the product and the bench run.  Must happen
+    before the first convolution."""
+    os.environ.setdefault('MIOPEN_LOG_LEVEL', '1')       # the fallback warnings of untuned test shapes otherwise bury the log
+    os.environ.setdefault('CFL_RUNTIME_TAG', 'tests')    # the tests' odd shapes are recorded apart from the bench's find-db
+    from creamfl_amd import runtime
+    runtime.configure_env()
 
 
 _miopen_env()

@@ -79,10 +79,10 @@ def test_bench_gpus_2_runs_two_ranks_end_to_end(launcher, tmp_path):
             '--no-cpu-baseline', '--no-recall', '--no-alone', '--no-mfu', '--watchdog', '300']
     script = os.path.join(ROOT, 'bench.py')
     if launcher == 'self':
-        cmd = [sys.executable, script] + args + ['--no-prewarm']
+        cmd = [sys.executable, script] + args
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-               '--master-port', str(bench.free_port()), script] + args
+               '--master-port', str(bench.free_port()), script] + args + ['--prewarm']
     t0 = time.time()
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
@@ -119,8 +119,9 @@ def test_prewarm_one_child_per_node_and_a_shared_marker(monkeypatch, tmp_path):
     monkeypatch.setenv('LOCAL_RANK', '0')
     monkeypatch.setenv('MASTER_PORT', '29999')
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '4,5,6,7')
-    args = bench.parse_args(['--gpus', '8'])
+    args = bench.parse_args(['--gpus', '8', '--prewarm'])
     bench.prewarm(args, 0)
+    assert bench.parse_args(['--gpus', '8']).prewarm is False          # opt-in: the default run is the product's
     assert len(calls) == 1
     cmd, env = calls[0]
     assert '--prewarm-child' in cmd and cmd[cmd.index('--gpus') + 1] == '1'
@@ -135,7 +136,7 @@ def test_prewarm_other_ranks_wait_bounded_and_see_a_failed_child(monkeypatch, tm
     import time
     calls = []
     _prewarm_env(monkeypatch, tmp_path, calls, rc=3)
-    args = bench.parse_args(['--gpus', '2'])
+    args = bench.parse_args(['--gpus', '2', '--prewarm'])
     t0 = time.perf_counter()
     bench.prewarm(args, 1, wait_s=0.4)                       # no marker yet: waits, but only as long as it was told to
     assert 0.3 < time.perf_counter() - t0 < 3.0 and not calls

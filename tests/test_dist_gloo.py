@@ -281,6 +281,24 @@ def _worker_adamp_broadcast_state(rank, world, path, out):
         if p.dim() == 4:
             ok &= torch.equal(st['master'], torch.randn_like(q, memory_format=torch.preserve_format))
             ok &= st['master'].is_contiguous(memory_format=torch.channels_last)
+    #  state held by rank 0 ONLY (it resumed from a checkpoint, the others did not): every rank still joins every
+    # collective -- no early return that would leave rank 0 alone in a broadcast -- and ends up with rank 0's state; state that
+    # rank 0 does not hold is dropped.
+    torch.manual_seed(7)
+    lin2 = torch.nn.Linear(3, 4)
+    extra = torch.nn.Parameter(torch.randn(2))
+    opt2 = AdamP(list(lin2.parameters()) + [extra], lr=1e-3)
+    if rank == 0:
+        for i, p in enumerate(lin2.parameters()):
+            opt2.state[p].update(step=5 + i, exp_avg=torch.full_like(p, 0.25 + i), exp_avg_sq=torch.full_like(p, 2.0 + i))
+    else:
+        opt2.state[extra].update(step=9, exp_avg=torch.ones_like(extra), exp_avg_sq=torch.ones_like(extra))
+    opt2.broadcast_state(0)
+    for i, p in enumerate(lin2.parameters()):
+        st = opt2.state[p]
+        ok &= st['step'] == 5 + i and bool((st['exp_avg'] == 0.25 + i).all()) and bool((st['exp_avg_sq'] == 2.0 + i).all())
+    ok &= not opt2.state.get(extra)
+    AdamP([torch.nn.Parameter(torch.randn(3))], lr=1e-3).broadcast_state(0)       # nobody holds anything: returns, no hang
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -338,8 +356,35 @@ def _worker_rep_gather_buffer(rank, world, path, out):
     dist.destroy_process_group()
 
 
+def _worker_average_buffers_and_comm_stats(rank, world, path, out):
+    """ data-parallel server phases leave per-shard BatchNorm running statistics on every rank: average_buffers makes
+    them the mean over the ranks (integer batch counters untouched); comm_stats() reports what GradBuckets moves per step."""
+    _init(rank, world, path)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    net.train()
+    net(torch.randn(8, 3, 5, 5, generator=torch.Generator().manual_seed(10 + rank)) * (1 + rank))
+    mine = net[1].running_var.clone()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    cdist.average_buffers(net)
+    ok = torch.allclose(net[1].running_var, (both[0] + both[1]) / 2, rtol=1e-6)
+    ok &= not torch.allclose(both[0], both[1])
+    ok &= int(net[1].num_batches_tracked) == 1
+    red = cdist.GradBuckets(list(net.parameters()), bucket_cap_mb=0.00004)       # ~40 bytes per bucket
+    st = red.comm_stats()
+    ok &= st['allreduce_bytes_per_step'] == 4 * sum(p.numel() for p in net.parameters())
+    ok &= st['buckets'] == len(red.buckets) >= 2 and sum(st['bucket_bytes']) == st['allreduce_bytes_per_step']
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(bool(flag.item() == 1.0))
+    dist.destroy_process_group()
+
+
 @pytest.mark.parametrize('worker', [_worker_global_contrast, _worker_clients_conw, _worker_config2_eight_clients,
-                                    _worker_reducer_lifecycle, _worker_adamp_broadcast_state, _worker_rep_gather_buffer])
+                                    _worker_reducer_lifecycle, _worker_adamp_broadcast_state, _worker_rep_gather_buffer,
+                                    _worker_average_buffers_and_comm_stats])
 def test_two_rank_gloo(worker):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()

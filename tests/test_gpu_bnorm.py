@@ -438,6 +438,61 @@ def test_gradient_join_ignores_recycled_addresses(monkeypatch):
     assert ops.JOIN['fused'] - fused0 == 12 * 3                      # blocks 1..3 take the join, the downsample block cannot
 
 
+def test_gradient_join_refuses_a_second_consumer_and_scope_cleans_up():
+    """ the fused join assumes that a pre-joined BatchNorm output feeds the block's first 1x1 convolution and nothing
+    else.  A feature TAP on that output (here: the block output also enters the loss directly) makes autograd add an unmasked
+    gradient to the joined one: the BatchNorm backward must notice (it is not handed the tensor the GEMM wrote) and raise, not
+    back-propagate a wrong sum.  And `join_scope()` leaves nothing armed or referenced behind, exception or not."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import _lib, ops
+    from creamfl_amd.networks.backbones import Bottleneck
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    blocks = torch.nn.Sequential(*[Bottleneck(256, 64) for _ in range(3)]).to(dev).to(torch.bfloat16)
+    blocks = blocks.to(memory_format=torch.channels_last).train()
+    for m in blocks.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.float()
+    convs = [m.weight for m in blocks.modules() if isinstance(m, torch.nn.Conv2d)]
+    x = torch.randn(16, 256, 14, 14, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(tap, fuse=True):
+        ops._NO_JOIN_FUSE = not fuse
+        try:
+            for p in blocks.parameters():
+                p.grad = None
+            xin = x.clone().requires_grad_(True)
+            with ops.join_scope():
+                mid = blocks[0](xin)
+                out = blocks[2](blocks[1](mid))
+                loss = out[0].float().sum()
+                if tap:
+                    loss = loss + (mid[0].float() ** 2).sum()          # a second consumer of the pre-joined output
+                ops.prepare_weight_transposes(convs)
+                try:
+                    loss.backward()
+                finally:
+                    ops.release_weight_transposes()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().float().clone() for k, p in blocks.named_parameters()}
+        finally:
+            ops._NO_JOIN_FUSE = False
+
+    run(False)                                                        # the plain structure still fuses
+    ref = run(True, fuse=False)                                       # the tap is fine without the fusion
+    assert all(torch.isfinite(v).all() for v in ref.values())
+    with pytest.raises((_lib.CreamflHipError, RuntimeError), match='fused gradient join'):
+        run(True)
+    for k in ('armed', 'on'):
+        assert not ops.JOIN[k], k
+    for k in ('mask', 'consumer', 'pending', 'pre'):
+        assert not ops.JOIN[k], k                                     # nothing kept alive past the step
+    # a forward pass outside any scope registers nothing
+    blocks(x.clone())
+    assert not ops.JOIN['mask'] and not ops.JOIN['consumer']
+
+
 @pytest.mark.parametrize('n,hw,ci,co', [(64, 28, 128, 512), (40, 31, 64, 256), (256, 14, 256, 1024), (48, 28, 256, 128)])
 def test_bn_statistics_from_the_conv_epilogue(n, hw, ci, co):
     """Round 3: a 1x1 convolution that a training-mode BatchNorm follows runs its forward on the B-resident streaming GEMM with

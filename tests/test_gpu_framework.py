@@ -389,3 +389,29 @@ def test_every_parameter_steps_every_step(dev):
     assert not lag, sorted(lag.items())[:6]
     assert any('downsample' in n for n in steps), 'the trunk under test has no downsample branch'
     del builds, orig
+
+
+def test_device_prefetcher_on_the_gpu(dev):
+    """utils/prefetch.py: batches staged by the copy thread one ahead arrive bit-identical and in order (pageable and pinned
+    sources), non-tensor items pass through, a consumer that breaks early does not hang, a loader error reaches the consumer."""
+    from creamfl_amd.utils.prefetch import DevicePrefetcher
+    from creamfl_amd.utils.synthetic import SyntheticCocoLoader
+    loader = SyntheticCocoLoader(40, 8, seed=5, img=32)
+    want = list(loader)
+    got = list(DevicePrefetcher(loader, dev))
+    assert len(got) == len(want) == 5
+    for g, w in zip(got, want):
+        assert g[0].is_cuda and g[1].is_cuda and g[3].is_cuda and g[2] is None and g[6] == w[6]
+        assert torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1].cpu(), w[1]) and torch.equal(g[3].cpu(), w[3])
+    pinned = [tuple(t.pin_memory() if torch.is_tensor(t) else t for t in b) for b in want]
+    for g, w in zip(DevicePrefetcher(pinned, dev, depth=1), want):
+        assert torch.equal(g[0].cpu(), w[0])
+    for i, g in enumerate(DevicePrefetcher(loader, dev)):
+        if i == 1:
+            break                                             # the copy thread must notice and stop
+
+    def broken():
+        yield want[0]
+        raise ValueError('loader failed')
+    with pytest.raises(ValueError, match='loader failed'):
+        list(DevicePrefetcher(broken(), dev))

@@ -238,7 +238,8 @@ def test_a34_mm_client_contrast_shapes(dev, b, m, d, scale):
     out_txt = torch.nn.functional.normalize(g_txt[d_idx] + 0.8 * _unit(gen, b, d), dim=-1)
     old_img = torch.nn.functional.normalize(out_img + 0.4 * _unit(gen, b, d), dim=-1)
     old_txt = torch.nn.functional.normalize(out_txt + 0.4 * _unit(gen, b, d), dim=-1)
-    args = (out_img, out_txt, g_img, g_txt, d_idx, old_img, old_txt)
+    # the banks live on the device for the whole round (MMClientTrainer.train_epoch): their images are built once, not per step
+    args = (out_img, out_txt, g_img.to(dev), g_txt.to(dev), d_idx, old_img, old_txt)
     w = 0.5
     fused = ops.bank_attn_supported(b, m, d)
     assert fused == (d % 4 == 0)

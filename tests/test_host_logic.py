@@ -334,3 +334,36 @@ def test_vit_patch_embedding_gemm_equals_the_convolution():
         rx, rw, rb = torch.autograd.grad((ref * g).sum(), [xi, m.conv_proj.weight, m.conv_proj.bias])
         for a, b in ((gx, rx), (gw, rw), (gb, rb)):
             np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_build_flags_register_on_the_reference_parser_and_default_to_reference_semantics():
+    """ the build-defined flags have a parser (creamfl_amd/flags.py) and default to the reference's semantics:
+    server phases replicated (full-batch BatchNorm statistics), fp32 wire; the reference's own Namespace (no such attributes)
+    reads the same defaults."""
+    import argparse
+    from conftest import reference_main_namespace
+    from creamfl_amd import flags
+    ns, spec = reference_main_namespace()
+    for name in flags.BUILD_FLAGS:
+        assert not hasattr(ns, name) or name in {f['dest'] for f in spec['flags']}
+    assert flags.get(ns, 'server_dp') == 0 and flags.get(ns, 'rep_wire') == 'fp32' and flags.get(ns, 'bucket_mb') == 32
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--feature_dim', type=int, default=256)
+    flags.add_build_flags(parser)
+    flags.add_build_flags(parser)                              # idempotent
+    a = parser.parse_args([])
+    assert a.server_dp == 0 and a.rep_wire == 'fp32' and a.bucket_mb == 32 and a.quiet is False
+    a = parser.parse_args(['--server_dp', '1', '--rep_wire', 'bf16', '--bucket_mb', '64'])
+    assert flags.get(a, 'server_dp') == 1 and flags.get(a, 'rep_wire') == 'bf16' and flags.get(a, 'bucket_mb') == 64
+    with pytest.raises(SystemExit):
+        parser.parse_args(['--rep_wire', 'fp8'])
+
+
+def test_device_prefetcher_passes_cpu_loaders_through_and_keeps_the_contract():
+    """utils/prefetch.py on a CPU device is the loader itself (no thread, no copies); len() and .dataset are forwarded."""
+    from creamfl_amd.utils.prefetch import DevicePrefetcher
+    loader = SyntheticCocoLoader(10, 4, seed=3, img=8)
+    pf = DevicePrefetcher(loader, 'cpu')
+    assert len(pf) == len(loader) == 3 and pf.dataset is loader.dataset
+    for a, b in zip(pf, loader):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[6] == b[6]

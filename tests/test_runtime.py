@@ -1,0 +1,73 @@
+"""creamfl_amd/runtime.py -- the library set-up every entry point of the package shares (CPU; each case in a fresh interpreter,
+because the set-up is process state)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+_PROBE = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+import creamfl_amd                      # the environment half runs at import
+from creamfl_amd import runtime
+before = runtime._STATE['torch']
+if os.environ.get('PROBE_ENGINE'):
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    import torch
+    assert torch.backends.cudnn.benchmark is False
+    cfg = default_config(embed_dim=32, cnn_type='resnet18', not_bert=True)
+    eng = TrainerEngine(device='cpu')
+    eng.create(cfg, {i: i for i in range(64)}, None, False)
+    bench = torch.backends.cudnn.benchmark
+else:
+    bench = None
+print(json.dumps({'find': os.environ.get('MIOPEN_FIND_MODE'), 'queues': os.environ.get('GPU_MAX_HW_QUEUES'),
+                  'db': os.environ.get('MIOPEN_USER_DB_PATH'), 'cache': os.environ.get('MIOPEN_CUSTOM_CACHE_DIR'),
+                  'files': sorted(os.listdir(os.environ['MIOPEN_USER_DB_PATH'])) if os.environ.get('MIOPEN_USER_DB_PATH') and
+                  os.path.isdir(os.environ['MIOPEN_USER_DB_PATH']) else None, 'benchmark': bench,
+                  'child': sorted(k for k in ('MIOPEN_USER_DB_PATH', 'MIOPEN_CUSTOM_CACHE_DIR', 'CFL_SEEDED_DB', 'CFL_SEEDED_CACHE') if k in runtime.child_env())}))
+''' % ROOT
+
+
+def _run(tmp_path, **extra):
+    env = {k: v for k, v in os.environ.items() if not k.startswith(('MIOPEN_', 'CFL_', 'GPU_MAX')) and k != 'LOCAL_RANK'}
+    env['TMPDIR'] = str(tmp_path)
+    env.update(extra)
+    out = subprocess.run([sys.executable, '-c', _PROBE], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return json.loads(out.stdout.decode().strip().splitlines()[-1])
+
+
+def test_import_applies_the_environment_half(tmp_path):
+    r = _run(tmp_path)
+    assert r['find'] == '2' and r['queues'] == '8'
+    shipped = sorted(os.listdir(os.path.join(ROOT, 'creamfl_amd', 'miopen_db')))
+    assert r['db'].startswith(str(tmp_path)) and r['db'].endswith(os.sep + '0') and r['files'] == shipped
+    assert r['child'] == []                       # ranks we launch seed their own directories
+    assert r['cache'].startswith(str(tmp_path)) and os.path.exists(os.path.join(r['cache'], 'gfx950100.ukdb'))
+    r5 = _run(tmp_path, LOCAL_RANK='5')
+    assert r5['db'].endswith(os.sep + '5') and r5['files'] == shipped          # one find-db directory per local rank
+
+
+def test_a_callers_own_settings_are_kept(tmp_path):
+    r = _run(tmp_path, MIOPEN_FIND_MODE='1', MIOPEN_USER_DB_PATH='/somewhere/else', GPU_MAX_HW_QUEUES='4')
+    assert r['find'] == '1' and r['db'] == '/somewhere/else' and r['queues'] == '4'
+    assert r['child'] == ['MIOPEN_USER_DB_PATH']  # not ours to drop (our own kernel-cache directory is)
+    r = _run(tmp_path, CFL_NO_SEEDED_DB='1')
+    assert r['db'] is None and r['find'] == '2'
+
+
+def test_a_launched_rank_re_derives_its_own_directory(tmp_path):
+    # what a rank sees when the launching process exported its own seeded directory (bench.py must_spawn / torchrun)
+    r = _run(tmp_path, CFL_SEEDED_DB='1', MIOPEN_USER_DB_PATH=str(tmp_path / 'creamfl_miopen_db_0' / '0'), LOCAL_RANK='3')
+    assert r['db'].endswith(os.sep + '3')
+
+
+def test_building_an_engine_switches_find_mode_on(tmp_path):
+    """TrainerEngine.create() -- what src/main.py reaches through MMFL.load_dataset (retrieval_trainer.py:53) -- turns
+    cudnn.benchmark on: without it PyTorch asks MIOpen for immediate-mode solutions and the find-db is never consulted."""
+    r = _run(tmp_path, PROBE_ENGINE='1')
+    assert r['benchmark'] is True
