@@ -211,9 +211,13 @@ def parse_args(argv=None):
     ap.add_argument('--force-dp', action='store_true', help='exercise the multi-GPU code path even with one rank')
     ap.add_argument('--bucket-mb', type=int, default=32,
                     help='gradient all-reduce bucket size (MB): ~10 buckets for 310 MB of gradients, all but the last overlap backward')
-    ap.add_argument('--cpu-batch', type=int, default=16)
-    ap.add_argument('--cpu-steps', type=int, default=5, help='timed CPU steps (median reported)')
+    ap.add_argument('--cpu-batch', type=int, default=0, help='batch of the CPU baseline (0 = the config\'s batch; falls back to 64 when '
+                                                            'a step takes longer than --cpu-step-limit or memory is short)')
+    ap.add_argument('--cpu-steps', type=int, default=10, help='timed CPU steps (median reported; BASELINE.md: >= 10)')
     ap.add_argument('--cpu-warmup', type=int, default=3)
+    ap.add_argument('--cpu-step-limit', type=float, default=25.0)
+    ap.add_argument('--cpu-timeout', type=int, default=540)
+    ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--config', type=int, default=1, choices=[1, 3],
                     help='BASELINE.json config: 1 = server step at 256 pairs per GPU (default, the metric\'s config); 3 = large-batch '
                          'global contrast, 512 pairs per GPU (N = 4096 over 8 GPUs)')
@@ -234,6 +238,8 @@ def parse_args(argv=None):
         ap.error('--gpus must be >= 1')
     if args.config == 3:
         args.batch = 512
+    if args.cpu_batch <= 0:
+        args.cpu_batch = min(args.batch, 256)
     return args
 
 
@@ -284,6 +290,8 @@ def prewarm(args, local_rank, wait_s=400.0):
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args)
     world, rank, local_rank, must_spawn = resolve_world(args, os.environ)
     if must_spawn:
         import subprocess
@@ -561,36 +569,100 @@ def usable_cores():
     return n
 
 
+def _cpu_model_string():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _host_memory_limit_gb():
+    """What this process may allocate: the cgroup limit if there is one, else MemAvailable."""
+    try:
+        v = open('/sys/fs/cgroup/memory.max').read().strip()
+        if v != 'max':
+            return int(v) / 2 ** 30
+    except (OSError, ValueError):
+        pass
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                return int(line.split()[1]) / 2 ** 20
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(cfg, args):
-    """The oracle port of the same step on the host cores, on a bounded sample (small batch, few steps)."""
+    """the CPU restatement of the SAME step on the GPU box's host cores -- identical seeded inputs (the
+    config's batch, 256), threads = all usable cores, >= 3 warm-ups, median of >= 10 timed steps; core count, CPU model string and
+    thread count in the line.  Runs in a CHILD process after the GPU timing (it cannot perturb the timed region, and its memory
+    is gone before the recall evaluation).  If one step at the config's batch takes longer than ~25 s, or the host cannot hold its
+    ~60 GB of fp32 activations, the child falls back to batch 64 and says so."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--batch', str(args.batch), '--dim', str(args.dim),
+           '--cnn', args.cnn, '--cpu-batch', str(args.cpu_batch), '--cpu-steps', str(args.cpu_steps), '--cpu-warmup',
+           str(args.cpu_warmup)]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    try:
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.cpu_timeout)
+        lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
+        if res.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {'value': None, 'error': 'cpu baseline child rc=%d: %s' % (res.returncode, res.stderr.decode()[-300:])}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'error': 'cpu baseline child exceeded %d s' % args.cpu_timeout}
+
+
+def cpu_baseline_child(args):
+    """The oracle port of the step on the host cores (the child process of cpu_baseline)."""
     import oracle.step as ostep
     from oracle.adamp import AdamP as OracleAdamP
     from creamfl_amd.networks.models import get_model
+    from creamfl_amd.utils.config import default_config
     from creamfl_amd.utils.synthetic import coco_batch
     from types import SimpleNamespace
     cores = usable_cores()
     torch.set_num_threads(cores)
-    torch.manual_seed(1234)
-    model = get_model({'<pad>': 0}, cfg.model, False).train()
-    crit = SimpleNamespace(negative_scale=torch.nn.Parameter(torch.tensor([15.0])),
-                           shift=torch.nn.Parameter(torch.tensor([15.0])))
-    params = [p for p in model.parameters() if p.requires_grad] + [crit.negative_scale, crit.shift]
-    opt = OracleAdamP(params, lr=cfg.optimizer.learning_rate, weight_decay=cfg.optimizer.weight_decay)
-    b = coco_batch(args.cpu_batch, 'cpu', seed=1234, bert=True)
-    for _ in range(max(1, args.cpu_warmup)):
-        ostep.contrastive_step_cpu(model, crit, opt, b, cfg.train.grad_clip)
-    times = []
-    for _ in range(max(1, args.cpu_steps)):
-        t0 = time.perf_counter()
-        ostep.contrastive_step_cpu(model, crit, opt, b, cfg.train.grad_clip)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {'value': round(args.cpu_batch / med, 3), 'unit': 'pairs/s', 'cores': cores,
-            'kind': 'port', 'threads': torch.get_num_threads(), 'step_s_median': round(med, 3),
-            'step_s_min_max': [round(times[0], 3), round(times[-1], 3)],
-            'sample': 'same step (ResNet101+BERT-base fp32, d=%d, oracle head+loss, clip, AdamP) at batch %d, '
-                      '%d warm-ups + median of %d timed steps' % (args.dim, args.cpu_batch, max(1, args.cpu_warmup), len(times))}
+    cfg = default_config(embed_dim=args.dim, cnn_type=args.cnn, not_bert=False)
+    mem = _host_memory_limit_gb()
+    note = ''
+    for batch in ([args.cpu_batch] if args.cpu_batch <= 64 else [args.cpu_batch, 64]):
+        if batch > 64 and mem is not None and mem < 0.35 * batch:        # ~0.25 GB of saved fp32 activations per ResNet-101 sample
+            note = '; batch %d needs ~%d GB of host memory, %.0f GB available -> batch 64' % (batch, int(0.25 * batch), mem)
+            continue
+        torch.manual_seed(1234)
+        model = get_model({'<pad>': 0}, cfg.model, False).train()
+        crit = SimpleNamespace(negative_scale=torch.nn.Parameter(torch.tensor([15.0])),
+                               shift=torch.nn.Parameter(torch.tensor([15.0])))
+        params = [p for p in model.parameters() if p.requires_grad] + [crit.negative_scale, crit.shift]
+        opt = OracleAdamP(params, lr=cfg.optimizer.learning_rate, weight_decay=cfg.optimizer.weight_decay)
+        b = coco_batch(batch, 'cpu', seed=1234, bert=True)        # the GPU run's rank-0 batch (same seed, same generator)
+
+        def one():
+            t0 = time.perf_counter()
+            ostep.contrastive_step_cpu(model, crit, opt, b, cfg.train.grad_clip)
+            return time.perf_counter() - t0
+        warm = [one(), one()]
+        if batch > 64 and warm[1] > args.cpu_step_limit:
+            note = '; one step at batch %d took %.1f s (> %.0f s) -> batch 64' % (batch, warm[1], args.cpu_step_limit)
+            del model, opt, b
+            continue
+        warm += [one() for _ in range(max(0, args.cpu_warmup - 2))]
+        times = sorted(one() for _ in range(max(1, args.cpu_steps)))
+        med = times[len(times) // 2]
+        print(json.dumps({
+            'value': round(batch / med, 3), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port', 'threads': torch.get_num_threads(),
+            'os_cpu_count': os.cpu_count(), 'cpu_model': _cpu_model_string(), 'batch': batch,
+            'step_s_median': round(med, 3), 'step_s_min_max': [round(times[0], 3), round(times[-1], 3)],
+            'protocol': 'BASELINE.md section 3: %d warm-ups + median of %d timed steps, threads = usable cores' % (len(warm), len(times)),
+            'sample': 'same step (%s+BERT-base fp32, d=%d, oracle head+loss, clip, AdamP) on the same seeded batch, batch %d%s'
+                      % (args.cnn, args.dim, batch, note)}))
+        return
+    raise SystemExit('cpu baseline: no batch size fits')
 
 
 if __name__ == '__main__':

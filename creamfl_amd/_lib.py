@@ -23,8 +23,6 @@ SIGNATURES = {
     'cfl_prof_select': (c_int, [c_int]),
     'cfl_prof_reset': (c_int, []),
     'cfl_prof_query': (c_int, [c_int, POINTER(c_longlong), POINTER(c_double)]),
-    'cfl_gemm_nt': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
-    'cfl_gemm_ablate': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'cfl_pair_loss_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_pair_loss_fwd': (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P]),
     'cfl_pair_loss_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
@@ -33,10 +31,6 @@ SIGNATURES = {
     'cfl_bank_lse_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'cfl_get_exact_gemm': (c_int, []),
     'cfl_set_exact_gemm': (c_int, [c_int]),
-    'cfl_bank_attn_supported': (c_int, [c_int, c_int, c_int]),
-    'cfl_bank_attn_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
-    'cfl_client_contrast_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int,
-                                        _P, _P, _P, _P, _P, _P, _P, _P]),
     'cfl_client_contrast_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     'cfl_bank_image_bytes': (c_size_t, [c_int, c_int]),
     'cfl_bank_image_build': (c_int, [_P, c_int, c_int, _P, _P]),
@@ -54,8 +48,6 @@ SIGNATURES = {
     'cfl_gemm_bf16_nt_stats': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_int, c_int, c_int, _P, _P]),
     'cfl_transpose_bf16': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_transpose_bf16_multi': (c_int, [_P, c_int, c_int, _P]),
-    'cfl_gemm_bf16_tn_ws_bytes': (c_size_t, [c_longlong, c_int, c_int]),
-    'cfl_gemm_bf16_tn': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_int, c_longlong, c_int, c_int, _P, _P]),
     'cfl_daln_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_daln_fwd': (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint, _P, _P, _P, _P, _P]),
     'cfl_daln_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint, _P, _P, _P, _P, c_int, _P, _P]),

@@ -18,7 +18,8 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from .. import losses, ops, runtime
+from .. import flags, losses, ops, runtime
+from ..graphs import GraphedStep
 from ..networks.language_model import EncoderText
 from ..networks.resnet_client import resnet18_client
 from ..utils.Utils import to_one_hot
@@ -211,10 +212,38 @@ class ClientTrainer:
         self._log('Start %s Contrasting!' % ('Intra & Inter' if use_intra and use_inter else
                                              'Intra-modal' if use_intra else 'Inter-modal'))
         self.last_contrast_loss = None
+
+        def contrast_step(images, d_idx):
+            """One contrast step on an image batch (ClientTrainer.py:376-421) with no host synchronisation inside: the unit the
+            HIP graph captures (creamfl_amd/graphs.py).  d_idx: int64 device tensor of bank positions."""
+            self.optimizer.zero_grad(set_to_none=True)
+            im_feature = self.model(images)
+            old_im_feature = None
+            if use_intra:
+                with torch.no_grad():
+                    old_im_feature = self.old_model(images)
+            loss, _, _ = client_contrast_loss(im_feature, g_same, g_other, d_idx, old_im_feature,
+                                              interintra_weight=self.args.interintra_weight,
+                                              loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
+                                              use_intra=use_intra)
+            loss.backward()
+            self.optimizer.step()
+            return loss.detach()
+
+        # Image clients have fixed batch shapes: the whole step replays from one HIP graph, re-captured every round (the banks,
+        # the old model and the learning rate are constants of a round).  Text clients' caption lengths vary per batch (packed
+        # GRU sequences): they stay eager.  --client_graph 0 switches it off.
+        graphed = None
+        if is_img and bool(int(flags.get(self.args, 'client_graph'))) and not is_test and torch.device(self.gpuid).type == 'cuda':
+            graphed = self._graphed_contrast = GraphedStep(contrast_step, warmup=3)
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):
-            self.optimizer.zero_grad()
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
+            if graphed is not None:
+                loss = graphed(images, torch.as_tensor(d_idx, dtype=torch.int64), device=torch.device(self.gpuid))
+                self.last_contrast_loss = loss
+                continue
+            self.optimizer.zero_grad()
             im_feature = self._features(self.model, images, captions, caption_lens)
             old_im_feature = None
             if use_intra:

@@ -1,4 +1,5 @@
-// bank_attn.hip -- rows A3 + A4 in ONE pass over the frozen global bank (D <= 256).
+// bank_attn.hip -- rows A3 + A4 in ONE pass over the frozen global bank: the finish / backward launches, the C entry points,
+// and (included below) the bank pass itself, csrc/bank_gsplit.h.
 //
 // Reference: src/algorithms/ClientTrainer.py:388,398-419 (inter CE over the 50 000-row bank + intra / MOON term and
 //            their combination), src/algorithms/MMClientTrainer.py:173-206.
@@ -6,26 +7,16 @@
 // The inter-modal term is  loss = mean_b [ LSE_m(f_b.G_m / tau) - f_b.G_idx[b] / tau ]  with gradient
 //   dF_b = (1 / (tau B)) (softmax_b . G - G_idx[b]),
 // i.e. exactly an attention forward with Q = F, K = V = G: the log-sum-exp AND the gradient come out of one stream
-// over G.  Round 1 ran an exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate: compute-bound at 28 %
-// of that peak), wrote the [M, B] logits, and streamed G a second time for the backward GEMM.  Here:
-//   * every fp32 operand is split x = hi + lo (two bf16, 16 mantissa bits) while it is staged into LDS, and each
-//     product runs as 3 v_mfma_f32_32x32x16_bf16 (hi.hi + lo.hi + hi.lo; the dropped lo.lo term is 2^-16 relative):
-//     logits to ~1e-6 absolute on unit-norm features, 5.3x fewer matrix-pipe cycles than the fp32 MFMA;
-//   * a workgroup = 8 waves = 128 feature rows (16 per wave, held as MFMA B-fragments in registers for the whole
-//     kernel; two waves per SIMD so that one wave's LDS / VALU / exp work hides behind the other's MFMAs); it walks its
-//     share of 32-row bank chunks; per chunk and wave: S^T[32 g, 16 f] = G F^T (swapped operands: a lane owns ONE
-//     feature row, so running max / sum need two lane exchanges), online soft-max with deferred rescaling,
-//     O^T[D, 16 f] += G^T P^T on v_mfma_f32_16x16x32_bf16.  P^T goes from the S accumulators straight into the B-operand registers of the second
-//     MFMA (the contraction index is permuted consistently on both operands: no cross-lane traffic);
-//   * the chunk is staged through registers (fp32 -> bf16 hi/lo) into TWO LDS images: [g][d] for the logits and a
-//     transposed [d][g] one (in the permuted g order) for G^T, both XOR-swizzled so that every ds_read_b128 /
-//     ds_write_b64 lane group is bank-conflict free (checked exhaustively offline); double-buffered, one barrier per chunk,
-//     the next chunk's global loads in flight during the MFMA block;
-//   * ONE finish kernel merges the (max, sum, O) partials of the S splits into lse + the unit gradient, does the exact-fp32
-//     positive dot and the intra / MOON term (A4) per row, and -- last block to finish -- the means and the loss combination.
-// HBM traffic: G once (M D 4 bytes) + the split partials; no [B, M] tensor exists.
+// over G (no [B, M] tensor, no second pass).  Every fp32 operand is split x = hi + lo (two bf16) and each product runs as
+// 3 bf16 MFMAs (hi.hi + lo.hi + hi.lo; the dropped lo.lo term is 2^-16 relative): logits to ~1e-6 absolute on unit-norm
+// features.  The bank pass (bank_gsplit.h, round 3) streams a PRE-SPLIT image of the bank; ONE finish kernel merges the
+// (max, sum, O) partials of the S bank splits into lse + the unit gradient, does the exact-fp32 positive dot and the intra /
+// MOON term (A4) per row, and -- last block to finish -- the means and the loss combination.
+// History: round 2's pass over the fp32 bank (128-row groups, D <= 256, conversion while staging: cfl_bank_attn_kernel /
+// cfl_client_contrast_fwd) was kept through round 3 as an A/B reference and removed in round 4 (DESIGN.md section 4.3 has its
+// measurements); the exact-fp32 two-pass kernels of csrc/bank.hip remain as the one reference path.
 //
-// Workspace layout (floats): part_m[RG][S][128] part_l[RG][S][128] rowbuf[2][Bp] part_o[RG][128][S][DP]; `sync` is a
+// Workspace layout (floats): part_m[RG][S][128] part_l[RG][S][128] rowbuf[2][Bp] part_o[Bp][S][DP]; `sync` is a
 // caller-owned int that must be 0 before the first call and is left 0 (last-block election of the epilogue kernel).
 #include <stdlib.h>
 #include "common.h"
@@ -34,26 +25,11 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BR = 128;        // feature rows per workgroup
-constexpr int GC = 32;         // bank rows per chunk
 constexpr float RESCALE_THR = 5.f;   // log2 units: probabilities are kept <= 2^5 relative to the running max
 
 struct AttnPlan { int DT, DP, RG, S, Bp; };
-static AttnPlan attn_plan(int B, int M, int D) {
-    AttnPlan p;
-    p.DT = D <= 64 ? 2 : (D <= 128 ? 4 : 8);
-    p.DP = 32 * p.DT;
-    p.RG = cfl_cdiv(B, BR);
-    p.Bp = p.RG * BR;
-    const int nch = cfl_cdiv(M, GC);
-    int s = cfl_cdiv(256, p.RG);          // one workgroup per CU (128 KB of LDS each); the finish kernel assumes S <= 256
-    if (s > nch) s = nch;
-    if (s < 1) s = 1;
-    p.S = s;
-    return p;
-}
 
 __device__ __forceinline__ void split4(const f32x4 v, bool ok, bf16x4& hi, bf16x4& lo) {
 #pragma unroll
@@ -65,83 +41,8 @@ __device__ __forceinline__ void split4(const f32x4 v, bool ok, bf16x4& hi, bf16x
     }
 }
 
-// ---- LDS images (byte offsets) ----------------------------------------------------------------------------------------
-// row image: [plane][g 0..31][DP bf16], 16-byte slot s of row g stored at slot s ^ swz_row(g)
-template <int DP>
-__device__ __forceinline__ int swz_row(int g) { return (DP / 8 >= 16) ? (g & 15) : ((g >> 1) & 7); }
-template <int DP>
-__device__ __forceinline__ int row_off(int plane, int g, int slot) {
-    return plane * (GC * DP * 2) + g * (DP * 2) + ((slot ^ swz_row<DP>(g)) << 4);
-}
-// transposed image: 128 bytes per column d = 8 slots of 16 bytes, slot = 4 * plane + kg; slot kg holds the 8 bank rows
-//   g = 16 u + 4 kg + r  at position j = 4 u + r  (u = 0, 1; r = 0..3)
-// i.e. exactly the rows whose probabilities lane group kg of the 16x16x32 MFMA already owns in its two S^T accumulators.
-// Placement [d >> 2][(d & 3) ^ cx][slot ^ sig]: conflict-free for the ds_read_b128 fragment reads AND the ds_write_b64
-// staging writes (searched / checked exhaustively offline).
-__device__ __forceinline__ int t_off(int d, int slot) {
-    const int dq = d >> 2, c = d & 3;
-    const int cx = (dq >> 3) & 1;
-    const int sig = ((dq & 7) ^ (((c >> 1) | ((dq & 1) << 1)) << 1)) & 7;
-    return dq * 512 + ((c ^ cx) << 7) + ((slot ^ sig) << 4);
-}
-
-template <int DT, bool GRAD>
-struct Smem {
-    static constexpr int DP = 32 * DT;
-    static constexpr int ROW_BYTES = 2 * GC * DP * 2;
-    static constexpr int T_BYTES = GRAD ? DP * 128 : 0;
-    static constexpr int BUF = ROW_BYTES + T_BYTES;
-    static constexpr int TOTAL = 2 * BUF;
-};
-
-// global -> registers: thread (q, rs) fetches the 4 (g) x 4 (d) block of chunk rows 4 rs .. + 3, columns 4 q .. + 3
-// (one wave instruction = one full bank row when D = 256: perfectly coalesced)
-template <int DP>
-__device__ __forceinline__ void chunk_load(const float* __restrict__ G, int M, int D, int g0, f32x4 (&r)[4]) {
-    constexpr int QPR = DP / 4;
-    const int q = threadIdx.x % QPR, rs = threadIdx.x / QPR;
-    if (rs >= 8) return;
-    int d0 = 4 * q;
-    d0 = d0 < D ? d0 : D - 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int g = g0 + 4 * rs + i;
-        g = g < M ? g : M - 1;
-        r[i] = *reinterpret_cast<const f32x4*>(G + (long long)g * D + d0);
-    }
-}
-
-template <int DP, bool GRAD>
-__device__ __forceinline__ void chunk_store(char* buf, int M, int D, int g0, const f32x4 (&r)[4]) {
-    constexpr int QPR = DP / 4;
-    const int q = threadIdx.x % QPR, rs = threadIdx.x / QPR;
-    if (rs >= 8) return;
-    const bool colok = 4 * q < D;
-    bf16x4 hi[4], lo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split4(r[i], colok && (g0 + 4 * rs + i < M), hi[i], lo[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gl = 4 * rs + i;
-        *reinterpret_cast<bf16x4*>(buf + row_off<DP>(0, gl, q >> 1) + (q & 1) * 8) = hi[i];
-        *reinterpret_cast<bf16x4*>(buf + row_off<DP>(1, gl, q >> 1) + (q & 1) * 8) = lo[i];
-    }
-    if (GRAD) {
-        // rows 4 rs .. + 3 = (u = rs >> 2, kg = rs & 3, r = 0..3): one 8-byte piece of slot kg at byte 8 u, per column and plane
-        char* tb = buf + 2 * GC * DP * 2;
-        const int kg = rs & 3, piece = 8 * (rs >> 2);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int d = 4 * q + c;
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vh[e] = hi[e][c]; vl[e] = lo[e][c]; }
-            *reinterpret_cast<bf16x4*>(tb + t_off(d, kg) + piece) = vh;
-            *reinterpret_cast<bf16x4*>(tb + t_off(d, 4 + kg) + piece) = vl;
-        }
-    }
-}
-
+// v_mfma_f32_16x16x32_bf16: A lane (i = l & 15, kg = l >> 4) holds k = 8 kg + j; B likewise with n = l & 15;
+// C / D: 4 registers, column n = l & 15, row 4 (l >> 4) + r.
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // 16-byte write-through store (sc1): the split partials are consumed by the NEXT kernel, possibly on another XCD; written
@@ -149,163 +50,6 @@ __device__ __forceinline__ void chunk_store(char* buf, int M, int D, int g0, con
 // "publish-large", 8.2 -> 3.0 us per 64 KB per workgroup).
 __device__ __forceinline__ void store_wt_x4(float* p, const f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
-// grid (S, RG), 512 threads = 8 waves of 16 feature rows, two waves per SIMD (256 registers each) so that one wave's LDS /
-// VALU / exp work hides behind the other's MFMAs.  F [B, D], G [M, D] fp32 row-major, D % 4 == 0, D <= DP.
-// v_mfma_f32_16x16x32_bf16: A lane (i = l & 15, kg = l >> 4) holds k = 8 kg + j; B likewise with n = l & 15;
-// C / D: 4 registers, column n = l & 15, row 4 (l >> 4) + r.
-template <int DT, bool GRAD>
-__global__ __launch_bounds__(512, 2) void cfl_bank_attn_kernel(const float* __restrict__ F, const float* __restrict__ G, int B, int M,
-                                                            int D, float sc2, float* __restrict__ part_m,
-                                                            float* __restrict__ part_l, float* __restrict__ part_o) {
-    constexpr int DP = 32 * DT, KS = DP / 32, NDT = DP / 16;
-    using SM = Smem<DT, GRAD>;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int S = gridDim.x, x = blockIdx.x, rg = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, kg = lane >> 4;
-    const int nch = (M + GC - 1) / GC;
-    const int ntiles = x < nch ? (nch - x + S - 1) / S : 0;
-
-    // a wave whose 16 feature rows all lie beyond B (small client batches) only helps staging the chunks: no MFMA work, no
-    // partial rows written for it
-    const bool wave_live = rg * BR + 16 * w < B;
-    f32x4 stage[4];
-    if (ntiles > 0) chunk_load<DP>(G, M, D, x * GC, stage);        // in flight while the feature fragments are fetched
-
-    // this wave's 16 feature rows as B-operand fragments: lane (f, kg) holds k = 32 ks + 8 kg + j
-    bf16x8 fh[KS], fl[KS];
-    {
-        const int fr = rg * BR + 16 * w + fi;
-        const float* fp = F + (long long)(fr < B ? fr : B - 1) * D;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k0 = 32 * ks + 8 * kg;
-            const bool ok0 = fr < B && k0 < D, ok1 = fr < B && k0 + 4 < D;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
-            bf16x4 h0, l0, h1, l1;
-            split4(v0, ok0, h0, l0);
-            split4(v1, ok1, h1, l1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { fh[ks][e] = h0[e]; fh[ks][4 + e] = h1[e]; fl[ks][e] = l0[e]; fl[ks][4 + e] = l1[e]; }
-        }
-    }
-
-    f32x4 O[GRAD ? NDT : 1];
-#pragma unroll
-    for (int i = 0; i < (GRAD ? NDT : 1); ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float run_m = -INFINITY, run_l = 0.f;
-
-    if (ntiles > 0) chunk_store<DP, GRAD>(lds, M, D, x * GC, stage);
-    __syncthreads();
-    int buf = 0;
-    for (int i = 0; i < ntiles; ++i) {
-        const int g0 = (x + i * S) * GC;
-        const bool more = i + 1 < ntiles;
-        const int g0n = (x + (i + 1) * S) * GC;
-        if (more) chunk_load<DP>(G, M, D, g0n, stage);
-        const char* rb = lds + buf * SM::BUF;
-        if (wave_live) {
-        // ---- logits S^T[g, f] = sum_k G[g, k] F[f, k], two 16-row tiles u; hi.hi on one accumulator, cross terms on another
-        // three independent accumulator chains per tile (hi.hi, lo.hi, hi.lo): no MFMA waits for the one before it
-        f32x4 sa[2], sb[2], sc[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { sa[u] = f32x4{0.f, 0.f, 0.f, 0.f}; sb[u] = sa[u]; sc[u] = sa[u]; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 ah[2], al[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                ah[u] = *reinterpret_cast<const bf16x8*>(rb + row_off<DP>(0, 16 * u + fi, 4 * ks + kg));
-                al[u] = *reinterpret_cast<const bf16x8*>(rb + row_off<DP>(1, 16 * u + fi, 4 * ks + kg));
-            }
-            sa[0] = MFMA16(ah[0], fh[ks], sa[0]);
-            sa[1] = MFMA16(ah[1], fh[ks], sa[1]);
-            sb[0] = MFMA16(al[0], fh[ks], sb[0]);
-            sb[1] = MFMA16(al[1], fh[ks], sb[1]);
-            sc[0] = MFMA16(ah[0], fl[ks], sc[0]);
-            sc[1] = MFMA16(ah[1], fl[ks], sc[1]);
-        }
-        // ---- online log-sum-exp in the base-2 domain; element (u, r) of this lane is bank row g0 + 16 u + 4 kg + r
-        const bool full = g0 + GC <= M;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float y = (sa[u][r] + (sb[u][r] + sc[u][r])) * sc2;
-                if (!full && g0 + 16 * u + 4 * kg + r >= M) y = -INFINITY;
-                sa[u][r] = y;
-                mx = fmaxf(mx, y);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));              // the 4 lanes l, l^16, l^32, l^48 share feature row f
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // Deferred rescaling: keep the old reference while no probability would exceed 2^THR.  The decision is taken
-        // per wave (uniform branch); the four lanes of a feature row always agree on its reference.
-        if (__any(mx > run_m + RESCALE_THR)) {
-            const float mn = fmaxf(run_m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(run_m - mn);        // 0 for the first chunk (run_m = -inf)
-            run_l *= alpha;
-            if (GRAD) {
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) O[dt] *= alpha;
-            }
-            run_m = mn;
-        }
-        float ls = 0.f;
-        bf16x8 ph, pl;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(sa[u][r] - run_m);
-                ls += pv;
-                const __bf16 hh = (__bf16)pv;
-                ph[4 * u + r] = hh;
-                pl[4 * u + r] = (__bf16)(pv - (float)hh);
-            }
-        run_l += ls;
-        if (GRAD) {
-            // ---- O^T[d, f] += sum_g G[g, d] P[f, g]: the B operand is the probabilities as they lie (k slot j = 4 u + r)
-            const char* tb = rb + SM::ROW_BYTES;
-            // groups of 4 column tiles, term-major: consecutive MFMAs hit different accumulators
-#pragma unroll
-            for (int d4 = 0; d4 < NDT; d4 += 4) {
-                bf16x8 gh[4], gl[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int d = 16 * (d4 + e) + fi;
-                    gh[e] = *reinterpret_cast<const bf16x8*>(tb + t_off(d, kg));
-                    gl[e] = *reinterpret_cast<const bf16x8*>(tb + t_off(d, 4 + kg));
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) O[d4 + e] = MFMA16(gh[e], ph, O[d4 + e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) O[d4 + e] = MFMA16(gl[e], ph, O[d4 + e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) O[d4 + e] = MFMA16(gh[e], pl, O[d4 + e]);
-            }
-        }
-        }   // wave_live
-        if (more) chunk_store<DP, GRAD>(lds + (buf ^ 1) * SM::BUF, M, D, g0n, stage);
-        __syncthreads();
-        buf ^= 1;
-    }
-    // ---- split partials: (max, sum) per feature row and O as [128 rows][DP] (16-byte stores, 64 contiguous bytes per row)
-    run_l += __shfl_xor(run_l, 16, 64);
-    run_l += __shfl_xor(run_l, 32, 64);
-    const size_t slab = (size_t)rg * S + x;
-    if (!wave_live) return;
-    if (kg == 0) {
-        part_m[slab * BR + 16 * w + fi] = run_m;
-        part_l[slab * BR + 16 * w + fi] = run_l;
-    }
-    if (GRAD) {
-        float* po = part_o + (((size_t)rg * BR + 16 * w + fi) * S + x) * DP + 4 * kg;      // [row][split][DP]: see finish kernel
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) store_wt_x4(po + 16 * dt, O[dt]);
-    }
 }
 
 // Finish kernel = split merge + per-row terms + losses, ONE launch.  Block = (feature row f, quarter of the columns):
@@ -547,62 +291,9 @@ static int launch_finish(const AttnWs& w, int S, int DP, int RGF, int Bp, const 
     return 0;
 }
 
-template <int DT, bool GRAD>
-static int launch_attn(const float* F, const float* G, int B, int M, int D, float sc2, const AttnPlan& p, const AttnWs& w,
-                       hipStream_t stream) {
-    using SM = Smem<DT, GRAD>;
-    CFL_SET_LDS((cfl_bank_attn_kernel<DT, GRAD>), SM::TOTAL);
-    CFL_LAUNCH(K_BANK_FWD, (cfl_bank_attn_kernel<DT, GRAD>), dim3(p.S, p.RG), dim3(512), SM::TOTAL, stream, F, G, B, M, D, sc2,
-               w.part_m, w.part_l, w.part_o);
-    return 0;
-}
-
 }  // namespace
 
 extern "C" {
-
-int cfl_bank_attn_supported(int B, int M, int D) {
-    return (B > 0 && M > 0 && D >= 4 && D <= 256 && D % 4 == 0) ? 1 : 0;
-}
-
-size_t cfl_bank_attn_ws_bytes(int B, int M, int D, int want_grad) {
-    if (!cfl_bank_attn_supported(B, M, D)) return 256;
-    const AttnPlan p = attn_plan(B, M, D);
-    size_t n = (size_t)2 * p.RG * p.S * BR + (size_t)2 * p.Bp;
-    if (want_grad) n += (size_t)p.RG * p.S * p.DP * BR;
-    return cfl_align256(n * sizeof(float));
-}
-
-int cfl_client_contrast_fwd(const float* F, const float* G_other, const float* G_same, const long long* idx, const float* F_old,
-                            int B, int M, int D, int B_div, float inv_tau, float weight, int mode, int want_grad,
-                            float* out5, float* lse, float* pos, float* dF_inter, float* dF_moon, void* ws, int* sync,
-                            void* stream_) {
-    if (!F || !idx || !out5 || !ws || !sync || B <= 0 || M <= 0 || D <= 0 || !(inv_tau > 0.f) || !(mode & 3)) return CFL_EINVAL;
-    if ((mode & 1) && (!G_other || !lse)) return CFL_EINVAL;
-    if ((mode & 2) && (!G_same || !F_old || B_div <= 0)) return CFL_EINVAL;
-    if (want_grad && (((mode & 1) && !dF_inter) || ((mode & 2) && !dF_moon))) return CFL_EINVAL;
-    if (!cfl_bank_attn_supported(B, M, D)) return CFL_ELIMIT;
-    if ((((uintptr_t)F | (uintptr_t)G_other) & 15)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    const AttnPlan p = attn_plan(B, M, D);
-    const AttnWs w = attn_ws(ws, p);
-    if (mode & 1) {
-        const float sc2 = inv_tau * 1.4426950408889634f;
-        int rc;
-        if (want_grad) {
-            rc = p.DT == 2 ? launch_attn<2, true>(F, G_other, B, M, D, sc2, p, w, stream)
-               : p.DT == 4 ? launch_attn<4, true>(F, G_other, B, M, D, sc2, p, w, stream)
-                           : launch_attn<8, true>(F, G_other, B, M, D, sc2, p, w, stream);
-        } else {
-            rc = p.DT == 2 ? launch_attn<2, false>(F, G_other, B, M, D, sc2, p, w, stream)
-               : p.DT == 4 ? launch_attn<4, false>(F, G_other, B, M, D, sc2, p, w, stream)
-                           : launch_attn<8, false>(F, G_other, B, M, D, sc2, p, w, stream);
-        }
-        if (rc) return rc;
-    }
-    return launch_finish(w, p.S, p.DP, p.RG, p.Bp, F, G_other, G_same, F_old, idx, B, M, D, B_div, inv_tau, weight, mode, want_grad, out5,
-                         lse, pos, dF_inter, dF_moon, sync, stream);
-}
 
 // ---- round 3: the same step on a pre-split bank image (bank_gsplit.h) ---------------------------------------------------
 size_t cfl_bank_image_bytes(int M, int D) {

@@ -7,7 +7,8 @@
 //   NT  C[M,N] = A[M,K] B[N,K]^T : ties MIOpen's FORWARD (14x14 256->1024: 49 vs 46 us; 56x56 64->64: 35 vs 34 us) but
 //       beats its BACKWARD-DATA kernels on every ResNet-101 shape (14x14 1024->256: 78 -> 48 us; 56x56 256->64:
 //       184 -> 110 us)  => the product routes the data gradient of the 1x1 convolutions here (ops.conv1x1).
-//   TN  C[N1,N2] = A[M,N1]^T B[M,N2] (weight gradient): on par with MIOpen, not used (see below).
+//   (A TN kernel for the weight gradient C[N1,N2] = A[M,N1]^T B[M,N2] -- transposing register loader, split-K -- measured on
+//   par with MIOpen alone and +0.8 ms inside the step (its 32 MB of split-K partials); removed in round 4)
 // Why the forward stalls: with 128x128 workgroup tiles the LDS pipe (fragment reads 128 KB + direct-to-LDS writes 64 KB
 // per CU per K step vs 1024 MFMA cycles) caps the matrix pipe at ~1/3; 256x256 tiles lift that cap but leave one
 // workgroup per CU and 1-16 K steps per tile, where prologue / epilogue latency dominates.  A 3-stage LDS ring with the
@@ -491,166 +492,6 @@ __global__ __launch_bounds__(256) void cfl_transpose_multi_kernel(const TrMeta* 
     }
 }
 
-// ---- "TN": C[N1, N2] = A[M, N1]^T * B[M, N2] -- the weight gradient dW[Co, Ci] = dY^T X of a 1x1 convolution ------------
-// The reduction runs along M, the slow axis of both operands, so the MFMA fragments (8 consecutive reduction elements
-// per lane) cannot be read from the global layout.  The loader transposes on the way in: a thread fetches an 8 (m) x
-// 8 (column) block as eight 16-byte loads, transposes it in registers (32 v_perm_b32), and writes eight 16-byte rows
-// of the SAME swizzled [column][64 m] LDS image the NT kernel uses -- so the compute core is shared.  Lanes of a
-// 16-lane group differ in the m-block (the swizzle slot) first, so every ds_write_b128 group covers 2 full 128-byte
-// rows: conflict-free.  Split-K over M with fp32 partial tiles and a fixed-order reduction (deterministic).
-struct TLoad { f32x4 r[8]; int nvalid; };
-
-// The loads are UNCONDITIONAL (addresses clamped into the tensor): a load under a branch makes the compiler lose count
-// of the outstanding loads and fall back to s_waitcnt vmcnt(0) at every use, which serialises the whole pipeline.
-// Rows past M are zeroed when the block is consumed (tn_store); columns past the tensor only reach masked outputs.
-__device__ __forceinline__ void tn_load(const u16* __restrict__ src, long long ld, long long m0, long long Mtot, int c0, int Ctot,
-                                        int t128, TLoad& t) {
-    const int mb = t128 & 7, cc = t128 >> 3;
-    int c = c0 + cc * 8;
-    c = c < Ctot ? c : Ctot - 8;
-    const long long mbase = m0 + mb * 8;
-    const long long left = Mtot - mbase;
-    t.nvalid = left >= 8 ? 8 : (left > 0 ? (int)left : 0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        long long m = mbase + j;
-        m = m < Mtot ? m : Mtot - 1;
-        t.r[j] = *reinterpret_cast<const f32x4*>(src + m * ld + c);
-    }
-}
-__device__ __forceinline__ void tn_store(float* stage, int t128, const TLoad& t) {
-    const int mb = t128 & 7, cc = t128 >> 3;
-    f32x4 r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                        // ragged end of M: rows past the tensor contribute zero
-        const float keep = j < t.nvalid ? 1.f : 0.f;     // (bf16 pairs: zero the dwords by an integer mask)
-        const unsigned msk = keep != 0.f ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[j][q] = __uint_as_float(__float_as_uint(t.r[j][q]) & msk);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        f32x4 o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const unsigned lo = __float_as_uint(r[2 * p][i >> 1]), hi = __float_as_uint(r[2 * p + 1][i >> 1]);
-            o[p] = __uint_as_float(__builtin_amdgcn_perm(hi, lo, (i & 1) ? 0x07060302u : 0x05040100u));
-        }
-        const int row = cc * 8 + i;
-        const int slot = mb ^ ((row >> 1) & 7);
-        *reinterpret_cast<f32x4*>(stage + row * 32 + slot * 4) = o;
-    }
-}
-
-// grid: ntiles * nsplit workgroups; virtual id v (XCD-contiguous): split = v / ntiles, tile = v % ntiles, so that the
-// tiles of one M range -- which share both operand slabs -- sit on one XCD.
-__global__ __launch_bounds__(256, 2) void cfl_gemm_bf16_tn_kernel(const u16* __restrict__ A, long long lda, const u16* __restrict__ B,
-                                                                  long long ldb, long long M, int N1, int N2, int ksteps_per_split,
-                                                                  float* __restrict__ part) {
-    constexpr int TM = 2, TN = 2, BM = 128, BN = 128, STAGE = (BM + BN) * 32;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int nt2 = (N2 + BN - 1) / BN, ntiles = ((N1 + BM - 1) / BM) * nt2;
-    const int v = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = v / ntiles, tile = v % ntiles;
-    const int row0 = (tile / nt2) * BM, col0 = (tile % nt2) * BN;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
-    const long long nk = (M + 63) / 64;
-    const long long kbeg = (long long)split * ksteps_per_split;
-    long long kend = kbeg + ksteps_per_split;
-    if (kend > nk) kend = nk;
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    const bool isA = threadIdx.x < 128;                 // waves 0,1 stage the A tile, waves 2,3 the B tile
-    const int t128 = threadIdx.x & 127;
-    const u16* src = isA ? A : B;
-    const long long ld = isA ? lda : ldb;
-    const int c0 = isA ? row0 : col0, Ctot = isA ? N1 : N2;
-    float* my_stage = lds + (isA ? 0 : BM * 32);
-    // Software pipeline, prefetch distance 2: two register sets alternate, so a global load has two K steps of MFMA
-    // work (and the other workgroup of the CU) to hide behind.  Every load is unconditional (past the end the last
-    // K step is simply loaded again and never stored): conditional loads would force vmcnt(0) waits.
-    if (kbeg >= kend) {                                   // an empty split still owns a (zero) partial tile
-        kend = kbeg;
-    }
-    TLoad t0, t1;
-    const long long klast = kend > kbeg ? kend - 1 : kbeg;
-    tn_load(src, ld, kbeg * 64, M, c0, Ctot, t128, t0);
-    tn_load(src, ld, (kbeg + 1 <= klast ? kbeg + 1 : klast) * 64, M, c0, Ctot, t128, t1);
-    if (kbeg < kend) tn_store(my_stage, t128, t0);
-    __syncthreads();
-    for (long long kt = kbeg; kt < kend; kt += 2) {
-        // LDS[0] holds step kt, t1 holds kt+1, t0 is free
-        tn_load(src, ld, (kt + 2 <= klast ? kt + 2 : klast) * 64, M, c0, Ctot, t128, t0);
-        tile_compute_bf16<TM, TN>(lds, lds + BM * 32, acc, lane, wr, wc);
-        if (kt + 1 < kend) tn_store(my_stage + STAGE, t128, t1);
-        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the loads that were just issued
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 1 >= kend) break;
-        // LDS[1] holds step kt+1, t0 holds kt+2, t1 is free
-        tn_load(src, ld, (kt + 3 <= klast ? kt + 3 : klast) * 64, M, c0, Ctot, t128, t1);
-        tile_compute_bf16<TM, TN>(lds + STAGE, lds + STAGE + BM * 32, acc, lane, wr, wc);
-        if (kt + 2 < kend) tn_store(my_stage, t128, t0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    float* out = part + (long long)split * N1 * N2;
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-            const int j = col0 + acc_col<TN>(wc, n, lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = row0 + acc_row<TM>(wr, m, r, lane);
-                if (i < N1 && j < N2) out[(long long)i * N2 + j] = acc[m][n][r];
-            }
-        }
-}
-
-// C = sum over splits (fixed order), written in the weight's dtype.  4 elements per thread, 8 independent 16-byte loads
-// in flight (a serial one-load-per-iteration loop is pure latency: 32 splits x ~1.5 us).
-__global__ __launch_bounds__(256) void cfl_gemm_tn_reduce_kernel(const float* __restrict__ part, int nsplit, long long n, void* out,
-                                                                 int out_bf16) {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= nsplit; k += 8) {
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (long long)(k + u) * n + i);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(part + (long long)k * n + i);
-    if (out_bf16) {
-        unsigned lo = f2bf(s[0]) | ((unsigned)f2bf(s[1]) << 16), hi = f2bf(s[2]) | ((unsigned)f2bf(s[3]) << 16);
-        reinterpret_cast<unsigned*>(out)[i / 2] = lo;
-        reinterpret_cast<unsigned*>(out)[i / 2 + 1] = hi;
-    } else {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + i) = s;
-    }
-}
-
-struct TnPlan { int ntiles, nsplit, kps; };
-inline TnPlan tn_plan(long long M, int N1, int N2) {
-    TnPlan p;
-    p.ntiles = cfl_cdiv(N1, 128) * cfl_cdiv(N2, 128);
-    const long long nk = (M + 63) / 64;
-    long long want = 512 / p.ntiles;                    // ~2 workgroups per CU
-    const long long cap = (32ll << 20) / ((long long)N1 * N2 * 4);   // partial tiles: at most 32 MB written + read back
-    if (want > cap) want = cap;
-    if (want < 1) want = 1;
-    if (want > nk) want = nk;
-    p.kps = (int)((nk + want - 1) / want);
-    p.nsplit = (int)((nk + p.kps - 1) / p.kps);
-    return p;
-}
-
 }  // namespace
 
 extern "C" int cfl_gemm_bf16_nt(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
@@ -714,27 +555,6 @@ extern "C" int cfl_gemm_bf16_nt_join(const void* A, long long lda, const void* B
     }
     if (N >= 128) return launch_nt<2, 2, 2, true>(Ao, Bo, M, N, (u16*)C, N, stream, (const u16*)add, mask);
     return launch_nt<2, 1, 2, true>(Ao, Bo, M, N, (u16*)C, N, stream, (const u16*)add, mask);
-}
-
-extern "C" size_t cfl_gemm_bf16_tn_ws_bytes(long long M, int N1, int N2) {
-    if (M <= 0 || N1 <= 0 || N2 <= 0) return 256;
-    return cfl_align256((size_t)tn_plan(M, N1, N2).nsplit * N1 * N2 * sizeof(float));
-}
-
-extern "C" int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, long long ldb, void* C, int c_bf16, long long M, int N1,
-                                int N2, void* ws, void* stream_) {
-    if (!A || !B || !C || !ws || M <= 0 || N1 <= 0 || N2 <= 0) return CFL_EINVAL;
-    if (N1 % 8 != 0 || N2 % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    const TnPlan p = tn_plan(M, N1, N2);
-    constexpr size_t LDS = (size_t)2 * 256 * 32 * sizeof(float);
-    CFL_SET_LDS(cfl_gemm_bf16_tn_kernel, LDS);
-    CFL_LAUNCH(K_GEMM_BF16, cfl_gemm_bf16_tn_kernel, dim3(p.ntiles * p.nsplit), dim3(256), LDS, stream, (const u16*)A, lda,
-               (const u16*)B, ldb, M, N1, N2, p.kps, (float*)ws);
-    const long long n = (long long)N1 * N2;
-    CFL_LAUNCH(K_GEMM_BF16, cfl_gemm_tn_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)ws,
-               p.nsplit, n, C, c_bf16);
-    return 0;
 }
 
 extern "C" int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream_) {

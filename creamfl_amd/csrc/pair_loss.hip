@@ -12,13 +12,21 @@
 // coef^T @ I  read K-contiguous operands and take the direct-to-LDS path); ws (floats):
 //   ni[N] nt[N] dd[N] rowsum[N] colsum[N] rowpart[NT*N] colpart[NT*N] part[NT*NT*4] It[D*N] Tt[D*N]
 // with NT = ceil(N / 64) (sized for the smallest tile).
+//
+// IMAGE MODE (round 4; N >= 2048, N % 32 == 0, D % 32 == 0, 3 x bf16-split precision): every GEMM operand lives in HBM as a
+// PRE-SPLIT image (tile_x3.h: a 128-byte block = [32 x bf16 hi | 32 x bf16 lo] of 32 consecutive k, byte for byte the fp32
+// size) -- the features and their transposes written once by cfl_pair_images_kernel (It / Tt region of ws, plus 2 N D floats
+// for the untransposed images), the coefficient matrix and its transpose written in split form by the FORWARD EPILOGUE.  All
+// three GEMMs then stage by LDS-DMA (global_load_lds) with no conversion VALU and no ds_write; the backward GEMMs (K = N:
+// 128 stages at N = 4096, one 128 x 128 tile per CU) run through a 4-stage LDS ring with counted vmcnt waits (three stages
+// in flight) instead of a double buffer whose every barrier waits for a fresh round trip to L2 / HBM.
 #include "common.h"
 #include "tile_x3.h"
 
 namespace {
 
 struct PairWs {
-    float *ni, *nt, *dd, *rowsum, *colsum, *rowpart, *colpart, *part, *it, *tt;
+    float *ni, *nt, *dd, *rowsum, *colsum, *rowpart, *colpart, *part, *it, *tt, *img_i, *img_t;
 };
 static PairWs pair_ws(void* ws, int N, int D) {
     const int NT = cfl_cdiv(N, 64);
@@ -27,9 +35,11 @@ static PairWs pair_ws(void* ws, int N, int D) {
     w.ni = p; p += N; w.nt = p; p += N; w.dd = p; p += N;
     w.rowsum = p; p += N; w.colsum = p; p += N;
     w.rowpart = p; p += (size_t)NT * N; w.colpart = p; p += (size_t)NT * N;
+    p = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);      // part is read as float4
     w.part = p; p += (size_t)4 * NT * NT;
     p = (float*)cfl_align256((size_t)(uintptr_t)p);          // 16-byte alignment for vector access
-    w.it = p; p += (size_t)D * N; w.tt = p;
+    w.it = p; p += (size_t)D * N; w.tt = p; p += (size_t)D * N;
+    w.img_i = p; p += (size_t)N * D; w.img_t = p;          // image mode only (N % 32 == 0, D % 32 == 0)
     return w;
 }
 
@@ -65,6 +75,33 @@ __global__ __launch_bounds__(256) void cfl_pair_prep_kernel(const float* __restr
     if (lane == 0) { ni[row] = sa; nt[row] = sb; dd[row] = sd; }
 }
 
+// IMAGE MODE.  One pass over I and T (blockIdx.z selects) writes the four operand images of the three GEMMs: the feature image
+// [N rows][D k] for S = I T^T and the TRANSPOSED feature image [D rows][N k] (B operand of the backward GEMMs: K runs over the
+// pair index).  32 x 32 element tiles through LDS; a thread splits 4 consecutive k of one row (8 bytes hi, 8 bytes lo).
+__global__ __launch_bounds__(256) void cfl_pair_images_kernel(const float* __restrict__ I, const float* __restrict__ T, int N, int D,
+                                                              float* img_i, float* img_t, float* img_it, float* img_tt) {
+    __shared__ float tile[32][33];
+    const float* src = blockIdx.z ? T : I;
+    char* img = reinterpret_cast<char*>(blockIdx.z ? img_t : img_i);
+    char* img_tr = reinterpret_cast<char*>(blockIdx.z ? img_tt : img_it);
+    const int i0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(long long)(i0 + r) * D + k0 + tx];
+    __syncthreads();
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;            // 32 rows x 8 quads
+    x3::bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { __bf16 h, l; x3::split1(tile[r][4 * q + e], h, l); hi[e] = h; lo[e] = l; }
+    char* blk = img + ((long long)(i0 + r) * D + k0) * 4;         // row i0 + r, k block k0 / 32
+    *reinterpret_cast<x3::bf16x4*>(blk + q * 8) = hi;
+    *reinterpret_cast<x3::bf16x4*>(blk + 64 + q * 8) = lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { __bf16 h, l; x3::split1(tile[4 * q + e][r], h, l); hi[e] = h; lo[e] = l; }
+    blk = img_tr + ((long long)(k0 + r) * N + i0) * 4;            // row k0 + r of the transpose, k block i0 / 32
+    *reinterpret_cast<x3::bf16x4*>(blk + q * 8) = hi;
+    *reinterpret_cast<x3::bf16x4*>(blk + 64 + q * 8) = lo;
+}
+
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N, const float* __restrict__ a_dev, const float* __restrict__ b_dev, float eps,
                                                            const float* __restrict__ ni, const float* __restrict__ nt,
@@ -83,7 +120,19 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
     float* cs = lds;                                          // [BM][BN+1] coefficient tile (after the K loop)
     float pos = 0.f, neg = 0.f, da = 0.f, db = 0.f;
     f32x16 acc[TM][TN];
-    if (x3mode) x3::tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
+    if (x3mode == 2)         // A, B are pre-split images (cfl_pair_images_kernel): LDS-DMA staging, bf16 x 3 compute
+        tile_gemm_seq_glds_with<TM, TN>(A, B, 1, [&](int) { return TileDesc{row0, col0, 0, A.kdim}; }, lds,
+                                        [&](int, const f32x16 (&a)[TM][TN]) {
+#pragma unroll
+                                            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                                                for (int n = 0; n < TN; ++n) acc[m][n] = a[m][n];
+                                        },
+                                        [](const float* sa, const float* sb, f32x16 (&c)[TM][TN], int ln, int r_, int c_) {
+                                            x3::compute<TM, TN>(reinterpret_cast<const char*>(sa), reinterpret_cast<const char*>(sb), c,
+                                                                ln, r_, c_);
+                                        });
+    else if (x3mode) x3::tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
     else if (glds_ok(A, B)) tile_gemm_glds<TM, TN>(A, B, row0, col0, 0, A.kdim, lds, acc);
     else tile_gemm<TM, TN, true, true>(A, B, row0, col0, 0, A.kdim, lds, acc, XfIdentity());
 #pragma unroll
@@ -139,7 +188,34 @@ __global__ __launch_bounds__(256) void cfl_pair_fwd_kernel(Opnd A, Opnd B, int N
         for (int i = 0; i < C::BM; ++i) s += cs[i * CLD + cj];
         if (col0 + cj < N) colpart[(size_t)ti * N + col0 + cj] = s;
     }
-    if (coef) {
+    if (coef && x3mode == 2) {
+        // the coefficient tile and its transpose as split IMAGES (the A operands of the two backward GEMMs): per quad of 4
+        // consecutive k one 8-byte hi store and one 8-byte lo store; 8 threads fill one 128-byte block (N % 32 == 0 here)
+        char* ci = reinterpret_cast<char*>(coef);
+        char* ct = reinterpret_cast<char*>(coef + (long long)N * N);
+        for (int e = t; e < C::BM * C::BN / 4; e += 256) {
+            const int lr = e / (C::BN / 4), q = e % (C::BN / 4);            // row lr, columns 4 q .. 4 q + 3
+            if (row0 + lr < N && col0 + 4 * q < N) {
+                x3::bf16x4 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { __bf16 h, l; x3::split1(cs[lr * CLD + 4 * q + u], h, l); hi[u] = h; lo[u] = l; }
+                char* blk = ci + ((long long)(row0 + lr) * N + col0 + ((4 * q) & ~31)) * 4;
+                *reinterpret_cast<x3::bf16x4*>(blk + ((4 * q) & 31) * 2) = hi;
+                *reinterpret_cast<x3::bf16x4*>(blk + 64 + ((4 * q) & 31) * 2) = lo;
+            }
+        }
+        for (int e = t; e < C::BM * C::BN / 4; e += 256) {
+            const int lc = e / (C::BM / 4), q = e % (C::BM / 4);            // transposed: row = column lc, k = rows 4 q .. 4 q + 3
+            if (col0 + lc < N && row0 + 4 * q < N) {
+                x3::bf16x4 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { __bf16 h, l; x3::split1(cs[(4 * q + u) * CLD + lc], h, l); hi[u] = h; lo[u] = l; }
+                char* blk = ct + ((long long)(col0 + lc) * N + row0 + ((4 * q) & ~31)) * 4;
+                *reinterpret_cast<x3::bf16x4*>(blk + ((4 * q) & 31) * 2) = hi;
+                *reinterpret_cast<x3::bf16x4*>(blk + 64 + ((4 * q) & 31) * 2) = lo;
+            }
+        }
+    } else if (coef) {
         float* coef_t = coef + (long long)N * N;
         for (int e = t; e < C::BM * C::BN; e += 256) {
             const int lr = e / C::BN, lc = e % C::BN;
@@ -159,8 +235,10 @@ __global__ __launch_bounds__(256) void cfl_pair_final_kernel(const float* part, 
     __shared__ float red[4];
     if (blockIdx.x == 0) {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = threadIdx.x; t < ntiles; t += 256)
-            for (int e = 0; e < 4; ++e) v[e] += part[(size_t)t * 4 + e];
+        for (int t = threadIdx.x; t < ntiles; t += 256) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(part + (size_t)t * 4);
+            for (int e = 0; e < 4; ++e) v[e] += q[e];
+        }
         for (int e = 0; e < 4; ++e) v[e] = block_sum_256(v[e], red);
         if (threadIdx.x == 0) {
             out8[0] = 2.f * (v[0] + v[1]); out8[1] = v[0]; out8[2] = v[1]; out8[3] = v[2]; out8[4] = v[3];
@@ -169,12 +247,23 @@ __global__ __launch_bounds__(256) void cfl_pair_final_kernel(const float* part, 
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < N) {
-        float s = 0.f;
-        for (int t = 0; t < ntc; ++t) s += rowpart[(size_t)t * N + i];
-        rowsum[i] = s;
-        s = 0.f;
-        for (int t = 0; t < ntr; ++t) s += colpart[(size_t)t * N + i];
-        colsum[i] = s;
+        // 8 independent loads in flight per trip (one load per trip was a chain of ntc + ntr L2 round trips: 19 us at N = 4096);
+        // the summation order stays fixed (t ascending) => deterministic
+        auto colsum_of = [&](const float* src, int n) {
+            float s = 0.f;
+            int t = 0;
+            for (; t + 8 <= n; t += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(t + u) * N + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; t < n; ++t) s += src[(size_t)t * N + i];
+            return s;
+        };
+        rowsum[i] = colsum_of(rowpart, ntc);
+        colsum[i] = colsum_of(colpart, ntr);
     }
 }
 
@@ -220,6 +309,81 @@ __global__ __launch_bounds__(256) void cfl_pair_bwd_kernel(const float* __restri
         }
 }
 
+// IMAGE MODE backward: the same two GEMMs on pre-split operand images (coefficient image / its transpose written by the
+// forward epilogue, transposed feature images by cfl_pair_images_kernel), 128 x 128 tiles, K = N.  At N = 4096, D = 512 the
+// launch is exactly one tile per CU (256 workgroups, one wave per SIMD) with 128 K stages each: nothing else on the CU hides a
+// stage's round trip to L2 / HBM, so the stages run through a ring of NS LDS buffers with NS - 1 of them in flight -- the wait
+// before a stage's MFMA block is a COUNTED s_waitcnt (8 LDS-DMA instructions per wave and stage; the younger stages stay
+// outstanding) followed by a bare s_barrier; __syncthreads() would drain vmcnt to 0 and serialise memory latency with compute.
+template <int NS>
+__global__ __launch_bounds__(256) void cfl_pair_bwd_img_kernel(const float* __restrict__ I, const float* __restrict__ T,
+                                                               const float* __restrict__ coef, const float* __restrict__ img_it,
+                                                               const float* __restrict__ img_tt, int N, int D,
+                                                               const float* __restrict__ rowsum, const float* __restrict__ colsum,
+                                                               const float* __restrict__ gout, float* dI, float* dT) {
+    constexpr int TM = 2, TN = 2, BM = 128, BN = 128, STAGE = (BM + BN) * 32;      // floats per stage (32 KB)
+    static_assert(NS == 4, "the counted waits below are written for three stages in flight");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ntc = (D + BN - 1) / BN, ntr = (N + BM - 1) / BM;
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const int row0 = ti * BM, col0 = tj * BN;
+    const bool second = blockIdx.z != 0;
+    const float* X = second ? T : I;
+    const Opnd Ao{second ? coef + (long long)N * N : coef, N, N, N, 1};
+    const Opnd Bo{second ? img_it : img_tt, N, D, N, 1};
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int nk = N / 32;
+    auto issue = [&](int kt) {
+        float* st = lds + (kt % NS) * STAGE;
+        glds_stage<BM>(Ao, row0, kt * 32, st);
+        glds_stage<BN>(Bo, col0, kt * 32, st + BM * 32);
+    };
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s);
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt must have landed (this wave's part: vmcnt; everybody's: the barrier); stages kt + 1, kt + 2 may still fly.
+        // The barrier also says that every wave is done reading the buffer stage kt + 3 is about to overwrite (stage kt - 1).
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        const char* sa = reinterpret_cast<const char*>(lds + (kt % NS) * STAGE);
+        x3::compute<TM, TN>(sa, sa + BM * 128, acc, lane, wr, wc);
+    }
+    const float* sums = second ? colsum : rowsum;
+    float* out = second ? dT : dI;
+    const float g = gout[0];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int j = col0 + acc_col<TN>(wc, n, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = row0 + acc_row<TM>(wr, m, r, lane);
+                if (i < N && j < D) {
+                    const long long o = (long long)i * D + j;
+                    out[o] = g * (sums[i] * X[o] - acc[m][n][r]);
+                }
+            }
+        }
+}
+
+// image mode: 3 x bf16-split precision, shapes the split images tile without padding, and enough 128 x 128 tiles to fill the
+// chip (below N = 2048 the smaller tiles of the register-staged path give more workgroups)
+static inline bool pair_image_mode(int N, int D) {
+    return !cfl_get_exact_gemm() && N >= 2048 && N % 32 == 0 && D % 32 == 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -228,7 +392,8 @@ size_t cfl_pair_loss_ws_bytes(int N, int D) {
     (void)D;
     if (N <= 0) return 256;
     const size_t NT = (size_t)cfl_cdiv(N, 64);
-    return cfl_align256((5 * (size_t)N + 2 * NT * N + 4 * NT * NT + 2 * (size_t)N * (D > 0 ? D : 1)) * sizeof(float)) + 512;
+    // 2 N D: It, Tt (image mode: their split images); + 2 N D: the untransposed feature images of image mode
+    return cfl_align256((5 * (size_t)N + 2 * NT * N + 4 * NT * NT + 4 * (size_t)N * (D > 0 ? D : 1)) * sizeof(float)) + 512;
 }
 
 int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float* a_dev, const float* b_dev, float eps,
@@ -236,13 +401,18 @@ int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float*
     if (!I || !T || !a_dev || !b_dev || !out8 || !ws || N <= 0 || D <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     PairWs w = pair_ws(ws, N, D);
-    if (coef)
+    const bool img = pair_image_mode(N, D);
+    if (img)        // the four operand images in one pass (the transposed ones are only read by the backward, but cost nothing extra)
+        CFL_LAUNCH(K_PAIR_PREP, cfl_pair_images_kernel, dim3(D / 32, N / 32, 2), dim3(256), 0, stream, I, T, N, D, w.img_i, w.img_t,
+                   w.it, w.tt);
+    else if (coef)
         CFL_LAUNCH(K_PAIR_PREP, cfl_pair_transpose_kernel, dim3(cfl_cdiv(D, 32), cfl_cdiv(N, 32), 2), dim3(256), 0, stream,
                    I, T, N, D, w.it, w.tt);
     CFL_LAUNCH(K_PAIR_PREP, cfl_pair_prep_kernel, dim3(cfl_cdiv(N, 4)), dim3(256), 0, stream, I, T, N, D, w.ni, w.nt, w.dd);
-    Opnd A{I, D, N, D, cfl_opnd_vec(I, D, D)};
-    Opnd B{T, D, N, D, cfl_opnd_vec(T, D, D)};
-    const int x3mode = cfl_get_exact_gemm() ? 0 : 1;      // S = I T^T on the 3 x bf16-split MFMA (positives stay exact: dd)
+    Opnd A{img ? w.img_i : I, D, N, D, img ? 1 : cfl_opnd_vec(I, D, D)};
+    Opnd B{img ? w.img_t : T, D, N, D, img ? 1 : cfl_opnd_vec(T, D, D)};
+    // S = I T^T on the 3 x bf16-split MFMA (positives stay exact: dd); 2 = from pre-split images, coefficients written as images
+    const int x3mode = cfl_get_exact_gemm() ? 0 : (img ? 2 : 1);
     // 128x128 tiles once they fill the chip, 64x64 tiles below that (latency-bound regime)
     const bool big = (long long)cfl_cdiv(N, 128) * cfl_cdiv(N, 128) >= 256;
     int ntr, ntc;
@@ -268,6 +438,13 @@ int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, 
     if (!I || !T || !coef || !gout_dev || !dI || !dT || !ws || N <= 0 || D <= 0) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     PairWs w = pair_ws(ws, N, D);
+    if (pair_image_mode(N, D)) {          // coef / It / Tt hold split images (cfl_pair_loss_fwd took the same branch)
+        constexpr int NS = 4, LDSB = NS * 256 * 128;
+        CFL_SET_LDS((cfl_pair_bwd_img_kernel<NS>), LDSB);
+        CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_img_kernel<NS>), dim3(cfl_cdiv(N, 128) * cfl_cdiv(D, 128), 1, 2), dim3(256), LDSB, stream,
+                   I, T, coef, w.it, w.tt, N, D, w.rowsum, w.colsum, gout_dev, dI, dT);
+        return 0;
+    }
     const int vecN = (cfl_opnd_vec(coef, N, N) && cfl_vec_ok(w.it, N) && cfl_vec_ok(w.tt, N)) ? 1 : 0;
     const int x3mode = cfl_get_exact_gemm() ? 0 : 1;
     // tile choice by workgroup count (two GEMMs share the launch, grid.z = 2): 128x128 when that alone gives >= 2

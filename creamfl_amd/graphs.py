@@ -1,0 +1,75 @@
+"""HIP-graph capture of launch-bound training steps.
+
+The client contrast step (src/algorithms/ClientTrainer.py:376-421: features -> inter / intra contrast against the frozen global
+banks -> backward -> SGD step) is a few hundred small launches per batch on a ResNet-18-sized model; the contrast terms
+themselves are 3 kernels (44 us at B = 128, D = 256) behind ~135 us of Python / autograd / ctypes work per step.  The C ABI
+allocates nothing and never synchronises, so the WHOLE step replays from one hipGraph: `GraphedStep` runs the first calls
+eagerly (they are real training steps: the libraries pick their kernels, optimizers create their state, the bank images are
+built), captures the next call, and from then on copies each batch into the captured input tensors and replays.
+
+Contract of the wrapped function: fixed tensor shapes / dtypes, every input a device tensor (or copied into one here), no host
+synchronisation and no data-dependent Python control flow inside, outputs = tensors (returned as the graph's static outputs:
+valid until the next call).  A call whose input shapes differ from the captured ones (the ragged last batch of an epoch) runs
+eagerly.
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, fn, warmup=3, enabled=True):
+        self.fn = fn
+        self.warmup = max(1, int(warmup))
+        self.enabled = bool(enabled) and torch.cuda.is_available()
+        self.calls = 0
+        self.replays = 0
+        self.graph = None
+        self.static_in = None
+        self.static_out = None
+        self.sig = None
+        self.failed = None
+
+    @staticmethod
+    def _signature(inputs):
+        return tuple((tuple(t.shape), t.dtype) for t in inputs)
+
+    def _copy_in(self, inputs):
+        for s, t in zip(self.static_in, inputs):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t, non_blocking=True)
+
+    def _capture(self, inputs):
+        self.static_in = [torch.empty_like(t) if t.is_cuda else torch.empty(t.shape, dtype=t.dtype, device=self._device) for t in inputs]
+        self._copy_in(inputs)
+        self.sig = self._signature(inputs)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                out = self.fn(*self.static_in)
+        except Exception as e:                                    # noqa: BLE001  (capture not possible: stay eager, say why once)
+            self.failed = repr(e)[:300]
+            self.enabled = False
+            torch.cuda.synchronize()
+            return False
+        self.graph, self.static_out = graph, out
+        return True
+
+    def __call__(self, *inputs, device=None):
+        """inputs: tensors (host or device).  Returns fn's outputs."""
+        self.calls += 1
+        self._device = device if device is not None else next((t.device for t in inputs if t.is_cuda), torch.device('cuda'))
+        if not self.enabled:
+            return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])
+        if self.graph is None:
+            if self.calls <= self.warmup:
+                return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])           # eager: real steps
+            if not self._capture(inputs):
+                return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])
+            self.graph.replay()                                   # capture records, it does not execute: this runs the step
+            self.replays += 1
+            return self.static_out
+        if self._signature(inputs) != self.sig:
+            return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])               # ragged batch: eager
+        self._copy_in(inputs)
+        self.graph.replay()
+        self.replays += 1
+        return self.static_out

@@ -14,8 +14,20 @@ import torch
 from . import _lib
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _raw_stream(device):
+    """The current HIP stream of `device` as an integer handle.  torch.cuda.current_stream() builds a Stream object per call
+    (~6 us of host time, paid by every one of the ~650 hand-written launches of a server step); the raw getter is ~0.3 us."""
+    if _RAW_STREAM is not None:
+        idx = device.index
+        return _RAW_STREAM(idx if idx is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(_raw_stream(t.device))
 
 
 def _ptr(t):
@@ -128,8 +140,7 @@ def _contrast_state(device, ws_bytes):
 
 
 import os as _os
-_BANK_EXACT = bool(_os.environ.get('CFL_BANK_EXACT'))       # A/B switch: round-1 exact-fp32 two-pass kernels
-_BANK_NOIMG = bool(_os.environ.get('CFL_BANK_NOIMG'))       # A/B switch: round-2 bank pass (fp32 bank, 128-row groups)
+_BANK_EXACT = bool(_os.environ.get('CFL_BANK_EXACT'))       # A/B switch: the exact-fp32 two-pass kernels (csrc/bank.hip), the one reference path
 
 # Pre-split bank images (csrc/bank_gsplit.h).  The global banks are frozen while a client trains (ClientTrainer.py:369-372:
 # one pair of global feature tensors per round, hundreds of steps against them), so the fp32 -> (bf16 hi, bf16 lo) image is
@@ -163,7 +174,7 @@ def bank_image(G):
         ent[3] = _bank_tick[0]
         return ent[2]
     img = ent[2] if ent is not None else torch.empty(int(lib.cfl_bank_image_bytes(M, D)), dtype=torch.uint8, device=G.device)
-    _lib.check(lib.cfl_bank_image_build(G.data_ptr(), M, D, img.data_ptr(), torch.cuda.current_stream(G.device).cuda_stream),
+    _lib.check(lib.cfl_bank_image_build(G.data_ptr(), M, D, img.data_ptr(), _raw_stream(G.device)),
                'cfl_bank_image_build')
     BANK_IMAGE_BUILDS[0] += 1
     _BANK_IMAGES[key] = [G, G._version, img, _bank_tick[0]]
@@ -173,31 +184,26 @@ def bank_image(G):
 
 
 def bank_image_supported(B, M, D):
-    return (not _BANK_EXACT) and (not _BANK_NOIMG) and bool(_lib.load().cfl_bank_gsplit_supported(int(B), int(M), int(D)))
+    return (not _BANK_EXACT) and _bank_plan(int(B), int(M), int(D), False) is not None
 
 
 _BANK_PLAN = {}          # (B, M, D, need_grad) -> workspace bytes, or None when the fused path does not take the shape
 
 
-def _bank_plan(B, M, D, need, img=False):
-    key = (B, M, D, need, img)
+def _bank_plan(B, M, D, need):
+    key = (B, M, D, need)
     v = _BANK_PLAN.get(key, -1)
     if v == -1:
         lib = _lib.load()
-        if img:
-            v = int(lib.cfl_bank_gsplit_ws_bytes(B, M, D, int(need))) if lib.cfl_bank_gsplit_supported(B, M, D) else None
-        else:
-            v = int(lib.cfl_bank_attn_ws_bytes(B, M, D, int(need))) if lib.cfl_bank_attn_supported(B, M, D) else None
+        v = int(lib.cfl_bank_gsplit_ws_bytes(B, M, D, int(need))) if lib.cfl_bank_gsplit_supported(B, M, D) else None
         _BANK_PLAN[key] = v
     return v
 
 
 def bank_attn_supported(B, M, D):
-    """True when the single-pass 3 x bf16-split kernels take this shape: D <= 768 on a pre-split bank image
-    (csrc/bank_gsplit.h), D <= 256 on the fp32 bank (csrc/bank_attn.hip, CFL_BANK_NOIMG=1); D % 4 == 0."""
-    if _BANK_EXACT:
-        return False
-    return bank_image_supported(B, M, D) or _bank_plan(int(B), int(M), int(D), False) is not None
+    """True when the single-pass 3 x bf16-split kernels take this shape: D <= 768, D % 4 == 0, on a pre-split bank image
+    (csrc/bank_gsplit.h).  Other widths run the exact-fp32 two-pass kernels (csrc/bank.hip)."""
+    return bank_image_supported(B, M, D)
 
 
 class _ClientContrastFn(torch.autograd.Function):
@@ -215,27 +221,21 @@ class _ClientContrastFn(torch.autograd.Function):
         out = torch.empty(8, dtype=torch.float32, device=dev)          # out5 = out[0:5]; the differentiable loss = out[5]
         aux = torch.empty(2, B, dtype=torch.float32, device=dev) if (mode & 1) else None        # lse, pos
         dFs = torch.empty(2, B, D, dtype=torch.float32, device=dev) if need else None            # inter, moon unit gradients
-        # image path: whenever the inter term streams the bank; beyond D = 256 it is the only single-pass path (its finish
-        # launch also serves the intra-only mode)
-        use_img = bank_image_supported(B, M, D) and (bool(mode & 1) or D > 256)
-        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need), use_img))
+        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need)))
         p_out = out.data_ptr()
         p_aux = aux.data_ptr() if aux is not None else 0
         p_dfs = dFs.data_ptr() if need else 0
         tail = (B, M, D, b_div, inv_tau, weight, mode, int(need),
                 p_out, p_aux, p_aux + 4 * B if p_aux else 0, p_dfs if (need and (mode & 1)) else 0,
                 p_dfs + 4 * B * D if (need and (mode & 2)) else 0, st['ws'].data_ptr(), st['sync'].data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream)
+                _raw_stream(dev))
         p_same = G_same.data_ptr() if G_same is not None else 0
         p_old = F_old.data_ptr() if F_old is not None else 0
-        if use_img:
-            # bank pass on the pre-split image of G_other (built once per bank version), 32-row groups (csrc/bank_gsplit.h)
-            _lib.check(lib.cfl_client_contrast_img_fwd(F.data_ptr(), bank_image(G_other).data_ptr() if (mode & 1) else 0,
-                                                       G_other.data_ptr() if G_other is not None else 0, p_same,
-                                                       idx.data_ptr(), p_old, *tail), 'cfl_client_contrast_img_fwd')
-        else:
-            _lib.check(lib.cfl_client_contrast_fwd(F.data_ptr(), G_other.data_ptr() if G_other is not None else 0, p_same,
-                                                   idx.data_ptr(), p_old, *tail), 'cfl_client_contrast_fwd')
+        # bank pass on the pre-split image of G_other (built once per bank version), 32-row groups (csrc/bank_gsplit.h); with the
+        # inter term off only the finish launch runs
+        _lib.check(lib.cfl_client_contrast_img_fwd(F.data_ptr(), bank_image(G_other).data_ptr() if (mode & 1) else 0,
+                                                   G_other.data_ptr() if G_other is not None else 0, p_same,
+                                                   idx.data_ptr(), p_old, *tail), 'cfl_client_contrast_img_fwd')
         ctx.mode = mode
         ctx.save_for_backward(out, dFs if need else out)
         ctx.has = need
@@ -255,7 +255,7 @@ class _ClientContrastFn(torch.autograd.Function):
         dF = torch.empty(B, D, dtype=torch.float32, device=dFs.device)
         p = dFs.data_ptr()
         _lib.check(lib.cfl_client_contrast_bwd(p if (ctx.mode & 1) else 0, p + 4 * B * D if (ctx.mode & 2) else 0, out.data_ptr(),
-                                               g.data_ptr(), B, D, dF.data_ptr(), torch.cuda.current_stream(dF.device).cuda_stream),
+                                               g.data_ptr(), B, D, dF.data_ptr(), _raw_stream(dF.device)),
                    'cfl_client_contrast_bwd')
         return dF, None, None, None, None, None, None, None, None
 
@@ -300,9 +300,8 @@ class _MMClientContrastFn(torch.autograd.Function):
         out = torch.empty(8, dtype=torch.float32, device=dev)
         aux = torch.empty(2, 2, B, dtype=torch.float32, device=dev) if (mode & 1) else None     # [modality][lse, pos][B]
         dFs = torch.empty(2, 2, B, D, dtype=torch.float32, device=dev) if need else None          # [inter, moon][modality][B, D]
-        use_img = bank_image_supported(B, M, D) and (bool(mode & 1) or D > 256)
-        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need), use_img))
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        st = _contrast_state(dev, _bank_plan(B, M, D, bool(need)))
+        stream = _raw_stream(dev)
         for k, (F, G_other, G_same, F_old) in enumerate(((F_img, G_txt, G_img, Fo_img), (F_txt, G_img, G_txt, Fo_txt))):
             p_aux = aux.data_ptr() + 8 * B * k if aux is not None else 0
             p_dfi = dFs.data_ptr() + 4 * B * D * k if (need and (mode & 1)) else 0
@@ -312,13 +311,9 @@ class _MMClientContrastFn(torch.autograd.Function):
             p_other = G_other.data_ptr() if (mode & 1) else 0
             p_same = G_same.data_ptr() if (mode & 2) else 0
             p_old = F_old.data_ptr() if (mode & 2) else 0
-            if use_img:
-                _lib.check(lib.cfl_client_contrast_img_fwd(F.data_ptr(), bank_image(G_other).data_ptr() if (mode & 1) else 0,
-                                                           p_other, p_same, idx.data_ptr(), p_old, *tail),
-                           'cfl_client_contrast_img_fwd')
-            else:
-                _lib.check(lib.cfl_client_contrast_fwd(F.data_ptr(), p_other, p_same, idx.data_ptr(), p_old, *tail),
-                           'cfl_client_contrast_fwd')
+            _lib.check(lib.cfl_client_contrast_img_fwd(F.data_ptr(), bank_image(G_other).data_ptr() if (mode & 1) else 0,
+                                                       p_other, p_same, idx.data_ptr(), p_old, *tail),
+                       'cfl_client_contrast_img_fwd')
         ctx.mode = mode
         ctx.save_for_backward(out, dFs if need else out)
         ctx.has = need
@@ -338,7 +333,7 @@ class _MMClientContrastFn(torch.autograd.Function):
         dF = torch.empty(2, B, D, dtype=torch.float32, device=dFs.device)
         p = dFs.data_ptr()
         _lib.check(lib.cfl_client_contrast_bwd(p if (ctx.mode & 1) else 0, p + 8 * B * D if (ctx.mode & 2) else 0, out.data_ptr(),
-                                               g.data_ptr(), 2 * B, D, dF.data_ptr(), torch.cuda.current_stream(dF.device).cuda_stream),
+                                               g.data_ptr(), 2 * B, D, dF.data_ptr(), _raw_stream(dF.device)),
                    'cfl_client_contrast_bwd')
         return dF[0], dF[1], None, None, None, None, None, None, None, None
 
@@ -366,8 +361,7 @@ def mm_client_contrast_fused(out_img, out_txt, global_img, global_txt, d_idx, ol
 
 
 class _BankInterFn(torch.autograd.Function):
-    """Round-1 exact-fp32 two-pass path (v_mfma_f32_32x32x2_f32): kept for D > 256 / D % 4 != 0 and as the A/B reference
-    (CFL_BANK_EXACT=1)."""
+    """Exact-fp32 two-pass path (v_mfma_f32_32x32x2_f32): D > 768 / D % 4 != 0, and the one A/B reference (CFL_BANK_EXACT=1)."""
 
     @staticmethod
     def forward(ctx, F, G, idx, inv_tau):
@@ -1023,36 +1017,6 @@ def gemm_bf16_nt(a, b, out=None, variant=0, add=None, mask=None):
     return out
 
 
-WGRAD_TN = [0]             # measurement knob: deferred 1x1 weight gradients on cfl_gemm_bf16_tn instead of the library
-_WS_SIDE = {}
-
-
-def _gemm_bf16_tn_side(a, b):
-    lib = _lib.load()
-    M, N1 = a.shape
-    N2 = b.shape[1]
-    out = torch.empty(N1, N2, dtype=torch.bfloat16, device=a.device)
-    need = int(lib.cfl_gemm_bf16_tn_ws_bytes(M, N1, N2))
-    ws = _WS_SIDE.get(a.device)
-    if ws is None or ws.numel() < need:
-        ws = _WS_SIDE[a.device] = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=a.device)
-    _lib.check(lib.cfl_gemm_bf16_tn(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), 1, M, N1, N2, _ptr(ws), _stream(a)),
-               'cfl_gemm_bf16_tn')
-    return out
-
-
-def gemm_bf16_tn(a, b, out_dtype=torch.bfloat16):
-    """out[N1, N2] = a[M, N1]^T @ b[M, N2] (reduction along the slow axis; csrc/gemm_bf16.hip: cfl_gemm_bf16_tn)."""
-    lib = _lib.load()
-    M, N1 = a.shape
-    N2 = b.shape[1]
-    out = torch.empty(N1, N2, dtype=out_dtype, device=a.device)
-    ws = _ws(lib.cfl_gemm_bf16_tn_ws_bytes(M, N1, N2), a.device)
-    _lib.check(lib.cfl_gemm_bf16_tn(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(out_dtype == torch.bfloat16), M, N1, N2,
-                                    _ptr(ws), _stream(a)), 'cfl_gemm_bf16_tn')
-    return out
-
-
 # ---- all weight transposes of a backward pass in one launch -----------------------------------------------------------
 _WT = {'key': None, 'meta': None, 'flat': None, 'views': {}, 'tiles': 0, 'n': 0, 'valid': False}
 
@@ -1196,16 +1160,7 @@ class _ConvSplitFn(torch.autograd.Function):
                     # what AccumulateGrad would have done (a tensor handed over now and filled later does not work:
                     # AccumulateGrad clones a gradient that something else still references).
                     def task(main, side, args=args, weight=weight):
-                        if (WGRAD_TN[0] and weight.shape[2] == 1 and stride == 1 and weight.dtype == torch.bfloat16
-                                and args[1].is_contiguous(memory_format=torch.channels_last)):
-                            # measurement knob (tools/ab_step.py --knob wgradtn): the 1x1 weight gradient dW = dY^T X on the
-                            # hand-written TN GEMM (own split-K workspace: the shared one belongs to the main stream)
-                            dy_, x_ = args[0], args[1]
-                            Mr = dy_.shape[0] * dy_.shape[2] * dy_.shape[3]
-                            g = _gemm_bf16_tn_side(dy_.permute(0, 2, 3, 1).reshape(Mr, dy_.shape[1]),
-                                                   x_.permute(0, 2, 3, 1).reshape(Mr, x_.shape[1])).view(weight.shape)
-                        else:
-                            g = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                        g = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
                         args[0].record_stream(side)
                         args[1].record_stream(side)
                         g.record_stream(main)

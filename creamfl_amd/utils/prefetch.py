@@ -32,23 +32,44 @@ class DevicePrefetcher:
         self.depth = max(1, int(depth))
         self.pin = pin
         self.dataset = getattr(loader, 'dataset', None)
+        self._pool = {}
 
     def __len__(self):
         return len(self.loader)
 
-    def _stage(self, batch, stream):
-        out, moved = [], False
+    def _pinned_like(self, item, slot):
+        """A reusable pinned staging buffer for pageable tensors of this shape (hipHostMalloc per batch costs more than the copy:
+        154 MB of images pinned afresh every step held the loop at 0.88 of the resident step).  `slot` cycles over depth + 2
+        buffers; a buffer is reused only after the copy that last read it has completed (its event)."""
+        key = (slot, tuple(item.shape), item.dtype)
+        ent = self._pool.get(key)
+        if ent is None:
+            ent = self._pool[key] = [torch.empty(item.shape, dtype=item.dtype, pin_memory=True), None]
+        if ent[1] is not None:
+            ent[1].synchronize()                     # (copy thread only: the training thread never waits here)
+        return ent
+
+    def _stage(self, batch, stream, slot=0):
+        out, moved, used = [], False, []
         with torch.cuda.stream(stream):
             for item in batch:
                 if torch.is_tensor(item) and not item.is_cuda:
-                    src = item.pin_memory() if (self.pin and not item.is_pinned()) else item
-                    item = src.to(self.device, non_blocking=True)    # the pinned-host allocator keeps `src` alive until the copy ran
+                    if self.pin and not item.is_pinned() and item.numel() >= 4096:
+                        ent = self._pinned_like(item, slot)
+                        ent[0].copy_(item)
+                        src = ent[0]
+                        used.append(ent)
+                    else:
+                        src = item
+                    item = src.to(self.device, non_blocking=True)    # (a loader's own pinned tensors: the host allocator keeps them alive)
                     moved = True
                 out.append(item)
         ev = None
         if moved:
             ev = torch.cuda.Event()
             ev.record(stream)
+            for ent in used:
+                ent[1] = ev
         return tuple(out) if isinstance(batch, tuple) else out, ev
 
     def __iter__(self):
@@ -71,8 +92,8 @@ class DevicePrefetcher:
         def worker():
             try:
                 torch.cuda.set_device(self.device)
-                for batch in self.loader:
-                    if not put(self._stage(batch, h2d)):
+                for n, batch in enumerate(self.loader):
+                    if not put(self._stage(batch, h2d, n % (self.depth + 2))):
                         return
                 put(None)
             except BaseException as e:          # re-raised in the consumer

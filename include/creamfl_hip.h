@@ -41,12 +41,6 @@ int cfl_prof_select(int kernel_id);           /* time only this kernel (-1 = all
 int cfl_prof_reset(void);
 int cfl_prof_query(int kernel_id, long long* launches, double* total_ms);
 
-/* ---- calibration probe: C[M,N] = A[M,K] * B[N,K]^T on the fp32-MFMA tile GEMM every A1/A3/A5 kernel is built on
- * (no reference counterpart; used by tools/kernel_bench.py and the tile_gemm parity test). */
-int cfl_gemm_nt(const float* A, const float* B, int M, int N, int K, float* C, void* stream);
-/* K-loop ablation of the same tile (mode 0 MFMA only .. 4 full loop), 1024 workgroups x nk K-steps; A, B [M>=4096, K]. */
-int cfl_gemm_ablate(const float* A, const float* B, int M, int K, int mode, int nk, float* sink, void* stream);
-
 /* ---- A1: all-pairs soft-contrastive loss ------------------------------------------------
  * Replaces MCSoftContrastiveLoss.forward / _compute_loss / pairwise_sampling / full_sampling /
  * batchwise_cdist / soft_contrastive_nll  (src/criterions/probemb.py:7-86,150-256) for 2-D
@@ -94,9 +88,10 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
  * (Fold_b - G_same[idx_b])  (gradient for an upstream gradient of 1; may be NULL).
  * `B_div` is the CE mean divisor (B, or 2B when two modalities are stacked, MMClientTrainer.py:188).
  */
-/* ---- A3 + A4 fused, single pass over the bank (csrc/bank_attn.hip) -------------------------
+/* ---- A3 + A4 fused, single pass over the bank (csrc/bank_attn.hip: finish + backward; csrc/bank_gsplit.h: the bank pass) ----
  * Replaces the loop body src/algorithms/ClientTrainer.py:386-419 (and the inter-only :493-502 / intra-only :458-468
- * variants, and MMClientTrainer.py:173-206 with B_div = 2B) for D <= 256, D % 4 == 0 (cfl_bank_attn_supported):
+ * variants, and MMClientTrainer.py:173-206 with B_div = 2B) for D <= 768, D % 4 == 0 (cfl_bank_gsplit_supported); the entry
+ * point is cfl_client_contrast_img_fwd below (the bank as a pre-split image):
  *   inter:  li = mean_b [ LSE_m(inv_tau F_b.G_other_m) - inv_tau F_b.G_other_idx[b] ]          (mode bit 0)
  *   intra:  lm = (1/B_div) sum_b softplus(inv_tau (F_b.Fold_b - F_b.G_same_idx[b]))             (mode bit 1)
  *   loss = (lm + li) w | (lm + li / (li/lm)) w with mode bit 2 (--loss_scale) | li | lm
@@ -110,21 +105,15 @@ int cfl_bank_lse_bwd(const float* logits_t, const float* G, const long long* idx
  * out5 (>= 6 floats) = {loss, li, lm, c_inter, c_moon, loss again}; dF_inter / dF_moon [B, D] are the UNIT gradients of li / lm
  * (want_grad), and
  * cfl_client_contrast_bwd writes dF = gout * (c_inter dF_inter + c_moon dF_moon).
- * lse [B] (required with bit 0), pos [B] (optional).  ws >= cfl_bank_attn_ws_bytes; `sync` points at an int that is 0
+ * lse [B] (required with bit 0), pos [B] (optional).  ws >= cfl_bank_gsplit_ws_bytes; `sync` points at an int that is 0
  * before the first call (left 0).  idx outside [0, M) contributes a zero positive (as cfl_bank_lse_fwd).
  */
-/* Precision of the dense kernels that exist in two forms (cfl_pair_loss_*, cfl_bank_lse_*, cfl_conw_logprob, cfl_gemm_nt):
+/* Precision of the dense kernels that exist in two forms (cfl_pair_loss_*, cfl_bank_lse_*, cfl_conw_logprob):
  * 0 = 3 x bf16-split MFMA with fp32 accumulation (default; dot products of unit-norm rows to ~1e-6), 1 = exact fp32 MFMA.
  * Process-wide; initialised from the environment variable CFL_GEMM_EXACT. */
 int cfl_get_exact_gemm(void);
 int cfl_set_exact_gemm(int exact);
 
-int cfl_bank_attn_supported(int B, int M, int D);
-size_t cfl_bank_attn_ws_bytes(int B, int M, int D, int want_grad);
-int cfl_client_contrast_fwd(const float* F, const float* G_other, const float* G_same, const long long* idx, const float* F_old,
-                            int B, int M, int D, int B_div, float inv_tau, float weight, int mode, int want_grad,
-                            float* out5, float* lse, float* pos, float* dF_inter, float* dF_moon, void* ws, int* sync,
-                            void* stream);
 int cfl_client_contrast_bwd(const float* dF_inter, const float* dF_moon, const float* out5, const float* gout_dev, int B, int D,
                             float* dF, void* stream);
 
@@ -133,10 +122,12 @@ int cfl_client_contrast_bwd(const float* dF_inter, const float* dF_moon, const f
  * every step of the round contrasts against them, :386-419), so its fp32 -> (bf16 hi, bf16 lo) split is done ONCE:
  *   cfl_bank_image_build(G [M, D] fp32) -> image of cfl_bank_image_bytes(M, D) bytes (= the fp32 bank's size, rows padded to 16
  *   and columns to 128 / 256): 16-row slots, [plane][row][column] bf16, 16-byte pieces XOR-swizzled -- the LDS image itself.
- * cfl_client_contrast_img_fwd = cfl_client_contrast_fwd with the bank pass running on that image (same outputs, same finish
- * launch, same cfl_client_contrast_bwd): 32 feature rows per workgroup, so a client batch of 128 needs 64 bank splits instead
- * of 256 and writes a quarter of the split partials.  G_other (fp32) is still needed for the exact positive rows G_other[idx].
- * D <= 256, D % 4 == 0 (cfl_bank_gsplit_supported); ws >= cfl_bank_gsplit_ws_bytes.
+ * cfl_client_contrast_img_fwd = the fused step described above with the bank pass running on that image: 32 (64 beyond
+ * D = 256) feature rows per workgroup, so a client batch of 128 needs 64 bank splits.  G_other (fp32) is still needed for the
+ * exact positive rows G_other[idx]; with mode bit 0 clear (intra only) image_other / G_other may be NULL and only the finish
+ * launch runs.  D <= 768, D % 4 == 0 (cfl_bank_gsplit_supported); ws >= cfl_bank_gsplit_ws_bytes.
+ * (Rounds 1-3 kept two earlier generations of the bank pass as A/B references; round 4 keeps ONE: the exact-fp32 two-pass
+ * kernels cfl_bank_lse_fwd / _bwd, which also serve D % 4 != 0 and D > 768.)
  */
 size_t cfl_bank_image_bytes(int M, int D);
 int cfl_bank_image_build(const float* G, int M, int D, void* image, void* stream);
@@ -241,9 +232,6 @@ int cfl_bn_fwd_pre(const void* x, const void* residual, const float* gamma, cons
  * through registers) when M >= min_m and K <= 256, the tile kernel otherwise.  Default 32768 (CFL_GEMM_BRES_MIN_M overrides it;
  * CFL_GEMM_NO_BRES=1 disables the streaming kernel).  Returns the previous value; min_m < 0 only queries. */
 int cfl_gemm_bf16_bres_min_m(int min_m);
-/* tn: C[N1,N2] = A[M,N1]^T * B[M,N2] (reduction along the slow axis M): the weight gradient dW[Co,Ci] = dy^T x of a 1x1
- * convolution.  C dense row-major, bf16 (c_bf16 = 1) or fp32; split-K over M with fp32 partials in ws
- * (cfl_gemm_bf16_tn_ws_bytes) and a fixed-order reduction.  N1 % 8 == N2 % 8 == 0, lda % 8 == ldb % 8 == 0. */
 /* dst[C][R] = src[R][C]^T, dense bf16 (the weight transpose the data gradient needs). */
 int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream);
 /* every weight transpose of a backward pass in one launch: meta = device array of ntensors 40-byte records
@@ -251,9 +239,6 @@ int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream);
  * dst[c * ldd + r] = src[r * lds + c].  Dense matrices: lds = C, ldd = R; the taps of a k x k channels_last weight are
  * strided [Co, Ci] matrices (ops.prepare_weight_transposes builds the rotated, transposed weight of the data gradient). */
 int cfl_transpose_bf16_multi(const void* meta, int ntensors, int total_tiles, void* stream);
-size_t cfl_gemm_bf16_tn_ws_bytes(long long M, int N1, int N2);
-int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, long long ldb, void* C, int c_bf16, long long M, int N1, int N2,
-                     void* ws, void* stream);
 
 /* ---- client supervised step glue ------------------------------------------------
  * Replaces, per local batch (src/algorithms/ClientTrainer.py:344-361 with to_one_hot src/utils/Utils.py:6-13 and

@@ -95,6 +95,40 @@ def test_bench_gpus_2_runs_two_ranks_end_to_end(launcher, tmp_path):
     assert time.time() - t0 < 330                                     # nobody sat out a marker time-out
 
 
+@pytest.mark.gpu
+def test_bench_gpus_8_gloo_on_one_gpu(tmp_path):
+    """8-GPU readiness without an 8-GPU node (VERDICT r3 #8b): `python bench.py --gpus 8 --backend gloo --batch 8 --cnn resnet18`
+    on the one GPU of the box -- the script starts its 8 ranks itself, they build the data-parallel step (process group,
+    gradient-aware feature gather, GradBuckets at --bucket-mb, optimizer-state broadcast), run it, and rank 0 prints ONE line
+    with n_gpus = 8, global batch 64 and the `comm` block (bytes per step on the wire, bucket count); the multi-rank watchdog
+    stays at its default.  SMOKE mode of the path (shared GPU, collectives through host memory), not a scaling number."""
+    import json
+    import subprocess
+    import time
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['TMPDIR'] = str(tmp_path)
+    env.pop('MIOPEN_USER_DB_PATH', None)
+    env['OMP_NUM_THREADS'] = '2'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--batch', '8', '--cnn', 'resnet18',
+           '--steps', '2', '--warmup', '1', '--bucket-mb', '16', '--no-cpu-baseline', '--no-recall', '--no-alone', '--no-mfu']
+    t0 = time.time()
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['ranks']['world_size'] == 8 and out['ranks']['rccl_ranks'] == 0
+    assert out['config']['global_batch'] == 64 and out['value'] > 0 and out['scaling'] == 'weak'
+    assert out['config']['loss'] == out['config']['loss']            # not NaN
+    comm = out['comm']
+    assert comm['bucket_mb'] == 16 and comm['buckets'] >= 8 and comm['allreduce_bytes_per_step'] > 200e6
+    assert comm['gather_bytes_per_step'] == 2 * 64 * 512 * 4
+    assert time.time() - t0 < 850
+
+
 def _prewarm_env(monkeypatch, tmp_path, calls, rc=0):
     import subprocess
     import tempfile

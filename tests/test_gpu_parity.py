@@ -82,9 +82,11 @@ def test_a1_pair_loss_golden(dev, fname):
 
 @pytest.mark.parametrize('n,d,matched', [(1, 8, False), (7, 5, False), (64, 64, True), (65, 130, False),
                                          (129, 257, True), (256, 512, True), (300, 768, False),
-                                         (2048, 512, True), (2049, 96, False)])
+                                         (2048, 512, True), (2049, 96, False), (2080, 96, True), (2112, 32, False)])
 def test_a1_pair_loss_shapes(dev, n, d, matched):
-    """ragged / odd sizes, both tile variants (64x64 below 2048 rows, 128x128 from 2048), unaligned D."""
+    """ragged / odd sizes, both tile variants (64x64 below 2048 rows, 128x128 from 2048), unaligned D; from N = 2048 with
+    N % 32 == 0 and D % 32 == 0 the IMAGE mode (pre-split operand images, coefficients written in split form, ring-buffered
+    backward): full tiles (2048, 512), a partial column tile and an odd tile-row count (2080, 96), a single K stage (2112, 32)."""
     gen = torch.Generator().manual_seed(n * 1000 + d)
     I = _unit(gen, n, d)
     T = torch.nn.functional.normalize(I + 0.5 * _unit(gen, n, d), dim=-1) if matched else _unit(gen, n, d)
@@ -314,9 +316,9 @@ def test_a34_image_cache_follows_the_bank(dev):
 
 @pytest.mark.parametrize('b,m,d', [(128, 50000, 256), (96, 7001, 512), (40, 3000, 768), (33, 1500, 64)])
 def test_a34_image_path_equals_fp32_bank_path(dev, b, m, d, monkeypatch):
-    """Same step through the round-3 bank pass (pre-split image, 16-row slots; column-split wave pairs beyond D = 256) and
-    through the previous paths (fp32 bank, 128-row groups for D <= 256; exact-fp32 two-pass kernels beyond): same loss terms
-    and gradients within the 3 x bf16-split error (both are separately compared with the oracle elsewhere)."""
+    """Same step through the single-pass bank kernels (pre-split image, 16-row slots; column-split wave pairs beyond D = 256)
+    and through the ONE reference path kept beside them, the exact-fp32 two-pass kernels of csrc/bank.hip (CFL_BANK_EXACT):
+    same loss terms and gradients within the 3 x bf16-split error (both are separately compared with the oracle elsewhere)."""
     from creamfl_amd import ops
     gen = torch.Generator().manual_seed(b + m + d)
     G, Gs = _unit(gen, m, d), _unit(gen, m, d)
@@ -324,7 +326,8 @@ def test_a34_image_path_equals_fp32_bank_path(dev, b, m, d, monkeypatch):
     f = torch.nn.functional.normalize(Gs[idx] + 0.9 * _unit(gen, b, d), dim=-1)
     fo = torch.nn.functional.normalize(f + 0.4 * _unit(gen, b, d), dim=-1)
     got = _run_contrast(dev, f, Gs, G, idx, fo, 0.5, True)
-    monkeypatch.setattr(ops, '_BANK_NOIMG', True)
+    monkeypatch.setattr(ops, '_BANK_EXACT', True)
+    assert not ops.bank_attn_supported(b, m, d)
     ref = _run_contrast(dev, f, Gs, G, idx, fo, 0.5, True)
     for a, r in zip(got[:3], ref[:3]):
         _close(a, r, 2e-5, 0)
@@ -736,25 +739,6 @@ def test_gemm_bf16_nt_b_resident(dev, m, n, k, join):
     assert bool((c[~keep] == 0).all())
 
 
-@pytest.mark.parametrize('m,n1,n2', [(64, 64, 64), (1000, 128, 72), (50176, 1024, 256), (12544, 512, 2048), (777, 8, 264), (200, 136, 128)])
-def test_gemm_bf16_tn_matches_torch(dev, m, n1, n2):
-    """cfl_gemm_bf16_tn (C = A^T B, reduction along the slow axis, split-K) vs an fp32 matmul of the same bf16 inputs:
-    ragged M (not a multiple of 64), ragged tile edges, asymmetric operands; fp32 output."""
-    from creamfl_amd import ops
-    gen = torch.Generator().manual_seed(m + n1 + n2)
-    a = torch.randn(m, n1, generator=gen).to(torch.bfloat16).to(dev)
-    b = (torch.randn(m, n2, generator=gen) * 0.3).to(torch.bfloat16).to(dev)
-    c = ops.gemm_bf16_tn(a, b, torch.float32)
-    if m <= 4096:
-        ref = a.float().t() @ b.float()
-    else:
-        ref = a.double().t() @ b.double()
-    scale = float(ref.abs().max())
-    assert float((c.double() - ref.double()).abs().max()) <= 2e-5 * scale + 1e-4
-    cb = ops.gemm_bf16_tn(a, b, torch.bfloat16)
-    assert float((cb.double() - ref.double()).abs().max()) <= 2 ** -8 * scale + 1e-4
-
-
 # ------------------------------------------------------------- A2c / tower glue / KD vs the reference-generated fixtures
 import sys as _sys
 _sys.path.insert(0, GOLDEN)
@@ -921,34 +905,7 @@ def test_f1_kd_terms_golden(dev, fname):
     _scale_close(ot.grad if ot.grad is not None else torch.zeros_like(ot), z['d_out_txt'], 1e-5)
 
 
-# ------------------------------------------------------------------ the 3 x bf16-split tile GEMM vs the exact fp32 one
-@pytest.mark.parametrize('m,n,k', [(128, 128, 256), (300, 200, 100), (1024, 512, 512), (65, 33, 31)])
-def test_tile_gemm_x3_and_exact_vs_fp64(dev, m, n, k):
-    """cfl_gemm_nt (C = A B^T through the tile GEMM that the pair loss, the two-pass bank kernels and con_w share) in both
-    precisions against an fp64 product: the exact-fp32 MFMA path to fp32 round-off, the 3 x bf16-split path to
-    2^-15 * sum_k |a_k b_k| (two bf16 per operand = 16 mantissa bits; the lo.lo term is dropped)."""
-    import ctypes
-    from creamfl_amd import _lib
-    lib = _lib.load()
-    gen = torch.Generator().manual_seed(m + n + k)
-    A = torch.randn(m, k, generator=gen)
-    B = torch.randn(n, k, generator=gen)
-    want = (A.double() @ B.double().T).numpy()
-    bound = (A.abs().double() @ B.abs().double().T).numpy()
-    Ad, Bd = A.to(dev), B.to(dev)
-    C = torch.empty(m, n, device=dev)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    old = lib.cfl_get_exact_gemm()
-    try:
-        for exact, eps in ((1, 2.0 ** -21), (0, 2.0 ** -15)):
-            lib.cfl_set_exact_gemm(exact)
-            _lib.check(lib.cfl_gemm_nt(Ad.data_ptr(), Bd.data_ptr(), m, n, k, C.data_ptr(), st), 'cfl_gemm_nt')
-            err = np.abs(C.cpu().numpy().astype(np.float64) - want)
-            assert np.all(err <= eps * bound + 1e-30), (exact, float((err / (bound + 1e-30)).max()))
-    finally:
-        lib.cfl_set_exact_gemm(old)
-
-
+# ------------------------------------------------------------------ the dense kernels on the 3 x bf16-split and the exact fp32 tile GEMM
 @pytest.mark.parametrize('exact', [0, 1])
 def test_dense_kernels_in_both_precisions(dev, exact):
     """The pair loss (A1), the two-pass bank kernels (A3 at D > 256) and con_w (A5) against their goldens / fp64 closed forms

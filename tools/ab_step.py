@@ -31,7 +31,6 @@ def main():
     from creamfl_amd.utils.synthetic import coco_batch
     lib = _lib.load()
     dev = torch.device('cuda', 0)
-    torch.backends.cudnn.benchmark = True
     torch.manual_seed(1234)
     cfg = default_config(embed_dim=512, cnn_type='resnet101', not_bert=False)
     eng = TrainerEngine(device=dev)
@@ -48,10 +47,6 @@ def main():
         elif args.knob.startswith('dgradlib'):
             from creamfl_amd import ops
             ops.DGRAD_PLAIN_LIB[0] = int(args.knob[8:] or 64) if on else 0
-        elif args.knob == 'wgradtn':
-            from creamfl_amd import ops
-            torch.cuda.synchronize()
-            ops.WGRAD_TN[0] = 1 if on else 0
         elif args.knob.startswith('flush'):
             from creamfl_amd import streams
             torch.cuda.synchronize()

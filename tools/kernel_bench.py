@@ -237,29 +237,6 @@ def case_gemm16(H, Ci, Co, variants=(0,), N=256, join=False):
     return out
 
 
-def case_wgrad16(H, Ci, Co, N=256):
-    """1x1 convolution weight gradient dW = dY^T X: hand-written TN GEMM vs MIOpen."""
-    lib = _lib.load()
-    M = N * H * H
-    g = torch.Generator(device='cuda').manual_seed(11)
-    x = torch.randn(M, Ci, generator=g, device='cuda').to(torch.bfloat16)
-    dy = torch.randn(M, Co, generator=g, device='cuda').to(torch.bfloat16)
-    out = ops.gemm_bf16_tn(dy, x, torch.float32)
-    ref = dy[:65536].float().t() @ x[:65536].float()
-    chk = ops.gemm_bf16_tn(dy[:65536], x[:65536], torch.float32)
-    err = (chk - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
-    us, prof = timed(lambda: ops.gemm_bf16_tn(dy, x), iters=20)
-    x4 = x.view(N, H, H, Ci).permute(0, 3, 1, 2)
-    dy4 = dy.view(N, H, H, Co).permute(0, 3, 1, 2)
-    w4 = torch.zeros(Co, Ci, 1, 1, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    torch.backends.cudnn.benchmark = True
-    args = (dy4, x4, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
-    us_m, _ = timed(lambda: torch.ops.aten.convolution_backward(*args), iters=20)
-    return {'case': f'wgrad16 1x1 {H}x{H} {Ci}->{Co} M={M}', 'roof_us': round(M * (Ci + Co) * 2 / 6.0e6, 1),
-            'tn_us_per_launch_avg (gemm + reduce)': prof.get('cfl_gemm_bf16_kernel'), 'tn_wall_us': round(us, 1), 'relerr': round(err, 6),
-            'miopen_wgrad_us': round(us_m, 1)}
-
-
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -277,40 +254,6 @@ def case_opt(cnn='resnet101'):
     return {'case': f'opt_clip_adamp {cnn}+bert-base n_params={n}', 'us_per_step': round(us, 1), 'kernels_us': prof,
             'pass1_GBps': round(24 * n / prof['cfl_adamp_pass1_kernel'] / 1e3, 1),
             'pass3_GBps': round(16 * n / prof['cfl_adamp_pass3_kernel'] / 1e3, 1)}
-
-
-def case_gemm(M, N, K):
-    import ctypes
-    lib = _lib.load()
-    g = torch.Generator(device='cuda').manual_seed(5)
-    A = torch.rand(M, K, generator=g, device='cuda') * 2 - 1
-    B = torch.rand(N, K, generator=g, device='cuda') * 2 - 1
-    C = torch.empty(M, N, device='cuda')
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    fn = lambda: _lib.check(lib.cfl_gemm_nt(A.data_ptr(), B.data_ptr(), M, N, K, C.data_ptr(), st), 'gemm')
-    us, prof = timed(fn, iters=5, warm=2)
-    ref = A[:256] @ B[:256].T
-    err = (C[:256, :256] - ref).abs().max().item()
-    k_us = prof['cfl_gemm_nt_kernel']
-    return {'case': f'gemm_nt fp32 MFMA {M}x{N}x{K}', 'kernel_us': k_us, 'TFLOPs': round(2 * M * N * K / k_us / 1e6, 1),
-            'max_err_vs_torch': err}
-
-
-def case_ablate():
-    import ctypes
-    lib = _lib.load()
-    A = torch.rand(4096, 4096, device='cuda')
-    B = torch.rand(4096, 4096, device='cuda')
-    sink = torch.zeros(256, device='cuda')
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    nk = 128
-    out = {}
-    for mode in range(5):
-        fn = lambda: _lib.check(lib.cfl_gemm_ablate(A.data_ptr(), B.data_ptr(), 4096, 4096, mode, nk, sink.data_ptr(), st), 'ablate')
-        us, prof = timed(fn, iters=5, warm=2)
-        k_us = prof['cfl_gemm_nt_kernel']
-        out[f'mode{mode}'] = round(1024 * nk * 2 * 128 * 128 * 32 / k_us / 1e6, 1)
-    return {'case': 'gemm K-loop ablation (TFLOP/s): 0 mfma, 1 +lds reads, 2 +barrier, 3 +stage writes, 4 +global loads', **out}
 
 
 def main():
@@ -381,15 +324,6 @@ def main():
             out.append(case_gemm16(H, Ci, Co, (0,), join=True))
         for (H, Ci, Co) in [(56, 256, 64), (28, 512, 128), (14, 1024, 256), (7, 2048, 512)]:
             out.append(case_gemm16(H, Ci, Co, (0,)))
-    if 'wgrad16' in cases:
-        os.environ.setdefault('MIOPEN_FIND_MODE', '2')
-        for (H, Ci, Co) in [(56, 64, 64), (56, 64, 256), (56, 256, 64), (28, 128, 512), (28, 512, 128),
-                            (14, 256, 1024), (14, 1024, 256), (7, 512, 2048), (7, 2048, 512)]:
-            out.append(case_wgrad16(H, Ci, Co))
-    if 'gemm' in cases:
-        out += [case_gemm(4096, 4096, 4096), case_gemm(8192, 8192, 512), case_gemm(8192, 8192, 256)]
-    if 'ablate' in cases:
-        out += [case_ablate()]
     if 'opt' in cases:
         out += [case_opt()]
     for r in out:
