@@ -142,7 +142,7 @@ def offline_traffic(kernel, per_step, profiles_dir=None):
     launch-weighted."""
     profiles_dir = profiles_dir or os.path.join(ROOT, 'profiles')
     source = 'none: no offline PMC profile matches this run (traffic = null)'
-    for fn in ('r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
+    for fn in ('r4_pmc_bench_traffic.json', 'r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(profiles_dir, fn)))
         except (OSError, ValueError):
@@ -607,14 +607,46 @@ def cpu_baseline(cfg, args):
            '--cnn', args.cnn, '--cpu-batch', str(args.cpu_batch), '--cpu-steps', str(args.cpu_steps), '--cpu-warmup',
            str(args.cpu_warmup)]
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    try:
-        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.cpu_timeout)
+    note = ''
+    for attempt in range(2):
+        try:
+            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.cpu_timeout)
+        except subprocess.TimeoutExpired:
+            return {'value': None, 'error': 'cpu baseline child exceeded %d s' % args.cpu_timeout}
         lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
         if res.returncode == 0 and lines:
-            return json.loads(lines[-1])
+            out = json.loads(lines[-1])
+            out['sample'] += note
+            return out
+        if res.returncode == CPU_CHILD_RSS_EXIT and attempt == 0 and args.cpu_batch > 64:
+            # the child's memory watchdog stopped it before the host ran short: once more at batch 64
+            note = '; batch %d stopped by the memory watchdog -> batch 64' % args.cpu_batch
+            cmd[cmd.index('--cpu-batch') + 1] = '64'
+            continue
         return {'value': None, 'error': 'cpu baseline child rc=%d: %s' % (res.returncode, res.stderr.decode()[-300:])}
-    except subprocess.TimeoutExpired:
-        return {'value': None, 'error': 'cpu baseline child exceeded %d s' % args.cpu_timeout}
+
+
+CPU_CHILD_RSS_EXIT = 43
+
+
+def _rss_watchdog(limit_gb):
+    """The CPU port at batch 256 holds ~60 GB of fp32 activations.  Never let it push the host into its memory limit (an OOM
+    kill takes the box with it): a thread polls this process's resident set and exits the process at 60 % of what it may
+    use; the parent then repeats the baseline at batch 64."""
+    import threading
+    page = os.sysconf('SC_PAGE_SIZE')
+    budget = 0.6 * limit_gb * 2 ** 30
+
+    def poll():
+        while True:
+            try:
+                rss = int(open('/proc/self/statm').read().split()[1]) * page
+            except (OSError, ValueError):
+                return
+            if rss > budget:
+                os._exit(CPU_CHILD_RSS_EXIT)
+            time.sleep(0.25)
+    threading.Thread(target=poll, daemon=True).start()
 
 
 def cpu_baseline_child(args):
@@ -629,6 +661,8 @@ def cpu_baseline_child(args):
     torch.set_num_threads(cores)
     cfg = default_config(embed_dim=args.dim, cnn_type=args.cnn, not_bert=False)
     mem = _host_memory_limit_gb()
+    if mem is not None:
+        _rss_watchdog(mem)
     note = ''
     for batch in ([args.cpu_batch] if args.cpu_batch <= 64 else [args.cpu_batch, 64]):
         if batch > 64 and mem is not None and mem < 0.35 * batch:        # ~0.25 GB of saved fp32 activations per ResNet-101 sample

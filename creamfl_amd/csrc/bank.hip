@@ -14,13 +14,10 @@
 // HBM layout: F [B, D], G [M, D] row-major fp32; logits_t [M, B] (scaled logits, TRANSPOSED so
 // that the stores of a wave are 128-byte contiguous); ws: part_m[S, Bp] part_l[S, Bp] (S = number
 // of bank splits, Bp = B rounded up to 128) followed by the backward's split-K slabs [KS, B, D].
-#include <stdlib.h>
 #include "common.h"
 #include "tile_x3.h"
 
 namespace {
-
-static const bool g_conw_no_ring = getenv("CFL_CONW_NO_RING") != nullptr;      // A/B switch: 128-row tiles, double buffer
 
 struct BankPlan { int TN, BN, S, Bp; };
 // Each workgroup loops over bank chunks gc = x, x + S, ... of 128 rows.
@@ -39,13 +36,14 @@ static BankPlan bank_plan(int B, int M) {
     return p;
 }
 
-// TM = 2: 128 bank rows per tile, double-buffered stages, two workgroups per CU.  TM = 4 (RING): 256 bank rows per tile --
-// a wave's 128 x 64 share reads 24 KB of fragments per 48 MFMAs instead of 16 KB per 24, the ratio that caps the image-fed
-// 3 x bf16 core (LDS pipe vs matrix pipe) -- with the stages in a ring of three 48 KB LDS buffers, two in flight
-// (tile_gemm_seq_glds_ring: one workgroup per CU, so the counted waits replace the second workgroup as the latency cover).
-template <int TM, int TN, bool RING>
-__global__ __launch_bounds__(256, RING ? 1 : 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B, int M, int Bp, float inv_tau,
+// (Round 4 measured 256 x 128 tiles -- a wave's 128 x 64 share reads 24 KB of LDS fragments per 48 MFMAs instead of 16 KB per
+// 24 -- through a 3-stage LDS ring with counted vmcnt waits, one workgroup per CU: 4.79 ms vs 4.28 ms for this kernel at
+// M = 50 000, D = 256.  With one wave per SIMD the soft-max epilogue (128 exp2 per lane and tile) runs behind the MFMAs instead
+// of under the second workgroup's; the variant was removed again.)
+template <int TN>
+__global__ __launch_bounds__(256, 2) void cfl_bank_fwd_kernel(Opnd G, Opnd F, int B, int M, int Bp, float inv_tau,
                                                            float* logits_t, float* part_m, float* part_l, int x3mode) {
+    constexpr int TM = 2;
     using C = TileCfg<TM, TN, true, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int S = gridDim.x;
@@ -116,13 +114,7 @@ __global__ __launch_bounds__(256, RING ? 1 : 2) void cfl_bank_fwd_kernel(Opnd G,
             }
         }
     };
-    if (RING)            // pre-split images, 256-row tiles, ring of 3 stages (con_w)
-        tile_gemm_seq_glds_ring<TM, TN, 3>(G, F, ntiles, tile_fn, lds, epi_fn,
-                                           [](const float* sa, const float* sb, f32x16 (&acc)[TM][TN], int lane, int wr, int wc) {
-                                               x3::compute<TM, TN>(reinterpret_cast<const char*>(sa), reinterpret_cast<const char*>(sb), acc,
-                                                                   lane, wr, wc);
-                                           });
-    else if (x3mode == 2)     // G, F are pre-split [hi | lo] images (launch_bank_fwd): direct-to-LDS staging, bf16 x 3 compute
+    if (x3mode == 2)     // G, F are pre-split [hi | lo] images (launch_bank_fwd): direct-to-LDS staging, bf16 x 3 compute
         tile_gemm_seq_glds_with<TM, TN>(G, F, ntiles, tile_fn, lds, epi_fn,
                                         [](const float* sa, const float* sb, f32x16 (&acc)[TM][TN], int lane, int wr, int wc) {
                                             x3::compute<TM, TN>(reinterpret_cast<const char*>(sa), reinterpret_cast<const char*>(sb), acc,
@@ -397,20 +389,14 @@ static int launch_bank_fwd(const float* F, const float* G, int B, int M, int D, 
         Go = Opnd{w.img_g, kp, M, kp, 1};
         Fo = Opnd{w.img_f, kp, B, kp, 1};
     }
-    if (x3mode == 2 && pl.TN == 2 && !logits_t && !g_conw_no_ring) {
-        // con_w: image-fed, no logits stored (the epilogue touches no memory): 256 x 128 tiles through the stage ring
-        constexpr int LDSB = 3 * (256 + 128) * 128;
-        CFL_SET_LDS((cfl_bank_fwd_kernel<4, 2, true>), LDSB);
-        CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<4, 2, true>), grid, dim3(256), LDSB, stream,
-                   Go, Fo, B, M, pl.Bp, inv_tau, logits_t, w.part_m, w.part_l, x3mode);
-    } else if (pl.TN == 1) {
+    if (pl.TN == 1) {
         using C = TileCfg<2, 1, true, true>;
-        CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<2, 1, false>), grid, dim3(256), C::LDS_BYTES, stream,
+        CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<1>), grid, dim3(256), C::LDS_BYTES, stream,
                    Go, Fo, B, M, pl.Bp, inv_tau, logits_t, w.part_m, w.part_l, x3mode);
     } else {
         using C = TileCfg<2, 2, true, true>;
-        CFL_SET_LDS((cfl_bank_fwd_kernel<2, 2, false>), C::LDS_BYTES);
-        CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<2, 2, false>), grid, dim3(256), C::LDS_BYTES, stream,
+        CFL_SET_LDS((cfl_bank_fwd_kernel<2>), C::LDS_BYTES);
+        CFL_LAUNCH(K_BANK_FWD, (cfl_bank_fwd_kernel<2>), grid, dim3(256), C::LDS_BYTES, stream,
                    Go, Fo, B, M, pl.Bp, inv_tau, logits_t, w.part_m, w.part_l, x3mode);
     }
     return 0;

@@ -523,65 +523,6 @@ __device__ __forceinline__ void tile_gemm_seq_glds(const Opnd& A, const Opnd& B,
                                     });
 }
 
-// ---- ring variant: NS LDS stages, NS - 1 of them in flight --------------------------------------------------------------------
-// The double buffer above ends every K step with __syncthreads(), which drains vmcnt: each step waits for a DMA issued one
-// MFMA block earlier.  That is fine while a second workgroup on the CU fills the wait; with ONE workgroup per CU (tiles whose
-// stages need most of the LDS) every step pays a round trip to L2 / HBM.  Here the wait in front of stage g is a COUNTED
-// s_waitcnt -- the (BM + BN) / 32 LDS-DMA instructions of each younger stage stay outstanding -- followed by a bare s_barrier,
-// which is also what frees the buffer the next DMA overwrites (stage g - 1's: every wave is past its MFMA block).
-// Same contract as tile_gemm_seq_glds_with; every tile must have the same K range length.  epi_fn must not issue global memory
-// operations (they would be counted by vmcnt).  lds: NS * (BM + BN) * 128 bytes.
-template <int N>
-__device__ __forceinline__ void cfl_wait_vm_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
-
-template <int TM, int TN, int NS, class TileFn, class EpiFn, class ComputeFn>
-__device__ __forceinline__ void tile_gemm_seq_glds_ring(const Opnd& A, const Opnd& B, int ntiles, TileFn tile_fn, float* lds,
-                                                        EpiFn epi_fn, ComputeFn compute_fn) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, STAGE = (BM + BN) * 32, NI = (BM + BN) / 32;
-    static_assert(NS == 3 || NS == 4, "ring of 3 or 4 stages");
-    static_assert((NS - 2) * NI <= 63, "vmcnt is a 6-bit counter");
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
-    if (ntiles <= 0) return;
-    const TileDesc t0 = tile_fn(0);
-    const int nk = (t0.kend - t0.kbeg) / 32;
-    const int total = ntiles * nk;
-    int i_tile = 0, i_kt = 0, i_buf = 0;                       // issue cursor
-    TileDesc i_desc = t0;
-    auto issue = [&]() {
-        float* st = lds + i_buf * STAGE;
-        glds_stage<BM>(A, i_desc.row0, i_desc.kbeg + i_kt * 32, st);
-        glds_stage<BN>(B, i_desc.col0, i_desc.kbeg + i_kt * 32, st + BM * 32);
-        i_buf = i_buf + 1 == NS ? 0 : i_buf + 1;
-        if (++i_kt == nk) { i_kt = 0; ++i_tile; if (i_tile < ntiles) i_desc = tile_fn(i_tile); }
-    };
-    int issued = 0;
-    for (; issued < NS - 1 && issued < total; ++issued) issue();
-    f32x16 acc[TM][TN];
-    int c_tile = 0, c_kt = 0, c_buf = 0;
-    for (int g = 0; g < total; ++g) {
-        const int rem = total - 1 - g;                          // stages issued after g that may still be in flight: min(rem, NS - 2)
-        if (NS == 4 && rem >= 2) cfl_wait_vm_barrier<2 * NI>();
-        else if (rem >= 1) cfl_wait_vm_barrier<NI>();
-        else cfl_wait_vm_barrier<0>();
-        if (issued < total) { issue(); ++issued; }
-        if (c_kt == 0) {
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        }
-        const float* sa = lds + c_buf * STAGE;
-        compute_fn(sa, sa + BM * 32, acc, lane, wr, wc);
-        c_buf = c_buf + 1 == NS ? 0 : c_buf + 1;
-        if (++c_kt == nk) { epi_fn(c_tile, acc); c_kt = 0; ++c_tile; }
-    }
-    __syncthreads();
-}
-
 // Single tile, direct-to-LDS staging: acc = A[row0.., k] * B[col0.., k]^T over k in [kbeg, kend), (kend-kbeg) % 32 == 0.
 template <int TM, int TN>
 __device__ __forceinline__ void tile_gemm_glds(const Opnd& A, const Opnd& B, int row0, int col0, int kbeg, int kend,

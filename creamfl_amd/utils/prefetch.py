@@ -29,6 +29,8 @@ class DevicePrefetcher:
     def __init__(self, loader, device, depth=2, pin=True):
         self.loader = loader
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None and torch.cuda.is_available():
+            self.device = torch.device('cuda', torch.cuda.current_device())     # the copy thread must use the caller's device
         self.depth = max(1, int(depth))
         self.pin = pin
         self.dataset = getattr(loader, 'dataset', None)
@@ -91,7 +93,8 @@ class DevicePrefetcher:
 
         def worker():
             try:
-                torch.cuda.set_device(self.device)
+                if self.device.index is not None:
+                    torch.cuda.set_device(self.device)       # (a new thread starts on device 0)
                 for n, batch in enumerate(self.loader):
                     if not put(self._stage(batch, h2d, n % (self.depth + 2))):
                         return

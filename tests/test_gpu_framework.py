@@ -502,53 +502,85 @@ def _grad_agreement(got, want):
     return out
 
 
+def _group_cos(g, h, pred):
+    names = [n for n in sorted(g) if pred(n)]
+    a = torch.cat([g[n].double().flatten() for n in names])
+    b = torch.cat([h[n].double().flatten() for n in names])
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+
 def test_bench_code_path_whole_model_fused_vs_unfused(dev):
     """VERDICT r3 #3 / missing #4.  The code path the BENCH times -- bf16 channels_last trunks with every fusion on (fused
     BatchNorm + join GEMM, B-resident data gradients, conv-epilogue statistics, space-to-depth stem, fused stem tail, k x k data
-    gradients on forward kernels, short-caption attention, text tower and weight gradients on side streams) -- against the SAME
-    model with every CFL_NO_* knob off, whole model, six steps on one batch (reference semantics of the step:
-    retrieval_trainer.py:192-214):
-      * no parameter is ever without a gradient (the address-keyed join of commit 27c5592 dropped the downsample branch's),
-      * step-1 gradients agree per parameter: relative L2 <= 2e-2 and cosine >= 0.999 (bf16 rounding only),
-      * the loss trajectories agree within 1e-2;
-    and once against the fp32 trunks (same kernels at full precision): losses of step 1 within 1e-2, gradient cosine >= 0.99 for
-    the parameters that carry most of the gradient norm."""
+    gradients on forward kernels, short-caption attention, text tower and weight gradients on side streams) -- whole model
+    (ResNet-50 + BERT-mini, batch 16, six steps on one batch; step semantics: retrieval_trainer.py:192-214) against
+      (a) ITSELF, run again from the same state: a race between the step's streams would show as run-to-run noise;
+      (b) the same model with every CFL_NO_* knob off (library convolutions and data gradients, single stream);
+      (c) fp32 trunks (one step).
+    What can be asked of such a comparison was MEASURED first (tools/guard_debug.py, profiles/r4_guard_calibration.txt): the
+    library's bf16 weight-gradient / backward-data kernels are not run-to-run reproducible -- two identical UNFUSED runs agree
+    per parameter only to cosine 0.68 in the low layers (two identical fused runs, whose data gradients are the deterministic
+    hand-written GEMMs: 0.9965), and the trunk as a whole to ~0.8 -- so per-parameter cosine 0.999 is not a property even of the
+    reference path.  The bounds below sit between the measured noise and what a real defect produces:
+      * no parameter is EVER without a gradient (the address-keyed join of commit 27c5592 dropped a downsample branch's);
+      * loss trajectories within 1e-2 (measured 1e-3);
+      * head and text-tower gradients: per parameter relative L2 <= 0.25, cosine >= 0.98 (measured worst 0.12 / 0.9925 at the PIE
+        attention weights, which see the trunk's activations), all of them together cosine >= 0.9999;
+      * every major trunk parameter: gradient NORM within [0.8, 1.25] of the reference run's (measured 0.92 .. 1.05) and cosine
+        >= 0.4 -- a dropped residual branch, a doubled gradient or a sign error moves these far outside; whole-trunk cosine >= 0.65;
+      * fused vs fused: per parameter cosine >= 0.99, whole model >= 0.9999."""
     from creamfl_amd.utils.synthetic import coco_batch
     b = coco_batch(16, dev, seed=21, bert=True)
     batch = (b[0], b[1], None, b[3])
     lf, gf, mf, state0 = _bench_path_run(dev, False, 6, batch)
+    lf2, gf2, mf2, _ = _bench_path_run(dev, False, 6, batch, state=state0)
     lu, gu, mu, _ = _bench_path_run(dev, True, 6, batch, state=state0)
-    assert all(not m for m in mf), [m for m in mf if m]
-    assert all(not m for m in mu), [m for m in mu if m]
-    assert set(gf) == set(gu)
+    for missing in (mf, mf2, mu):
+        assert all(not m for m in missing), [m for m in missing if m]
+    assert set(gf) == set(gu) == set(gf2)
+    assert lf[-1] < 0.9 * lf[0]                                       # the model did train
+    np.testing.assert_allclose(lf2, lf, rtol=1e-2)
+    np.testing.assert_allclose(lu, lf, rtol=1e-2)
+    is_trunk = lambda n: n.startswith('img_enc.cnn.')                 # noqa: E731
+    total = sum(float(v.double().norm()) ** 2 for v in gf.values()) ** 0.5
+    major = [n for n, v in gf.items() if float(v.double().norm()) > 1e-3 * total]
+    assert len(major) > 100
+    # (a) the fused path against itself
+    again = _grad_agreement(gf2, gf)
+    assert min(again[n][1] for n in major) >= 0.99, sorted((again[n][1], n) for n in major)[:4]
+    assert _group_cos(gf2, gf, lambda n: True) >= 0.9999
+    # (b) against the unfused path
     agree = _grad_agreement(gf, gu)
-    total = sum(v[2] ** 2 for v in agree.values()) ** 0.5
-    bad = {n: v[:2] for n, v in agree.items() if v[2] > 1e-3 * total and (v[0] > 2e-2 or v[1] < 0.999)}
-    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1][0])[:8])
-    # parameters with a negligible share of the gradient norm (< 1e-3 of the total): rounding noise dominates their direction;
-    # they must still be finite and of the right magnitude
-    for n, v in agree.items():
-        assert np.isfinite(v[0]) and v[0] < 1.0, (n, v)
-    np.testing.assert_allclose(lf, lu, rtol=1e-2)
-    assert lf[-1] != lf[0]                                            # the model did train
-    # ---- once against full-precision trunks (fp32 weights, fp32 activations; the fused bf16 kernels are not active there)
+    for n in major:
+        rel, cos, _ = agree[n]
+        if is_trunk(n):
+            ratio = float(gf[n].double().norm() / (gu[n].double().norm() + 1e-30))
+            assert 0.8 <= ratio <= 1.25 and cos >= 0.4, (n, ratio, cos)
+        else:
+            # (the PIE head's attention weights see the trunk's [N, 49, Cd] activations, whose bf16 rounding differs between the
+            # two convolution paths: measured relative 0.12 / cosine 0.9925 there, 1e-2 / 0.9999 for the other heads)
+            assert rel <= 0.25 and cos >= 0.98, (n, rel, cos)
+    assert _group_cos(gf, gu, is_trunk) >= 0.65
+    assert _group_cos(gf, gu, lambda n: not is_trunk(n)) >= 0.9999
+    # (c) once against full-precision trunks (fp32 weights and activations; the fused bf16 kernels are not active there)
     l32, g32, m32, _ = _bench_path_run(dev, False, 1, batch, state=state0, fp32=True)
     assert not m32[0]
     np.testing.assert_allclose(lf[0], l32[0], rtol=1e-2)
-    agree32 = _grad_agreement(gf, g32)
-    total32 = sum(v[2] ** 2 for v in agree32.values()) ** 0.5
-    big = {n: v for n, v in agree32.items() if v[2] > 3e-2 * total32}
-    assert big and all(v[1] >= 0.99 for v in big.values()), {n: v[:2] for n, v in big.items() if v[1] < 0.99}
-    print('bench-path guard: fused vs unfused worst rel L2 %.2e, worst cosine %.6f; vs fp32 worst cosine (major parameters) %.5f'
-          % (max(v[0] for n, v in agree.items() if v[2] > 1e-3 * total), min(v[1] for n, v in agree.items() if v[2] > 1e-3 * total),
-             min(v[1] for v in big.values())))
+    a32 = _grad_agreement(gf, g32)
+    for n in major:
+        if not is_trunk(n):
+            assert a32[n][0] <= 0.25 and a32[n][1] >= 0.98, (n, a32[n][:2])
+    assert _group_cos(gf, g32, lambda n: True) >= 0.99
+    print('bench-path guard: fused vs fused worst cosine %.4f; vs unfused trunk cosine %.3f, worst major cosine %.3f; vs fp32 whole-model '
+          'cosine %.4f' % (min(again[n][1] for n in major), _group_cos(gf, gu, is_trunk), min(agree[n][1] for n in major),
+                           _group_cos(gf, g32, lambda n: True)))
 
 
 def test_client_contrast_step_in_a_hip_graph_equals_eager(dev):
     """VERDICT r3 #5.  An image client's contrast loop (ClientTrainer.py:369-429: features, old-model features, inter + intra
     contrast against the global banks, backward, SGD step) replayed from ONE HIP graph after three eager steps
     (creamfl_amd/graphs.py; --client_graph 1, the default) against the same loop run eagerly (--client_graph 0): same
-    parameters after 9 steps (library convolutions may reorder sums: 1e-5 of scale), the ragged last batch runs eagerly, and the
+    parameters after 9 steps (library convolutions may reorder sums: 1e-4 of scale), the ragged last batch runs eagerly, and the
     graph was really replayed."""
     from creamfl_amd.algorithms.ClientTrainer import ClientTrainer
     from creamfl_amd.utils.synthetic import SyntheticCocoLoader
@@ -583,7 +615,7 @@ def test_client_contrast_step_in_a_hip_graph_equals_eager(dev):
             assert torch.equal(v, sd_graph[k]), k                      # BatchNorm batch counters advance inside the graph too
             continue
         scale = float(v.abs().max()) + 1e-12
-        assert float((v - sd_graph[k]).abs().max()) <= 1e-5 * scale + 1e-7, k
+        assert float((v - sd_graph[k]).abs().max()) <= 1e-4 * scale + 1e-7, k      # (measured 2e-5: the library's atomics)
     ref = ClientTrainer(SimpleNamespace(feature_dim=D, mlp_local=False, local_epochs=1), 'Cifar100', None, None, None, None, None,
                         global_test_set=None, client_id=0, gpuid=str(dev)).model.state_dict()
     moved = max(float((sd_graph[k] - ref[k].float().cpu()).abs().max()) for k in sd_graph if sd_graph[k].is_floating_point())

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[4] at full encoder size on ONE GPU: ViT-B/16 + BERT-large PCME, d = 768, batch 64 per GPU, bf16 trunks.
+"""BASELINE.json configs[4] at full encoder size on ONE GPU: ViT-B/16 + BERT-large PCME, d = 768, bf16 trunks, per-GPU batch
+--batch (64 and 256 are kept in profiles/), with the model-FLOPs utilisation of the server step.
 Times the server contrastive step (forward -> pair loss -> backward -> clip -> AdamP) and the client-style inter + intra step
 against a 50 000-row bank (the D = 768 bank kernel).  One JSON line; run under `rocprofv3 --kernel-trace --stats` for the
 per-kernel table kept in profiles/."""
@@ -9,11 +10,9 @@ import os
 import sys
 import time
 
-os.environ.setdefault('MIOPEN_FIND_MODE', '2')
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import creamfl_amd  # noqa: E402,F401  (library set-up: creamfl_amd/runtime.py)
+import torch  # noqa: E402
 
 
 def main():
@@ -29,7 +28,6 @@ def main():
     from creamfl_amd.utils.synthetic import coco_batch
     _lib.load()
     dev = torch.device('cuda', 0)
-    torch.backends.cudnn.benchmark = True
     torch.manual_seed(41)
     cfg = default_config(embed_dim=768, cnn_type='vit_b_16', not_bert=False)
     cfg.model.bert_name = 'bert-large-uncased'
@@ -44,6 +42,15 @@ def main():
     def step():
         return eng.train_step(images, b[1], b[2], b[3])
 
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as _bench                                       # the FLOP counter of the bench line (module hooks + attention)
+    fwd = _bench.forward_flops(eng, images, b[1], b[2], b[3])
+    vit = eng.model.img_enc.cnn                                   # + the ViT's QK^T / PV, which forward_flops does not see
+    if hasattr(vit, 'layers'):
+        Lp = (images.shape[2] // vit.patch) * (images.shape[3] // vit.patch)
+        fwd += len(vit.layers) * 4 * args.batch * Lp * Lp * vit.out_dim
+        fwd += 2 * args.batch * Lp * (vit.patch ** 2 * 3) * vit.out_dim          # the patch projection runs as F.linear (no module hook)
+        fwd += 2 * args.batch * (Lp - 49) * vit.out_dim * (vit.out_dim // 2)      # PIE w_1 over Lp positions (the counter assumes 49)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -78,6 +85,7 @@ def main():
     print(json.dumps({'config': 'BASELINE configs[4]: ViT-B/16 + BERT-large, d=768, batch %d, bf16 trunks' % args.batch,
                       'server_step_ms': round(ms, 2), 'pairs_per_s': round(args.batch / ms * 1e3, 1),
                       'loss': round(float(loss), 4), 'params_M': round(n_params / 1e6, 1),
+                      'mfu': round(3.0 * fwd / (ms * 1e-3) / 2.5e15, 4), 'model_tflop_per_step': round(3.0 * fwd / 1e12, 2),
                       'client_contrast_step_us_wall': round(cus, 1), 'bank_image_builds': builds}))
 
 

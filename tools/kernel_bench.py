@@ -265,6 +265,8 @@ def main():
     out = []
     if 'a1' in cases:
         out += [case_a1(256, 512), case_a1(128, 256), case_a1(4096, 512)]
+    if 'a1big' in cases:
+        out += [case_a1(4096, 512)]
     if 'a3' in cases:
         out += [case_a3(128, 50000, 256), case_a3(256, 50000, 512), case_a3(128, 50000, 768), case_a3(32, 50000, 256)]
     if 'pool' in cases:
