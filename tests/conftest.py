@@ -41,6 +41,20 @@ def pytest_collection_modifyitems(session, config, items):
     items.sort(key=key)                      # stable: the order inside a module is kept
 
 
+@pytest.fixture(autouse=True)
+def _library_flags_do_not_leak():
+    """creamfl_amd.runtime.configure() -- called whenever an engine or a client trainer is built -- switches cudnn.benchmark on for
+    the process (that is the product's set-up).  In a test process that would make every LATER test's library convolutions depend
+    on which tests ran before it (MIOpen picks other kernels in benchmark mode; the bf16-ulp comparisons against library results
+    in test_gpu_bnorm.py are sensitive to that): every test starts from the flag's default and configure() applies again."""
+    import torch
+    from creamfl_amd import runtime
+    old = torch.backends.cudnn.benchmark
+    yield
+    torch.backends.cudnn.benchmark = old
+    runtime._STATE['torch'] = False
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

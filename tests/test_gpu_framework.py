@@ -456,9 +456,13 @@ def _bench_path_run(dev, unfused, steps, batch, state=None, fp32=False, lr=5e-6)
     carried 91 % of the gradient norm) and every rounding difference grows with it -- two IDENTICAL bf16 runs then agree only to
     cosine 0.995 / relative 0.10 on the low layers and the fp32 run to cosine ~0 (ReLU patterns decorrelate), which says
     nothing about the kernels."""
+    from creamfl_amd import runtime
     from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
     from creamfl_amd.networks.backbones import BasicBlock, Bottleneck
-    with _Knobs(unfused):
+    runtime.configure()
+    # the library convolutions in immediate mode: PyTorch's benchmark mode re-times every MIOpen solver of every new problem
+    # (~60 s per model variant here, 4 variants); which library kernel runs is not what this test is about
+    with _Knobs(unfused), torch.backends.cudnn.flags(enabled=True, benchmark=False):
         torch.manual_seed(11)
         cfg = _small_cfg(dim=128, cnn='resnet50')
         cfg.optimizer.learning_rate = lr
@@ -598,7 +602,8 @@ def test_client_contrast_step_in_a_hip_graph_equals_eager(dev):
         t = ClientTrainer(args, 'Cifar100', None, None, None, None, None, global_test_set=None, client_id=0, gpuid=str(dev))
         t.train_loader = None
         t.cur_epoch = 0
-        t.run(g_img, g_txt, distill_index, batches)
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):   # (immediate mode: no minute of solver timing per variant)
+            t.run(g_img, g_txt, distill_index, batches)
         torch.cuda.synchronize()
         return t, {k: v.detach().float().cpu() for k, v in t.model.state_dict().items()}
 
@@ -615,7 +620,7 @@ def test_client_contrast_step_in_a_hip_graph_equals_eager(dev):
             assert torch.equal(v, sd_graph[k]), k                      # BatchNorm batch counters advance inside the graph too
             continue
         scale = float(v.abs().max()) + 1e-12
-        assert float((v - sd_graph[k]).abs().max()) <= 1e-4 * scale + 1e-7, k      # (measured 2e-5: the library's atomics)
+        assert float((v - sd_graph[k]).abs().max()) <= 1e-4 * scale + 1e-6, k      # (measured 2e-5 of scale: the library's atomics)
     ref = ClientTrainer(SimpleNamespace(feature_dim=D, mlp_local=False, local_epochs=1), 'Cifar100', None, None, None, None, None,
                         global_test_set=None, client_id=0, gpuid=str(dev)).model.state_dict()
     moved = max(float((sd_graph[k] - ref[k].float().cpu()).abs().max()) for k in sd_graph if sd_graph[k].is_floating_point())
