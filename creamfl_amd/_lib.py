@@ -48,8 +48,6 @@ SIGNATURES = {
     'cfl_gemm_bf16_nt_stats': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_int, c_int, c_int, _P, _P]),
     'cfl_transpose_bf16': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_transpose_bf16_multi': (c_int, [_P, c_int, c_int, _P]),
-    'cfl_gemm_bf16_tn_ws_bytes': (c_size_t, [c_longlong, c_int, c_int]),
-    'cfl_gemm_bf16_tn': (c_int, [_P, c_longlong, _P, c_longlong, _P, c_int, c_longlong, c_int, c_int, _P, _P]),
     'cfl_daln_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_daln_fwd': (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint, _P, _P, _P, _P, _P]),
     'cfl_daln_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint, _P, _P, _P, _P, c_int, _P, _P]),

@@ -27,10 +27,10 @@ enum CflKernel {
     K_RANK_POSMAX, K_RANK_COUNT,
     K_GRADNORM, K_ADAMP_PASS1, K_ADAMP_DECIDE, K_ADAMP_PASS3,
     K_BN_STATS, K_BN_FINAL, K_BN_APPLY, K_BN_BWD_REDUCE, K_BN_BWD_FINAL, K_BN_BWD_APPLY,
-    K_WGRAD, K_KD_MSE, K_SUP_GLUE, K_GEMM_BF16, K_BERT_DALN, K_BERT_GELU, K_ATTN_SMALL, K_MAXPOOL, K_TRANSPOSE,
+    K_GEMM_PROBE, K_KD_MSE, K_SUP_GLUE, K_GEMM_BF16, K_BERT_DALN, K_BERT_GELU, K_ATTN_SMALL, K_MAXPOOL, K_TRANSPOSE,
     K_PIE_FWD_FUSED, K_PIE_BWD_FUSED,
     K_BN_POOL_FWD, K_BN_POOL_BWD_REDUCE, K_BN_POOL_BWD_APPLY,
-    K_BANK_IMAGE, K_BANK_STREAM, K_WGRAD_REDUCE,
+    K_BANK_IMAGE, K_BANK_STREAM,
     K_NUM
 };
 

@@ -14,11 +14,11 @@ static const char* const g_kernel_names[K_NUM] = {
     "cfl_l2norm_bwd_kernel", "cfl_rank_posmax_kernel", "cfl_rank_count_kernel",
     "cfl_gradnorm_kernel", "cfl_adamp_pass1_kernel", "cfl_adamp_decide_kernel", "cfl_adamp_pass3_kernel",
     "cfl_bn_stats_kernel", "cfl_bn_final_kernel", "cfl_bn_apply_kernel", "cfl_bn_bwd_reduce_kernel",
-    "cfl_bn_bwd_final_kernel", "cfl_bn_bwd_apply_kernel", "cfl_wgrad_tr_kernel",
+    "cfl_bn_bwd_final_kernel", "cfl_bn_bwd_apply_kernel", "cfl_gemm_nt_kernel",
     "cfl_kd_mse_kernel", "cfl_sup_glue_kernel", "cfl_gemm_bf16_kernel", "cfl_bert_daln_kernel", "cfl_bert_gelu_kernel", "cfl_attn_small_kernel", "cfl_maxpool_kernel", "cfl_transpose_bf16_kernel",
     "cfl_pie_fwd_fused_kernel", "cfl_pie_bwd_fused_kernel",
     "cfl_bn_pool_fwd_kernel", "cfl_bn_pool_bwd_reduce_kernel", "cfl_bn_pool_bwd_apply_kernel",
-    "cfl_bank_image_kernel", "cfl_bank_stream_kernel", "cfl_wgrad_reduce_kernel",
+    "cfl_bank_image_kernel", "cfl_bank_stream_kernel",
 };
 
 namespace {

@@ -1017,36 +1017,6 @@ def gemm_bf16_nt(a, b, out=None, variant=0, add=None, mask=None):
     return out
 
 
-WGRAD_TN = [0]             # measurement knob: deferred 1x1 weight gradients on cfl_gemm_bf16_tn instead of the library
-_WS_SIDE = {}
-
-
-def _gemm_bf16_tn_side(a, b):
-    lib = _lib.load()
-    M, N1 = a.shape
-    N2 = b.shape[1]
-    out = torch.empty(N1, N2, dtype=torch.bfloat16, device=a.device)
-    need = int(lib.cfl_gemm_bf16_tn_ws_bytes(M, N1, N2))
-    ws = _WS_SIDE.get(a.device)
-    if ws is None or ws.numel() < need:
-        ws = _WS_SIDE[a.device] = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=a.device)
-    _lib.check(lib.cfl_gemm_bf16_tn(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), 1, M, N1, N2, _ptr(ws), _stream(a)),
-               'cfl_gemm_bf16_tn')
-    return out
-
-
-def gemm_bf16_tn(a, b, out_dtype=torch.bfloat16):
-    """out[N1, N2] = a[M, N1]^T @ b[M, N2] (reduction along the slow axis; csrc/gemm_bf16.hip: cfl_gemm_bf16_tn)."""
-    lib = _lib.load()
-    M, N1 = a.shape
-    N2 = b.shape[1]
-    out = torch.empty(N1, N2, dtype=out_dtype, device=a.device)
-    ws = _ws(lib.cfl_gemm_bf16_tn_ws_bytes(M, N1, N2), a.device)
-    _lib.check(lib.cfl_gemm_bf16_tn(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(out_dtype == torch.bfloat16), M, N1, N2,
-                                    _ptr(ws), _stream(a)), 'cfl_gemm_bf16_tn')
-    return out
-
-
 # ---- all weight transposes of a backward pass in one launch -----------------------------------------------------------
 _WT = {'key': None, 'meta': None, 'flat': None, 'views': {}, 'tiles': 0, 'n': 0, 'valid': False}
 
@@ -1190,16 +1160,7 @@ class _ConvSplitFn(torch.autograd.Function):
                     # what AccumulateGrad would have done (a tensor handed over now and filled later does not work:
                     # AccumulateGrad clones a gradient that something else still references).
                     def task(main, side, args=args, weight=weight):
-                        if (WGRAD_TN[0] and weight.shape[2] == 1 and stride == 1 and weight.dtype == torch.bfloat16
-                                and args[1].is_contiguous(memory_format=torch.channels_last)):
-                            # the 1x1 weight gradient dW = dY^T X on the hand-written TN GEMM (csrc/wgrad_tr.hip; own split-K
-                            # workspace: the shared one belongs to the main stream)
-                            dy_, x_ = args[0], args[1]
-                            Mr = dy_.shape[0] * dy_.shape[2] * dy_.shape[3]
-                            g = _gemm_bf16_tn_side(dy_.permute(0, 2, 3, 1).reshape(Mr, dy_.shape[1]),
-                                                   x_.permute(0, 2, 3, 1).reshape(Mr, x_.shape[1])).view(weight.shape)
-                        else:
-                            g = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                        g = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
                         args[0].record_stream(side)
                         args[1].record_stream(side)
                         g.record_stream(main)

@@ -232,15 +232,6 @@ int cfl_bn_fwd_pre(const void* x, const void* residual, const float* gamma, cons
  * through registers) when M >= min_m and K <= 256, the tile kernel otherwise.  Default 32768 (CFL_GEMM_BRES_MIN_M overrides it;
  * CFL_GEMM_NO_BRES=1 disables the streaming kernel).  Returns the previous value; min_m < 0 only queries. */
 int cfl_gemm_bf16_bres_min_m(int min_m);
-/* tn: C[N1,N2] = A[M,N1]^T * B[M,N2] (reduction along the slow axis M): the weight gradient dW[Co,Ci] = dy^T x of a 1x1
- * convolution (torchvision Bottleneck conv1 / conv3 inside src/networks/models/image_encoder.py:27-36; the reference delegates to
- * cuDNN).  csrc/wgrad_tr.hip (round 4): both operands staged row-major by LDS-DMA, MFMA fragments read transposed out of LDS
- * (ds_read_b64_tr_b16).  C dense row-major, bf16 (c_bf16 = 1) or fp32; split-K over M with fp32 partials in ws
- * (cfl_gemm_bf16_tn_ws_bytes, <= 16 MB) and a fixed-order reduction (deterministic).  N1 % 8 == N2 % 8 == 0,
- * lda % 8 == ldb % 8 == 0, 16-byte aligned pointers. */
-size_t cfl_gemm_bf16_tn_ws_bytes(long long M, int N1, int N2);
-int cfl_gemm_bf16_tn(const void* A, long long lda, const void* B, long long ldb, void* C, int c_bf16, long long M, int N1, int N2,
-                     void* ws, void* stream);
 /* dst[C][R] = src[R][C]^T, dense bf16 (the weight transpose the data gradient needs). */
 int cfl_transpose_bf16(const void* src, int R, int C, void* dst, void* stream);
 /* every weight transpose of a backward pass in one launch: meta = device array of ntensors 40-byte records

@@ -47,10 +47,6 @@ def main():
         elif args.knob.startswith('dgradlib'):
             from creamfl_amd import ops
             ops.DGRAD_PLAIN_LIB[0] = int(args.knob[8:] or 64) if on else 0
-        elif args.knob == 'wgradtn':
-            from creamfl_amd import ops
-            torch.cuda.synchronize()
-            ops.WGRAD_TN[0] = 1 if on else 0
         elif args.knob.startswith('flush'):
             from creamfl_amd import streams
             torch.cuda.synchronize()

@@ -237,30 +237,6 @@ def case_gemm16(H, Ci, Co, variants=(0,), N=256, join=False):
     return out
 
 
-def case_wgrad16(H, Ci, Co, N=256):
-    """1x1 convolution weight gradient dW = dY^T X: hand-written TN GEMM vs MIOpen."""
-    lib = _lib.load()
-    M = N * H * H
-    g = torch.Generator(device='cuda').manual_seed(11)
-    x = torch.randn(M, Ci, generator=g, device='cuda').to(torch.bfloat16)
-    dy = torch.randn(M, Co, generator=g, device='cuda').to(torch.bfloat16)
-    out = ops.gemm_bf16_tn(dy, x, torch.float32)
-    ref = dy[:65536].float().t() @ x[:65536].float()
-    chk = ops.gemm_bf16_tn(dy[:65536], x[:65536], torch.float32)
-    err = (chk - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
-    us, prof = timed(lambda: ops.gemm_bf16_tn(dy, x), iters=20)
-    x4 = x.view(N, H, H, Ci).permute(0, 3, 1, 2)
-    dy4 = dy.view(N, H, H, Co).permute(0, 3, 1, 2)
-    w4 = torch.zeros(Co, Ci, 1, 1, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    torch.backends.cudnn.benchmark = True
-    args = (dy4, x4, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
-    us_m, _ = timed(lambda: torch.ops.aten.convolution_backward(*args), iters=20)
-    return {'case': f'wgrad16 1x1 {H}x{H} {Ci}->{Co} M={M}', 'roof_us': round(M * (Ci + Co) * 2 / 6.0e6, 1),
-            'tn_gemm_us': prof.get('cfl_wgrad_tr_kernel'), 'tn_reduce_us': prof.get('cfl_wgrad_reduce_kernel'), 'tn_wall_us': round(us, 1),
-            'relerr': round(err, 6),
-            'miopen_wgrad_us': round(us_m, 1)}
-
-
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -350,11 +326,6 @@ def main():
             out.append(case_gemm16(H, Ci, Co, (0,), join=True))
         for (H, Ci, Co) in [(56, 256, 64), (28, 512, 128), (14, 1024, 256), (7, 2048, 512)]:
             out.append(case_gemm16(H, Ci, Co, (0,)))
-    if 'wgrad16' in cases:
-        os.environ.setdefault('MIOPEN_FIND_MODE', '2')
-        for (H, Ci, Co) in [(56, 64, 64), (56, 64, 256), (56, 256, 64), (28, 128, 512), (28, 512, 128),
-                            (14, 256, 1024), (14, 1024, 256), (7, 512, 2048), (7, 2048, 512)]:
-            out.append(case_wgrad16(H, Ci, Co))
     if 'opt' in cases:
         out += [case_opt()]
     for r in out:
