@@ -202,7 +202,16 @@ def test_offline_traffic_is_quoted_only_for_the_same_launch_count(tmp_path):
     t, src = bench.offline_traffic('cfl_pie_fwd_fused_kernel', 2.0, str(tmp_path))
     assert t is None and src.startswith('none')
     # the committed profile matches the committed bench line
-    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r3_bench_line.json')).read().strip().splitlines()[-1])
-    r = line['roofline']
-    t, _ = bench.offline_traffic(r['kernel'], r['launches'] / float(line['steps']))
-    assert t == r['traffic']
+    import re
+    import shutil
+    for rnd in ('r3', 'r4'):
+        line = json.loads(open(os.path.join(ROOT, 'profiles', rnd + '_bench_line.json')).read().strip().splitlines()[-1])
+        r = line['roofline']
+        quoted = re.search(r'profiles/(r\d_pmc_bench_traffic\.json)', r['traffic_source']).group(1)
+        only = tmp_path / rnd
+        only.mkdir()
+        shutil.copy(os.path.join(ROOT, 'profiles', quoted), str(only / quoted))          # the file the line says it quoted
+        t, _ = bench.offline_traffic(r['kernel'], r['launches'] / float(line['steps']), str(only))
+        assert t == r['traffic'], (rnd, quoted)
+        newest, _ = bench.offline_traffic(r['kernel'], r['launches'] / float(line['steps']))
+        assert newest is not None and abs(newest - r['traffic']) <= 0.01 * r['traffic']     # same kernel mix, profile of the next round
