@@ -56,14 +56,21 @@ def _seed(src, dst):
 
 
 def configure_env(tag=None):
-    """The environment half (idempotent; no torch).  `tag` names the private find-db directory (default: $CFL_RUNTIME_TAG, else
-    one per LOCAL_RANK, so that no two processes of a node append to one text database)."""
+    """The environment half (idempotent; no torch).  `tag` names the private find-db directory (default: $CFL_RUNTIME_TAG and / or
+    LOCAL_RANK, so that no two ranks of a launch append to one text database or compile into one kernel cache)."""
     if _STATE['env']:
         return _STATE
     _STATE['env'] = True
     os.environ.setdefault('MIOPEN_FIND_MODE', '2')
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-    tag = str(tag if tag is not None else os.environ.get('CFL_RUNTIME_TAG') or os.environ.get('LOCAL_RANK', '0'))
+    if tag is None:
+        # $CFL_RUNTIME_TAG names a family of processes (the test suite, a tool); the ranks of ONE launch still get a directory
+        # each: eight ranks compiling into one sqlite kernel cache abort inside the library (seen with `bench.py --gpus 8`
+        # started from a process that had exported its tag)
+        tag = os.environ.get('CFL_RUNTIME_TAG') or ''
+        rank = os.environ.get('LOCAL_RANK')
+        tag = (tag + ('_r' if tag else '') + rank) if rank is not None else (tag or '0')
+    tag = str(tag)
     if os.environ.get('CFL_NO_SEEDED_DB'):
         return _STATE
     # a variable this function set itself (a parent that launched us) is re-derived for OUR rank; a caller's own is kept

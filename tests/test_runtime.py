@@ -64,6 +64,13 @@ def test_a_launched_rank_re_derives_its_own_directory(tmp_path):
     # what a rank sees when the launching process exported its own seeded directory (bench.py must_spawn / torchrun)
     r = _run(tmp_path, CFL_SEEDED_DB='1', MIOPEN_USER_DB_PATH=str(tmp_path / 'creamfl_miopen_db_0' / '0'), LOCAL_RANK='3')
     assert r['db'].endswith(os.sep + '3')
+    # ... also when the launching process named its family of processes (the test suite does): eight ranks of `bench.py --gpus 8`
+    # compiling into ONE kernel cache aborted inside the library
+    a = _run(tmp_path, CFL_RUNTIME_TAG='tests', LOCAL_RANK='3')
+    b = _run(tmp_path, CFL_RUNTIME_TAG='tests', LOCAL_RANK='4')
+    c = _run(tmp_path, CFL_RUNTIME_TAG='tests')
+    assert a['db'].endswith(os.sep + 'tests_r3') and b['db'].endswith(os.sep + 'tests_r4') and c['db'].endswith(os.sep + 'tests')
+    assert len({a['cache'], b['cache'], c['cache']}) == 3
 
 
 def test_building_an_engine_switches_find_mode_on(tmp_path):
