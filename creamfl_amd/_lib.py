@@ -67,6 +67,9 @@ SIGNATURES = {
     'cfl_conw_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cfl_conw_logprob': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_conw_combine': (c_int, [POINTER(c_void_p), _P, c_int, c_int, c_int, _P, _P, _P]),
+    'cfl_conw_img_supported': (c_int, [c_int, c_int, c_int]),
+    'cfl_conw_img_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cfl_conw_logprob_img': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_pie_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'cfl_pie_pool_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'cfl_pie_pool_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

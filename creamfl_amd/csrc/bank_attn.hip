@@ -261,14 +261,40 @@ static AttnWs attn_ws(void* ws, const AttnPlan& p) {
 
 #include "bank_gsplit.h"
 
-template <int DT, int NGG, int NWAVE, int NDS, int LA, bool GRAD>
+template <int DT, int NGG, int NWAVE, int NDS, int LA, bool GRAD, int NRG = 1>
 static int launch_stream(const float* F, const void* img, int B, int M, int D, float sc2, const gs::GsPlan& p, const AttnWs& w,
                          hipStream_t stream) {
-    using SM = gs::StSmem<DT, NGG, NWAVE, NDS>;
-    CFL_SET_LDS((gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD>), SM::TOTAL);
-    CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD>), dim3(p.S * p.RG), dim3(64 * NWAVE), SM::TOTAL, stream,
+    using SM = gs::StSmem<DT, NGG, NWAVE, NDS, NRG>;
+    CFL_SET_LDS((gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD, NRG>), SM::TOTAL);
+    CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD, NRG>), dim3(p.S * p.RG), dim3(64 * NWAVE), SM::TOTAL, stream,
                F, (const char*)img, B, M, D, sc2, p.S, p.RG, w.part_m, w.part_l, w.part_o);
     return 0;
+}
+
+// con_w (row A5) on the bank pass: out[i] = <V[row0 + i], G[row0 + i]> - log sum_j exp <V[row0 + i], G[j]>   (MMFL.py:304-307).
+// The stream kernel leaves per split (max, sum) of 2^(s log2 e - max); one thread per row merges the S splits in fixed order and
+// takes the positive as an exact fp32 dot product.
+__global__ __launch_bounds__(256) void cfl_conw_finish_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l, int S,
+                                                              const float* __restrict__ V, const float* __restrict__ G, int rows, int D,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);                    // one wave per row
+    if (f >= rows) return;
+    const size_t o = (size_t)(f >> 7) * S * BR + (f & (BR - 1));
+    float mm = -INFINITY;
+    for (int x = 0; x < S; ++x) mm = fmaxf(mm, part_m[o + (size_t)x * BR]);
+    float L = 0.f;
+    for (int x = 0; x < S; ++x) L = fmaf(__builtin_amdgcn_exp2f(part_m[o + (size_t)x * BR] - mm), part_l[o + (size_t)x * BR], L);
+    const float* v = V + (size_t)f * D;
+    const float* g = G + (size_t)f * D;
+    float dot = 0.f;
+    for (int d = 4 * lane; d < D; d += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(v + d), b = *reinterpret_cast<const f32x4*>(g + d);
+        dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) dot += __shfl_xor(dot, sft, 64);
+    if (lane == 0) out[f] = dot - (mm + __builtin_amdgcn_logf(L)) * 0.6931471805599453f;
 }
 
 // the finish launch both bank passes share; S = number of splits of the partials
@@ -351,6 +377,41 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
     }
     return launch_finish(w, p.S, p.DP, p.RGF, p.Bp, F, G_other, G_same, F_old, idx, B, M, D, B_div, inv_tau, weight, mode, want_grad,
                          out5, lse, pos, dF_inter, dF_moon, sync, stream);
+}
+
+// ---- round 4: con_w log-probabilities on the bank pass (wide-batch forward of bank_gsplit.h) -------------------------------
+int cfl_conw_img_supported(int rows, int M, int D) {
+    return (rows >= 512 && M > 0 && D >= 4 && D <= 512 && D % 4 == 0) ? 1 : 0;
+}
+
+size_t cfl_conw_img_ws_bytes(int rows, int M, int D) {
+    if (!cfl_conw_img_supported(rows, M, D)) return 256;
+    const gs::GsPlan p = gs::gs_plan(rows, M, D, 1);
+    return cfl_align256((size_t)2 * p.RGF * p.S * BR * sizeof(float));
+}
+
+int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int M, int D, int row0, int rows, float* out, void* ws,
+                         void* stream_) {
+    if (!V || !image || !G || !out || !ws || M <= 0 || D <= 0 || row0 < 0 || rows <= 0 || row0 + rows > M) return CFL_EINVAL;
+    if (!cfl_conw_img_supported(rows, M, D)) return CFL_ELIMIT;
+    if ((((uintptr_t)V | (uintptr_t)G | (uintptr_t)image) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const gs::GsPlan p = gs::gs_plan(rows, M, D, 1);
+    AttnWs w;
+    float* q = (float*)ws;
+    w.part_m = q; q += (size_t)p.RGF * p.S * BR;
+    w.part_l = q;
+    w.rowbuf = nullptr; w.part_o = nullptr;
+    const float* F = V + (size_t)row0 * D;
+    const float sc2 = 1.4426950408889634f;
+    int rc;
+    rc = p.DT == 16 ? launch_stream<16, 1, 8, 1, 0, false, 1>(F, image, rows, M, D, sc2, p, w, stream)
+       : p.DT == 8 ? launch_stream<8, 1, 8, 1, 0, false, 2>(F, image, rows, M, D, sc2, p, w, stream)
+                   : launch_stream<4, 1, 8, 1, 0, false, 2>(F, image, rows, M, D, sc2, p, w, stream);
+    if (rc) return rc;
+    CFL_LAUNCH(K_LSE_FINAL, cfl_conw_finish_kernel, dim3(cfl_cdiv(rows, 4)), dim3(256), 0, stream, w.part_m, w.part_l, p.S, F,
+               G + (size_t)row0 * D, rows, D, out);
+    return 0;
 }
 
 int cfl_client_contrast_bwd(const float* dF_inter, const float* dF_moon, const float* out5, const float* gout_dev, int B, int D,

@@ -149,6 +149,7 @@ _BANK_EXACT = bool(_os.environ.get('CFL_BANK_EXACT'))       # A/B switch: the ex
 _BANK_IMAGES = {}            # (data_ptr, M, D) -> [source tensor, version, image, last-use tick]
 _BANK_IMAGES_MAX = 4         # the two live banks of a round (image + text) and, briefly, the next round's two
 _bank_tick = [0]
+_CONW_NOIMG = bool(_os.environ.get('CFL_CONW_NOIMG'))     # A/B: the tile GEMM of bank.hip for every con_w shape
 BANK_IMAGE_BUILDS = [0]      # how many images were built (tests / benches read it)
 
 
@@ -535,6 +536,14 @@ def conw_logprob(vec, global_other, row0=0, rows=None):
         raise RuntimeError(f'shape mismatch {tuple(V.shape)} vs {tuple(G.shape)}')
     rows = M - row0 if rows is None else rows
     out = torch.empty(rows, dtype=torch.float32, device=V.device)
+    if (not _CONW_NOIMG and lib.cfl_conw_img_supported(rows, M, D) and V.data_ptr() % 16 == 0 and G.data_ptr() % 16 == 0
+            and not _os.environ.get('CFL_BANK_EXACT')):
+        # the bank pass of rows A3/A4 on the (cached) pre-split image of G: the bank moves through a CU once per 256 rows
+        img = bank_image(G)
+        ws = _ws(lib.cfl_conw_img_ws_bytes(rows, M, D), V.device)
+        _lib.check(lib.cfl_conw_logprob_img(_ptr(V), img.data_ptr(), _ptr(G), M, D, row0, rows, _ptr(out), _ptr(ws), _stream(V)),
+                   'cfl_conw_logprob_img')
+        return out
     ws = _ws(lib.cfl_conw_ws_bytes(rows, M, D), V.device)
     _lib.check(lib.cfl_conw_logprob(_ptr(V), _ptr(G), M, D, row0, rows, _ptr(out), _ptr(ws), _stream(V)),
                'cfl_conw_logprob')

@@ -55,6 +55,36 @@ def _seed(src, dst):
     return dst
 
 
+def visible_gpus(environ=None, kfd_root='/sys/class/kfd/kfd/topology/nodes'):
+    """GPUs this process will see, WITHOUT touching the HIP runtime (its queue count is read when it initialises): the
+    visible-devices variables if one is set, else the KFD topology (nodes that have SIMDs); 0 = unknown."""
+    environ = os.environ if environ is None else environ
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = environ.get(var)
+        if v is not None and v.strip():
+            return len([x for x in v.split(',') if x.strip()])
+    n = 0
+    try:
+        for node in os.listdir(kfd_root):
+            with open(os.path.join(kfd_root, node, 'properties')) as f:
+                for line in f:
+                    if line.startswith('simd_count') and int(line.split()[1]) > 0:
+                        n += 1
+    except (OSError, ValueError, IndexError):
+        return 0
+    return n
+
+
+def hw_queues(local_world, gpus, full=8):
+    """Hardware queues per process: `full` when every rank of the node has a GPU of its own; ranks that SHARE a GPU (the smoke mode
+    of the multi-rank path: `bench.py --gpus 8 --backend gloo` on a one-GPU box) split them.  8 processes x 8 queues oversubscribe
+    the queues of one MI355X, the scheduler starts switching queue contexts in and out, and library kernels died with
+    HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (4 of 4 runs of the 8-rank test behind other tests; 0 of 2 with 2 queues per rank)."""
+    if gpus <= 0 or local_world <= gpus:
+        return full
+    return max(1, full // -(-local_world // gpus))
+
+
 def configure_env(tag=None):
     """The environment half (idempotent; no torch).  `tag` names the private find-db directory (default: $CFL_RUNTIME_TAG and / or
     LOCAL_RANK, so that no two ranks of a launch append to one text database or compile into one kernel cache)."""
@@ -62,7 +92,13 @@ def configure_env(tag=None):
         return _STATE
     _STATE['env'] = True
     os.environ.setdefault('MIOPEN_FIND_MODE', '2')
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    try:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE') or 1)
+    except ValueError:
+        local_world = 1
+    if 'GPU_MAX_HW_QUEUES' not in os.environ or os.environ.get('CFL_SET_HWQ') == '1':      # ours (or a launching parent's): re-derived per rank
+        os.environ['GPU_MAX_HW_QUEUES'] = str(hw_queues(local_world, visible_gpus() if local_world > 1 else 0))
+        os.environ['CFL_SET_HWQ'] = '1'
     if tag is None:
         # $CFL_RUNTIME_TAG names a family of processes (the test suite, a tool); the ranks of ONE launch still get a directory
         # each: eight ranks compiling into one sqlite kernel cache abort inside the library (seen with `bench.py --gpus 8`
@@ -99,7 +135,8 @@ def configure(tag=None):
 def child_env(env=None):
     """Environment for ranks this process launches: they must seed their OWN per-rank directories."""
     env = dict(os.environ if env is None else env)
-    for var, mark in (('MIOPEN_USER_DB_PATH', 'CFL_SEEDED_DB'), ('MIOPEN_CUSTOM_CACHE_DIR', 'CFL_SEEDED_CACHE')):
+    for var, mark in (('MIOPEN_USER_DB_PATH', 'CFL_SEEDED_DB'), ('MIOPEN_CUSTOM_CACHE_DIR', 'CFL_SEEDED_CACHE'),
+                      ('GPU_MAX_HW_QUEUES', 'CFL_SET_HWQ')):
         if env.pop(mark, None):
             env.pop(var, None)
     return env

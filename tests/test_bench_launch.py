@@ -116,6 +116,9 @@ def test_bench_gpus_8_gloo_on_one_gpu(tmp_path):
            '--steps', '2', '--warmup', '1', '--bucket-mb', '16', '--no-cpu-baseline', '--no-recall', '--no-alone', '--no-mfu']
     t0 = time.time()
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    if res.returncode != 0 and os.path.isdir(os.path.join(ROOT, 'gpurun_out')):          # the launcher's summary hides the rank's own words
+        with open(os.path.join(ROOT, 'gpurun_out', 'test_gpus8.stderr'), 'wb') as f:
+            f.write(res.stderr)
     assert res.returncode == 0, res.stderr.decode()[-3000:]
     lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
     assert len(lines) == 1, res.stdout.decode()[-2000:]

@@ -427,6 +427,52 @@ def test_a5_conw_row_shards(dev, m, d, row0, rows):
     _close(got.numpy(), want.numpy(), 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize('m,d,row0,rows', [(4096, 256, 0, 4096), (3000, 512, 1024, 1500), (2600, 128, 0, 2600),
+                                           (1554, 36, 16, 1000), (5000, 256, 4096, 904)])
+def test_a5_conw_bank_pass_equals_tile_gemm(dev, m, d, row0, rows, monkeypatch):
+    """Round 4: the con_w log-probabilities on the bank pass of rows A3 / A4 (pre-split image of G, 256 rows of V per workgroup
+    in registers, online log-sum-exp, exact fp32 positives) against the fp64 oracle (MMFL.py:304-307) and against the tile GEMM of
+    bank.hip; the profiler must have seen the bank pass, not the GEMM, and one image build serves every client of the round."""
+    from creamfl_amd import _lib, ops
+    gen = torch.Generator().manual_seed(3 * m + d)
+    G = _unit(gen, m, d)
+    V = torch.nn.functional.normalize(G + 0.5 * _unit(gen, m, d), dim=-1)
+    V[row0 + 5] = 3.0 * G[row0 + 700]            # a dominant logit far from the diagonal (late slot), and an early one
+    V[row0 + rows - 1] = 2.5 * G[3]
+    Gd, Vd = G.to(dev), V.to(dev)
+    ops.invalidate_bank_images()
+    builds0 = ops.BANK_IMAGE_BUILDS[0]
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    got = ops.conw_logprob(Vd, Gd, row0, rows)
+    got2 = ops.conw_logprob(Vd, Gd, row0, rows)                       # a second client against the same bank
+    launches = {k: v[0] for k, v in _lib.prof_query().items()}
+    _lib.prof_enable(False)
+    assert launches.get('cfl_bank_stream_kernel', 0) == 2 and ops.BANK_IMAGE_BUILDS[0] == builds0 + 1, launches
+    assert torch.equal(got, got2)
+    want = oracle.conw_logprob(V.double(), G.double(), literal=False)[row0:row0 + rows]
+    _close(got.cpu().numpy(), want.numpy(), 1e-5, 1e-5)
+    monkeypatch.setattr(ops, '_CONW_NOIMG', True)
+    ref = ops.conw_logprob(Vd, Gd, row0, rows)
+    _close(got.cpu().numpy(), ref.cpu().numpy(), 1e-5, 1e-5)
+
+
+def test_a5_conw_small_shards_stay_on_the_tile_gemm(dev):
+    """Below 512 rows (a shard of a small public set) the bank pass is refused and conw_logprob runs the tile GEMM."""
+    from creamfl_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.cfl_conw_img_supported(511, 5000, 256) == 0 and lib.cfl_conw_img_supported(512, 5000, 256) == 1
+    assert lib.cfl_conw_img_supported(4096, 4096, 768) == 0 and lib.cfl_conw_img_supported(4096, 4096, 258) == 0
+    gen = torch.Generator().manual_seed(5)
+    G = _unit(gen, 1000, 64)
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    ops.conw_logprob(G.to(dev), G.to(dev), 300, 333)
+    launches = {k: v[0] for k, v in _lib.prof_query().items()}
+    _lib.prof_enable(False)
+    assert 'cfl_bank_stream_kernel' not in launches, launches
+
+
 # ------------------------------------------------------------------------------------------ A2-head
 NAMES = ['attention__w_1__weight', 'attention__w_2__weight', 'fc__weight', 'fc__bias',
          'layer_norm__weight', 'layer_norm__bias']

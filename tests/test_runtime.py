@@ -73,6 +73,25 @@ def test_a_launched_rank_re_derives_its_own_directory(tmp_path):
     assert len({a['cache'], b['cache'], c['cache']}) == 3
 
 
+def test_ranks_that_share_a_gpu_split_the_hardware_queues(tmp_path):
+    """8 ranks x 8 hardware queues on ONE GPU made library kernels die with an illegal-instruction fault (queue oversubscription);
+    a rank that has a GPU to itself keeps all 8, and a caller's own setting is kept."""
+    from creamfl_amd import runtime
+    assert runtime.hw_queues(8, 8) == 8 and runtime.hw_queues(1, 1) == 8 and runtime.hw_queues(8, 0) == 8
+    assert runtime.hw_queues(8, 1) == 1 and runtime.hw_queues(2, 1) == 4 and runtime.hw_queues(8, 4) == 4 and runtime.hw_queues(16, 1) == 1
+    assert runtime.visible_gpus({'HIP_VISIBLE_DEVICES': '0,3'}) == 2 and runtime.visible_gpus({'ROCR_VISIBLE_DEVICES': '1'}) == 1
+    root = tmp_path / 'nodes'
+    for i, simd in enumerate((0, 1024, 1024)):                      # a CPU node and two GPUs
+        (root / str(i)).mkdir(parents=True)
+        (root / str(i) / 'properties').write_text('cpu_cores_count 0\nsimd_count %d\n' % simd)
+    assert runtime.visible_gpus({}, str(root)) == 2 and runtime.visible_gpus({}, str(tmp_path / 'missing')) == 0
+    assert _run(tmp_path, LOCAL_WORLD_SIZE='8', LOCAL_RANK='2', HIP_VISIBLE_DEVICES='0')['queues'] == '1'
+    assert _run(tmp_path, LOCAL_WORLD_SIZE='8', LOCAL_RANK='2', HIP_VISIBLE_DEVICES='0,1,2,3,4,5,6,7')['queues'] == '8'
+    assert _run(tmp_path, LOCAL_WORLD_SIZE='8', LOCAL_RANK='2', HIP_VISIBLE_DEVICES='0', GPU_MAX_HW_QUEUES='4')['queues'] == '4'
+    # a launching parent's own default travels with its marker and is re-derived by the rank
+    assert _run(tmp_path, LOCAL_WORLD_SIZE='8', LOCAL_RANK='2', HIP_VISIBLE_DEVICES='0', GPU_MAX_HW_QUEUES='8', CFL_SET_HWQ='1')['queues'] == '1'
+
+
 def test_building_an_engine_switches_find_mode_on(tmp_path):
     """TrainerEngine.create() -- what src/main.py reaches through MMFL.load_dataset (retrieval_trainer.py:53) -- turns
     cudnn.benchmark on: without it PyTorch asks MIOpen for immediate-mode solutions and the find-db is never consulted."""
