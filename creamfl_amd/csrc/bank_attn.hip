@@ -277,24 +277,37 @@ static int launch_stream(const float* F, const void* img, int B, int M, int D, f
 __global__ __launch_bounds__(256) void cfl_conw_finish_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l, int S,
                                                               const float* __restrict__ V, const float* __restrict__ G, int rows, int D,
                                                               float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);                    // one wave per row
-    if (f >= rows) return;
-    const size_t o = (size_t)(f >> 7) * S * BR + (f & (BR - 1));
-    float mm = -INFINITY;
-    for (int x = 0; x < S; ++x) mm = fmaxf(mm, part_m[o + (size_t)x * BR]);
-    float L = 0.f;
-    for (int x = 0; x < S; ++x) L = fmaf(__builtin_amdgcn_exp2f(part_m[o + (size_t)x * BR] - mm), part_l[o + (size_t)x * BR], L);
-    const float* v = V + (size_t)f * D;
-    const float* g = G + (size_t)f * D;
-    float dot = 0.f;
-    for (int d = 4 * lane; d < D; d += 256) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(v + d), b = *reinterpret_cast<const f32x4*>(g + d);
-        dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    __shared__ float lse[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f0 = blockIdx.x * 64;                                        // 64 consecutive rows per block
+    if (threadIdx.x < 64) {                                               // lane = row: the partials of a split are contiguous over rows
+        const int f = f0 + lane;
+        float v = 0.f;
+        if (f < rows) {
+            const size_t o = (size_t)(f >> 7) * S * BR + (f & (BR - 1));
+            float mm = -INFINITY;
+            for (int x = 0; x < S; ++x) mm = fmaxf(mm, part_m[o + (size_t)x * BR]);
+            float L = 0.f;
+            for (int x = 0; x < S; ++x) L = fmaf(__builtin_amdgcn_exp2f(part_m[o + (size_t)x * BR] - mm), part_l[o + (size_t)x * BR], L);
+            v = (mm + __builtin_amdgcn_logf(L)) * 0.6931471805599453f;
+        }
+        lse[lane] = v;
     }
+    __syncthreads();
+    for (int i = wv; i < 64; i += 4) {                                    // one wave per row: the positive as an exact fp32 dot product
+        const int f = f0 + i;
+        if (f >= rows) break;
+        const float* v = V + (size_t)f * D;
+        const float* g = G + (size_t)f * D;
+        float dot = 0.f;
+        for (int d = 4 * lane; d < D; d += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(v + d), b = *reinterpret_cast<const f32x4*>(g + d);
+            dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
 #pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) dot += __shfl_xor(dot, sft, 64);
-    if (lane == 0) out[f] = dot - (mm + __builtin_amdgcn_logf(L)) * 0.6931471805599453f;
+        for (int sft = 32; sft >= 1; sft >>= 1) dot += __shfl_xor(dot, sft, 64);
+        if (lane == 0) out[f] = dot - lse[i];
+    }
 }
 
 // the finish launch both bank passes share; S = number of splits of the partials
@@ -409,7 +422,7 @@ int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int 
        : p.DT == 8 ? launch_stream<8, 1, 8, 1, 0, false, 2>(F, image, rows, M, D, sc2, p, w, stream)
                    : launch_stream<4, 1, 8, 1, 0, false, 2>(F, image, rows, M, D, sc2, p, w, stream);
     if (rc) return rc;
-    CFL_LAUNCH(K_LSE_FINAL, cfl_conw_finish_kernel, dim3(cfl_cdiv(rows, 4)), dim3(256), 0, stream, w.part_m, w.part_l, p.S, F,
+    CFL_LAUNCH(K_LSE_FINAL, cfl_conw_finish_kernel, dim3(cfl_cdiv(rows, 64)), dim3(256), 0, stream, w.part_m, w.part_l, p.S, F,
                G + (size_t)row0 * D, rows, D, out);
     return 0;
 }

@@ -221,8 +221,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
         for (int ks = 0; ks < KSW; ++ks) {
             const int k0 = 32 * (dh * KSW + ks) + 8 * kg;
             const bool ok0 = fr < B && k0 < D, ok1 = fr < B && k0 + 4 < D;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
+            if (!GRAD && NDS == 1) { v0 *= sc2; v1 *= sc2; }      // forward-only passes: the logits come out of the MFMAs in the log2 domain
             bf16x4 h0, l0, h1, l1;
             split4(v0, ok0, h0, l0);
             split4(v1, ok1, h1, l1);
@@ -257,6 +258,34 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     }
     f32x4* xs = reinterpret_cast<f32x4*>(lds + SM::BODY);        // NDS > 1: [wave][group][lane] partial logits
 
+    // Forward-only passes (no gradient GEMM behind the soft-max) defer the soft-max of a slot by one iteration: it runs between
+    // the fragment reads and the MFMAs of the NEXT slot, i.e. inside that burst's LDS latency instead of behind a drained matrix pipe
+    constexpr bool LAZY = (!GRAD && NDS == 1);
+    f32x4 pend[NRG];
+    int pend_g0 = 0;
+    bool pend_ok = false;
+    // (the logits arrive in the log2 domain: LAZY passes fold sc2 into the feature fragments; rows past M exist only in the bank's
+    // last slot; every slot has at least one real row, so the running maximum is finite from the first slot on)
+    auto soft_fwd = [&](f32x4 (&sv)[NRG], int g0) {
+        const bool tail = __builtin_amdgcn_readfirstlane(g0 - 4 * kg) + SG > M;
+#pragma unroll
+        for (int g = 0; g < NRG; ++g) {
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (g0 + r >= M) sv[g][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(sv[g][0], sv[g][1]), fmaxf(sv[g][2], sv[g][3]));
+            mx = row_max4(mx);
+            if (__any(mx > run_m[g] + RESCALE_THR)) {
+                const float mn = fmaxf(run_m[g], mx);
+                run_l[g] *= run_m[g] == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(run_m[g] - mn);
+                run_m[g] = mn;
+            }
+            run_l[g] += (__builtin_amdgcn_exp2f(sv[g][0] - run_m[g]) + __builtin_amdgcn_exp2f(sv[g][1] - run_m[g])) +
+                        (__builtin_amdgcn_exp2f(sv[g][2] - run_m[g]) + __builtin_amdgcn_exp2f(sv[g][3] - run_m[g]));
+        }
+    };
+
     // one iteration: `ld` receives the loads of slot it + LA, `wr` (holding slot it + 1) goes to the other buffer at the end
     auto iteration = [&](int it, u32x4v (&ld)[DMA ? 1 : NPT], u32x4v (&wr)[DMA ? 1 : NPT]) {
         if (DMA) {
@@ -286,6 +315,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
                     ah[e] = *reinterpret_cast<const bf16x8*>(sb + off);
                     al[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
                 }
+                if (LAZY && k0 == 0 && pend_ok) soft_fwd(pend, pend_g0);
 #pragma unroll
                 for (int e = 0; e < RB; ++e) {
 #pragma unroll
@@ -298,6 +328,14 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
             }
 #pragma unroll
             for (int g = 0; g < NRG; ++g) sa[g] += sbb[g] + sc[g];
+        } else if (LAZY && pend_ok) {
+            soft_fwd(pend, pend_g0);
+        }
+        if (LAZY) {
+#pragma unroll
+            for (int g = 0; g < NRG; ++g) pend[g] = sa[g];
+            pend_g0 = (c0 + gg + it * NGG) * SG + 4 * kg;
+            pend_ok = work;
         }
         if (NDS > 1) {                                           // the pair's partial logits meet (all waves take the barrier)
 #pragma unroll
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
                 for (int g = 0; g < NRG; ++g) sa[g] += xs[(pw * NRG + g) * 64 + lane];
             }
         }
-        if (work) {
+        if (work && !LAZY) {
             const int g0 = (c0 + gg + it * NGG) * SG + 4 * kg;
             union B8 { unsigned u[4]; bf16x8 v; };
             B8 b1[NRG], b2[NRG];
@@ -383,6 +421,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
         iteration(it, stage[0], stage[NSET - 1]);
         if (NSET == 2 && it + 1 < niter) iteration(it + 1, stage[NSET - 1], stage[0]);
     }
+    if (LAZY && pend_ok) soft_fwd(pend, pend_g0);
 
 #pragma unroll
     for (int g = 0; g < NRG; ++g) {
@@ -476,9 +515,8 @@ static GsPlan gs_plan(int B, int M, int D, int big = 0) {
     p.Bp = p.RGF * BR;
     int s = (256 / p.RG) & ~7;             // ~one workgroup per CU; a multiple of 8 (block id -> XCD mapping), <= 256 (finish)
     if (s < 8) s = 8;
-    if (big) {                             // many row groups: enough splits that the last round of workgroups is a small share
-        static const int sb = [] { const char* e = getenv("CFL_CONW_S"); return e ? atoi(e) : 32; }();
-        while (s < sb && p.RG * s < 256 * 24) s += 8;
+    if (big) {                             // many row groups, one workgroup per CU: enough splits that the last round of workgroups
+        while (s < 32 && p.RG * s < 256 * 24) s += 8;     // is a small share (M = 50 000: 8 splits 3.58 ms, 16: 3.42, 32: 3.36, 64: 3.40)
     }
     const int nslot = cfl_cdiv(M, SG);
     while (s > 8 && s > nslot) s -= 8;
