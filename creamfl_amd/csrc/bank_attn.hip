@@ -261,12 +261,12 @@ static AttnWs attn_ws(void* ws, const AttnPlan& p) {
 
 #include "bank_gsplit.h"
 
-template <int DT, int NGG, int NWAVE, int NDS, int LA, bool GRAD, int NRG = 1>
+template <int DT, int NGG, int NWAVE, int NDS, int LA, bool GRAD>
 static int launch_stream(const float* F, const void* img, int B, int M, int D, float sc2, const gs::GsPlan& p, const AttnWs& w,
                          hipStream_t stream) {
-    using SM = gs::StSmem<DT, NGG, NWAVE, NDS, NRG>;
-    CFL_SET_LDS((gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD, NRG>), SM::TOTAL);
-    CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD, NRG>), dim3(p.S * p.RG), dim3(64 * NWAVE), SM::TOTAL, stream,
+    using SM = gs::StSmem<DT, NGG, NWAVE, NDS>;
+    CFL_SET_LDS((gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD>), SM::TOTAL);
+    CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_stream_kernel<DT, NGG, NWAVE, NDS, LA, GRAD>), dim3(p.S * p.RG), dim3(64 * NWAVE), SM::TOTAL, stream,
                F, (const char*)img, B, M, D, sc2, p.S, p.RG, w.part_m, w.part_l, w.part_o);
     return 0;
 }
@@ -394,7 +394,7 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
 
 // ---- round 4: con_w log-probabilities on the bank pass (wide-batch forward of bank_gsplit.h) -------------------------------
 int cfl_conw_img_supported(int rows, int M, int D) {
-    return (rows >= 512 && M > 0 && D >= 4 && D <= 512 && D % 4 == 0) ? 1 : 0;
+    return (rows >= 512 && M > 0 && D >= 4 && D <= 256 && D % 4 == 0) ? 1 : 0;
 }
 
 size_t cfl_conw_img_ws_bytes(int rows, int M, int D) {
@@ -417,11 +417,14 @@ int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int 
     w.rowbuf = nullptr; w.part_o = nullptr;
     const float* F = V + (size_t)row0 * D;
     const float sc2 = 1.4426950408889634f;
-    int rc;
-    rc = p.DT == 16 ? launch_stream<16, 1, 8, 1, 0, false, 1>(F, image, rows, M, D, sc2, p, w, stream)
-       : p.DT == 8 ? launch_stream<8, 1, 8, 1, 0, false, 2>(F, image, rows, M, D, sc2, p, w, stream)
-                   : launch_stream<4, 1, 8, 1, 0, false, 2>(F, image, rows, M, D, sc2, p, w, stream);
-    if (rc) return rc;
+    CFL_SET_LDS((gs::cfl_bank_wide32_kernel<8>), 4 * 64 * 32 * 8);
+    CFL_SET_LDS((gs::cfl_bank_wide32_kernel<4>), 4 * 64 * 32 * 4);
+    if (p.DT == 8)
+        CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_wide32_kernel<8>), dim3(p.S * p.RG), dim3(512), 4 * 64 * 32 * 8, stream, F, (const char*)image,
+                   rows, M, D, sc2, p.S, p.RG, w.part_m, w.part_l);
+    else
+        CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_wide32_kernel<4>), dim3(p.S * p.RG), dim3(512), 4 * 64 * 32 * 4, stream, F, (const char*)image,
+                   rows, M, D, sc2, p.S, p.RG, w.part_m, w.part_l);
     CFL_LAUNCH(K_LSE_FINAL, cfl_conw_finish_kernel, dim3(cfl_cdiv(rows, 64)), dim3(256), 0, stream, w.part_m, w.part_l, p.S, F,
                G + (size_t)row0 * D, rows, D, out);
     return 0;

@@ -129,46 +129,38 @@ __device__ __forceinline__ float row_max4(float v) {
 //     64 rows per workgroup (at D = 768 F + O = 192 registers per wave; with the slots arriving by LDS-DMA and read bursts
 //     of 4 the kernel fits 249 registers without spilling.  Measured on the way at D = 768, B = 128, M = 50 000: F 192 + O
 //     192 in ONE wave: 166 registers spilled into the loop, 442 us; 2 pairs with one wave per SIMD: 105 us; 4 pairs: 73 us).
-template <int DT, int NGG, int NWAVE, int NDS, int NRG = 1>
+template <int DT, int NGG, int NWAVE, int NDS>
 struct StSmem {
     static constexpr int DP = 32 * DT;
     static constexpr int SLOT = 64 * DP;
     static constexpr int STREAMS = NGG * 2 * SLOT;
-    static constexpr int ROWB = DP * 4 + 16;                              // merge image: [16 rows][DP floats + 16 B pad]
-    static constexpr int NIMG = (NWAVE / NDS) * NRG;                      // one image per (stream, 16-row feature group)
-    static constexpr int MERGE = NGG > 1 ? NIMG * 16 * ROWB : 0;
+    static constexpr int ROWB = DP * 4 + 16;                              // merge image: [16 rows][DP floats + 16 B pad] per wave
+    static constexpr int MERGE = NGG > 1 ? NWAVE * 16 * ROWB : 0;
     static constexpr int BODY = STREAMS > MERGE ? STREAMS : MERGE;
-    static constexpr int ML = NIMG * 16 * 2 * 4;                          // (max, sum) per image row | logit exchange (NDS > 1)
-    static constexpr int XS = NDS > 1 ? NWAVE * NRG * 1024 : 0;
+    static constexpr int ML = NWAVE * 16 * 2 * 4;                         // (max, sum) per wave and row | logit exchange (NDS > 1)
+    static constexpr int XS = NDS > 1 ? NWAVE * 1024 : 0;
     static constexpr int TOTAL = BODY + (ML > XS ? ML : XS);
 };
 
-// Round 4, NRG = 2: a wave owns TWO 16-row groups of feature rows, so every bank fragment it reads from LDS feeds two MFMA
-// chains.  Used by the wide-batch forward (con_w, row A5: B = M = 50 000 feature rows against the same bank): one slot stream
-// shared by all 8 waves, 256 feature rows per workgroup held in registers (F: 2 groups x D/4 registers, no gradient state),
-// so the bank image passes through a CU once per 256 rows -- 196 passes x 51 MB = 10 GB through the L2 -> LDS path where the
-// 128 x 128 tile GEMM of bank.hip moves 39 GB (its bound: 4.3 ms at the ~8 TB/s that path sustains).  (Measured and not kept
-// for the client step: NRG = 2 as a column-split PAIR on 32 rows -- half the LDS reads, but the second barrier per slot costs
-// more: 38.4 vs 33.3 us.)
-template <int DT, int NGG, int NWAVE, int NDS, int LA, bool GRAD, int NRG = 1>
+template <int DT, int NGG, int NWAVE, int NDS, int LA, bool GRAD>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(const float* __restrict__ F, const char* __restrict__ img,
                                                                               int B, int M, int D, float sc2, int S, int RG,
                                                                               float* __restrict__ part_m, float* __restrict__ part_l,
                                                                               float* __restrict__ part_o) {
-    static_assert(NRG == 1 || !GRAD || NDS == 2, "two row groups per wave: forward only, or a column-split pair");
-    constexpr int DP = 32 * DT, NSW = NWAVE / NGG, NFG = NSW / NDS, FR = 16 * NFG * NRG, NG16 = NFG * NRG;
+    static_assert(NDS == 1 || NGG == 1, "column-split pairs run on a single slot stream");
+    constexpr int DP = 32 * DT, NSW = NWAVE / NGG, NFG = NSW / NDS, FR = 16 * NFG;
     constexpr int KSW = DT / NDS, NDTW = 2 * DT / NDS;                   // contraction steps / gradient column tiles per wave
     static_assert(NDS == 1 || (KSW % 4 == 0 && NDTW % 8 == 0), "a wave's share must start on a 256-byte window");
     constexpr int STRIDE = NSW * 1024, NPT = (64 * DP) / STRIDE;         // 16-byte loads per thread and slot
     constexpr bool TIGHT = (DT == 24 && NWAVE == 8);                     // 2 waves per SIMD at D = 768: shorter bursts
-    constexpr int RB = (TIGHT || (NRG > 1 && GRAD)) ? 4 : (KSW % 8 == 0 ? 8 : (KSW % 6 == 0 ? 6 : 4));   // contraction steps per read burst of the logits block
-    constexpr int GW = (NDTW >= 8 && LA <= 1 && !TIGHT && NRG == 1) ? 8 : 4;       // column tiles per read burst of the gradient block
+    constexpr int RB = TIGHT ? 4 : (KSW % 8 == 0 ? 8 : (KSW % 6 == 0 ? 6 : 4));   // contraction steps per read burst of the logits block
+    constexpr int GW = (NDTW >= 8 && LA <= 1 && !TIGHT) ? 8 : 4;                   // column tiles per read burst of the gradient block
     static_assert(KSW % RB == 0 && NDTW % GW == 0, "bursts must tile the wave's share");
-    using SM = StSmem<DT, NGG, NWAVE, NDS, NRG>;
+    using SM = StSmem<DT, NGG, NWAVE, NDS>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gg = w % NGG, sw = w / NGG;                                // stream, wave of the stream
-    const int dh = sw % NDS, fg = sw / NDS;                              // column half, feature group (of NRG 16-row groups)
+    const int dh = sw % NDS, fg = sw / NDS;                              // column half, feature group
     const int f16 = lane & 15, kg = lane >> 4;
     const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
     const int rg = j8 % RG, x = (j8 / RG) * 8 + xcd;
@@ -177,7 +169,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     const int c0 = x * base + (x < extra ? x : extra);
     const int nmine = base + (x < extra ? 1 : 0);                        // slots of this split
     const int niter = (nmine + NGG - 1) / NGG;
-    const bool wave_live = rg * FR + 16 * NRG * fg < B;
+    const bool wave_live = rg * FR + 16 * fg < B;
     char* sbuf = lds + gg * 2 * SM::SLOT;                                // this stream's two slot buffers
     const int toff = (sw * 64 + lane) * 16;                              // this thread's 16 bytes of every STRIDE-byte stripe
     const char* sbase = img + toff;
@@ -211,34 +203,28 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
             for (int j = 0; j < NPT; ++j) stage[NSET - 1][j] = *reinterpret_cast<const u32x4v*>(slot_src(1) + j * STRIDE);
         }
     }
-    // this wave's share of its feature rows: contraction steps dh KSW .. + KSW - 1 of NRG groups of 16 rows
-    bf16x8 fh[NRG][KSW], fl[NRG][KSW];
-#pragma unroll
-    for (int g = 0; g < NRG; ++g) {
-        const int fr = rg * FR + 16 * (NRG * fg + g) + f16;
+    // this wave's share of its 16 feature rows: contraction steps dh KSW .. + KSW - 1
+    bf16x8 fh[KSW], fl[KSW];
+    {
+        const int fr = rg * FR + 16 * fg + f16;
         const float* fp = F + (long long)(fr < B ? fr : B - 1) * D;
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks) {
             const int k0 = 32 * (dh * KSW + ks) + 8 * kg;
             const bool ok0 = fr < B && k0 < D, ok1 = fr < B && k0 + 4 < D;
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
-            if (!GRAD && NDS == 1) { v0 *= sc2; v1 *= sc2; }      // forward-only passes: the logits come out of the MFMAs in the log2 domain
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
             bf16x4 h0, l0, h1, l1;
             split4(v0, ok0, h0, l0);
             split4(v1, ok1, h1, l1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { fh[g][ks][e] = h0[e]; fh[g][ks][4 + e] = h1[e]; fl[g][ks][e] = l0[e]; fl[g][ks][4 + e] = l1[e]; }
+            for (int e = 0; e < 4; ++e) { fh[ks][e] = h0[e]; fh[ks][4 + e] = h1[e]; fl[ks][e] = l0[e]; fl[ks][4 + e] = l1[e]; }
         }
     }
-    f32x4 O[NRG][GRAD ? NDTW : 1];
+    f32x4 O[GRAD ? NDTW : 1];
 #pragma unroll
-    for (int g = 0; g < NRG; ++g)
-#pragma unroll
-        for (int i = 0; i < (GRAD ? NDTW : 1); ++i) O[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float run_m[NRG], run_l[NRG];
-#pragma unroll
-    for (int g = 0; g < NRG; ++g) { run_m[g] = -INFINITY; run_l[g] = 0.f; }
+    for (int i = 0; i < (GRAD ? NDTW : 1); ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float run_m = -INFINITY, run_l = 0.f;
     if (!DMA && has_slot(0)) {
 #pragma unroll
         for (int j = 0; j < NPT; ++j) *reinterpret_cast<u32x4v*>(sbuf + j * STRIDE + toff) = stage[0][j];
@@ -256,35 +242,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
         for (int j = 0; j < 8; ++j)
             ta[j] = tr_row * (DP * 2) + dh * (NDTW * 32) + 8 * (f16 & 1) + (((2 * j + ((f16 & 3) >> 1)) ^ img_swz(tr_row)) << 4);
     }
-    f32x4* xs = reinterpret_cast<f32x4*>(lds + SM::BODY);        // NDS > 1: [wave][group][lane] partial logits
-
-    // Forward-only passes (no gradient GEMM behind the soft-max) defer the soft-max of a slot by one iteration: it runs between
-    // the fragment reads and the MFMAs of the NEXT slot, i.e. inside that burst's LDS latency instead of behind a drained matrix pipe
-    constexpr bool LAZY = (!GRAD && NDS == 1);
-    f32x4 pend[NRG];
-    int pend_g0 = 0;
-    bool pend_ok = false;
-    // (the logits arrive in the log2 domain: LAZY passes fold sc2 into the feature fragments; rows past M exist only in the bank's
-    // last slot; every slot has at least one real row, so the running maximum is finite from the first slot on)
-    auto soft_fwd = [&](f32x4 (&sv)[NRG], int g0) {
-        const bool tail = __builtin_amdgcn_readfirstlane(g0 - 4 * kg) + SG > M;
-#pragma unroll
-        for (int g = 0; g < NRG; ++g) {
-            if (tail) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (g0 + r >= M) sv[g][r] = -INFINITY;
-            }
-            float mx = fmaxf(fmaxf(sv[g][0], sv[g][1]), fmaxf(sv[g][2], sv[g][3]));
-            mx = row_max4(mx);
-            if (__any(mx > run_m[g] + RESCALE_THR)) {
-                const float mn = fmaxf(run_m[g], mx);
-                run_l[g] *= run_m[g] == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(run_m[g] - mn);
-                run_m[g] = mn;
-            }
-            run_l[g] += (__builtin_amdgcn_exp2f(sv[g][0] - run_m[g]) + __builtin_amdgcn_exp2f(sv[g][1] - run_m[g])) +
-                        (__builtin_amdgcn_exp2f(sv[g][2] - run_m[g]) + __builtin_amdgcn_exp2f(sv[g][3] - run_m[g]));
-        }
-    };
+    f32x4* xs = reinterpret_cast<f32x4*>(lds + SM::BODY);        // NDS > 1: [wave][lane] partial logits
 
     // one iteration: `ld` receives the loads of slot it + LA, `wr` (holding slot it + 1) goes to the other buffer at the end
     auto iteration = [&](int it, u32x4v (&ld)[DMA ? 1 : NPT], u32x4v (&wr)[DMA ? 1 : NPT]) {
@@ -296,13 +254,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
         }
         const char* sb = sbuf + (it & 1) * SM::SLOT;
         const bool work = wave_live && has_slot(it);
-        f32x4 sa[NRG];
-#pragma unroll
-        for (int g = 0; g < NRG; ++g) sa[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f};
         if (work) {
-            f32x4 sbb[NRG], sc[NRG];
-#pragma unroll
-            for (int g = 0; g < NRG; ++g) { sbb[g] = sa[g]; sc[g] = sa[g]; }
+            f32x4 sbb = sa, sc = sa;
             // bank fragments in bursts of RB contraction steps: all reads of a burst are issued before its first MFMA, so the
             // LDS latency is paid once per burst (one read at a time -- what the compiler does when registers are short --
             // leaves the matrix pipe 30 % busy: every MFMA pair waits for its own ds_read)
@@ -315,82 +269,58 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
                     ah[e] = *reinterpret_cast<const bf16x8*>(sb + off);
                     al[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
                 }
-                if (LAZY && k0 == 0 && pend_ok) soft_fwd(pend, pend_g0);
 #pragma unroll
                 for (int e = 0; e < RB; ++e) {
-#pragma unroll
-                    for (int g = 0; g < NRG; ++g) {
-                        sa[g] = MFMA16(ah[e], fh[g][k0 + e], sa[g]);
-                        sbb[g] = MFMA16(al[e], fh[g][k0 + e], sbb[g]);
-                        sc[g] = MFMA16(ah[e], fl[g][k0 + e], sc[g]);
-                    }
+                    sa = MFMA16(ah[e], fh[k0 + e], sa);
+                    sbb = MFMA16(al[e], fh[k0 + e], sbb);
+                    sc = MFMA16(ah[e], fl[k0 + e], sc);
                 }
             }
-#pragma unroll
-            for (int g = 0; g < NRG; ++g) sa[g] += sbb[g] + sc[g];
-        } else if (LAZY && pend_ok) {
-            soft_fwd(pend, pend_g0);
-        }
-        if (LAZY) {
-#pragma unroll
-            for (int g = 0; g < NRG; ++g) pend[g] = sa[g];
-            pend_g0 = (c0 + gg + it * NGG) * SG + 4 * kg;
-            pend_ok = work;
+            sa += sbb + sc;
         }
         if (NDS > 1) {                                           // the pair's partial logits meet (all waves take the barrier)
-#pragma unroll
-            for (int g = 0; g < NRG; ++g) xs[(w * NRG + g) * 64 + lane] = sa[g];
+            xs[w * 64 + lane] = sa;
             __syncthreads();
 #pragma unroll
-            for (int o = 1; o < NDS; ++o) {
-                const int pw = gg + NGG * (fg * NDS + (dh + o) % NDS);                  // the pair's other wave
-#pragma unroll
-                for (int g = 0; g < NRG; ++g) sa[g] += xs[(pw * NRG + g) * 64 + lane];
-            }
+            for (int o = 1; o < NDS; ++o) sa += xs[(w - dh + (dh + o) % NDS) * 64 + lane];
         }
-        if (work && !LAZY) {
+        if (work) {
             const int g0 = (c0 + gg + it * NGG) * SG + 4 * kg;
-            union B8 { unsigned u[4]; bf16x8 v; };
-            B8 b1[NRG], b2[NRG];
+            float mx = -INFINITY;
 #pragma unroll
-            for (int g = 0; g < NRG; ++g) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float y = sa[g][r] * sc2;
-                    if (g0 + r >= M) y = -INFINITY;
-                    sa[g][r] = y;
-                    mx = fmaxf(mx, y);
-                }
-                mx = row_max4(mx);
-                if (__any(mx > run_m[g] + RESCALE_THR)) {
-                    const float mn = fmaxf(run_m[g], mx);
-                    const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(run_m[g] - mn);
-                    run_l[g] *= alpha;
-                    if (GRAD) {
-#pragma unroll
-                        for (int dt = 0; dt < NDTW; ++dt) O[g][dt] *= alpha;
-                    }
-                    run_m[g] = mn;
-                }
-                float pv[4], ls = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[r] = run_m[g] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sa[g][r] - run_m[g]);
-                    ls += pv[r];
-                }
-                run_l[g] += ls;
+            for (int r = 0; r < 4; ++r) {
+                float y = sa[r] * sc2;
+                if (g0 + r >= M) y = -INFINITY;
+                sa[r] = y;
+                mx = fmaxf(mx, y);
+            }
+            mx = row_max4(mx);
+            if (__any(mx > run_m + RESCALE_THR)) {
+                const float mn = fmaxf(run_m, mx);
+                const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(run_m - mn);
+                run_l *= alpha;
                 if (GRAD) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const unsigned ph = pack_bf16(pv[2 * h], pv[2 * h + 1]);
-                        b1[g].u[h] = ph; b1[g].u[2 + h] = ph;                                                   // [ph | ph]
-                        b2[g].u[h] = pack_bf16(pv[2 * h] - bf16_lo_f(ph), pv[2 * h + 1] - bf16_hi_f(ph));       // [pl | 0]
-                        b2[g].u[2 + h] = 0u;
-                    }
+                    for (int dt = 0; dt < NDTW; ++dt) O[dt] *= alpha;
                 }
+                run_m = mn;
             }
+            float pv[4], ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[r] = run_m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sa[r] - run_m);
+                ls += pv[r];
+            }
+            run_l += ls;
             if (GRAD) {
+                union { unsigned u[4]; bf16x8 v; } b1, b2;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned ph = pack_bf16(pv[2 * h], pv[2 * h + 1]);
+                    b1.u[h] = ph; b1.u[2 + h] = ph;                                                      // [ph | ph]
+                    b2.u[h] = pack_bf16(pv[2 * h] - bf16_lo_f(ph), pv[2 * h + 1] - bf16_hi_f(ph));       // [pl | 0]
+                    b2.u[2 + h] = 0u;
+                }
                 const char* sl1 = sb + SG * DP * 2;
 #pragma unroll
                 for (int d4 = 0; d4 < NDTW; d4 += GW) {
@@ -401,12 +331,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
                         ga[e] = tr_read8(sb + o, sl1 + o);           // [4 rows hi | the same 4 rows lo] of column 16 dt + f16
                     }
 #pragma unroll
-                    for (int g = 0; g < NRG; ++g) {
+                    for (int e = 0; e < GW; ++e) O[d4 + e] = MFMA16(ga[e], b1.v, O[d4 + e]);
 #pragma unroll
-                        for (int e = 0; e < GW; ++e) O[g][d4 + e] = MFMA16(ga[e], b1[g].v, O[g][d4 + e]);
-#pragma unroll
-                        for (int e = 0; e < GW; ++e) O[g][d4 + e] = MFMA16(ga[e], b2[g].v, O[g][d4 + e]);
-                    }
+                    for (int e = 0; e < GW; ++e) O[d4 + e] = MFMA16(ga[e], b2.v, O[d4 + e]);
                 }
             }
         }
@@ -421,58 +348,46 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
         iteration(it, stage[0], stage[NSET - 1]);
         if (NSET == 2 && it + 1 < niter) iteration(it + 1, stage[NSET - 1], stage[0]);
     }
-    if (LAZY && pend_ok) soft_fwd(pend, pend_g0);
 
-#pragma unroll
-    for (int g = 0; g < NRG; ++g) {
-        run_l[g] += __shfl_xor(run_l[g], 16, 64);
-        run_l[g] += __shfl_xor(run_l[g], 32, 64);
-    }
+    run_l += __shfl_xor(run_l, 16, 64);
+    run_l += __shfl_xor(run_l, 32, 64);
+    const int f = rg * FR + 16 * fg + f16;
     if (NGG == 1) {
         if (!wave_live) return;
+        if (kg == 0 && dh == 0) {
+            const size_t o = (size_t)(f >> 7) * S * BR + (size_t)x * BR + (f & (BR - 1));
+            part_m[o] = run_m;
+            part_l[o] = run_l;
+        }
+        if (GRAD) {
+            float* po = part_o + ((size_t)f * S + x) * DP + dh * (NDTW * 16) + 4 * kg;
 #pragma unroll
-        for (int g = 0; g < NRG; ++g) {
-            const int f = rg * FR + 16 * (NRG * fg + g) + f16;
-            if (kg == 0 && dh == 0) {
-                const size_t o = (size_t)(f >> 7) * S * BR + (size_t)x * BR + (f & (BR - 1));
-                part_m[o] = run_m[g];
-                part_l[o] = run_l[g];
-            }
-            if (GRAD) {
-                float* po = part_o + ((size_t)f * S + x) * DP + dh * (NDTW * 16) + 4 * kg;
-#pragma unroll
-                for (int dt = 0; dt < NDTW; ++dt) store_wt_x4(po + 16 * dt, O[g][dt]);
-            }
+            for (int dt = 0; dt < NDTW; ++dt) store_wt_x4(po + 16 * dt, O[dt]);
         }
         return;
     }
-    // ---- merge of the NGG streams of every 16-row feature group through LDS (the slot buffers are free: last barrier above).
-    // Image (stream v, group g2 of the workgroup's NG16) = v * NG16 + g2: 16 rows of (max, sum) and of O; the waves of a
-    // column-split pair fill the two halves of the same image.
+    // ---- merge of the NGG streams of every feature group through LDS (the slot buffers are free: last barrier above)
     float* ml = reinterpret_cast<float*>(lds + SM::BODY);
+    if (kg == 0) { ml[(w * 16 + f16) * 2] = run_m; ml[(w * 16 + f16) * 2 + 1] = run_l; }
+    if (GRAD) {
+        char* ro = lds + w * 16 * SM::ROWB + f16 * SM::ROWB + 16 * kg;
 #pragma unroll
-    for (int g = 0; g < NRG; ++g) {
-        const int im = gg * NG16 + NRG * fg + g;
-        if (kg == 0 && dh == 0) { ml[(im * 16 + f16) * 2] = run_m[g]; ml[(im * 16 + f16) * 2 + 1] = run_l[g]; }
-        if (GRAD) {
-            char* ro = lds + (im * 16 + f16) * SM::ROWB + dh * (NDTW * 64) + 16 * kg;
-#pragma unroll
-            for (int dt = 0; dt < NDTW; ++dt) *reinterpret_cast<f32x4*>(ro + 64 * dt) = O[g][dt];
-        }
+        for (int dt = 0; dt < NDTW; ++dt) *reinterpret_cast<f32x4*>(ro + 64 * dt) = O[dt];
     }
     __syncthreads();
+    // waves of a feature group: fg NGG + 0 .. NGG - 1 in wave order  (w = (fg) * NGG + gg when NDS = 1)
     const int t = threadIdx.x;
-    auto image_of = [&](int g2, int v) { return v * NG16 + g2; };
-    if (t < FR) {                                               // row t of the workgroup: 16-row group t / 16, row t % 16
+    auto wave_of = [&](int g2, int v) { return g2 * NGG + v; };      // gg = w % NGG, fg = w / NGG
+    if (t < FR) {                                               // row t of the workgroup: feature group t / 16, row t % 16
         const int g2 = t >> 4, r = t & 15;
         float mm = -INFINITY;
 #pragma unroll
-        for (int v = 0; v < NGG; ++v) mm = fmaxf(mm, ml[(image_of(g2, v) * 16 + r) * 2]);
+        for (int v = 0; v < NGG; ++v) mm = fmaxf(mm, ml[(wave_of(g2, v) * 16 + r) * 2]);
         float L = 0.f;
 #pragma unroll
         for (int v = 0; v < NGG; ++v) {
-            const float mv = ml[(image_of(g2, v) * 16 + r) * 2];
-            L = fmaf(mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mv - mm), ml[(image_of(g2, v) * 16 + r) * 2 + 1], L);
+            const float mv = ml[(wave_of(g2, v) * 16 + r) * 2];
+            L = fmaf(mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mv - mm), ml[(wave_of(g2, v) * 16 + r) * 2 + 1], L);
         }
         const int fo = rg * FR + t;
         if (fo < B) {
@@ -487,13 +402,13 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
             const int g2 = row >> 4, r = row & 15;
             float mm = -INFINITY;
 #pragma unroll
-            for (int v = 0; v < NGG; ++v) mm = fmaxf(mm, ml[(image_of(g2, v) * 16 + r) * 2]);
+            for (int v = 0; v < NGG; ++v) mm = fmaxf(mm, ml[(wave_of(g2, v) * 16 + r) * 2]);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int v = 0; v < NGG; ++v) {
-                const int im = image_of(g2, v);
-                const float wgt = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ml[(im * 16 + r) * 2] - mm);
-                acc += *reinterpret_cast<const f32x4*>(lds + (im * 16 + r) * SM::ROWB + 16 * d4) * wgt;
+                const int wv = wave_of(g2, v);
+                const float wgt = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ml[(wv * 16 + r) * 2] - mm);
+                acc += *reinterpret_cast<const f32x4*>(lds + (wv * 16 + r) * SM::ROWB + 16 * d4) * wgt;
             }
             const int fo = rg * FR + row;
             if (fo < B) store_wt_x4(part_o + ((size_t)fo * S + x) * DP + 4 * d4, acc);
@@ -501,9 +416,152 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     }
 }
 
+// ---- the wide-batch forward on v_mfma_f32_32x32x16_bf16 (row A5, con_w; D <= 256) ------------------------------------------
+// con_w is the A3 problem with B = M = 50 000 feature rows and no gradient: one side of the product can live in REGISTERS.  The 8
+// waves of a workgroup hold 256 rows of V (32 per wave, pre-scaled and pre-split: D/2 registers) and stream the bank image through
+// ONE slot stream, so the image passes through a CU once per 256 rows: 196 x 51 MB = 10 GB through the L2 -> LDS path where the 128 x
+// 128 tile GEMM of bank.hip moves 39 GB (its bound: ~4.3 ms at the 8-9 TB/s that path sustains).  A wave multiplies 32 bank rows
+// (two 16-row slots) by its 32 feature rows with 32 x 32 x 16 MFMAs (the stream kernel's 16 x 16 x 32 arrangement with two row
+// groups per wave was built first: same time, twice the matrix instructions, two cross-lane swaps per 16 rows): 32 cycles and ~5
+// free issue slots beside each, and the
+// accumulator layout (lane = feature row, 16 registers = 16 of the 32 bank rows, the other 16 in lane ^ 32) makes the row
+// maximum 15 in-lane v_max + ONE v_permlane32_swap instead of two swaps per 16 rows.  Same image (the A fragment of lane l is
+// piece 2 ks + (l >> 5) of bank row l & 15 of slot (l >> 4) & 1: conflict-free under the image's swizzle,
+// tools/lds_swizzle_check.py), same splits, same partial layout; two 32-row buffers, LDS-DMA one step ahead, the soft-max of a
+// step deferred into the next step's first fragment-read latency.
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void cfl_bank_wide32_kernel(const float* __restrict__ F, const char* __restrict__ img, int B, int M,
+                                                               int D, float sc2, int S, int RG, float* __restrict__ part_m,
+                                                               float* __restrict__ part_l) {
+    constexpr int DP = 32 * DT, SLOT = 64 * DP, STEP = 2 * SLOT, KS = DP / 16, RB = 4, FR = 256;
+    constexpr int NPT = STEP / 8192;                                      // 16-byte DMA pieces per thread and step
+    static_assert(KS % RB == 0, "bursts tile the contraction");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+    const int rg = j8 % RG, x = (j8 / RG) * 8 + xcd;
+    const int nslot = (M + SG - 1) / SG;
+    const int base = nslot / S, extra = nslot % S;
+    const int c0 = x * base + (x < extra ? x : extra);
+    const int nmine = base + (x < extra ? 1 : 0);                        // 16-row slots of this split
+    const int nstep = (nmine + 1) >> 1;
+    const int limit = min(M, (c0 + nmine) * SG);                         // first bank row that is not this split's
+    const bool wave_live = rg * FR + 32 * w < B;
+    const char* sbase = img + (size_t)c0 * SLOT + (w * 64 + lane) * 16;
+    auto dma_step = [&](int it) {
+        const char* src = sbase + (size_t)it * STEP;
+        char* dst = lds + (it & 1) * STEP + w * 1024;
+        const int valid = (2 * it + 1 < nmine) ? STEP : SLOT;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (j * 8192 < valid)
+                __builtin_amdgcn_global_load_lds((glb_vptr)(src + j * 8192), (lds_vptr)(dst + j * 8192), 16, 0, 0);
+    };
+    if (nstep > 0) dma_step(0);
+    bf16x8 fh[KS], fl[KS];                                       // B operand: feature row r32, k = 16 ks + 8 kh .. + 7, pre-scaled
+    {
+        const int fr = rg * FR + 32 * w + r32;
+        const float* fp = F + (long long)(fr < B ? fr : B - 1) * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 16 * ks + 8 * kh;
+            const bool ok0 = fr < B && k0 < D, ok1 = fr < B && k0 + 4 < D;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
+            v0 *= sc2; v1 *= sc2;
+            bf16x4 h0, l0, h1, l1;
+            split4(v0, ok0, h0, l0);
+            split4(v1, ok1, h1, l1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { fh[ks][e] = h0[e]; fh[ks][4 + e] = h1[e]; fl[ks][e] = l0[e]; fl[ks][4 + e] = l1[e]; }
+        }
+    }
+    int la[8];                                                   // A operand: bank row r32 of the step, piece 2 ks + kh
+    {
+        const int g = r32 & 15;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) la[j] = (r32 >> 4) * SLOT + g * (DP * 2) + (((2 * j + kh) ^ img_swz(g)) << 4);
+    }
+    float run_m = -INFINITY, run_l = 0.f;
+    auto soft = [&](f32x16& v, int row0) {                       // v[r]: bank row row0 + 8 (r >> 2) + 4 kh + (r & 3), feature row r32
+        if (__builtin_amdgcn_readfirstlane(row0) + 32 > limit) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (row0 + 8 * (r >> 2) + 4 * kh + (r & 3) >= limit) v[r] = -INFINITY;
+        }
+        float mx = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, v[r]);
+        {
+            const unsigned u = __float_as_uint(mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (__any(mx > run_m + RESCALE_THR)) {
+            const float mn = fmaxf(run_m, mx);
+            run_l *= run_m == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(run_m - mn);
+            run_m = mn;
+        }
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            a0 += __builtin_amdgcn_exp2f(v[r] - run_m);
+            a1 += __builtin_amdgcn_exp2f(v[r + 1] - run_m);
+        }
+        run_l += a0 + a1;
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 pend;
+    int pend_row0 = 0;
+    bool pend_ok = false;
+    for (int it = 0; it < nstep; ++it) {
+        if (it + 1 < nstep) dma_step(it + 1);
+        const char* sb = lds + (it & 1) * STEP;
+        f32x16 sa, sbb, sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sbb[r] = 0.f; sc[r] = 0.f; }
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += RB) {
+            bf16x8 ah[RB], al[RB];
+#pragma unroll
+            for (int e = 0; e < RB; ++e) {
+                const int off = la[(k0 + e) & 7] + ((k0 + e) >> 3) * 256;
+                ah[e] = *reinterpret_cast<const bf16x8*>(sb + off);
+                al[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
+            }
+            if (k0 == 0 && pend_ok) soft(pend, pend_row0);       // the previous step's soft-max, inside this burst's LDS latency
+            if (wave_live) {
+#pragma unroll
+                for (int e = 0; e < RB; ++e) {
+                    sa = MFMA32(ah[e], fh[k0 + e], sa);
+                    sbb = MFMA32(al[e], fh[k0 + e], sbb);
+                    sc = MFMA32(ah[e], fl[k0 + e], sc);
+                }
+            }
+        }
+        pend = sa + (sbb + sc);
+        pend_row0 = (c0 + 2 * it) * SG;
+        pend_ok = wave_live;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (pend_ok) soft(pend, pend_row0);
+    if (!wave_live) return;
+    run_l += __shfl_xor(run_l, 32, 64);
+    const int f = rg * FR + 32 * w + r32;
+    if (kh == 0 && f < B) {
+        const size_t o = (size_t)(f >> 7) * S * BR + (size_t)x * BR + (f & (BR - 1));
+        part_m[o] = run_m;
+        part_l[o] = run_l;
+    }
+}
+
 struct GsPlan { int DT, DP, RG, S, RGF, Bp, wide, big; };
 // big: the wide-batch forward (no gradient state): 8 waves x NRG x 16 rows per workgroup on one slot stream
-static int gs_big_rows(int D) { return D <= 256 ? 256 : 128; }
+static int gs_big_rows(int) { return 256; }
 static GsPlan gs_plan(int B, int M, int D, int big = 0) {
     GsPlan p;
     p.wide = D > 256;
