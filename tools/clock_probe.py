@@ -37,10 +37,10 @@ def run(label, fn, seconds=2.0):
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < seconds:
-        for _ in range(20):
+        for _ in range(10):
             fn()
         torch.cuda.synchronize()
-        n += 20
+        n += 10
     dt = time.perf_counter() - t0
     stop.set()
     th.join()
@@ -61,6 +61,23 @@ def main():
     res = [run('idle', lambda: None, 0.5),
            run('con_w log-probabilities (dense 3 x bf16 MFMA)', lambda: ops.conw_logprob(V, G)),
            run('bf16 elementwise stream (HBM-bound)', lambda: x.mul_(1.0))]
+    if '--step' in sys.argv:                                       # the bench step (BASELINE configs[1]) under the same sampler
+        from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+        from creamfl_amd.utils.config import default_config
+        from creamfl_amd.utils.synthetic import coco_batch
+        del x
+        torch.manual_seed(1234)
+        cfg = default_config(embed_dim=512, cnn_type='resnet101', not_bert=False)
+        eng = TrainerEngine(device=dev)
+        eng.create(cfg, {'<pad>': 0}, None, False)
+        eng.model_to_device()
+        eng.to_half()
+        eng.model.train()
+        b = coco_batch(256, dev, seed=1234, bert=True)
+        images = b[0].contiguous(memory_format=torch.channels_last)
+        for _ in range(4):
+            eng.train_step(images, b[1], b[2], b[3])
+        res.append(run('server contrastive step (R101 + BERT-base, batch 256)', lambda: eng.train_step(images, b[1], b[2], b[3]), 4.0))
     print(json.dumps(res))
 
 
