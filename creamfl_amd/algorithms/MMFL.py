@@ -49,6 +49,8 @@ class _NullWandb:
 class MMFL(object):
     def __init__(self, args, wandb=None):
         self.args = args
+        if int(flags.get(args, 'miopen_immediate') or 0):            # before the first engine is built (creamfl_amd/runtime.py)
+            os.environ['CFL_MIOPEN_IMMEDIATE'] = '1'
         self.wandb = wandb if wandb is not None else _NullWandb()
         self.device = None
         self.img_local_trainers = None

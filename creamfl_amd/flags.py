@@ -32,6 +32,10 @@ BUILD_FLAGS = {
     'quiet': (dict(action='store_true'), 'no console logging'),
     'client_graph': (dict(type=int, default=1, choices=[0, 1]),
                      'capture the client contrast step (fixed B, M, D) in a HIP graph'),
+    'miopen_immediate': (dict(type=int, default=0, choices=[0, 1]),
+                         '1 = MIOpen immediate mode (no solver timing in the first step of every process: seconds instead of ~1 min); '
+                         'only for the convolution shapes the shipped / recorded find-db holds -- other shapes silently get a '
+                         'fallback kernel.  Same as CFL_MIOPEN_IMMEDIATE=1'),
 }
 
 

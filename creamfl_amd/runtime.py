@@ -128,7 +128,10 @@ def configure(tag=None):
     if not _STATE['torch']:
         _STATE['torch'] = True
         import torch
-        torch.backends.cudnn.benchmark = True           # PyTorch then asks MIOpen to FIND (mode 2) instead of immediate mode
+        # PyTorch then asks MIOpen to FIND (mode 2) instead of immediate mode.  CFL_MIOPEN_IMMEDIATE=1 keeps immediate mode: MIOpen
+        # answers from the find-db without timing anything, so the first step takes seconds instead of ~1 min -- right only for the
+        # shapes the shipped / recorded find-db holds (anything else silently gets a fallback kernel), hence opt-in
+        torch.backends.cudnn.benchmark = not os.environ.get('CFL_MIOPEN_IMMEDIATE')
     return _STATE
 
 

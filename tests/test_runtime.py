@@ -97,3 +97,5 @@ def test_building_an_engine_switches_find_mode_on(tmp_path):
     cudnn.benchmark on: without it PyTorch asks MIOpen for immediate-mode solutions and the find-db is never consulted."""
     r = _run(tmp_path, PROBE_ENGINE='1')
     assert r['benchmark'] is True
+    # opt-in: immediate mode (the find-db answers without timing anything: the first step of a process in seconds, not ~1 min)
+    assert _run(tmp_path, PROBE_ENGINE='1', CFL_MIOPEN_IMMEDIATE='1')['benchmark'] is False
