@@ -1118,6 +1118,88 @@ def _queue_stream_join(device):
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
+# ---- MIOpen immediate mode where the recorded find-db holds the problem ---------------------------------------------------------
+# PyTorch's `cudnn.benchmark = True` (creamfl_amd/runtime.py) makes MIOpen TIME its solvers for every new convolution problem of a
+# process -- 56 s in the first server step of BASELINE configs[1] (12.6 s forward, 43.9 s backward), in EVERY process, although the
+# find-db this package ships already holds the answers (PyTorch asks for an exhaustive search, which skips the db).  Immediate mode
+# answers from the db without timing anything (first step < 1 s, same step time) but hands a shape the db does NOT hold a fallback
+# kernel without saying so.  The trunk's convolution calls below therefore ask for immediate mode per call, and only when the
+# problem's key is in the find-db the process uses (MIOPEN_USER_DB_PATH/*.ufdb.txt: `Ci-H-W-kxk-Co-Ho-Wo-N-pad-stride-dilation-0-
+# layouts-dtype-F`, backward problems written from the output side); every other problem keeps the timed search.  A key this code
+# builds wrongly (another MIOpen version) is simply not found: slower start, never a slower kernel.  CFL_MIOPEN_AUTO=0 disables.
+_FDB = {'keys': None, 'known': {}, 'hits': 0, 'misses': 0, 'on': _os.environ.get('CFL_MIOPEN_AUTO', '1') != '0'}
+
+
+def _fdb_keys():
+    if _FDB['keys'] is None:
+        keys = set()
+        path = _os.environ.get('MIOPEN_USER_DB_PATH')
+        try:
+            for fn in (_os.listdir(path) if path else ()):
+                if fn.endswith('.ufdb.txt'):
+                    with open(_os.path.join(path, fn)) as f:
+                        for line in f:
+                            if '=' in line:
+                                keys.add(line.split('=', 1)[0])
+        except OSError:
+            pass
+        _FDB['keys'] = keys
+    return _FDB['keys']
+
+
+def fdb_key(direction, xs, ws, os_, stride, padding):
+    """The find-db key of a bf16 NHWC convolution problem: xs = input [N, Ci, H, W], ws = weight [Co, Ci, kh, kw], os_ = output
+    [N, Co, Ho, Wo]; direction 'F' (forward), 'B' (data gradient), 'W' (weight gradient)."""
+    N, Ci, H, W = xs
+    Co, _, kh, kw = ws
+    Ho, Wo = os_[2], os_[3]
+    a = (Ci, H, W, Co, Ho, Wo) if direction == 'F' else (Co, Ho, Wo, Ci, H, W)
+    return '%d-%d-%d-%dx%d-%d-%d-%d-%d-%dx%d-%dx%d-1x1-0-NHWC-NHWC-NHWC-BF16-%s' % (
+        a[0], a[1], a[2], kh, kw, a[3], a[4], a[5], N, padding, padding, stride, stride, direction)
+
+
+def _fdb_covered(direction, x, w, out_shape, stride, padding):
+    if not _FDB['on'] or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        return False
+    k = (direction, x.shape, w.shape, stride, padding)
+    hit = _FDB['known'].get(k)
+    if hit is None:
+        hit = (x.is_contiguous(memory_format=torch.channels_last)
+               and fdb_key(direction, tuple(x.shape), tuple(w.shape), tuple(out_shape), stride, padding) in _fdb_keys())
+        _FDB['known'][k] = hit
+        _FDB['hits' if hit else 'misses'] += 1
+    return hit
+
+
+def _miopen(covered, fn, *args):
+    """fn(*args) in MIOpen immediate mode when the find-db covers the problem, else as the process is configured."""
+    if not covered or not torch.backends.cudnn.benchmark:
+        return fn(*args)
+    torch._C._set_cudnn_benchmark(False)
+    try:
+        return fn(*args)
+    finally:
+        torch._C._set_cudnn_benchmark(True)
+
+
+def _conv_wgrad(args):
+    dy, x, w = args[0], args[1], args[2]
+    cov = _fdb_covered('W', x, w, dy.shape, args[4][0], args[5][0])
+    return _miopen(cov, torch.ops.aten.convolution_backward, *args, [False, True, False])[1]
+
+
+def _conv_dgrad(args):
+    dy, x, w = args[0], args[1], args[2]
+    cov = _fdb_covered('B', x, w, dy.shape, args[4][0], args[5][0])
+    return _miopen(cov, torch.ops.aten.convolution_backward, *args, [True, False, False])[0]
+
+
+def _conv_fwd(x, w, stride, padding):
+    kh = w.shape[2]
+    out_shape = (x.shape[0], w.shape[0], (x.shape[2] + 2 * padding - kh) // stride + 1, (x.shape[3] + 2 * padding - w.shape[3]) // stride + 1)
+    return _miopen(_fdb_covered('F', x, w, out_shape, stride, padding), torch.nn.functional.conv2d, x, w, None, stride, padding)
+
+
 class _ConvSplitFn(torch.autograd.Function):
     """y = conv2d(x, w, stride, padding) (no bias, groups 1) with the backward split in two:
       * the DATA gradient stays on the critical path (main stream); for 1x1 / stride-1 kernels it runs on the
@@ -1147,7 +1229,7 @@ class _ConvSplitFn(torch.autograd.Function):
                                                           _stream(x)), 'cfl_gemm_bf16_nt_stats')
             _LAST_STATS[0] = (pstat, stats_nblk, N * H * W, Co)
             return y
-        return torch.nn.functional.conv2d(x, weight, None, stride, padding)
+        return _conv_fwd(x, weight, stride, padding)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1169,7 +1251,7 @@ class _ConvSplitFn(torch.autograd.Function):
                     # what AccumulateGrad would have done (a tensor handed over now and filled later does not work:
                     # AccumulateGrad clones a gradient that something else still references).
                     def task(main, side, args=args, weight=weight):
-                        g = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                        g = _conv_wgrad(args)
                         args[0].record_stream(side)
                         args[1].record_stream(side)
                         g.record_stream(main)
@@ -1186,13 +1268,13 @@ class _ConvSplitFn(torch.autograd.Function):
                     side = streams.get(x.device, 'wgrad')
                     side.wait_stream(main)                               # dy (and x) are ready on the main stream
                     with torch.cuda.stream(side):
-                        dw = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                        dw = _conv_wgrad(args)
                     dy.record_stream(side)
                     x.record_stream(side)
                     dw.record_stream(main)
                 _queue_stream_join(x.device)
             else:
-                dw = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+                dw = _conv_wgrad(args)
         if ctx.needs_input_grad[0]:
             if gemm_dgrad:
                 dx = torch.empty_like(x)                                 # channels_last: the [M, Ci] matrix
@@ -1223,11 +1305,11 @@ class _ConvSplitFn(torch.autograd.Function):
                     # not prepared (client trainers): two small kernels, repaid by the faster convolution on large maps only
                     wr = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
                 if wr is not None:
-                    dx = torch.nn.functional.conv2d(dy, wr, None, 1, padding)
+                    dx = _conv_fwd(dy, wr, 1, padding)
                 else:
-                    dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
+                    dx = _conv_dgrad(args)
             else:
-                dx = torch.ops.aten.convolution_backward(*args, [True, False, False])[0]
+                dx = _conv_dgrad(args)
         return dx, dw, None, None, None, None, None
 
 
@@ -1289,7 +1371,7 @@ class _StemConvFn(torch.autograd.Function):
         ctx.save_for_backward(xs, w4, weight)
         ctx.side_wgrad = side_wgrad
         with torch.autocast('cuda', enabled=False):
-            return torch.nn.functional.conv2d(xs, w4, None, 1, 0)
+            return _conv_fwd(xs, w4, 1, 0)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1302,7 +1384,7 @@ class _StemConvFn(torch.autograd.Function):
             return None, None, None
 
         def wgrad():
-            return _stem_weight_s2d_inverse(torch.ops.aten.convolution_backward(*args, [False, True, False])[1], weight)
+            return _stem_weight_s2d_inverse(_conv_wgrad(args), weight)
         from . import streams
         if ctx.side_wgrad and streams.DEFER_WGRAD[0]:
             def task(main, side, weight=weight):

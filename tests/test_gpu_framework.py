@@ -625,3 +625,42 @@ def test_client_contrast_step_in_a_hip_graph_equals_eager(dev):
                         global_test_set=None, client_id=0, gpuid=str(dev)).model.state_dict()
     moved = max(float((sd_graph[k] - ref[k].float().cpu()).abs().max()) for k in sd_graph if sd_graph[k].is_floating_point())
     assert moved > 1e-6                                                # the steps did train
+
+
+@pytest.mark.gpu
+def test_first_server_step_answers_from_the_find_db(dev):
+    """Every process used to spend ~56 s of its first server step letting MIOpen time solvers whose answers the shipped find-db
+    already holds (PyTorch's cudnn.benchmark asks for an exhaustive search).  The trunk's convolution calls now use immediate mode
+    per call where the problem's key is in the find-db of the process (ops._fdb_covered) and keep the timed search elsewhere:
+    at BASELINE configs[1] every problem is covered, and the first step takes seconds."""
+    import time
+    from creamfl_amd import ops
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import coco_batch
+    if not ops._FDB['on']:
+        pytest.skip('CFL_MIOPEN_AUTO=0')
+    torch.manual_seed(7)
+    cfg = default_config(embed_dim=512, cnn_type='resnet101', not_bert=False)
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    eng.model.train()
+    b = coco_batch(256, dev, seed=7, bert=True)
+    images = b[0].contiguous(memory_format=torch.channels_last)
+    saved, ops._FDB['known'] = ops._FDB['known'], {}               # this step's problems only (the decision is re-derived from the db)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.time()
+        loss, _ = eng.train_step(images, b[1], b[2], b[3])
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        new = dict(ops._FDB['known'])
+    finally:
+        saved.update(ops._FDB['known'])
+        ops._FDB['known'] = saved
+    assert torch.isfinite(loss)
+    assert len(new) >= 40 and all(new.values()), [k for k, v in new.items() if not v]
+    assert dt < 30.0, dt
+    assert torch.backends.cudnn.benchmark is True                    # the per-call switch leaves the process setting alone

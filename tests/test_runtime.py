@@ -99,3 +99,29 @@ def test_building_an_engine_switches_find_mode_on(tmp_path):
     assert r['benchmark'] is True
     # opt-in: immediate mode (the find-db answers without timing anything: the first step of a process in seconds, not ~1 min)
     assert _run(tmp_path, PROBE_ENGINE='1', CFL_MIOPEN_IMMEDIATE='1')['benchmark'] is False
+
+
+def test_find_db_keys_of_the_trunk_convolutions_match_the_shipped_db():
+    """ops.fdb_key builds the key MIOpen files a convolution problem under; the trunk's convolution calls use immediate mode only
+    for problems whose key is in the find-db of the process (creamfl_amd/ops.py: _fdb_covered).  The key format is MIOpen's, so it
+    is pinned here against the db this package ships: forward, strided data gradient, weight gradient, the space-to-depth stem."""
+    from creamfl_amd import ops
+    db = os.path.join(ROOT, 'creamfl_amd', 'miopen_db')
+    keys = set()
+    for fn in os.listdir(db):
+        if fn.endswith('.ufdb.txt'):
+            keys |= {ln.split('=', 1)[0] for ln in open(os.path.join(db, fn)) if '=' in ln}
+    assert len(keys) >= 60
+    N = 256
+    cases = [('F', (N, 64, 56, 56), (64, 64, 3, 3), (N, 64, 56, 56), 1, 1),
+             ('F', (N, 3, 224, 224), (64, 3, 7, 7), (N, 64, 112, 112), 2, 3),
+             ('F', (N, 16, 115, 115), (64, 16, 4, 4), (N, 64, 112, 112), 1, 0),
+             ('F', (N, 256, 56, 56), (512, 256, 1, 1), (N, 512, 28, 28), 2, 0),
+             ('B', (N, 128, 56, 56), (128, 128, 3, 3), (N, 128, 28, 28), 2, 1),
+             ('B', (N, 256, 14, 14), (1024, 256, 1, 1), (N, 1024, 14, 14), 1, 0),
+             ('W', (N, 256, 14, 14), (1024, 256, 1, 1), (N, 1024, 14, 14), 1, 0),
+             ('W', (N, 16, 115, 115), (64, 16, 4, 4), (N, 64, 112, 112), 1, 0),
+             ('W', (N, 512, 14, 14), (512, 512, 3, 3), (N, 512, 7, 7), 2, 1)]
+    for c in cases:
+        assert ops.fdb_key(*c) in keys, (c, ops.fdb_key(*c))
+    assert ops.fdb_key('F', (32, 64, 56, 56), (64, 64, 3, 3), (32, 64, 56, 56), 1, 1) not in keys      # another batch: not covered

@@ -50,4 +50,6 @@ torch.cuda.synchronize()
 t['steady_ms_per_step'] = (time.perf_counter() - t0) * 100
 t['find_mode'] = os.environ.get('MIOPEN_FIND_MODE')
 t['total_s'] = time.perf_counter() - t00
+from creamfl_amd import ops as _ops
+t['find_db'] = {'covered_problems': _ops._FDB['hits'], 'uncovered_problems': _ops._FDB['misses'], 'auto': _ops._FDB['on']}
 print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in t.items()}))
