@@ -1124,23 +1124,29 @@ def _queue_stream_join(device):
 # find-db this package ships already holds the answers (PyTorch asks for an exhaustive search, which skips the db).  Immediate mode
 # answers from the db without timing anything (first step < 1 s, same step time) but hands a shape the db does NOT hold a fallback
 # kernel without saying so.  The trunk's convolution calls below therefore ask for immediate mode per call, and only when the
-# problem's key is in the find-db the process uses (MIOPEN_USER_DB_PATH/*.ufdb.txt: `Ci-H-W-kxk-Co-Ho-Wo-N-pad-stride-dilation-0-
+# problem's key is in the find-db this package ships and the process runs on (`Ci-H-W-kxk-Co-Ho-Wo-N-pad-stride-dilation-0-
 # layouts-dtype-F`, backward problems written from the output side); every other problem keeps the timed search.  A key this code
 # builds wrongly (another MIOpen version) is simply not found: slower start, never a slower kernel.  CFL_MIOPEN_AUTO=0 disables.
 _FDB = {'keys': None, 'known': {}, 'hits': 0, 'misses': 0, 'on': _os.environ.get('CFL_MIOPEN_AUTO', '1') != '0'}
 
 
 def _fdb_keys():
+    """Keys of the find-db files THIS PACKAGE ships (creamfl_amd/miopen_db, seeded into the process's MIOPEN_USER_DB_PATH by
+    runtime.configure_env) -- not of whatever the user directory has accumulated since: for the shipped problems immediate mode
+    was measured against the timed search (same step time); a problem recorded later by some run has not been, and one such
+    check (batch 512: 132 vs 86 ms per step) says it must not be assumed."""
     if _FDB['keys'] is None:
         keys = set()
-        path = _os.environ.get('MIOPEN_USER_DB_PATH')
+        from . import runtime as _rt
+        user = _os.environ.get('MIOPEN_USER_DB_PATH')
         try:
-            for fn in (_os.listdir(path) if path else ()):
-                if fn.endswith('.ufdb.txt'):
-                    with open(_os.path.join(path, fn)) as f:
-                        for line in f:
-                            if '=' in line:
-                                keys.add(line.split('=', 1)[0])
+            if user and _os.environ.get('CFL_SEEDED_DB') == '1':          # the process really runs on (a copy of) the shipped db
+                for fn in _os.listdir(_rt.DB_SRC):
+                    if fn.endswith('.ufdb.txt') and _os.path.exists(_os.path.join(user, fn)):
+                        with open(_os.path.join(_rt.DB_SRC, fn)) as f:
+                            for line in f:
+                                if '=' in line:
+                                    keys.add(line.split('=', 1)[0])
         except OSError:
             pass
         _FDB['keys'] = keys
