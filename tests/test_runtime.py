@@ -125,3 +125,24 @@ def test_find_db_keys_of_the_trunk_convolutions_match_the_shipped_db():
     for c in cases:
         assert ops.fdb_key(*c) in keys, (c, ops.fdb_key(*c))
     assert ops.fdb_key('F', (32, 64, 56, 56), (64, 64, 3, 3), (32, 64, 56, 56), 1, 1) not in keys      # another batch: not covered
+
+
+def test_find_db_gate_trusts_only_the_shipped_db(tmp_path, monkeypatch):
+    """Immediate mode is used for the problems of the db this package ships -- and only while the process runs on a seeded copy of
+    it; a caller's own db directory (no seeding marker) or CFL_MIOPEN_AUTO=0 leave every call on the timed search."""
+    import shutil
+    from creamfl_amd import ops, runtime
+    user = tmp_path / 'db'
+    shutil.copytree(runtime.DB_SRC, str(user))
+    with open(str(user / os.listdir(runtime.DB_SRC)[0]), 'a') as f:                     # something a later run recorded
+        f.write('64-56-56-3x3-64-56-56-32-1x1-1x1-1x1-0-NHWC-NHWC-NHWC-BF16-F=Solver:0.1,0,algo\n')
+    monkeypatch.setenv('MIOPEN_USER_DB_PATH', str(user))
+    monkeypatch.setenv('CFL_SEEDED_DB', '1')
+    monkeypatch.setitem(ops._FDB, 'keys', None)
+    keys = ops._fdb_keys()
+    assert '64-56-56-3x3-64-56-56-256-1x1-1x1-1x1-0-NHWC-NHWC-NHWC-BF16-F' in keys
+    assert '64-56-56-3x3-64-56-56-32-1x1-1x1-1x1-0-NHWC-NHWC-NHWC-BF16-F' not in keys
+    monkeypatch.delenv('CFL_SEEDED_DB')
+    monkeypatch.setitem(ops._FDB, 'keys', None)
+    assert ops._fdb_keys() == set()
+    monkeypatch.setitem(ops._FDB, 'keys', None)                                          # (the next user re-reads its own environment)
