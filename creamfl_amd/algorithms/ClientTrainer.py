@@ -156,6 +156,9 @@ class ClientTrainer:
                        f'./saved_clients/{self.dset_name}/Client{self.client_id}-model_{self.local_epoch}.pth')
         del self.old_model
         self.old_model = None
+        gs = getattr(self, '_graphed_contrast', None)
+        self.graph_stats = None if gs is None else {'calls': gs.calls, 'replays': gs.replays, 'failed': gs.failed}
+        self._graphed_contrast = self._graphed_key = None       # the round's graph (and its private pool) goes with the old model
 
     # -- step 3: learning ----------------------------------------------------------------------------------------
     def _features(self, model, images, captions, caption_lens):
@@ -235,7 +238,14 @@ class ClientTrainer:
         # GRU sequences): they stay eager.  --client_graph 0 switches it off.
         graphed = None
         if is_img and bool(int(flags.get(self.args, 'client_graph'))) and not is_test and torch.device(self.gpuid).type == 'cuda':
-            graphed = self._graphed_contrast = GraphedStep(contrast_step, warmup=3)
+            # ONE capture per round: the local epochs of a round see the same banks, the same old model and the same learning
+            # rate, so the later epochs replay the first one's graph (the closure it captured holds exactly those objects)
+            key = (self.cur_epoch, g_same.data_ptr(), g_other.data_ptr(), id(self.old_model), use_intra, use_inter,
+                   tuple(g['lr'] for g in self.optimizer.param_groups))
+            graphed = getattr(self, '_graphed_contrast', None)
+            if graphed is None or getattr(self, '_graphed_key', None) != key:
+                graphed = self._graphed_contrast = GraphedStep(contrast_step, warmup=3, log=self._log)
+                self._graphed_key = key
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)

@@ -12,12 +12,18 @@ synchronisation and no data-dependent Python control flow inside, outputs = tens
 valid until the next call).  A call whose input shapes differ from the captured ones (the ragged last batch of an epoch) runs
 eagerly.
 """
+import warnings
+
 import torch
 
 
 class GraphedStep:
-    def __init__(self, fn, warmup=3, enabled=True):
+    def __init__(self, fn, warmup=3, enabled=True, log=None):
+        """log: callable(str) that is told ONCE why a capture failed (default: warnings.warn) -- a step that silently stays eager
+        looks like a performance regression with no trace."""
         self.fn = fn
+        self.log = log
+        self._side = None
         self.warmup = max(1, int(warmup))
         self.enabled = bool(enabled) and torch.cuda.is_available()
         self.calls = 0
@@ -49,9 +55,27 @@ class GraphedStep:
             self.failed = repr(e)[:300]
             self.enabled = False
             torch.cuda.synchronize()
+            msg = 'GraphedStep: HIP-graph capture failed, the step stays eager: %s' % self.failed
+            (self.log or warnings.warn)(msg)
             return False
         self.graph, self.static_out = graph, out
         return True
+
+    def _warm(self, inputs):
+        """An eager warm-up step on a SIDE stream (the capture recipe: the libraries bind their handles and workspaces, and the
+        allocator its blocks, away from the stream the rest of the program runs on); the caller's stream waits for it."""
+        cur = torch.cuda.current_stream(self._device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self._device)
+        args = [t.to(self._device, non_blocking=True) for t in inputs]
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            out = self.fn(*args)
+        cur.wait_stream(self._side)
+        for t in args + [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(o)]:
+            if t.is_cuda:
+                t.record_stream(cur)
+        return out
 
     def __call__(self, *inputs, device=None):
         """inputs: tensors (host or device).  Returns fn's outputs."""
@@ -61,7 +85,7 @@ class GraphedStep:
             return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])
         if self.graph is None:
             if self.calls <= self.warmup:
-                return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])           # eager: real steps
+                return self._warm(inputs)                          # eager: real steps
             if not self._capture(inputs):
                 return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])
             self.graph.replay()                                   # capture records, it does not execute: this runs the step

@@ -537,7 +537,7 @@ def conw_logprob(vec, global_other, row0=0, rows=None):
     rows = M - row0 if rows is None else rows
     out = torch.empty(rows, dtype=torch.float32, device=V.device)
     if (not _CONW_NOIMG and lib.cfl_conw_img_supported(rows, M, D) and V.data_ptr() % 16 == 0 and G.data_ptr() % 16 == 0
-            and not _os.environ.get('CFL_BANK_EXACT')):
+            and not (_BANK_EXACT or lib.cfl_get_exact_gemm())):
         # the bank pass of rows A3/A4 on the (cached) pre-split image of G: the bank moves through a CU once per 256 rows
         img = bank_image(G)
         ws = _ws(lib.cfl_conw_img_ws_bytes(rows, M, D), V.device)
@@ -769,7 +769,7 @@ def bn_act_supported(x, num_features):
 _NO_JOIN_FUSE = _os.environ.get('CFL_NO_JOIN_FUSE', '0') == '1'      # measurement switch
 # Structural assumption, CHECKED in the BatchNorm backward: the pre-joined output object `y` is consumed by the block's first 1x1
 # convolution ONLY (and its alias y2 by the next bn3's residual input only).  JOIN['pre'][tok] records the address of the g the
-# GEMM wrote; the BatchNorm backward requires the gradient it is handed to BE that tensor -- if anything else consumed y (a
+# GEMM wrote (and holds the tensor, so that autograd cannot accumulate another gradient into it in place); the BatchNorm backward requires the gradient it is handed to BE that tensor -- if anything else consumed y (a
 # feature tap, a hook, another block variant) autograd has added an UNMASKED gradient into a new tensor, and the layer raises
 # instead of back-propagating a silently wrong sum.
 JOIN = {'armed': False, 'on': False, 'serial': 0, 'mask': {}, 'consumer': set(), 'pending': {}, 'pre': {}, 'fused': 0}
@@ -863,7 +863,8 @@ class _BNActFn(torch.autograd.Function):
         # JOIN: the data-gradient GEMM of the consumer already produced g = (A + B) . mask for this layer's output
         pre = bool(JOIN['on'] and ctx.tok and ctx.tok in JOIN['pre'])
         if pre:
-            joined_at = JOIN['pre'].pop(ctx.tok)
+            joined_at, _held = JOIN['pre'].pop(ctx.tok)
+            del _held
             if dy2 is not None or dy.data_ptr() != joined_at:
                 raise _lib.CreamflHipError(
                     'fused gradient join: the output of a pre-joined BatchNorm layer was consumed by something besides the '
@@ -1134,7 +1135,9 @@ def _fdb_keys():
     """Keys of the find-db files THIS PACKAGE ships (creamfl_amd/miopen_db, seeded into the process's MIOPEN_USER_DB_PATH by
     runtime.configure_env) -- not of whatever the user directory has accumulated since: for the shipped problems immediate mode
     was measured against the timed search (same step time); a problem recorded later by some run has not been, and one such
-    check (batch 512: 132 vs 86 ms per step) says it must not be assumed."""
+    check (batch 512: 132 vs 86 ms per step) says it must not be assumed.  A shipped record counts only while the copy MIOpen
+    answers from still holds the SAME record (a copy seeded by another package version, or a record a later timed search rewrote,
+    is not what was measured: that problem goes back to the timed search)."""
     if _FDB['keys'] is None:
         keys = set()
         from . import runtime as _rt
@@ -1143,9 +1146,11 @@ def _fdb_keys():
             if user and _os.environ.get('CFL_SEEDED_DB') == '1':          # the process really runs on (a copy of) the shipped db
                 for fn in _os.listdir(_rt.DB_SRC):
                     if fn.endswith('.ufdb.txt') and _os.path.exists(_os.path.join(user, fn)):
+                        with open(_os.path.join(user, fn)) as f:
+                            live = {line.rstrip('\n') for line in f if '=' in line}
                         with open(_os.path.join(_rt.DB_SRC, fn)) as f:
                             for line in f:
-                                if '=' in line:
+                                if '=' in line and line.rstrip('\n') in live:
                                     keys.add(line.split('=', 1)[0])
         except OSError:
             pass
@@ -1167,10 +1172,11 @@ def fdb_key(direction, xs, ws, os_, stride, padding):
 def _fdb_covered(direction, x, w, out_shape, stride, padding):
     if not _FDB['on'] or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         return False
-    k = (direction, x.shape, w.shape, stride, padding)
+    nhwc = x.is_contiguous(memory_format=torch.channels_last)      # part of the problem: the db's records are NHWC ones
+    k = (direction, x.shape, w.shape, stride, padding, nhwc)
     hit = _FDB['known'].get(k)
     if hit is None:
-        hit = (x.is_contiguous(memory_format=torch.channels_last)
+        hit = (nhwc
                and fdb_key(direction, tuple(x.shape), tuple(w.shape), tuple(out_shape), stride, padding) in _fdb_keys())
         _FDB['known'][k] = hit
         _FDB['hits' if hit else 'misses'] += 1
@@ -1293,7 +1299,12 @@ class _ConvSplitFn(torch.autograd.Function):
                     # dX = (dY W + skip gradient) . ReLU mask of the BatchNorm that produced x: pre-joined for that layer
                     gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci),
                                  add=skip, mask=JOIN['mask'][ctx.x_tok])
-                    JOIN['pre'][ctx.x_tok] = dx.data_ptr()       # the BatchNorm backward must be handed exactly this tensor
+                    # the BatchNorm backward must be handed exactly this tensor.  The registry keeps a REFERENCE to it next to
+                    # the address: were there a second consumer of the pre-joined output, autograd's input buffer could
+                    # otherwise add the other (unmasked) gradient into this freshly allocated dx IN PLACE (it does so when it
+                    # holds the only reference) and the sum would keep dx's address; with the reference held it must allocate
+                    # a new tensor, and the address check below sees it whatever the arrival order
+                    JOIN['pre'][ctx.x_tok] = (dx.data_ptr(), dx)
                     JOIN['fused'] += 1
                 elif DGRAD_PLAIN_LIB[0] and Co >= DGRAD_PLAIN_LIB[0]:
                     # measurement knob (tools/ab_step.py --knob dgradlib): the un-joined data gradient as the library's FORWARD

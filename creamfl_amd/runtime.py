@@ -32,20 +32,87 @@ import tempfile
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DB_SRC = os.path.join(_HERE, 'miopen_db')
 CACHE_SRC = os.path.join(_HERE, 'miopen_cache')
-_STATE = {'env': False, 'torch': False, 'db': None, 'cache': None}
+_STATE = {'env': False, 'torch': False, 'db': None, 'cache': None, 'lock': None, 'tag': None}
 
 
-def _private_dir(kind, tag):
-    return os.path.join(tempfile.gettempdir(), 'creamfl_%s_%d' % (kind, os.getuid()), tag)
+def _tree_digest(src):
+    """Short content hash of a shipped directory (names + bytes): the private copy lives under it, so a package upgrade that
+    changes the find-db or the kernel cache starts from a fresh copy instead of answering from a stale one."""
+    import hashlib
+    h = hashlib.sha256()
+    for root, dirs, files in os.walk(src):
+        dirs.sort()
+        for f in sorted(files):
+            h.update(os.path.relpath(os.path.join(root, f), src).encode())
+            with open(os.path.join(root, f), 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:10]
+
+
+def _owned_private(path):
+    """True if `path` is a directory of THIS user that nobody else may write (a predictable name under a shared /tmp can be
+    pre-created by another user with a poisoned kernel cache that MIOpen would then load)."""
+    try:
+        st = os.lstat(path)
+    except OSError:
+        return False
+    import stat
+    return stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o022)
+
+
+def _private_root(kind):
+    """<tmp>/creamfl_<kind>_<uid>, created 0700 and verified (owner, no group / other write bit); a directory that fails the
+    check is not used: a fresh mkdtemp one is (unpredictable name, this process's lifetime)."""
+    root = os.path.join(tempfile.gettempdir(), 'creamfl_%s_%d' % (kind, os.getuid()))
+    try:
+        os.makedirs(root, mode=0o700, exist_ok=True)
+    except OSError:
+        pass
+    if _owned_private(root):
+        return root
+    return tempfile.mkdtemp(prefix='creamfl_%s_' % kind)
+
+
+def _private_dir(kind, tag, digest=''):
+    root = _private_root(kind)
+    if digest:
+        root = os.path.join(root, digest)
+        os.makedirs(root, mode=0o700, exist_ok=True)
+    return os.path.join(root, tag)
+
+
+def _claim_slot(tag):
+    """`tag`, or `tag_s1`, `tag_s2` ... -- the first one no LIVING process of this user holds (an flock on a lock file, kept for the
+    life of the process).  Ranks started without any rank variable (torch.multiprocessing.spawn children, which also inherit the
+    parent's CFL_SEEDED_* markers; two independent single-GPU jobs of one user) would otherwise all derive the same directory and
+    append to one text find-db / compile into one sqlite kernel cache -- the case that aborted inside the library with 8 ranks."""
+    try:
+        import fcntl
+        root = _private_root('locks')
+        for slot in range(256):
+            name = tag if slot == 0 else '%s_s%d' % (tag, slot)
+            fd = os.open(os.path.join(root, name + '.lock'), os.O_CREAT | os.O_RDWR, 0o600)
+            try:
+                fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
+            except OSError:
+                os.close(fd)
+                continue
+            _STATE['lock'] = fd                       # held until the process exits
+            return name
+    except (OSError, ImportError):
+        pass
+    return '%s_p%d' % (tag, os.getpid())
 
 
 def _seed(src, dst):
     """Copy the files of `src` that `dst` does not have yet (a later process keeps what an earlier one recorded)."""
-    os.makedirs(dst, exist_ok=True)
+    os.makedirs(dst, mode=0o700, exist_ok=True)
+    if not _owned_private(dst):
+        raise OSError('refusing a library directory that is not exclusively ours: %s' % dst)
     for root, _dirs, files in os.walk(src):
         rel = os.path.relpath(root, src)
         out = dst if rel == '.' else os.path.join(dst, rel)
-        os.makedirs(out, exist_ok=True)
+        os.makedirs(out, mode=0o700, exist_ok=True)
         for f in files:
             target = os.path.join(out, f)
             if not os.path.exists(target):
@@ -85,53 +152,90 @@ def hw_queues(local_world, gpus, full=8):
     return max(1, full // -(-local_world // gpus))
 
 
+def _env_int(environ, names):
+    for n in names:
+        v = environ.get(n)
+        if v:
+            try:
+                return int(v.split('(')[0])                       # SLURM writes "8(x2)"
+            except ValueError:
+                pass
+    return None
+
+
+# who am I on this node, whoever launched me: torchrun, SLURM srun, Open MPI / MVAPICH mpirun; the global RANK as the last resort
+LOCAL_RANK_VARS = ('LOCAL_RANK', 'SLURM_LOCALID', 'OMPI_COMM_WORLD_LOCAL_RANK', 'MV2_COMM_WORLD_LOCAL_RANK', 'RANK', 'SLURM_PROCID')
+LOCAL_WORLD_VARS = ('LOCAL_WORLD_SIZE', 'SLURM_NTASKS_PER_NODE', 'OMPI_COMM_WORLD_LOCAL_SIZE', 'MV2_COMM_WORLD_LOCAL_SIZE')
+
+
+def local_rank(environ=None):
+    """This process's rank on its node from whichever launcher variable is set, else None."""
+    return _env_int(os.environ if environ is None else environ, LOCAL_RANK_VARS)
+
+
+def local_world(environ=None):
+    return _env_int(os.environ if environ is None else environ, LOCAL_WORLD_VARS) or 1
+
+
+def immediate_mode(environ=None):
+    """CFL_MIOPEN_IMMEDIATE=1 (exactly '1': exporting 0 does not switch it on)."""
+    return (os.environ if environ is None else environ).get('CFL_MIOPEN_IMMEDIATE', '').strip() == '1'
+
+
 def configure_env(tag=None):
     """The environment half (idempotent; no torch).  `tag` names the private find-db directory (default: $CFL_RUNTIME_TAG and / or
-    LOCAL_RANK, so that no two ranks of a launch append to one text database or compile into one kernel cache)."""
+    the launcher's local rank -- LOCAL_RANK, SLURM_LOCALID, OMPI_COMM_WORLD_LOCAL_RANK, ..., RANK -- and, whatever the tag, a slot
+    no other living process of this user holds: no two processes ever append to one text database or compile into one kernel
+    cache, also when nothing tells them apart (multiprocessing spawn, two jobs of one user))."""
     if _STATE['env']:
         return _STATE
     _STATE['env'] = True
     os.environ.setdefault('MIOPEN_FIND_MODE', '2')
-    try:
-        local_world = int(os.environ.get('LOCAL_WORLD_SIZE') or 1)
-    except ValueError:
-        local_world = 1
+    lw = local_world()
     if 'GPU_MAX_HW_QUEUES' not in os.environ or os.environ.get('CFL_SET_HWQ') == '1':      # ours (or a launching parent's): re-derived per rank
-        os.environ['GPU_MAX_HW_QUEUES'] = str(hw_queues(local_world, visible_gpus() if local_world > 1 else 0))
+        os.environ['GPU_MAX_HW_QUEUES'] = str(hw_queues(lw, visible_gpus() if lw > 1 else 0))
         os.environ['CFL_SET_HWQ'] = '1'
+    if os.environ.get('CFL_NO_SEEDED_DB'):
+        return _STATE
     if tag is None:
         # $CFL_RUNTIME_TAG names a family of processes (the test suite, a tool); the ranks of ONE launch still get a directory
         # each: eight ranks compiling into one sqlite kernel cache abort inside the library (seen with `bench.py --gpus 8`
         # started from a process that had exported its tag)
         tag = os.environ.get('CFL_RUNTIME_TAG') or ''
-        rank = os.environ.get('LOCAL_RANK')
-        tag = (tag + ('_r' if tag else '') + rank) if rank is not None else (tag or '0')
-    tag = str(tag)
-    if os.environ.get('CFL_NO_SEEDED_DB'):
-        return _STATE
+        rank = local_rank()
+        tag = (tag + ('_r' if tag else '') + str(rank)) if rank is not None else (tag or '0')
     # a variable this function set itself (a parent that launched us) is re-derived for OUR rank; a caller's own is kept
+    todo = []
+    for var, mark, src, kind in (('MIOPEN_USER_DB_PATH', 'CFL_SEEDED_DB', DB_SRC, 'miopen_db'),
+                                 ('MIOPEN_CUSTOM_CACHE_DIR', 'CFL_SEEDED_CACHE', CACHE_SRC, 'miopen_cache')):
+        ours = os.environ.get(mark) == '1'
+        if (var not in os.environ or ours) and os.path.isdir(src) and os.listdir(src):
+            todo.append((var, mark, src, kind))
+    if not todo:
+        return _STATE
+    tag = _STATE['tag'] = _claim_slot(str(tag))
     try:
-        for var, mark, src, kind in (('MIOPEN_USER_DB_PATH', 'CFL_SEEDED_DB', DB_SRC, 'miopen_db'),
-                                     ('MIOPEN_CUSTOM_CACHE_DIR', 'CFL_SEEDED_CACHE', CACHE_SRC, 'miopen_cache')):
-            ours = os.environ.get(mark) == '1'
-            if (var not in os.environ or ours) and os.path.isdir(src) and os.listdir(src):
-                os.environ[var] = _STATE[kind[7:]] = _seed(src, _private_dir(kind, tag))
-                os.environ[mark] = '1'
+        for var, mark, src, kind in todo:
+            os.environ[var] = _STATE[kind[7:]] = _seed(src, _private_dir(kind, tag, _tree_digest(src)))
+            os.environ[mark] = '1'
     except OSError:
         pass                                            # read-only temp directory: the library falls back to its own defaults
     return _STATE
 
 
 def configure(tag=None):
-    """Environment + the torch switches (idempotent).  Call before the first convolution of the process."""
+    """Environment + the torch switches.  Call before the first convolution of the process; calling it again re-applies the
+    find / immediate switch (MMFL's --miopen_immediate may arrive after an engine was built)."""
     configure_env(tag)
-    if not _STATE['torch']:
-        _STATE['torch'] = True
-        import torch
-        # PyTorch then asks MIOpen to FIND (mode 2) instead of immediate mode.  CFL_MIOPEN_IMMEDIATE=1 keeps immediate mode: MIOpen
-        # answers from the find-db without timing anything, so the first step takes seconds instead of ~1 min -- right only for the
-        # shapes the shipped / recorded find-db holds (anything else silently gets a fallback kernel), hence opt-in
-        torch.backends.cudnn.benchmark = not os.environ.get('CFL_MIOPEN_IMMEDIATE')
+    import torch
+    # PyTorch then asks MIOpen to FIND (mode 2) instead of immediate mode.  CFL_MIOPEN_IMMEDIATE=1 keeps immediate mode: MIOpen
+    # answers from the find-db without timing anything, so the first step takes seconds instead of ~1 min -- right only for the
+    # shapes the shipped / recorded find-db holds (anything else silently gets a fallback kernel), hence opt-in
+    want = not immediate_mode()
+    if not _STATE['torch'] or _STATE.get('benchmark') != want:
+        torch.backends.cudnn.benchmark = want
+        _STATE['benchmark'] = want
+    _STATE['torch'] = True
     return _STATE
 
 

@@ -146,3 +146,92 @@ def test_find_db_gate_trusts_only_the_shipped_db(tmp_path, monkeypatch):
     monkeypatch.setitem(ops._FDB, 'keys', None)
     assert ops._fdb_keys() == set()
     monkeypatch.setitem(ops._FDB, 'keys', None)                                          # (the next user re-reads its own environment)
+
+
+def test_private_directories_are_exclusively_ours_and_keyed_on_the_shipped_content(tmp_path):
+    """the find-db / kernel-cache copies live under a predictable /tmp name -- they are created 0700, verified
+    (owner, no group / other write bit) and a directory that fails the check is NOT used; the copy sits under a hash of the shipped
+    files, so another package version never answers from a stale copy."""
+    import stat
+    from creamfl_amd import runtime
+    r = _run(tmp_path)
+    root = os.path.dirname(os.path.dirname(r['db']))                       # <tmp>/creamfl_miopen_db_<uid>/<digest>/<tag>
+    assert os.path.basename(os.path.dirname(r['db'])) == runtime._tree_digest(runtime.DB_SRC)
+    for d in (root, os.path.dirname(r['db']), r['db']):
+        st = os.stat(d)
+        assert st.st_uid == os.getuid() and not (st.st_mode & 0o077), (d, oct(st.st_mode))
+    # somebody else could write into the well-known directory: it is not trusted, an unpredictable private one is used
+    os.chmod(root, 0o777)
+    assert not runtime._owned_private(root)
+    r2 = _run(tmp_path)
+    assert not r2['db'].startswith(root + os.sep) and r2['files'] == r['files']
+    assert stat.S_IMODE(os.stat(os.path.dirname(os.path.dirname(r2['db']))).st_mode) == 0o700
+    # the digest follows the content
+    a = tmp_path / 'a'
+    a.mkdir()
+    (a / 'x.txt').write_text('1')
+    d1 = runtime._tree_digest(str(a))
+    (a / 'x.txt').write_text('2')
+    assert runtime._tree_digest(str(a)) != d1
+
+
+def test_rank_fallbacks_and_slot_claim(tmp_path):
+    """ranks started by srun / mpirun (no LOCAL_RANK) get their own directory from the launcher's variable,
+    and processes nothing tells apart (multiprocessing spawn children that inherit the parent's markers, two jobs of one user)
+    claim distinct slots while both are alive."""
+    assert _run(tmp_path, SLURM_LOCALID='3')['db'].endswith(os.sep + '3')
+    assert _run(tmp_path, OMPI_COMM_WORLD_LOCAL_RANK='2')['db'].endswith(os.sep + '2')
+    assert _run(tmp_path, RANK='6')['db'].endswith(os.sep + '6')
+    assert _run(tmp_path, LOCAL_RANK='1', RANK='9')['db'].endswith(os.sep + '1')          # the local one wins
+    # shared GPU, SLURM: the queue split sees the node's task count
+    assert _run(tmp_path, SLURM_NTASKS_PER_NODE='8(x2)', SLURM_LOCALID='2', HIP_VISIBLE_DEVICES='0')['queues'] == '1'
+    # two living processes without any rank variable
+    env = {k: v for k, v in os.environ.items() if not k.startswith(('MIOPEN_', 'CFL_', 'GPU_MAX')) and k not in ('LOCAL_RANK', 'RANK')}
+    env['TMPDIR'] = str(tmp_path)
+    prog = ('import sys, os; sys.path.insert(0, %r); import creamfl_amd; print(os.environ["MIOPEN_USER_DB_PATH"], flush=True); '
+            'sys.stdin.readline()' % ROOT)
+    procs = [subprocess.Popen([sys.executable, '-c', prog], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE) for _ in range(2)]
+    try:
+        dirs = [p.stdout.readline().decode().strip() for p in procs]
+    finally:
+        for p in procs:
+            p.stdin.close()
+            p.wait(timeout=60)
+    assert len(set(dirs)) == 2 and sorted(os.path.basename(d) for d in dirs) == ['0', '0_s1'], dirs
+    assert _run(tmp_path)['db'].endswith(os.sep + '0')                                   # both gone: the slot is free again
+
+
+def test_immediate_switch_is_exact_and_reapplied(tmp_path):
+    """CFL_MIOPEN_IMMEDIATE=0 must not switch immediate mode ON, and a flag that arrives after the first engine
+    was built (MMFL --miopen_immediate) still takes effect."""
+    assert _run(tmp_path, PROBE_ENGINE='1', CFL_MIOPEN_IMMEDIATE='0')['benchmark'] is True
+    prog = ('import sys, os, json; sys.path.insert(0, %r); import torch; from creamfl_amd import runtime; runtime.configure(); '
+            'a = torch.backends.cudnn.benchmark; os.environ["CFL_MIOPEN_IMMEDIATE"] = "1"; runtime.configure(); '
+            'print(json.dumps([a, torch.backends.cudnn.benchmark]))' % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith(('MIOPEN_', 'CFL_', 'GPU_MAX'))}
+    env['TMPDIR'] = str(tmp_path)
+    out = subprocess.run([sys.executable, '-c', prog], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-1500:]
+    assert json.loads(out.stdout.decode().strip().splitlines()[-1]) == [True, False]
+
+
+def test_find_db_gate_needs_the_live_copy_to_hold_the_shipped_record(tmp_path, monkeypatch):
+    """the gate's key set is what the shipped db AND the copy MIOpen answers from agree on -- a record the copy
+    lacks (seeded by an older package) or holds differently (rewritten by a later timed search) goes back to the timed search."""
+    import shutil
+    from creamfl_amd import ops, runtime
+    user = tmp_path / 'db'
+    shutil.copytree(runtime.DB_SRC, str(user))
+    fn = [f for f in os.listdir(runtime.DB_SRC) if f.endswith('.ufdb.txt')][0]
+    lines = open(str(user / fn)).read().splitlines()
+    rec = [i for i, ln in enumerate(lines) if '=' in ln]
+    dropped, changed = lines[rec[0]].split('=', 1)[0], lines[rec[1]].split('=', 1)[0]
+    lines[rec[1]] = changed + '=SomeOtherSolver:0.5,0,algo'
+    del lines[rec[0]]
+    open(str(user / fn), 'w').write('\n'.join(lines) + '\n')
+    monkeypatch.setenv('MIOPEN_USER_DB_PATH', str(user))
+    monkeypatch.setenv('CFL_SEEDED_DB', '1')
+    monkeypatch.setitem(ops._FDB, 'keys', None)
+    keys = ops._fdb_keys()
+    assert dropped not in keys and changed not in keys and len(keys) >= 50
+    monkeypatch.setitem(ops._FDB, 'keys', None)
