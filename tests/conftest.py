@@ -90,3 +90,22 @@ def reference_main_namespace(**overrides):
     for k, v in overrides.items():
         setattr(ns, k, v)
     return ns, spec
+
+
+def integration_stubs():
+    """The reference-side ctypes binding stubs printed in INTEGRATION.md section B, EXECUTED: every ```python block between the
+    heading of section B and the next `## ` heading, in document order, in one namespace (the second stub builds on the first's
+    `_lib` / `P`), with the library name resolved to the in-tree build.  Returns that namespace (PairLoss, ClientContrast, _lib)."""
+    import re
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    sec = doc[doc.index('## B. Bind the C ABI directly'):]
+    nxt = re.search(r'^## (?!B\.)', sec, flags=re.M)
+    sec = sec[:nxt.start()] if nxt else sec
+    blocks = re.findall(r'```python\n(.*?)```', sec, flags=re.S)
+    assert len(blocks) >= 2, 'INTEGRATION.md section B lost its binding stubs'
+    from creamfl_amd import _lib
+    ns = {'__name__': 'integration_stub'}
+    for b in blocks:
+        assert 'creamfl_amd' not in b, 'a reference-side stub must not import this package'
+        exec(compile(b.replace('ctypes.CDLL("libcreamfl_hip.so")', 'ctypes.CDLL(%r)' % _lib.LIB_PATH), 'INTEGRATION.md#B', 'exec'), ns)
+    return ns

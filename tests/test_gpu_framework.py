@@ -664,3 +664,36 @@ def test_first_server_step_answers_from_the_find_db(dev):
     assert len(new) >= 40 and all(new.values()), [k for k, v in new.items() if not v]
     assert dt < 30.0, dt
     assert torch.backends.cudnn.benchmark is True                    # the per-call switch leaves the process setting alone
+
+
+@pytest.mark.gpu
+def test_bench_forward_flops_counts_both_towers(dev):
+    """`mfu` in the bench line counted nn.Linear MODULES only, and the fused BERT path calls F.linear on the
+    weights -- the whole text tower was missing (12.2 instead of ~15 TFLOP per step).  bench.forward_flops now wraps F.linear:
+    the text tower's count must be the analytic 2 * tokens * (4 H^2 + 2 H I) per layer (+ attention), less what the [CLS]-only
+    last layer saves, and the image tower's the ResNet's convolutions + fc + PIE."""
+    import bench
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.networks.backbones import BERT_CONFIGS
+    from creamfl_amd.utils.synthetic import coco_batch
+    cfg = _small_cfg(dim=64, cnn='resnet18', not_bert=False)
+    cfg.model.bert_name = 'bert-mini'
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, None, False)
+    eng.model_to_device()
+    eng.to_half()
+    eng.model.train()
+    N = 16
+    b = coco_batch(N, dev, seed=5, bert=True, img=64)
+    images = b[0].contiguous(memory_format=torch.channels_last)
+    f = bench.forward_flops(eng, images, b[1], b[2], b[3])
+    c = BERT_CONFIGS['bert-mini']
+    H, I, layers = c['hidden_size'], c['intermediate_size'], c['num_hidden_layers']
+    L = int(b[1].shape[1])
+    full = layers * (2 * N * L * (4 * H * H + 2 * H * I) + 4 * N * L * L * H) + 2 * N * H * 64
+    assert 0.70 * full <= f['text'] <= 1.001 * full, (f, full)          # the last layer runs for the [CLS] row only
+    assert f['text'] >= (layers - 1) / layers * 0.98 * full - 4 * N * L * L * H
+    # ResNet-18 at 64 x 64: 1.814 GMAC at 224 x 224 scales with the pixel count (fc + PIE on top)
+    conv = 2 * 1.814e9 * (64 * 64) / (224 * 224) * N
+    assert 0.9 * conv <= f['image'] <= 1.25 * conv, (f, conv)
+    assert f['total'] == f['image'] + f['text']

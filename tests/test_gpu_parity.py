@@ -1030,3 +1030,43 @@ def test_kernel_profiler_counts_and_times_launches(dev):
         _lib.prof_reset()
     for o in outs:
         assert torch.equal(o, ref)
+
+
+# ------------------------------------------------------------------------- boundary (b): the DOCUMENTED binding
+def test_integration_md_binding_stubs_run_against_the_oracle(dev):
+    """INTEGRATION.md section B is the reference-side ctypes binding a maintainer would add next to src/criterions/probemb.py and
+    src/algorithms/ClientTrainer.py.  Both stubs are extracted from the document and executed as printed (conftest.
+    integration_stubs): the pair loss (probemb.py:221-256) against the fp64 closed forms, the client contrast block
+    (ClientTrainer.py:386-419, both --loss_scale settings) against the oracle -- the tolerances of the rest of this file."""
+    from conftest import integration_stubs
+    ns = integration_stubs()
+    gen = torch.Generator().manual_seed(77)
+    N, D = 96, 128
+    I = _unit(gen, N, D)
+    T = torch.nn.functional.normalize(I + 0.5 * _unit(gen, N, D), dim=-1)
+    Ig, Tg = I.to(dev).requires_grad_(True), T.to(dev).requires_grad_(True)
+    a = torch.tensor([15.0], device=dev, requires_grad=True)
+    b = torch.tensor([14.0], device=dev, requires_grad=True)
+    loss = ns['PairLoss'].apply(Ig, Tg, a, b)
+    loss.backward()
+    cf = oracle.pair_loss_closed_form(I, T, 15.0, 14.0)
+    gr = oracle.pair_loss_grads_closed_form(I, T, 15.0, 14.0)
+    _close(loss.item(), cf['loss'].item(), 2e-5, 0, 'stub pair loss')
+    for got, want, nm in ((Ig.grad, gr['dI'], 'dI'), (Tg.grad, gr['dT'], 'dT')):
+        _close(got.cpu().numpy(), want.numpy(), 1e-4, 1e-4 * float(want.abs().max()), 'stub ' + nm)
+    _close(a.grad.item(), gr['da'].item(), 1e-4, 1e-3, 'stub da')
+    _close(b.grad.item(), gr['db'].item(), 1e-4, 1e-3, 'stub db')
+    # the client contrast block
+    B, M = 48, 3000
+    G, Gs = _unit(gen, M, D), _unit(gen, M, D)
+    idx = torch.randperm(M, generator=gen)[:B]
+    f, fo = _unit(gen, B, D), _unit(gen, B, D)
+    for loss_scale in (False, True):
+        fg = f.to(dev).requires_grad_(True)
+        l = ns['ClientContrast'].apply(fg, Gs.to(dev), G.to(dev), idx.to(dev), fo.to(dev), 0.5, loss_scale)
+        l.backward()
+        f64 = f.double().requires_grad_(True)
+        lo, _, _ = oracle.client_contrast_loss(f64, Gs.double(), G.double(), idx.tolist(), fo.double(), 0.5, loss_scale)
+        lo.backward()
+        _close(l.item(), lo.item(), 1e-4, 0, 'stub client contrast loss_scale=%s' % loss_scale)
+        _close(fg.grad.cpu().numpy(), f64.grad.numpy(), 1e-3, 1e-3 * float(f64.grad.abs().max()), 'stub df')
