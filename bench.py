@@ -237,9 +237,12 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-step-limit', type=float, default=25.0)
     ap.add_argument('--cpu-timeout', type=int, default=540)
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--config', type=int, default=1, choices=[1, 3],
-                    help='BASELINE.json config: 1 = server step at 256 pairs per GPU (default, the metric\'s config); 3 = large-batch '
-                         'global contrast, 512 pairs per GPU (N = 4096 over 8 GPUs)')
+    ap.add_argument('--config', type=int, default=1, choices=[1, 2, 3],
+                    help='BASELINE.json config: 1 = server step at 256 pairs per GPU (default, the metric\'s config); 2 = the client '
+                         'side: contrast step of an image / text / multi-modal client and one full round, one client per GPU '
+                         '(bench_clients.py); 3 = large-batch global contrast, 512 pairs per GPU (N = 4096 over 8 GPUs)')
+    import bench_clients
+    bench_clients.add_arguments(ap)
     ap.add_argument('--no-recall', action='store_true')
     ap.add_argument('--no-mfu', action='store_true', help='skip the FLOP-counting forward pass (profiling runs: every launch then belongs to a step)')
     ap.add_argument('--prewarm', action='store_true',
@@ -311,6 +314,9 @@ def main():
     args = parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child(args)
+    if args.cpu_client_child:
+        import bench_clients
+        return bench_clients.cpu_client_child(args)
     world, rank, local_rank, must_spawn = resolve_world(args, os.environ)
     if must_spawn:
         import subprocess
@@ -355,6 +361,16 @@ def main():
     from creamfl_amd.utils.config import default_config
     from creamfl_amd.utils.synthetic import coco_batch
     _lib.load()
+    if args.config == 2:
+        # the client side of a round: contrast step per client kind + one MMFL round, one client per rank (bench_clients.py)
+        import bench_clients
+        bench_clients.run(args, world, rank, dev, use_dp, json_out)
+        if use_dp:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        if wd > 0:
+            faulthandler.cancel_dump_traceback_later()
+        return
 
     torch.manual_seed(1234)                       # identical initial weights on every rank
     cfg = default_config(embed_dim=args.dim, cnn_type=args.cnn, not_bert=False)

@@ -198,6 +198,28 @@ class ClientTrainer:
                 float(self.top1.avg), float(self.top5.val), float(self.top5.avg)))
         self.losses, self.top1, self.top5 = AverageMeter(), AverageMeter(), AverageMeter()
 
+    def contrast_step_fn(self, g_same, g_other, use_intra, use_inter):
+        """The contrast step of this client against the round's frozen banks (ClientTrainer.py:376-421) as a function
+        `step(images, captions, caption_lens, d_idx) -> detached loss`: zero_grad, features, old-model features (intra),
+        inter / intra contrast, backward, SGD step -- no host synchronisation inside for an image client (d_idx an int64 device
+        tensor), which is the unit the HIP graph captures (creamfl_amd/graphs.py).  `tra` iterates it over the public loader;
+        bench.py --config 2 times exactly this function."""
+        def step(images, captions, caption_lens, d_idx):
+            self.optimizer.zero_grad(set_to_none=True)
+            feature = self._features(self.model, images, captions, caption_lens)
+            old_feature = None
+            if use_intra:
+                with torch.no_grad():
+                    old_feature = self._features(self.old_model, images, captions, caption_lens)
+            loss, _, _ = client_contrast_loss(feature, g_same, g_other, d_idx, old_feature,
+                                              interintra_weight=self.args.interintra_weight,
+                                              loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
+                                              use_intra=use_intra)
+            loss.backward()
+            self.optimizer.step()
+            return loss.detach()
+        return step
+
     def tra(self, global_img_feature, global_txt_feature, distill_index, global_train_loader):
         self._supervised_epoch()
         use_intra = bool(self.args.contrast_local_intra)
@@ -216,22 +238,7 @@ class ClientTrainer:
                                              'Intra-modal' if use_intra else 'Inter-modal'))
         self.last_contrast_loss = None
 
-        def contrast_step(images, d_idx):
-            """One contrast step on an image batch (ClientTrainer.py:376-421) with no host synchronisation inside: the unit the
-            HIP graph captures (creamfl_amd/graphs.py).  d_idx: int64 device tensor of bank positions."""
-            self.optimizer.zero_grad(set_to_none=True)
-            im_feature = self.model(images)
-            old_im_feature = None
-            if use_intra:
-                with torch.no_grad():
-                    old_im_feature = self.old_model(images)
-            loss, _, _ = client_contrast_loss(im_feature, g_same, g_other, d_idx, old_im_feature,
-                                              interintra_weight=self.args.interintra_weight,
-                                              loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
-                                              use_intra=use_intra)
-            loss.backward()
-            self.optimizer.step()
-            return loss.detach()
+        contrast_step = self.contrast_step_fn(g_same, g_other, use_intra, use_inter)
 
         # Image clients have fixed batch shapes: the whole step replays from one HIP graph, re-captured every round (the banks,
         # the old model and the learning rate are constants of a round).  Text clients' caption lengths vary per batch (packed
@@ -244,28 +251,17 @@ class ClientTrainer:
                    tuple(g['lr'] for g in self.optimizer.param_groups))
             graphed = getattr(self, '_graphed_contrast', None)
             if graphed is None or getattr(self, '_graphed_key', None) != key:
-                graphed = self._graphed_contrast = GraphedStep(contrast_step, warmup=3, log=self._log)
+                graphed = self._graphed_contrast = GraphedStep(lambda images, d_idx: contrast_step(images, None, None, d_idx),
+                                                               warmup=3, log=self._log)
                 self._graphed_key = key
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
             if graphed is not None:
                 loss = graphed(images, torch.as_tensor(d_idx, dtype=torch.int64), device=torch.device(self.gpuid))
-                self.last_contrast_loss = loss
-                continue
-            self.optimizer.zero_grad()
-            im_feature = self._features(self.model, images, captions, caption_lens)
-            old_im_feature = None
-            if use_intra:
-                with torch.no_grad():
-                    old_im_feature = self._features(self.old_model, images, captions, caption_lens)
-            loss, _, _ = client_contrast_loss(im_feature, g_same, g_other, d_idx, old_im_feature,
-                                              interintra_weight=self.args.interintra_weight,
-                                              loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
-                                              use_intra=use_intra)
-            loss.backward()
-            self.optimizer.step()
-            self.last_contrast_loss = loss.detach()
+            else:
+                loss = contrast_step(images, captions, caption_lens, d_idx)
+            self.last_contrast_loss = loss
             if is_test:
                 break
         for m in ([self.model, self.old_model] if use_intra else [self.model]):

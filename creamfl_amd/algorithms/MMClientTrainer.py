@@ -68,9 +68,20 @@ class MMClientTrainer(EngineBase):
         g_img, g_txt = global_img_feature.to(self.device), global_txt_feature.to(self.device)
         distill_dict = {b: a for a, b in enumerate(distill_index)}
         self.last_contrast_loss = None
+        contrast_step = self.contrast_step_fn(g_img, g_txt, use_intra, use_inter)
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(DevicePrefetcher(global_train_loader, self.device)):
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
+            self.last_contrast_loss = contrast_step(images, captions, captions_word, caption_lens, d_idx)
+            if is_test:
+                break
+
+    def contrast_step_fn(self, g_img, g_txt, use_intra, use_inter):
+        """The multi-modal client's contrast step against the round's frozen banks (MMClientTrainer.py:150-224) as a function
+        `step(images, captions, captions_word, caption_lens, d_idx) -> detached loss`: both towers forward, the old model's
+        forward (intra), the stacked intra / summed inter terms, backward, clip + optimizer.  `train_epoch` iterates it over the
+        public loader; bench.py --config 2 times exactly this function."""
+        def step(images, captions, captions_word, caption_lens, d_idx):
             images, captions, caption_lens = images.to(self.device), captions.to(self.device), caption_lens.to(self.device)
             output = self._forward(self.model, images, captions, captions_word, caption_lens)
             out_img, out_txt = output['image_features'], output['caption_features']
@@ -84,9 +95,8 @@ class MMClientTrainer(EngineBase):
                                                  loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
                                                  use_intra=use_intra)
             self._step(loss)
-            self.last_contrast_loss = loss.detach()
-            if is_test:
-                break
+            return loss.detach()
+        return step
 
     modalities = ('img', 'txt')          # generate_logits returns both representations (dist.client_plan)
 

@@ -71,6 +71,9 @@ class MMFL(object):
         self.distill_index = None
         self.best_scores, self.best_metadata = None, None
         self.total_local_trainers = []
+        # optional replacement of `random.sample` for the round's client choice (same signature; must return the same list on
+        # every rank).  dist.balanced_sample picks one client per rank where the ownership map (client_idx % world) allows it.
+        self.client_sampler = None
 
     def set_config(self, img='cifa100', txt='AG_NEWS'):
         """MMFL.py:70-88.  Reads ./src/coco.yaml when it exists (drop-in next to the reference tree), else
@@ -212,7 +215,8 @@ class MMFL(object):
             self.engine.train(tr_loader=self._dataloaders[self._pub_key(False)])
             if len(self.total_local_trainers) != 0:
                 # every rank must sample the same clients: the python RNG is seeded identically (main.py)
-                self.cur_trainers = random.sample(self.total_local_trainers, self.args.client_num_per_round)
+                sampler = getattr(self, 'client_sampler', None) or random.sample      # (MMFL.py:223: random.sample)
+                self.cur_trainers = sampler(self.total_local_trainers, self.args.client_num_per_round)
         if self.args.agg_method == "con_w" or self.args.contrast_local_intra or self.args.contrast_local_inter:
             self.extract_global_features()
 

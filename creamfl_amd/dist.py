@@ -387,6 +387,31 @@ def shard_clients(trainers, rank=None, world=None, group=None):
     return [t for pos, t in enumerate(trainers) if client_owner(t, pos, world) == rank]
 
 
+def balanced_sample(trainers, k, world=None, rng=None):
+    """A round's clients chosen like `random.sample(trainers, k)` (MMFL.py:223) but spread over the ranks: clients are drawn in
+    random order and one is taken only while its owner (client_owner: client_idx % world, the stable home of its model and
+    optimizer state) has fewer than ceil(k / world) clients this round -- with 8 clients per round on 8 GPUs every rank trains
+    exactly one.  Falls back to plain draws if the ownership map cannot be balanced.  Deterministic given `rng` (default: the
+    module-level `random`, which MMFL's driver seeds identically on every rank)."""
+    import random as _random
+    rng = rng or _random
+    if world is None:
+        world = _world()[1]
+    order = list(range(len(trainers)))
+    rng.shuffle(order)
+    cap = -(-k // max(1, world))
+    load, picked, rest = {}, [], []
+    for pos in order:
+        r = client_owner(trainers[pos], pos, world)
+        if len(picked) < k and load.get(r, 0) < cap:
+            load[r] = load.get(r, 0) + 1
+            picked.append(pos)
+        else:
+            rest.append(pos)
+    picked += rest[:k - len(picked)]
+    return [trainers[p] for p in picked]
+
+
 def allgather_client_reps(local_reps, plan, M, D, device, group=None):
     """All-gather of the public-set representations of this round's clients.
     local_reps: one {'img': [M, D] | None, 'txt': [M, D] | None} per client this rank trained, in plan[rank] order.

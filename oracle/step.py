@@ -46,3 +46,39 @@ def contrastive_step_cpu(model, criterion, optimizer, batch, grad_clip=2.0):
         nn.utils.clip_grad.clip_grad_norm_(model.parameters(), grad_clip)
     optimizer.step()
     return loss.detach(), loss_dict
+
+
+# ---------------------------------------------------------------------------------------------------- client side
+class ClientStepState:
+    """An image client between two contrast steps, as plain tensors: the trainable state dict of its ResNet client net
+    (resnet_client.py key names), the round-start copy the intra term compares against (ClientTrainer.py:195: deepcopy at the
+    start of `run`), and SGD(lr, momentum 0.9, weight decay 5e-5) over the parameters (ClientTrainer.py:287)."""
+
+    def __init__(self, state_dict, lr=1e-4, momentum=0.9, weight_decay=5e-5, layers=(2, 2, 2, 2)):
+        self.sd = {k: v.detach().clone().float() if v.is_floating_point() else v.detach().clone() for k, v in state_dict.items()}
+        self.old = {k: v.clone() for k, v in self.sd.items()}
+        self.params = [k for k, v in self.sd.items() if v.is_floating_point() and 'running_' not in k]
+        for k in self.params:
+            self.sd[k].requires_grad_(True)
+        self.opt = torch.optim.SGD([self.sd[k] for k in self.params], lr=lr, momentum=momentum, weight_decay=weight_decay)
+        self.layers = layers
+
+
+def client_contrast_step_cpu(state, images, global_img, global_txt, d_idx, interintra_weight=0.5, loss_scale=False):
+    """One contrast step of an IMAGE client on the CPU (ClientTrainer.py:376-421): features of the model (train mode) and of
+    the old model (eval mode, no grad) in the `extract_conv_feature` phase, inter term against the text bank + intra term
+    against the image bank and the old features, backward, SGD step.  The `cpu_baseline` of bench.py --config 2."""
+    from .bank_contrast import client_contrast_loss
+    from .client_encoders import resnet_client_forward
+    feat, new = resnet_client_forward(state.sd, images, 'extract_conv_feature', is_train=False, train_mode=True, layers=state.layers)
+    with torch.no_grad():
+        old, _ = resnet_client_forward(state.old, images, 'extract_conv_feature', is_train=False, train_mode=False, layers=state.layers)
+    loss, _, _ = client_contrast_loss(feat, global_img, global_txt, d_idx, old, interintra_weight=interintra_weight,
+                                      loss_scale=loss_scale)
+    state.opt.zero_grad()
+    loss.backward()
+    state.opt.step()
+    for k, v in new.items():
+        if k in state.sd and not state.sd[k].requires_grad:
+            state.sd[k] = v.detach()
+    return loss.detach()

@@ -218,3 +218,85 @@ def test_offline_traffic_is_quoted_only_for_the_same_launch_count(tmp_path):
         assert t == r['traffic'], (rnd, quoted)
         newest, _ = bench.offline_traffic(r['kernel'], r['launches'] / float(line['steps']))
         assert newest is not None and abs(newest - r['traffic']) <= 0.01 * r['traffic']     # same kernel mix, profile of the next round
+
+
+def test_config2_arguments_and_balanced_sampling():
+    """bench.py --config 2 (the client side of a round): its arguments parse; the round's clients are drawn so that every rank
+    owns exactly one where the ownership map (client_idx % world) allows it -- 8 clients per round on 8 GPUs -- and every
+    rank draws the same list from the same seed."""
+    import random
+    from types import SimpleNamespace
+    from creamfl_amd import dist as cdist
+    args = bench.parse_args(['--config', '2', '--gpus', '2', '--backend', 'gloo', '--pub', '256', '--client-batch', '32'])
+    assert args.config == 2 and args.pub == 256 and args.client_batch == 32 and args.round == 'full' and args.clients == '10,10,5'
+    trainers = [SimpleNamespace(client_idx=i + 1) for i in range(25)]
+    a = cdist.balanced_sample(trainers, 8, world=8, rng=random.Random(3))
+    b = cdist.balanced_sample(trainers, 8, world=8, rng=random.Random(3))
+    assert [t.client_idx for t in a] == [t.client_idx for t in b] and len(a) == 8
+    assert sorted(t.client_idx % 8 for t in a) == list(range(8))                 # one client per rank
+    c = cdist.balanced_sample(trainers, 8, world=2, rng=random.Random(4))
+    assert sorted(t.client_idx % 2 for t in c) == [0] * 4 + [1] * 4
+    d = cdist.balanced_sample(trainers[:3], 3, world=8, rng=random.Random(5))    # fewer clients than ranks: all of them
+    assert sorted(t.client_idx for t in d) == [1, 2, 3]
+    e = cdist.balanced_sample([SimpleNamespace(client_idx=8 * i) for i in range(6)], 4, world=8, rng=random.Random(6))
+    assert len(e) == 4                                                           # unbalanceable ownership: still k clients
+
+
+def test_phase_clock_wraps_and_restores():
+    import bench_clients
+    import torch
+
+    class Thing:
+        def work(self, x):
+            return x + 1
+    t = Thing()
+    clk = bench_clients.PhaseClock()
+    sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None              # (no GPU in the CPU suite)
+    try:
+        clk.wrap(t, 'work', 'phase')
+        assert t.work(1) == 2 and t.work(2) == 3
+    finally:
+        torch.cuda.synchronize = sync
+    assert clk.n == {'phase': 2} and clk.t['phase'] >= 0.0
+    clk.restore()
+    assert 'work' not in t.__dict__ and t.work(1) == 2
+
+
+@pytest.mark.gpu
+def test_bench_config2_two_ranks_gloo_runs_the_client_round(tmp_path):
+    """`python bench.py --config 2 --gpus 2 --backend gloo` (VERDICT r4 next #2c): two ranks on the one GPU of the box, rank r
+    times the contrast step of its client kind, then ONE MMFL round runs with the clients sharded one per rank -- representations
+    into the gather buffer, one all-gather, row-sharded con_w, the aggregate's all-gather, KD -- and rank 0 prints one line with
+    the step numbers, the phases of the round and the bytes / time of the collectives.  Small sizes (M = 256, B = 32, 64 x 64
+    images, ResNet-18 / BERT-mini server): the smoke mode of the path, not a measurement."""
+    import json
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['TMPDIR'] = str(tmp_path)
+    env.pop('MIOPEN_USER_DB_PATH', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '2', '--gpus', '2', '--backend', 'gloo', '--steps', '3',
+           '--warmup', '1', '--pub', '256', '--client-batch', '32', '--client-dim', '64', '--image-size', '64', '--server-cnn',
+           'resnet18', '--server-bert', 'bert-mini', '--clients', '2,2,2', '--clients-per-round', '4', '--no-cpu-baseline',
+           '--watchdog', '500']
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks']['world_size'] == 2 and out['ranks']['rccl_ranks'] == 0 and out['value'] > 0
+    assert out['config']['global_batch'] == 64 and 'configs[2]' in out['config']['workload']
+    assert list(out['clients']) == ['img'] and out['clients']['img']['eager']['pairs_per_s'] > 0
+    assert out['clients']['img']['graph']['capture_failed'] is None and out['clients']['img']['graph']['replays'] >= 3
+    rnd = out['round']
+    assert rnd['pub_data_num'] == 256 and len(rnd['clients_sampled']) == 4 and rnd['clients_trained_by_this_rank'] == 2
+    ph = rnd['phases_s_max_over_ranks']
+    for k in ('global_train', 'global_reps', 'clients_train', 'clients_reps', 'con_w', 'kd', 'evaluate', 'round_total'):
+        assert ph[k] > 0, (k, ph)
+    comm = out['comm']
+    assert comm['rep_collectives'] == 1 and comm['gather_bytes'] >= 2 * 2 * 256 * 64 * 4 and comm['rep_all_gather_ms'] > 0
+    assert comm['agg_gather_bytes'] > 0 and comm['con_w_ms'] > 0
+    assert out['roofline']['kernel'] == 'cfl_bank_stream_kernel' and 0 < out['roofline']['frac'] < 1
