@@ -345,6 +345,276 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
     }
 }
 
+
+// ---- channel-sliced block map (round 5) ------------------------------------------------------------------------------------
+// A workgroup owns a 64-CHANNEL SLICE (128-byte row segments: 8 threads x 16 bytes) of a ROW RANGE -- in the statistics /
+// reduce pass AND in the apply pass behind it.  The apply pass then needs only the few partial rows of its own slice
+// (768 * 64 / C of them: 48 at C = 1024, 192 at C = 256), sums them in its prologue in a fixed order (every workgroup of the
+// slice redundantly, bit-identically) and the `final` launch between the two passes disappears: 2 x 104 launches of
+// 5 - 10 us per server step sat serially between the BatchNorm passes (step 41.7 vs 42.9 ms with all of them skipped).
+// Streams as fast as whole rows (tools/hip/slice_stream_probe.hip: 1 - 10 % faster at the trunk shapes).  Narrow tensors
+// (C < 256: 384 / 768 partial rows per slice) keep the whole-row map above with its `final` kernels.
+constexpr int SL_RL = 32;                                        // row lanes of a sliced workgroup (256 threads / 8)
+
+// per-(part, slice) column sums of two per-thread 8-vectors over the 32 row lanes -> pa / pb [part][C]
+__device__ __forceinline__ void slice_col_reduce(const float (&a)[8], const float (&b)[8], int C, float* pa, float* pb, float* lds) {
+    const int cseg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    float* la = lds;                                             // [32][64]
+    float* lb = lds + SL_RL * 64;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { la[rl * 64 + cseg * 8 + k] = a[k]; lb[rl * 64 + cseg * 8 + k] = b[k]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const float* l = threadIdx.x < 64 ? la : lb;
+        const int c = threadIdx.x & 63;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < SL_RL; r += 4) { s0 += l[r * 64 + c]; s1 += l[(r + 1) * 64 + c]; s2 += l[(r + 2) * 64 + c]; s3 += l[(r + 3) * 64 + c]; }
+        (threadIdx.x < 64 ? pa : pb)[(long long)blockIdx.x * C + blockIdx.y * 64 + c] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+// totals of this workgroup's 64 channels over the `nparts` partial rows: four interleaved chains per channel, fixed order
+__device__ __forceinline__ void slice_totals(const float* __restrict__ pa, const float* __restrict__ pb, int nparts, int C,
+                                             float* lds, float (&ta)[8], float (&tb)[8]) {
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const float* qa = pa + blockIdx.y * 64 + cl;
+    const float* qb = pb + blockIdx.y * 64 + cl;
+    float a = 0.f, b = 0.f;
+    int q = g;
+    for (; q + 12 < nparts; q += 16) {
+        const float a0 = qa[(long long)q * C], a1 = qa[(long long)(q + 4) * C], a2 = qa[(long long)(q + 8) * C], a3 = qa[(long long)(q + 12) * C];
+        const float b0 = qb[(long long)q * C], b1 = qb[(long long)(q + 4) * C], b2 = qb[(long long)(q + 8) * C], b3 = qb[(long long)(q + 12) * C];
+        a += (a0 + a1) + (a2 + a3); b += (b0 + b1) + (b2 + b3);
+    }
+    for (; q < nparts; q += 4) { a += qa[(long long)q * C]; b += qb[(long long)q * C]; }
+    lds[g * 64 + cl] = a; lds[256 + g * 64 + cl] = b;
+    __syncthreads();
+    const int c = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        ta[k] = (lds[c + k] + lds[64 + c + k]) + (lds[128 + c + k] + lds[192 + c + k]);
+        tb[k] = (lds[256 + c + k] + lds[320 + c + k]) + (lds[384 + c + k] + lds[448 + c + k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cfl_bn_stats_sl_kernel(const U4* __restrict__ x, long long R, int C, int rows_per_block,
+                                                              float* psum, float* psq) {
+    __shared__ float lds[2 * SL_RL * 64];
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    const long long stride = (long long)SL_RL * (C >> 3);
+    long long r = rb + (threadIdx.x >> 3);
+    const U4* p = x + r * (C >> 3) + blockIdx.y * 8 + (threadIdx.x & 7);
+    for (; r + 3 * SL_RL < re; r += 4 * SL_RL, p += 4 * stride) {
+        const U4 u0 = p[0], u1 = p[stride], u2 = p[2 * stride], u3 = p[3 * stride];
+        float f[8];
+        unpack8(u0, f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+        unpack8(u1, f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+        unpack8(u2, f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+        unpack8(u3, f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+    }
+    for (; r < re; r += SL_RL, p += stride) {
+        float f[8];
+        unpack8(p[0], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] = fmaf(f[k], f[k], q[k]); }
+    }
+    slice_col_reduce(s, q, C, psum, psq, lds);
+}
+
+// apply pass of the forward on the sliced map; its prologue is the old `final` kernel for this slice (workgroup 0 of a slice
+// also stores mean / invstd for the backward and updates the running statistics)
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void cfl_bn_apply_sl_kernel(const U4* __restrict__ x, const U4* __restrict__ res,
+                                                              const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              long long R, int C, int rows_per_block, float eps, float momentum, U4* y,
+                                                              unsigned char* __restrict__ relu_mask, float* mean, float* invstd,
+                                                              float* rmean, float* rvar) {
+    __shared__ float lds[512];
+    float ta[8], tb[8], sc[8], sh[8];
+    slice_totals(psum, psq, nparts, C, lds, ta, tb);
+    const int c0 = blockIdx.y * 64 + (threadIdx.x & 7) * 8;
+    const bool writer = blockIdx.x == 0 && (threadIdx.x >> 3) == 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float mu = ta[k] / (float)R;
+        const float var = fmaxf(tb[k] / (float)R - mu * mu, 0.f);
+        const float is = rsqrtf(var + eps);
+        const float g = gamma[c0 + k] * is;
+        sc[k] = g;
+        sh[k] = beta[c0 + k] - mu * g;
+        if (writer) {
+            mean[c0 + k] = mu;
+            invstd[c0 + k] = is;
+            if (rmean) {
+                const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+                rmean[c0 + k] = (1.f - momentum) * rmean[c0 + k] + momentum * mu;
+                rvar[c0 + k] = (1.f - momentum) * rvar[c0 + k] + momentum * unb;
+            }
+        }
+    }
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    const long long stride = (long long)SL_RL * (C >> 3);
+    long long off = (rb + (threadIdx.x >> 3)) * (C >> 3) + blockIdx.y * 8 + (threadIdx.x & 7);
+#pragma unroll 4
+    for (long long r = rb + (threadIdx.x >> 3); r < re; r += SL_RL, off += stride) {
+        float f[8], g[8];
+        unpack8(x[off], f);
+        if (RES) unpack8(res[off], g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = fmaf(f[k], sc[k], sh[k]);
+            if (RES) v += g[k];
+            if (RELU) v = fmaxf(v, 0.f);
+            f[k] = v;
+        }
+        const U4 o = pack8(f);
+        y[off] = o;
+        if (RELU && relu_mask) {
+            unsigned b = 0;
+            b |= (o.x & 0xffffu) ? 1u : 0u;  b |= (o.x >> 16) ? 2u : 0u;
+            b |= (o.y & 0xffffu) ? 4u : 0u;  b |= (o.y >> 16) ? 8u : 0u;
+            b |= (o.z & 0xffffu) ? 16u : 0u; b |= (o.z >> 16) ? 32u : 0u;
+            b |= (o.w & 0xffffu) ? 64u : 0u; b |= (o.w >> 16) ? 128u : 0u;
+            relu_mask[off] = (unsigned char)b;
+        }
+    }
+}
+
+template <bool RELU, bool XMASK>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_sl_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
+                                                                   const U4* __restrict__ x, const U4* __restrict__ y,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   long long R, int C, int rows_per_block, float* pdb, float* pdg,
+                                                                   const unsigned char* __restrict__ relu_mask) {
+    __shared__ float lds[2 * SL_RL * 64];
+    float db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mu[8], is[8], sc[8], sh[8];
+    const int c0 = blockIdx.y * 64 + (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k];
+        if (XMASK) { sc[k] = gamma[c0 + k] * is[k]; sh[k] = beta[c0 + k] - mu[k] * sc[k]; }
+    }
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    const long long stride = (long long)SL_RL * (C >> 3);
+    long long off = (rb + (threadIdx.x >> 3)) * (C >> 3) + blockIdx.y * 8 + (threadIdx.x & 7);
+#pragma unroll 2
+    for (long long r = rb + (threadIdx.x >> 3); r < re; r += SL_RL, off += stride) {
+        float d[8], f[8], o[8];
+        unpack8(dy[off], d);
+        unpack8(x[off], f);
+        unsigned mb = 0;
+        if (RELU && !XMASK) {
+            if (relu_mask) mb = relu_mask[off];
+            else unpack8(y[off], o);
+        }
+        if (dy2) {
+            float d2[8];
+            unpack8(dy2[off], d2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] += d2[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool on = !RELU || (XMASK ? fmaf(f[k], sc[k], sh[k]) > 0.f : (relu_mask ? ((mb >> k) & 1u) != 0 : o[k] > 0.f));
+            const float dd = on ? d[k] : 0.f;
+            db[k] += dd;
+            dg[k] = fmaf(dd, (f[k] - mu[k]) * is[k], dg[k]);
+        }
+    }
+    slice_col_reduce(db, dg, C, pdb, pdg, lds);
+}
+
+template <bool RES, bool RELU, bool XMASK>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_sl_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
+                                                                  const U4* __restrict__ x, const U4* __restrict__ y,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ pdb, const float* __restrict__ pdg, int nparts,
+                                                                  float* dbeta, float* dgamma, long long R, int C, int rows_per_block,
+                                                                  U4* dx, U4* dres, const unsigned char* __restrict__ relu_mask) {
+    __shared__ float lds[512];
+    float tdb[8], tdg[8];
+    slice_totals(pdb, pdg, nparts, C, lds, tdb, tdg);
+    const int c0 = blockIdx.y * 64 + (threadIdx.x & 7) * 8;
+    const bool writer = blockIdx.x == 0 && (threadIdx.x >> 3) == 0;
+    float mu[8], is[8], a[8], b[8], c[8], sh[8];
+    const float invR = 1.f / (float)R;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k];
+        a[k] = gamma[c0 + k] * is[k];
+        b[k] = tdb[k] * invR;
+        c[k] = tdg[k] * invR;
+        if (XMASK) sh[k] = beta[c0 + k] - mu[k] * a[k];
+        if (writer) { dbeta[c0 + k] = tdb[k]; dgamma[c0 + k] = tdg[k]; }
+    }
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    const long long stride = (long long)SL_RL * (C >> 3);
+    long long off = (rb + (threadIdx.x >> 3)) * (C >> 3) + blockIdx.y * 8 + (threadIdx.x & 7);
+#pragma unroll 2
+    for (long long r = rb + (threadIdx.x >> 3); r < re; r += SL_RL, off += stride) {
+        float d[8], f[8], o[8];
+        unpack8(ld_nt(dy + off), d);
+        unpack8(ld_nt(x + off), f);
+        unsigned mb = 0;
+        if (RELU && !XMASK) {
+            if (relu_mask) mb = relu_mask[off];
+            else unpack8(ld_nt(y + off), o);
+        }
+        if (dy2) {
+            float d2[8];
+            unpack8(ld_nt(dy2 + off), d2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] += d2[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool on = !RELU || (XMASK ? fmaf(f[k], a[k], sh[k]) > 0.f : (relu_mask ? ((mb >> k) & 1u) != 0 : o[k] > 0.f));
+            const float dd = on ? d[k] : 0.f;
+            d[k] = dd;
+            f[k] = a[k] * (dd - b[k] - (f[k] - mu[k]) * is[k] * c[k]);
+        }
+        dx[off] = pack8(f);
+        if (RES) dres[off] = pack8(d);
+    }
+}
+
+struct SPlan { int rows_per_block, parts, slices; };
+static int& bn_sliced_on() {
+    static int on = getenv("CFL_BN_NO_SLICE") ? 0 : 1;
+    return on;
+}
+// the sliced map takes C = 256 ... 2048 in whole 64-channel slices (<= 192 partial rows per slice)
+static bool bn_use_sliced(long long R, int C) { return bn_sliced_on() && C >= 256 && C % 64 == 0 && C <= 2048 && R >= SL_RL; }
+static SPlan bn_splan(long long R, int C) {
+    SPlan p;
+    p.slices = C / 64;
+    long long want = 768 / p.slices;                      // ~3 workgroups per CU in all
+    if (want < 1) want = 1;
+    long long rpb = (R + want - 1) / want;
+    rpb = ((rpb + SL_RL - 1) / SL_RL) * SL_RL;
+    p.rows_per_block = (int)rpb;
+    p.parts = (int)((R + rpb - 1) / rpb);
+    return p;
+}
+
 struct Plan { int rows_per_block, nblk, gy; };
 static Plan bn_plan(long long R, int C) {
     Plan p;
@@ -369,7 +639,17 @@ extern "C" {
 size_t cfl_bn_ws_bytes(long long R, int C) {
     if (R <= 0 || C <= 0) return 256;
     const Plan p = bn_plan(R, C);
-    return cfl_align256((size_t)2 * p.nblk * C * sizeof(float));
+    size_t n = (size_t)p.nblk;
+    if (C >= 256 && C % 64 == 0 && (size_t)bn_splan(R, C).parts > n) n = (size_t)bn_splan(R, C).parts;
+    return cfl_align256((size_t)2 * n * C * sizeof(float));
+}
+
+// measurement / fallback switch of the channel-sliced map: on = 0 / 1 sets it, a negative value only queries; returns the
+// previous setting (also CFL_BN_NO_SLICE=1 in the environment)
+int cfl_bn_sliced(int on) {
+    const int old = bn_sliced_on();
+    if (on >= 0) bn_sliced_on() = on ? 1 : 0;
+    return old;
 }
 
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
@@ -378,6 +658,24 @@ int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const fl
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
     if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;
+    if (bn_use_sliced(R, C)) {
+        // two launches: statistics and apply on the same 64-channel slices; the apply pass sums its slice's partials itself
+        const SPlan sp = bn_splan(R, C);
+        float* qsum = (float*)ws;
+        float* qsq = qsum + (size_t)sp.parts * C;
+        const dim3 sg(sp.parts, sp.slices);
+        const U4* xs = (const U4*)x; const U4* rs = (const U4*)residual; U4* ys = (U4*)y;
+        CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_sl_kernel, sg, dim3(256), 0, stream, xs, R, C, sp.rows_per_block, qsum, qsq);
+#define BN_APPLY_SL(RES_, RELU_) CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_sl_kernel<RES_, RELU_>), sg, dim3(256), 0, stream, xs, rs, qsum, qsq, \
+                                            sp.parts, gamma, beta, R, C, sp.rows_per_block, eps, momentum, ys, relu_mask, save_mean,      \
+                                            save_invstd, running_mean, running_var)
+        if (residual && relu) BN_APPLY_SL(true, true);
+        else if (residual) BN_APPLY_SL(true, false);
+        else if (relu) BN_APPLY_SL(false, true);
+        else BN_APPLY_SL(false, false);
+#undef BN_APPLY_SL
+        return 0;
+    }
     const Plan p = bn_plan(R, C);
     float* psum = (float*)ws;
     float* psq = psum + (size_t)p.nblk * C;
@@ -450,11 +748,32 @@ int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, co
     if ((xmask && (has_residual || !beta)) || (has_residual && !dres)) return CFL_EINVAL;
     if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;
+    const U4 *d = (const U4*)dy, *d2 = (const U4*)dy2, *xx = (const U4*)x, *yy = (const U4*)y;
+    if (bn_use_sliced(R, C)) {
+        const SPlan sp = bn_splan(R, C);
+        float* qdb = (float*)ws;
+        float* qdg = qdb + (size_t)sp.parts * C;
+        const dim3 sg(sp.parts, sp.slices);
+#define BN_REDUCE_SL(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_sl_kernel<RELU_, XM_>), sg, dim3(256), 0, stream, d, d2, xx, yy, \
+                                            save_mean, save_invstd, gamma, beta, R, C, sp.rows_per_block, qdb, qdg, relu_mask)
+        if (xmask) BN_REDUCE_SL(true, true); else if (relu) BN_REDUCE_SL(true, false); else BN_REDUCE_SL(false, false);
+#undef BN_REDUCE_SL
+        U4 *sx = (U4*)dx, *sr = (U4*)dres;
+#define BN_APPLY_SL(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_sl_kernel<RES_, RELU_, XM_>), sg, dim3(256), 0, stream, d, d2, \
+                                                 xx, yy, save_mean, save_invstd, gamma, beta, qdb, qdg, sp.parts, dbeta, dgamma, R, C,       \
+                                                 sp.rows_per_block, sx, sr, relu_mask)
+        if (xmask) BN_APPLY_SL(false, true, true);
+        else if (has_residual && relu) BN_APPLY_SL(true, true, false);
+        else if (has_residual) BN_APPLY_SL(true, false, false);
+        else if (relu) BN_APPLY_SL(false, true, false);
+        else BN_APPLY_SL(false, false, false);
+#undef BN_APPLY_SL
+        return 0;
+    }
     const Plan p = bn_plan(R, C);
     float* pdb = (float*)ws;
     float* pdg = pdb + (size_t)p.nblk * C;
     const dim3 grid(p.nblk, p.gy);
-    const U4 *d = (const U4*)dy, *d2 = (const U4*)dy2, *xx = (const U4*)x, *yy = (const U4*)y;
 #define BN_REDUCE(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, xx, yy, \
                                          save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, relu_mask, (const B8*)nullptr, 0, 0)
     if (xmask) BN_REDUCE(true, true); else if (relu) BN_REDUCE(true, false); else BN_REDUCE(false, false);

@@ -359,6 +359,13 @@ int cfl_rank_count(const float* Q, const float* G, const long long* qlab, const 
  *        relu_mask (fwd: optional output, R*C/8 bytes; bwd: optional input replacing y): bit k of byte i = (y > 0) of
  *        element 8i+k -- with a residual the backward then reads 1 byte instead of 16 per 8 outputs, twice.
  */
+/* Channel-sliced block map of the BatchNorm kernels (round 5): for C = 256 ... 2048 (whole 64-channel slices) the statistics /
+ * reduce pass and the apply pass of cfl_bn_fwd / cfl_bn_bwd run on workgroups that own a 64-channel slice of a row range, the apply
+ * pass sums the partial rows of its own slice in its prologue and the `final` launch between the two passes is gone (torchvision
+ * BatchNorm2d inside the trunks of src/networks/models/image_encoder.py:27-36: same results up to fp32 summation order).
+ * cfl_bn_sliced(0 / 1) switches the map off / on, a negative argument only queries; returns the previous setting
+ * (CFL_BN_NO_SLICE=1 in the environment starts with it off).  Measurement switch of tools/ab_step.py --knob bnslice. */
+int cfl_bn_sliced(int on);
 size_t cfl_bn_ws_bytes(long long R, int C);
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,

@@ -284,7 +284,15 @@ def test_stem_tail_fused_is_bit_identical(n, c, h, w):
         torch.cuda.synchronize()
         return y.detach(), x.grad, wg.grad, bg.grad, rm, rv
 
-    a, b = run(True), run(False)
+    # bit identity holds between the fused and the unfused form ON THE SAME BLOCK MAP: the stem-tail kernels use the whole-row
+    # map (the stem has 64 channels), so the unfused side runs on it too where it would otherwise take the channel-sliced map
+    # (C >= 256: another fp32 summation order of the statistics -- compared with tolerances in test_bn_channel_sliced_map)
+    from creamfl_amd import _lib
+    was = _lib.load().cfl_bn_sliced(0)
+    try:
+        a, b = run(True), run(False)
+    finally:
+        _lib.load().cfl_bn_sliced(was)
     for name, ta, tb in zip(['y', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var'], a, b):
         assert ta.shape == tb.shape and torch.equal(ta, tb), name
 
@@ -544,3 +552,65 @@ def test_bn_statistics_from_the_conv_epilogue(n, hw, ci, co):
         scale = float(b.abs().max())
         tol = 2e-2 if names[k] in ('y', 'dx', 'dw') else 2e-3
         assert float((a - b).abs().max()) <= tol * scale + 1e-6, (names[k], float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize('n,c,h,w', [(256, 1024, 14, 14), (64, 256, 14, 14), (16, 256, 56, 56), (256, 2048, 7, 7), (5, 512, 13, 11),
+                                     (1, 256, 5, 7), (2, 1024, 4, 4)])
+@pytest.mark.parametrize('relu,res', [(True, True), (True, False), (False, False)])
+def test_bn_channel_sliced_map(n, c, h, w, relu, res):
+    """Round 5: for C = 256 ... 2048 the BatchNorm passes run on workgroups that own a 64-channel slice of a row range and the
+    apply passes sum their slice's partials themselves (no `final` launch: 2 launches forward, 2 backward).  Against the
+    whole-row map with its `final` kernels on the same inputs (cfl_bn_sliced(0)): the per-channel quantities (saved statistics via
+    the running statistics, dgamma, dbeta) agree to fp32 summation order, the bf16 tensors to one bf16 rounding of a few
+    elements; twice the same call is bit-identical (fixed summation order, no atomics); the launch count is what it says.
+    Shapes: the trunk's (batch 256: 48 / 192 / 24 partial rows per slice), ragged row counts, fewer rows than row lanes."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(n + c + h)
+    x0 = (torch.randn(n, c, h, w, generator=gen) * 1.3 + 0.2).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r0 = torch.randn(n, c, h, w, generator=gen).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    gy = torch.randn(n, c, h, w, generator=gen).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gamma = (1 + 0.2 * torch.randn(c, generator=gen)).to(dev)
+    beta = (0.3 * torch.randn(c, generator=gen)).to(dev)
+
+    def run(sliced):
+        was = lib.cfl_bn_sliced(int(sliced))
+        try:
+            x = x0.clone().requires_grad_(True)
+            r = r0.clone().requires_grad_(True) if res else None
+            wg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            _lib.prof_select(None); _lib.prof_reset(); _lib.prof_enable(True)
+            y = ops.bn_act_train(x, wg, bg, rm, rv, 0.1, 1e-5, relu=relu, residual=r)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            _lib.prof_enable(False)
+            launches = {k: v[0] for k, v in _lib.prof_query().items()}
+            return (y.detach(), x.grad, r.grad if res else None, wg.grad, bg.grad, rm, rv), launches
+        finally:
+            lib.cfl_bn_sliced(was)
+    R = n * h * w
+    (a, la), (b, lb) = run(True), run(False)
+    if R >= 32:
+        assert la == {'cfl_bn_stats_kernel': 1, 'cfl_bn_apply_kernel': 1, 'cfl_bn_bwd_reduce_kernel': 1, 'cfl_bn_bwd_apply_kernel': 1}, la
+    assert lb.get('cfl_bn_final_kernel') == 1 and lb.get('cfl_bn_bwd_final_kernel') == 1, lb
+    names = ['y', 'dx', 'dres', 'dgamma', 'dbeta', 'running_mean', 'running_var']
+    for name, ta, tb in zip(names, a, b):
+        if ta is None:
+            continue
+        ta, tb = ta.float(), tb.float()
+        scale = float(tb.abs().max()) + 1e-12
+        if name in ('y', 'dx', 'dres'):
+            # same arithmetic up to the last fp32 bit of mean / invstd / the reductions: an element may land on the neighbouring
+            # bf16 value (2^-8 relative), never further
+            assert float((ta - tb).abs().max()) <= 2.0 ** -7 * scale, (name, float((ta - tb).abs().max()), scale)
+            assert float(((ta - tb).abs() > 1e-6 * scale).float().mean()) < 0.02, name
+        else:
+            assert float((ta - tb).abs().max()) <= 2e-5 * scale + 1e-7, (name, float((ta - tb).abs().max()), scale)
+    (a2, _) = run(True)
+    for name, ta, tb in zip(names, a, a2):
+        if ta is not None:
+            assert torch.equal(ta, tb), ('not deterministic', name)

@@ -6,6 +6,7 @@ pool's boxes differ by several per cent from run to run, more than most of the e
 
 knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming kernel (default) vs the tile kernel
         join   the gradient join of the residual blocks in the data-gradient GEMM's epilogue (default) vs in the BatchNorm backward
+        bnslice  the BatchNorm passes on the channel-sliced block map (no `final` launches, default) vs the whole-row map
 """
 import argparse
 import json
@@ -54,6 +55,8 @@ def main():
         elif args.knob == 'convstats':
             from creamfl_amd import ops
             ops.CONV_STATS[0] = bool(on)
+        elif args.knob == 'bnslice':
+            lib.cfl_bn_sliced(1 if on else 0)
         elif args.knob == 'join':
             from creamfl_amd import ops
             ops._NO_JOIN_FUSE = not on
