@@ -1,0 +1,79 @@
+"""Training-outcome probe (VERDICT r4 missing #4): the SAME PCME trained on a learnable synthetic retrieval task
+(tests/learnable_task.py) with bf16 fused trunks (the bench's code path) and with fp32 trunks, from the same initial state; then
+COCOEvaluator.evaluate on held-out samples.  Prints one JSON line per run.
+
+    python tools/train_outcome_probe.py [--steps 150] [--batch 64] [--n-id 1000] [--lr 1e-3]
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from creamfl_amd import runtime  # noqa: E402
+
+runtime.configure_env()
+import torch  # noqa: E402
+
+
+def train_and_eval(task, steps, batch, lr, fp32, state, dev, cnn='resnet18', dim=64, n_eval=1000, log_every=50):
+    from creamfl_amd.algorithms.eval_coco import COCOEvaluator
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    from learnable_task import EvalLoader
+    torch.manual_seed(3)
+    cfg = default_config(embed_dim=dim, cnn_type=cnn, not_bert=False)
+    cfg.model.bert_name = 'bert-mini'
+    cfg.optimizer.learning_rate = lr
+    ev = COCOEvaluator(eval_method='matmul', verbose=False, eval_device=str(dev), extract_device=str(dev), n_crossfolds=5)
+    eng = TrainerEngine(device=dev)
+    eng.create(cfg, {'<pad>': 0}, ev, False)
+    if state is not None:
+        eng.model.load_state_dict(state)
+    state0 = copy.deepcopy(eng.model.state_dict())
+    eng.model_to_device()
+    if not fp32:
+        eng.to_half()
+    eng.model.train()
+    losses = []
+    t0 = time.time()
+    for s in range(steps):
+        b = task.train_batch(s, batch)
+        images = b[0] if fp32 else b[0].contiguous(memory_format=torch.channels_last)
+        loss, _ = eng.train_step(images, b[1], b[2], b[3])
+        if s % log_every == 0 or s == steps - 1:
+            losses.append(round(float(loss.detach()), 3))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    scores = eng.evaluate({'te': EvalLoader(task, n_eval=n_eval)}, n_crossfolds=5, n_images_per_crossfold=n_eval // 5,
+                          n_captions_per_crossfold=n_eval)['te']
+    return {'fp32': fp32, 'i2t_r1': scores['i2t']['recall_1'], 't2i_r1': scores['t2i']['recall_1'], 'i2t_r5': scores['i2t']['recall_5'],
+            'fold_i2t_r1': scores['n_fold']['i2t']['recall_1'], 'fold_t2i_r1': scores['n_fold']['t2i']['recall_1'],
+            'losses': losses, 'train_s': round(dt, 1)}, state0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=150)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--n-id', type=int, default=1000)
+    ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--img', type=int, default=64)
+    ap.add_argument('--cnn', default='resnet18')
+    args = ap.parse_args()
+    from learnable_task import LearnableTask
+    dev = torch.device('cuda', 0)
+    task = LearnableTask(n_id=args.n_id, img=args.img, seed=0, device=dev)
+    with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+        a, state = train_and_eval(task, args.steps, args.batch, args.lr, False, None, dev, cnn=args.cnn, n_eval=args.n_id)
+        print(json.dumps(dict(a, **vars(args))), flush=True)
+        b, _ = train_and_eval(task, args.steps, args.batch, args.lr, True, state, dev, cnn=args.cnn, n_eval=args.n_id)
+        print(json.dumps(dict(b, **vars(args))), flush=True)
+
+
+if __name__ == '__main__':
+    main()
