@@ -48,7 +48,14 @@ def add_arguments(ap):
     ap.add_argument('--client-dim', type=int, default=256, help='config 2: feature_dim D (src/main.py:103 default)')
     ap.add_argument('--image-size', type=int, default=224)
     ap.add_argument('--round', default='full', choices=['full', 'none'], help='config 2: also run and time one MMFL round')
-    ap.add_argument('--round-pub', type=int, default=0, help='config 2: public-set size of the ROUND (0 = --pub)')
+    ap.add_argument('--round-pub', type=int, default=6400,
+                    help='config 2: public-set size of the timed ROUND (0 = --pub).  The default is 50 public batches instead of 391: every '
+                         'loop of a round is linear in the number of public batches (reported per batch too); what is NOT linear -- con_w '
+                         'and the representation all-gather -- is timed separately at the full --pub (`full_M` in the line)')
+    ap.add_argument('--round-warm', type=int, default=1, choices=[0, 1],
+                    help='config 2: run a miniature round (2 public batches, 1 private batch per client) first: every convolution '
+                         'problem of a round is then known to the libraries (PyTorch asks MIOpen for a timed search per new shape: '
+                         '~1 min per network and batch size) and the timed round measures the round, not the searches')
     ap.add_argument('--server-cnn', default='resnet101')
     ap.add_argument('--server-bert', default='bert-base-uncased')
     ap.add_argument('--clients', default='10,10,5', help='config 2: image, text, multi-modal clients in the federation')
@@ -71,22 +78,26 @@ def reference_namespace(a, dev_index, M):
         quiet=True, save_checkpoints=False, server_dp=0, rep_wire=a.rep_wire, client_graph=1)
 
 
-def build_federation(a, dev, M):
-    """MMFL + its trainers + device-born loaders (public set, test set, every client's private set)."""
+def build_federation(a, dev, M, mini=False):
+    """MMFL + its trainers + device-born loaders (public set, test set, every client's private set).  Every loader yields FULL
+    batches only (sizes rounded to multiples of the batch): a ragged last batch is another convolution problem, i.e. another timed
+    search of every layer.  mini: one private batch per client, a 5-batch test set."""
     from creamfl_amd.algorithms.MMFL import MMFL
     from creamfl_amd import dist as cdist
     from creamfl_amd.utils.synthetic import DeviceClientLoader, DeviceCocoLoader
     ns = reference_namespace(a, dev.index or 0, M)
+    B, S = a.client_batch, a.image_size
+    ns.test_pairs = 5 * 2 * B if mini else (20 * 2 * B if M >= 5000 else 5 * 2 * B)
     algo = MMFL(ns, None)
     algo.device = dev
-    B, S = a.client_batch, a.image_size
     algo.config.dataloader.batch_size = B
-    n_img, n_txt, n_mm = (int(x) for x in a.client_train_n.split(','))
-    scale = 1.0 if M >= 50000 else max(0.02, M / 50000.0)              # a reduced public set shrinks the private sets with it
-    n_img, n_txt, n_mm = (max(B, int(n * scale)) for n in (n_img, n_txt, n_mm))
+    bs_uni = min(512, 4 * B)
+    scale = min(1.0, M / 50000.0)                      # a reduced public set shrinks the private sets with it
+    want = [int(x) for x in a.client_train_n.split(',')]
+    n_img, n_txt, n_mm = [(bs if mini else max(bs, int(round(n * scale / bs)) * bs)) for n, bs in zip(want, (bs_uni, bs_uni, B))]
     loaders = {
-        'img': [DeviceClientLoader('img', n_img, min(512, 4 * B), 100, dev, seed=11 + i, img=S) for i in range(ns.num_img_clients)],
-        'txt': [DeviceClientLoader('txt', n_txt, min(512, 4 * B), 4, dev, seed=31 + i) for i in range(ns.num_txt_clients)],
+        'img': [DeviceClientLoader('img', n_img, bs_uni, 100, dev, seed=11 + i, img=S) for i in range(ns.num_img_clients)],
+        'txt': [DeviceClientLoader('txt', n_txt, bs_uni, 4, dev, seed=31 + i) for i in range(ns.num_txt_clients)],
         'mm': [DeviceCocoLoader(n_mm, B, seed=51 + i, bert=False, device=dev, img=S) for i in range(ns.num_mm_clients)],
     }
     algo.create_model(ns, client_loaders=loaders)
@@ -95,7 +106,7 @@ def build_federation(a, dev, M):
         algo._pub_key(True): DeviceCocoLoader(M, 2 * B, seed=1, device=dev, img=S),
         'test': DeviceCocoLoader(ns.test_pairs, 2 * B, seed=2, device=dev, img=S, captions_per_image=5)})
     algo.client_sampler = lambda trainers, k: cdist.balanced_sample(trainers, k)
-    return algo, {'private_samples': {'img': n_img, 'txt': n_txt, 'mm': n_mm}}
+    return algo, {'private_samples': {'img': n_img, 'txt': n_txt, 'mm': n_mm}, 'test_pairs': ns.test_pairs}
 
 
 def first_of_kind(algo, kind, owner=None, world=1):
@@ -312,6 +323,42 @@ def timed_round(algo, use_dist):
     return ph, clk.n, comm, kinds
 
 
+def full_size_exchange(a, dev, banks, world, rank, use_dist):
+    """What does NOT scale with the number of public batches, at the full public-set size: the round's ONE representation
+    all-gather (every rank contributes the blocks of one multi-modal client = 2 x [M, D], the worst case of a slot) and con_w over
+    8 client representations per modality (row-sharded across the ranks + the all-gather of the aggregate rows)."""
+    from creamfl_amd import dist as cdist
+    M, D = banks[0].shape
+    g = torch.Generator(device=dev).manual_seed(777 + rank)
+    out = {'M': M, 'D': D, 'clients_per_modality': 8}
+    if use_dist:
+        plan = [[(r, ('img', 'txt'))] for r in range(world)]
+        wire = torch.bfloat16 if a.rep_wire == 'bf16' else torch.float32
+        buf = cdist.RepGatherBuffer(plan, M, D, dev, wire)
+        for v in buf.out_views(0).values():
+            v.copy_(torch.nn.functional.normalize(torch.randn(M, D, generator=g, device=dev), dim=-1))
+        buf.gather()                                     # warm
+        _fence(True)
+        t0 = time.perf_counter()
+        buf.gather()
+        _fence(True)
+        out['rep_all_gather_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+        out['gather_bytes'] = buf.buf.numel() * buf.buf.element_size()
+        del buf
+    gs = torch.Generator(device=dev).manual_seed(888)         # the same representations on every rank, as after the gather
+    vecs = [torch.nn.functional.normalize(banks[0] + 0.5 * torch.randn(M, D, generator=gs, device=dev), dim=-1) for _ in range(8)]
+    cdist.conw_aggregate_sharded(vecs, banks[1])         # warm (bank image build, workspace)
+    _fence(use_dist)
+    t0 = time.perf_counter()
+    agg = cdist.conw_aggregate_sharded(vecs, banks[1])
+    _fence(use_dist)
+    out['con_w_ms_per_modality'] = round((time.perf_counter() - t0) * 1e3, 3)
+    out['con_w_ms_per_client'] = round(out['con_w_ms_per_modality'] / 8, 3)
+    out['con_w_flop_per_client'] = 2.0 * M * M * D
+    out['agg_finite'] = bool(torch.isfinite(agg).all())
+    return out
+
+
 def cpu_client_child(a):
     """The oracle's port of the image client's contrast step on the host cores (bounded sample)."""
     import bench
@@ -370,7 +417,8 @@ def run(a, world, rank, dev, use_dist, json_out):
     torch.manual_seed(1234)
     random.seed(1234)
     M, B, D, S = a.pub, a.client_batch, a.client_dim, a.image_size
-    Mr = a.round_pub or M
+    Mr = min(a.round_pub or M, M)
+    Mr = max(2 * B, (Mr // (2 * B)) * (2 * B))            # whole batches of both public loaders (B and 2 B)
     algo, fed = build_federation(a, dev, Mr)
     g = torch.Generator(device=dev).manual_seed(4321)
     unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=g, device=dev), dim=-1)
@@ -405,7 +453,18 @@ def run(a, world, rank, dev, use_dist, json_out):
                 'how': 'HIP start / stop events of the launch inside the eager timed region of the %s client (the graph replays the '
                        'same kernel; events cannot ride in a captured graph)' % kinds[0]}
     rnd = None
+    full = None
     if a.round == 'full':
+        warm_s = None
+        if a.round_warm:
+            t0 = time.perf_counter()
+            mini, _ = build_federation(a, dev, 4 * B, mini=True)
+            random.seed(4321)
+            mini.train(0)
+            _fence(use_dist)
+            warm_s = round(time.perf_counter() - t0, 1)
+            del mini
+            torch.cuda.empty_cache()
         ph, counts, comm, sampled = timed_round(algo, use_dist)
         if use_dist:
             keys = sorted(ph)
@@ -415,7 +474,12 @@ def run(a, world, rank, dev, use_dist, json_out):
         else:
             ph_max = ph
         n_pub_batches = -(-Mr // B)
+        full = full_size_exchange(a, dev, banks, world, rank, use_dist)
+        per_batch = {k: round(ph_max[k] / n_pub_batches * 1e3, 2) for k in ('global_train', 'global_reps', 'kd') if k in ph_max}
         rnd = {'pub_data_num': Mr, 'public_batches': n_pub_batches, 'clients_sampled': sampled,
+               'miniature_warm_up_round_s': warm_s, 'ms_per_public_batch': per_batch,
+               'scaling_note': 'every loop of the round is linear in the public batches (391 at the full M = 50 000); con_w '
+                               '(quadratic in M) and the representation all-gather are in `full_M` at the full size',
                'clients_trained_by_this_rank': counts.get('clients_train', 0),
                'phases_s_rank0': {k: round(v, 3) for k, v in sorted(ph.items())},
                'phases_s_max_over_ranks': {k: round(v, 3) for k, v in sorted(ph_max.items())},
@@ -450,7 +514,7 @@ def run(a, world, rank, dev, use_dist, json_out):
             'ranks': {'world_size': world, 'backend': None if not use_dist else ('rccl' if a.backend == 'nccl' else
                                                                                'gloo (SMOKE MODE: not a scaling measurement)'),
                       'rccl_ranks': world if (use_dist and a.backend == 'nccl') else 0, 'gpus_visible': torch.cuda.device_count()},
-            'clients': clients, 'round': rnd, 'comm': None if rnd is None else rnd['comm'], 'roofline': roof, 'cpu_baseline': cpu,
+            'clients': clients, 'round': rnd, 'full_M': full, 'comm': None if rnd is None else rnd['comm'], 'roofline': roof, 'cpu_baseline': cpu,
         }
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()

@@ -122,6 +122,49 @@ def _seed(src, dst):
     return dst
 
 
+_SQLITE_SUFFIXES = ('.ukdb', '.kdb', '.udb', '.db')
+
+
+def _snapshot(base, dst):
+    """Bring `dst` (the directory of a slot > 0) up to what the BASE slot's directory holds right now, file by file, wherever the
+    base's copy is newer: sqlite databases (MIOpen's compiled-kernel cache, WAL mode) through the backup API -- a consistent copy
+    even while the process that owns the base directory is writing --, text databases by copy + rename.  A process that could not
+    get the base slot is typically a CHILD of the one that holds it (multiprocessing spawn, a test's ranks): without this it would
+    start from the shipped files only and re-compile every kernel its parent already has (measured: the two-rank GPU tests went
+    from ~1 to > 10 minutes)."""
+    if not (os.path.isdir(base) and _owned_private(base)):
+        return
+    os.makedirs(dst, mode=0o700, exist_ok=True)
+    for f in os.listdir(base):
+        s, d = os.path.join(base, f), os.path.join(dst, f)
+        if not os.path.isfile(s) or f.endswith(('-wal', '-shm', '-journal', '.lock')) or '.tmp' in f:
+            continue
+        try:
+            if os.path.exists(d) and os.path.getmtime(d) >= os.path.getmtime(s):
+                continue
+            tmp = d + '.tmp%d' % os.getpid()
+            if f.endswith(_SQLITE_SUFFIXES):
+                import sqlite3
+                con = sqlite3.connect('file:%s?mode=ro' % s, uri=True, timeout=10)
+                out = sqlite3.connect(tmp)
+                try:
+                    con.backup(out)
+                finally:
+                    out.close()
+                    con.close()
+                for side in ('-wal', '-shm'):
+                    if os.path.exists(d + side):
+                        os.remove(d + side)
+            else:
+                shutil.copy(s, tmp)
+            os.replace(tmp, d)
+        except Exception:                               # noqa: BLE001  (a snapshot is an optimisation: the shipped seed still applies)
+            try:
+                os.remove(d + '.tmp%d' % os.getpid())
+            except OSError:
+                pass
+
+
 def visible_gpus(environ=None, kfd_root='/sys/class/kfd/kfd/topology/nodes'):
     """GPUs this process will see, WITHOUT touching the HIP runtime (its queue count is read when it initialises): the
     visible-devices variables if one is set, else the KFD topology (nodes that have SIMDs); 0 = unknown."""
@@ -213,10 +256,15 @@ def configure_env(tag=None):
             todo.append((var, mark, src, kind))
     if not todo:
         return _STATE
-    tag = _STATE['tag'] = _claim_slot(str(tag))
+    base = str(tag)
+    tag = _STATE['tag'] = _claim_slot(base)
     try:
         for var, mark, src, kind in todo:
-            os.environ[var] = _STATE[kind[7:]] = _seed(src, _private_dir(kind, tag, _tree_digest(src)))
+            digest = _tree_digest(src)
+            dst = _private_dir(kind, tag, digest)
+            if tag != base:
+                _snapshot(_private_dir(kind, base, digest), dst)      # start from what the holder of the base slot has by now
+            os.environ[var] = _STATE[kind[7:]] = _seed(src, dst)
             os.environ[mark] = '1'
     except OSError:
         pass                                            # read-only temp directory: the library falls back to its own defaults

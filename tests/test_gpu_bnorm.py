@@ -598,18 +598,26 @@ def test_bn_channel_sliced_map(n, c, h, w, relu, res):
         assert la == {'cfl_bn_stats_kernel': 1, 'cfl_bn_apply_kernel': 1, 'cfl_bn_bwd_reduce_kernel': 1, 'cfl_bn_bwd_apply_kernel': 1}, la
     assert lb.get('cfl_bn_final_kernel') == 1 and lb.get('cfl_bn_bwd_final_kernel') == 1, lb
     names = ['y', 'dx', 'dres', 'dgamma', 'dbeta', 'running_mean', 'running_var']
+    # With a ReLU an output that is ~0 can land on the other side of zero when mean / invstd move by one fp32 ulp: its mask bit
+    # flips, and that ONE element's gradient (and the channel sums it enters) differs by a whole dy.  A handful of elements of 51 M:
+    # counted, not tolerated as a bound on everything else.
+    flips = 2e-6 if relu else 0.0
     for name, ta, tb in zip(names, a, b):
         if ta is None:
             continue
         ta, tb = ta.float(), tb.float()
         scale = float(tb.abs().max()) + 1e-12
+        d = (ta - tb).abs()
         if name in ('y', 'dx', 'dres'):
             # same arithmetic up to the last fp32 bit of mean / invstd / the reductions: an element may land on the neighbouring
             # bf16 value (2^-8 relative), never further
-            assert float((ta - tb).abs().max()) <= 2.0 ** -7 * scale, (name, float((ta - tb).abs().max()), scale)
-            assert float(((ta - tb).abs() > 1e-6 * scale).float().mean()) < 0.02, name
+            far = d > 2.0 ** -7 * scale
+            assert float(far.float().mean()) <= flips, (name, int(far.sum()), float(d.max()), scale)
+            assert float((d > 1e-6 * scale).float().mean()) < 0.02, name
         else:
-            assert float((ta - tb).abs().max()) <= 2e-5 * scale + 1e-7, (name, float((ta - tb).abs().max()), scale)
+            off = d > 2e-5 * scale + 1e-7
+            assert float(off.float().mean()) <= (0.02 if relu and name in ('dgamma', 'dbeta') else 0.0), (name, int(off.sum()), float(d.max()), scale)
+            assert float(d.max()) <= 5e-3 * scale, (name, float(d.max()), scale)
     (a2, _) = run(True)
     for name, ta, tb in zip(names, a, a2):
         if ta is not None:

@@ -21,7 +21,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _init(rank, world, path):
+    import faulthandler
     import torch.distributed as dist
+    # a worker that is still running after 9 minutes prints every thread's stack and exits: a hung collective (or a library stuck
+    # in a search) must show WHERE, the parent's join() only sees a missing exit code
+    faulthandler.dump_traceback_later(540, exit=True)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ.setdefault('MIOPEN_FIND_MODE', '2')
     torch.cuda.set_device(0)

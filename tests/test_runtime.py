@@ -235,3 +235,45 @@ def test_find_db_gate_needs_the_live_copy_to_hold_the_shipped_record(tmp_path, m
     keys = ops._fdb_keys()
     assert dropped not in keys and changed not in keys and len(keys) >= 50
     monkeypatch.setitem(ops._FDB, 'keys', None)
+
+
+def test_a_second_slot_starts_from_the_base_slots_state(tmp_path):
+    """A process that cannot have the base slot (its parent holds it) starts from a SNAPSHOT of the base slot's directory -- the
+    compiled-kernel cache through sqlite's backup API, text databases by copy -- not from the shipped files alone: a spawned rank
+    must not re-compile what its parent already has."""
+    import sqlite3
+    env = {k: v for k, v in os.environ.items() if not k.startswith(('MIOPEN_', 'CFL_', 'GPU_MAX')) and k not in ('LOCAL_RANK', 'RANK')}
+    env['TMPDIR'] = str(tmp_path)
+    prog = ('import sys, os; sys.path.insert(0, %r); import creamfl_amd; '
+            'print(os.environ["MIOPEN_USER_DB_PATH"] + "|" + os.environ["MIOPEN_CUSTOM_CACHE_DIR"], flush=True); sys.stdin.readline()' % ROOT)
+    first = subprocess.Popen([sys.executable, '-c', prog], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+    try:
+        db0, cache0 = first.stdout.readline().decode().strip().split('|')
+        # what the holder of the base slot has learned since it was seeded
+        with open(os.path.join(db0, 'extra.ufdb.txt'), 'w') as f:
+            f.write('some-problem=Solver:1.0,0,algo\n')
+        con = sqlite3.connect(os.path.join(cache0, 'gfx950100.ukdb'))
+        n0 = con.execute('select count(*) from kern_db').fetchone()[0]
+        cols = [r[1] for r in con.execute('pragma table_info(kern_db)')]
+        row = list(con.execute('select * from kern_db limit 1').fetchone())
+        row[cols.index('kernel_name')] = 'a_kernel_the_parent_compiled'
+        if 'id' in cols:
+            row[cols.index('id')] = None
+        con.execute('insert into kern_db values (%s)' % ','.join('?' * len(cols)), row)
+        con.commit()
+        con.close()
+        second = subprocess.Popen([sys.executable, '-c', prog], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+        try:
+            db1, cache1 = second.stdout.readline().decode().strip().split('|')
+        finally:
+            second.stdin.close()
+            second.wait(timeout=60)
+    finally:
+        first.stdin.close()
+        first.wait(timeout=60)
+    assert db1 != db0 and db1.endswith('0_s1') and cache1.endswith('0_s1')
+    assert os.path.exists(os.path.join(db1, 'extra.ufdb.txt'))
+    con = sqlite3.connect(os.path.join(cache1, 'gfx950100.ukdb'))
+    assert con.execute('select count(*) from kern_db').fetchone()[0] == n0 + 1
+    assert con.execute("select count(*) from kern_db where kernel_name = 'a_kernel_the_parent_compiled'").fetchone()[0] == 1
+    con.close()
