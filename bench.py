@@ -161,7 +161,7 @@ def offline_traffic(kernel, per_step, profiles_dir=None):
     launch-weighted."""
     profiles_dir = profiles_dir or os.path.join(ROOT, 'profiles')
     source = 'none: no offline PMC profile matches this run (traffic = null)'
-    for fn in ('r4_pmc_bench_traffic.json', 'r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
+    for fn in ('r5_pmc_bench_traffic.json', 'r4_pmc_bench_traffic.json', 'r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(profiles_dir, fn)))
         except (OSError, ValueError):
@@ -466,7 +466,7 @@ def main():
                 'cfl_bn_apply_kernel': 4 * bc['fwd'] + 2 * bc['fwd_res'] + bc['fwd_mask'] // 8,   # + the 1-bit ReLU mask
                 # bwd reduce: read dy (+ second upstream gradient), x and the ReLU mask bits (with a residual; otherwise
                 # the mask comes from x); bwd apply: the same reads, write dx (+ the residual gradient)
-                'cfl_bn_bwd_reduce_kernel': 4 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_two'],
+                'cfl_bn_bwd_reduce_kernel': 4 * (bc['bwd'] + bc['bwd_wg']) + bc['bwd_relu'] // 8 + 2 * bc['bwd_two'],   # (bwd_wg: layers whose apply pass is the fused weight-gradient kernel)
                 'cfl_bn_bwd_apply_kernel': 6 * bc['bwd'] + bc['bwd_relu'] // 8 + 2 * bc['bwd_res'] + 2 * bc['bwd_two'],
             }
             cost = algorithmic_cost(base, args.batch, 49, Cd, Cd // 2, args.dim, n_f32, n_bf16)

@@ -615,6 +615,230 @@ static SPlan bn_splan(long long R, int C) {
     return p;
 }
 
+
+// ---- conv3 weight gradient INSIDE the BatchNorm backward-apply pass that produces its dY (round 5) --------------------------
+// A bottleneck's bn3 backward (pre-joined gradient: no mask, no second gradient; ops.JOIN) writes dY3 = the upstream gradient of
+// conv3, a 1 x 1 convolution whose weight gradient dW3[c, k] = sum_r dY3[r, c] A2[r, k] the library computes on a side stream from
+// dY3 read back from memory (CK batched GEMM with fp32 atomics + memset + cast: 63 us alone, ~114 us inside the step at 14 x 14,
+// 1024 x 256 -- 4 of its 5 operand units are dY3).  Here the apply pass keeps the dY3 tile it has just computed: a workgroup
+// (512 threads) owns 128 channels of a row range; per 64-row stage it streams its dy / x segments through registers, writes
+// dY3 to memory AND -- bf16, row-major, 16-byte pieces XOR-swizzled by (row & 3) << 2 -- into an LDS tile, the stage's A2 rows
+// [64 x 256] arrive by LDS-DMA (same swizzle, applied on the source side), and both MFMA operands are read TRANSPOSED out of LDS
+// (ds_read_b64_tr_b16: 8 consecutive rows of one column per lane = the operand layout of v_mfma_f32_32x32x16_bf16).  8 waves =
+// 2 channel halves x 4 column quarters, 64 x 64 accumulators per wave; one barrier per stage (the MFMAs of stage s run in the
+// same phase as the arithmetic and LDS writes of stage s + 1, the DMA and register loads of stage s + 2 are issued behind the
+// barrier).  Split-K partials [parts][C][256] fp32 (one per workgroup row range: 32 MB at 32 parts), a fixed-order reduce that
+// casts: deterministic, unlike the library's atomics.  Stand-alone at R = 50 176, C = 1024 (tools/hip/bnwg_probe.hip): apply
+// 79 us -> apply + weight gradient 95 us + 3.6 us reduce.  P = 256 only (layer3 of ResNet-50 / -101: 23 of 33 blocks).
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* wg_lds_vptr;
+typedef const __attribute__((address_space(1))) void* wg_glb_vptr;
+typedef unsigned short u16;
+
+__device__ __attribute__((aligned(256))) unsigned char g_bn_zero_page[256];
+
+constexpr int WG_CH = 128;                 // channels per workgroup
+constexpr int WG_KS = 64;                  // rows per stage
+constexpr int WG_PN = 256;                 // columns of the convolution's input (planes)
+constexpr int WG_TILE_A = WG_KS * 256;     // 16 KB: [64 rows][128 channels] bf16
+constexpr int WG_TILE_B = 2 * WG_KS * 256; // 32 KB: two [64][128] sub-tiles
+
+__device__ __forceinline__ wg_bf16x8 wg_frag_tr(const char* p) {
+    const wg_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p));
+    const wg_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p + 4 * 256));
+    union { wg_s16x4 h[2]; wg_bf16x8 v; } u;
+    u.h[0] = a; u.h[1] = b;
+    return u.v;
+}
+
+// rows m0 .. m0 + 63 of A [R, 256] into two [64][128] sub-tiles; rows >= mend come from a page of zeros.  32 wave instructions
+// of 4 rows x 256 bytes, wave w of 8 issues 4.
+__device__ __forceinline__ void wg_stage_b(const u16* __restrict__ A, long long m0, long long mend, char* dst, int w, int lane) {
+    const int r4 = lane >> 4, pp = lane & 15;
+    const int lp = pp ^ (r4 << 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ins = w + 8 * j;
+        const int sub = ins >> 4, rg = ins & 15;
+        const long long m = m0 + rg * 4 + r4;
+        const void* p = m < mend ? (const void*)(A + m * WG_PN + sub * 128 + lp * 8) : (const void*)g_bn_zero_page;
+        __builtin_amdgcn_global_load_lds((wg_glb_vptr)p, (wg_lds_vptr)(dst + sub * (WG_KS * 256) + rg * 1024), 16, 0, 0);
+    }
+}
+
+// grid = (parts, C / 128), 512 threads, dynamic LDS = 2 WG_TILE_A + 2 WG_TILE_B + 4 KB.  pdb / pdg: the nparts_r partial rows
+// the reduce pass (64-channel slices) left for every channel.
+__global__ __launch_bounds__(512, 1) void cfl_bn_bwd_apply_wgrad_kernel(const U4* __restrict__ dy, const U4* __restrict__ x,
+                                                                       const u16* __restrict__ A, const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ pdb, const float* __restrict__ pdg,
+                                                                       int nparts_r, float* dbeta, float* dgamma, long long R, int C,
+                                                                       int rows_per_block, U4* __restrict__ dx, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    char* ldsA = wlds;
+    char* ldsB = wlds + 2 * WG_TILE_A;
+    float* tot = reinterpret_cast<float*>(wlds + 2 * WG_TILE_A + 2 * WG_TILE_B);      // [2][4][128]
+    const int seg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w & 1, wn = w >> 1;
+    // totals of this workgroup's 128 channels over the reduce pass's partial rows: four interleaved chains per channel (the
+    // order of slice_totals, so dbeta / dgamma are bit-identical to the plain sliced pass)
+    {
+        const int cl = threadIdx.x & 127, g = threadIdx.x >> 7;
+        const float* qa = pdb + blockIdx.y * WG_CH + cl;
+        const float* qb = pdg + blockIdx.y * WG_CH + cl;
+        float ta = 0.f, tb = 0.f;
+        int q = g;
+        for (; q + 12 < nparts_r; q += 16) {
+            const float a0 = qa[(long long)q * C], a1 = qa[(long long)(q + 4) * C], a2 = qa[(long long)(q + 8) * C], a3 = qa[(long long)(q + 12) * C];
+            const float b0 = qb[(long long)q * C], b1 = qb[(long long)(q + 4) * C], b2 = qb[(long long)(q + 8) * C], b3 = qb[(long long)(q + 12) * C];
+            ta += (a0 + a1) + (a2 + a3); tb += (b0 + b1) + (b2 + b3);
+        }
+        for (; q < nparts_r; q += 4) { ta += qa[(long long)q * C]; tb += qb[(long long)q * C]; }
+        tot[g * 128 + cl] = ta; tot[512 + g * 128 + cl] = tb;
+    }
+    __syncthreads();
+    const int c0 = blockIdx.y * WG_CH + seg * 8;
+    const bool writer = blockIdx.x == 0 && rl == 0;
+    float a[8], b[8], cc[8], mu[8], is[8];
+    const float invR = 1.f / (float)R;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = seg * 8 + k;
+        const float tdb = (tot[c] + tot[128 + c]) + (tot[256 + c] + tot[384 + c]);
+        const float tdg = (tot[512 + c] + tot[640 + c]) + (tot[768 + c] + tot[896 + c]);
+        mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k];
+        a[k] = gamma[c0 + k] * is[k];
+        b[k] = tdb * invR;
+        cc[k] = tdg * invR;
+        if (writer) { dbeta[c0 + k] = tdb; dgamma[c0 + k] = tdg; }
+    }
+    const long long rb = (long long)blockIdx.x * rows_per_block, re = min(R, rb + rows_per_block);
+    const int nst = (int)((re - rb + WG_KS - 1) / WG_KS);
+    const int g = lane >> 4, p = lane & 15;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ca = wm * 64 + 32 * t + 16 * (g & 1) + 4 * (p & 3);
+        const int cb = wn * 64 + 32 * t + 16 * (g & 1) + 4 * (p & 3);
+        const int row = 8 * (g >> 1) + (p >> 2);
+        offA[t] = row * 256 + ((((ca >> 3) ^ ((p >> 2) << 2)) & 15) << 4) + (ca & 7) * 2;
+        const int cs = cb & 127;
+        offB[t] = (cb >> 7) * (WG_KS * 256) + row * 256 + ((((cs >> 3) ^ ((p >> 2) << 2)) & 15) << 4) + (cs & 7) * 2;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const long long rowU4 = C >> 3;
+    const long long gbase = blockIdx.y * 16 + seg;
+    U4 rd[2], rx[2];
+    auto load_regs = [&](int st) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r = rb + (long long)st * WG_KS + rl + 32 * h;
+            const long long o = (r < re ? r : re - 1) * rowU4 + gbase;
+            rd[h] = dy[o];
+            rx[h] = x[o];
+        }
+    };
+    auto compute_store = [&](int st, char* tile) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rr = rl + 32 * h;
+            const long long r = rb + (long long)st * WG_KS + rr;
+            float d[8], f[8];
+            unpack8(rd[h], d);
+            unpack8(rx[h], f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = a[k] * (d[k] - b[k] - (f[k] - mu[k]) * is[k] * cc[k]);
+            U4 o = pack8(f);
+            if (r < re) dx[r * rowU4 + gbase] = o;
+            else { o.x = 0; o.y = 0; o.z = 0; o.w = 0; }
+            *reinterpret_cast<U4*>(tile + rr * 256 + ((seg ^ ((rr & 3) << 2)) << 4)) = o;
+        }
+    };
+    wg_stage_b(A, rb, re, ldsB, w, lane);
+    load_regs(0);
+    compute_store(0, ldsA);
+    if (nst > 1) { wg_stage_b(A, rb + WG_KS, re, ldsB + WG_TILE_B, w, lane); load_regs(1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const char* ta = ldsA + (st & 1) * WG_TILE_A;
+        const char* tb = ldsB + (st & 1) * WG_TILE_B;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            wg_bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = wg_frag_tr(ta + offA[t] + ks * 16 * 256);
+                fb[t] = wg_frag_tr(tb + offB[t] + ks * 16 * 256);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+        }
+        if (st + 1 < nst) compute_store(st + 1, ldsA + ((st + 1) & 1) * WG_TILE_A);
+        // everything issued one iteration ago has landed (the DMA of stage st + 1 included); the two dY stores just issued may
+        // stay out.  The last two iterations drain everything: a ragged last stage issues fewer stores than the count assumes.
+        if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 2 < nst) {
+            wg_stage_b(A, rb + (long long)(st + 2) * WG_KS, re, ldsB + (st & 1) * WG_TILE_B, w, lane);
+            load_regs(st + 2);
+        }
+    }
+    float* out = part + ((long long)blockIdx.x * C + blockIdx.y * WG_CH) * WG_PN;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int j = (wn * 2 + n) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(long long)i * WG_PN + j] = acc[m][n][r];
+            }
+        }
+}
+
+// dW = sum over the row parts (fixed order), bf16
+__global__ __launch_bounds__(256) void cfl_bn_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, long long n, u32* __restrict__ out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nparts; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (long long)(k + u) * n + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nparts; ++k) s += *reinterpret_cast<const f32x4*>(part + (long long)k * n + i);
+    out[i / 2] = bf16_rne(s[0]) | (bf16_rne(s[1]) << 16);
+    out[i / 2 + 1] = bf16_rne(s[2]) | (bf16_rne(s[3]) << 16);
+}
+
+struct WPlan { int rows_per_block, parts; };
+static WPlan bn_wplan(long long R, int C) {
+    WPlan p;
+    long long want = 256 / (C / WG_CH);                   // one workgroup per CU (96 KB of LDS)
+    if (want < 1) want = 1;
+    long long rpb = (R + want - 1) / want;
+    rpb = ((rpb + WG_KS - 1) / WG_KS) * WG_KS;
+    p.rows_per_block = (int)rpb;
+    p.parts = (int)((R + rpb - 1) / rpb);
+    return p;
+}
+
 struct Plan { int rows_per_block, nblk, gy; };
 static Plan bn_plan(long long R, int C) {
     Plan p;
@@ -788,6 +1012,43 @@ int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, co
     else if (relu) BN_APPLY(false, true, false);
     else BN_APPLY(false, false, false);
 #undef BN_APPLY
+    return 0;
+}
+
+// cfl_bn_bwd for a pre-joined gradient (no ReLU mask, no residual, one upstream gradient) whose apply pass also produces the
+// weight gradient of the 1 x 1 convolution that made x:  dw[C, P] (bf16) = dx^T a_in, a_in [R, P] bf16 = that convolution's input.
+int cfl_bn_bwd_wgrad_supported(long long R, int C, int P) {
+    return (P == WG_PN && C % WG_CH == 0 && C >= 256 && C <= 2048 && R >= 4 * WG_KS && bn_use_sliced(R, C)) ? 1 : 0;
+}
+
+size_t cfl_bn_bwd_wgrad_ws_bytes(long long R, int C, int P) {
+    if (!cfl_bn_bwd_wgrad_supported(R, C, P)) return 256;
+    const size_t red = cfl_align256((size_t)2 * bn_splan(R, C).parts * C * sizeof(float));
+    return red + cfl_align256((size_t)bn_wplan(R, C).parts * C * P * sizeof(float));
+}
+
+int cfl_bn_bwd_wgrad(const void* dy, const void* x, const void* a_in, int P, const float* gamma, const float* save_mean,
+                     const float* save_invstd, long long R, int C, void* dx, float* dgamma, float* dbeta, void* dw, void* ws,
+                     void* stream_) {
+    if (!dy || !x || !a_in || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !dw || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
+    if (!cfl_bn_bwd_wgrad_supported(R, C, P) || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)a_in | (uintptr_t)dx | (uintptr_t)dw) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const SPlan sp = bn_splan(R, C);
+    const WPlan wp = bn_wplan(R, C);
+    float* qdb = (float*)ws;
+    float* qdg = qdb + (size_t)sp.parts * C;
+    float* part = (float*)((char*)ws + cfl_align256((size_t)2 * sp.parts * C * sizeof(float)));
+    const U4 *d = (const U4*)dy, *xx = (const U4*)x, *none = nullptr;
+    CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_sl_kernel<false, false>), dim3(sp.parts, sp.slices), dim3(256), 0, stream, d, none, xx, none,
+               save_mean, save_invstd, gamma, (const float*)nullptr, R, C, sp.rows_per_block, qdb, qdg, (const unsigned char*)nullptr);
+    constexpr size_t LDS = (size_t)2 * WG_TILE_A + 2 * WG_TILE_B + 4096;
+    CFL_SET_LDS(cfl_bn_bwd_apply_wgrad_kernel, LDS);
+    CFL_LAUNCH(K_BN_BWD_APPLY_WG, cfl_bn_bwd_apply_wgrad_kernel, dim3(wp.parts, C / WG_CH), dim3(512), LDS, stream, d, xx, (const u16*)a_in,
+               save_mean, save_invstd, gamma, (const float*)qdb, (const float*)qdg, sp.parts, dbeta, dgamma, R, C, wp.rows_per_block,
+               (U4*)dx, part);
+    const long long n = (long long)C * P;
+    CFL_LAUNCH(K_BN_WGRAD_REDUCE, cfl_bn_wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)part,
+               wp.parts, n, (u32*)dw);
     return 0;
 }
 

@@ -31,6 +31,7 @@ enum CflKernel {
     K_PIE_FWD_FUSED, K_PIE_BWD_FUSED,
     K_BN_POOL_FWD, K_BN_POOL_BWD_REDUCE, K_BN_POOL_BWD_APPLY,
     K_BANK_IMAGE, K_BANK_STREAM,
+    K_BN_BWD_APPLY_WG, K_BN_WGRAD_REDUCE,
     K_NUM
 };
 

@@ -807,13 +807,13 @@ def _join_reset(on):
 
 
 # element counters of the fused BN kernels (python ints; bench.py turns them into algorithmic bytes)
-BN_COUNTERS = {'fwd': 0, 'fwd_pre': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0}
+BN_COUNTERS = {'fwd': 0, 'fwd_pre': 0, 'fwd_res': 0, 'fwd_mask': 0, 'bwd': 0, 'bwd_relu': 0, 'bwd_res': 0, 'bwd_two': 0, 'bwd_wg': 0}
 
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, tok=0, res_tok=0, pstat=None,
-                pstat_nblk=0):
+                pstat_nblk=0, wg=None):
         lib = _lib.load()
         N, C, H, W = x.shape
         R = N * H * W
@@ -844,6 +844,7 @@ class _BNActFn(torch.autograd.Function):
                                       _stream(x)), 'cfl_bn_fwd')
         ctx.save_for_backward(x, mask if need_mask else x, weight, bias, mean, invstd)
         ctx.set_materialize_grads(False)                  # an unused alias must arrive as None, not as a zero tensor
+        ctx.wg = wg                                       # weight-gradient holder of the convolution that made x (WGRAD_FUSE)
         ctx.tok = tok                                     # join tokens of the output / of the residual input (0 = none)
         ctx.res_tok = res_tok if residual is not None else 0
         if need_mask and JOIN['armed'] and tok:
@@ -859,7 +860,7 @@ class _BNActFn(torch.autograd.Function):
         if dy is None:
             dy, dy2 = dy2, None
         if dy is None:
-            return (None,) * 13
+            return (None,) * 14
         # JOIN: the data-gradient GEMM of the consumer already produced g = (A + B) . mask for this layer's output
         pre = bool(JOIN['on'] and ctx.tok and ctx.tok in JOIN['pre'])
         if pre:
@@ -897,7 +898,29 @@ class _BNActFn(torch.autograd.Function):
         dgamma = torch.empty_like(weight)
         dbeta = torch.empty_like(weight)
         ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
-        if pre:          # plain BatchNorm backward of an already masked, already summed gradient
+        wg = ctx.wg
+        if pre and wg is not None and WGRAD_FUSE[0] and wg['x'] is not None and not wg['done'] and \
+                lib.cfl_bn_bwd_wgrad_supported(R, C, wg['w'].shape[1]) and wg['x'].is_contiguous(memory_format=torch.channels_last):
+            # ... and the weight gradient of the convolution that made x, from the dY tile while it is on the chip
+            w = wg['w']
+            P = w.shape[1]
+            dw = torch.empty_like(w)
+            ws2 = _ws(lib.cfl_bn_bwd_wgrad_ws_bytes(R, C, P), x.device)
+            _lib.check(lib.cfl_bn_bwd_wgrad(_ptr(dy), _ptr(x), _ptr(wg['x']), P, _ptr(weight), _ptr(mean), _ptr(invstd), R, C, _ptr(dx),
+                                            _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(ws2), _stream(x)), 'cfl_bn_bwd_wgrad')
+            with torch.no_grad():
+                if w.grad is None:
+                    w.grad = dw
+                else:
+                    w.grad.add_(dw)
+            wg['done'] = True
+            WGRAD_FUSED[0] += 1
+            BN_COUNTERS['bwd'] -= R * C                   # (its apply pass is another kernel id: counted apart)
+            BN_COUNTERS['bwd_wg'] += R * C
+            from . import streams as _st
+            if _st.GRAD_READY[0] is not None:
+                _st.GRAD_READY[0](w)                      # multi-GPU: this gradient may now be bucketed
+        elif pre:          # plain BatchNorm backward of an already masked, already summed gradient
             _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(None), _ptr(x), _ptr(None), _ptr(None), _ptr(weight), _ptr(bias), _ptr(mean),
                                       _ptr(invstd), R, C, 0, 0, _ptr(dx), _ptr(None), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)),
                        'cfl_bn_bwd')
@@ -910,7 +933,7 @@ class _BNActFn(torch.autograd.Function):
             # autograd (None = no contribution): that GEMM adds it and masks the sum for the BatchNorm below
             JOIN['pending'][ctx.res_tok] = dres
             dres = None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None, two=False):
@@ -929,7 +952,7 @@ def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu
     if pre is not None and not (CONV_STATS[0] and pre[2] == x.shape[0] * x.shape[2] * x.shape[3] and pre[3] == x.shape[1]):
         pre = None
     y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), tok, res_tok,
-                           pre[0] if pre is not None else None, pre[1] if pre is not None else 0)
+                           pre[0] if pre is not None else None, pre[1] if pre is not None else 0, getattr(x, '_cfl_wg', None))
     if tok:
         y._cfl_tok = tok
         y2._cfl_tok = tok
@@ -1224,6 +1247,11 @@ class _ConvSplitFn(torch.autograd.Function):
     def forward(ctx, x, weight, stride, padding, gemm_dgrad, side_wgrad, stats_nblk=0):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, gemm_dgrad, side_wgrad)
+        # weight gradient inside the BatchNorm backward that follows (WGRAD_FUSE below): a per-call holder both nodes share
+        ctx.wg = None
+        if (WGRAD_FUSE[0] and gemm_dgrad and side_wgrad and ctx.needs_input_grad[1] and weight.dtype == torch.bfloat16
+                and _lib.load().cfl_bn_bwd_wgrad_supported(x.shape[0] * x.shape[2] * x.shape[3], weight.shape[0], weight.shape[1])):
+            ctx.wg = _LAST_WG[0] = {'x': x, 'w': weight, 'done': False}
         tok = getattr(x, '_cfl_tok', 0)
         ctx.x_tok = tok if (gemm_dgrad and ctx.needs_input_grad[0] and tok and tok in JOIN['mask']) else 0
         if ctx.x_tok:
@@ -1254,7 +1282,9 @@ class _ConvSplitFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         args = (dy, x, weight, None, [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1)
         dx = dw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.wg is not None:
+            ctx.wg['x'] = None                                        # (the holder must not outlive the step's activations)
+        if ctx.needs_input_grad[1] and not (ctx.wg is not None and ctx.wg['done']):
             if side_wgrad:
                 from . import streams
                 if streams.DEFER_WGRAD[0]:
@@ -1330,6 +1360,14 @@ class _ConvSplitFn(torch.autograd.Function):
         return dx, dw, None, None, None, None, None
 
 
+# The weight gradient of a bottleneck's conv3 inside the BatchNorm backward-apply pass that produces its dY (csrc/bnorm.hip:
+# cfl_bn_bwd_wgrad; round 5).  The convolution's forward leaves a holder {x: its input, w: its weight, done} on its output tensor
+# object; bn_act_train hands it to the BatchNorm node; in the backward, when the BatchNorm's gradient arrives pre-joined (ops.JOIN)
+# and the shape is taken, ONE launch sequence writes dY, dgamma, dbeta AND dW, accumulates dW into weight.grad (as the deferred
+# weight gradients do) and marks the holder done -- the convolution's own backward then skips its library weight gradient.
+WGRAD_FUSE = [_os.environ.get('CFL_NO_WGRAD_FUSE', '0') != '1']      # switch (tools/ab_step.py --knob wgfuse)
+WGRAD_FUSED = [0]                                                   # launches taken (tests / benches read it)
+_LAST_WG = [None]
 CONV_STATS = [_os.environ.get('CFL_NO_CONV_STATS', '0') != '1']     # switch (also flipped by tools/ab_step.py --knob convstats)
 CONV_STATS_MIN_M = 32768        # below: too few 32-row tiles per wave for the streaming kernel (as for the joined data gradient)
 _LAST_STATS = [None]
@@ -1344,9 +1382,14 @@ def conv_split(x, weight, stride=1, padding=0, side_wgrad=True, bn_follows=False
     nblk = 0
     if bn_follows and gemm and CONV_STATS[0] and x.shape[0] * x.shape[2] * x.shape[3] >= CONV_STATS_MIN_M:
         nblk = int(_lib.load().cfl_gemm_bf16_nt_stats_nblk(x.shape[0] * x.shape[2] * x.shape[3], weight.shape[0], weight.shape[1]))
+    _LAST_WG[0] = None
     y = _ConvSplitFn.apply(x, weight, int(stride), int(padding), bool(gemm), bool(side_wgrad), nblk)
     if nblk:
         y._cfl_bnstats, _LAST_STATS[0] = _LAST_STATS[0], None
+    if _LAST_WG[0] is not None:
+        if bn_follows:
+            y._cfl_wg = _LAST_WG[0]                       # bn_act_train picks it up; anything in between drops the fusion
+        _LAST_WG[0] = None
     return y
 
 

@@ -366,6 +366,19 @@ int cfl_rank_count(const float* Q, const float* G, const long long* qlab, const 
  * cfl_bn_sliced(0 / 1) switches the map off / on, a negative argument only queries; returns the previous setting
  * (CFL_BN_NO_SLICE=1 in the environment starts with it off).  Measurement switch of tools/ab_step.py --knob bnslice. */
 int cfl_bn_sliced(int on);
+/* cfl_bn_bwd for a PRE-JOINED gradient (relu = 0, has_residual = 0, one upstream gradient: the bn3 backward of a bottleneck whose
+ * gradient join ran in the data-gradient GEMM above, cfl_gemm_bf16_nt_join) whose apply pass ALSO produces the weight gradient of
+ * the 1 x 1 convolution that made x (torchvision Bottleneck.conv3 inside src/networks/models/image_encoder.py:27-36; the reference
+ * leaves it to cuDNN, this build's default is a library kernel on a side stream that re-reads dx from memory):
+ *   dx[R, C] bf16 as cfl_bn_bwd,  dw[C, P] bf16 = dx^T a_in,  a_in [R, P] bf16 = the convolution's input (channels_last rows).
+ * The dx tile of a stage goes to memory and, transposed through LDS, into the MFMAs; split-K partials + a fixed-order reduce
+ * (deterministic).  P = 256, C a multiple of 128 (layer3 of ResNet-50 / -101); `supported` says whether a shape is taken.
+ * ws: cfl_bn_bwd_wgrad_ws_bytes (the reduce pass's partials + parts x C x P floats). */
+int cfl_bn_bwd_wgrad_supported(long long R, int C, int P);
+size_t cfl_bn_bwd_wgrad_ws_bytes(long long R, int C, int P);
+int cfl_bn_bwd_wgrad(const void* dy, const void* x, const void* a_in, int P, const float* gamma, const float* save_mean,
+                     const float* save_invstd, long long R, int C, void* dx, float* dgamma, float* dbeta, void* dw, void* ws,
+                     void* stream);
 size_t cfl_bn_ws_bytes(long long R, int C);
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,

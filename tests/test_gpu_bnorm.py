@@ -622,3 +622,114 @@ def test_bn_channel_sliced_map(n, c, h, w, relu, res):
     for name, ta, tb in zip(names, a, a2):
         if ta is not None:
             assert torch.equal(ta, tb), ('not deterministic', name)
+
+
+@pytest.mark.parametrize('R,C', [(50176, 1024), (1000, 1024), (3137, 512), (256, 256)])
+def test_bn_bwd_with_the_conv3_weight_gradient_in_its_apply_pass(R, C):
+    """Round 5: cfl_bn_bwd_wgrad = the BatchNorm backward of a pre-joined gradient whose apply pass also produces the weight
+    gradient of the 1 x 1 convolution that made x (dW[C, 256] = dX^T A).  dX, dgamma, dbeta must be BIT-IDENTICAL to cfl_bn_bwd on
+    the sliced map (same arithmetic, same summation order); dW against an fp32 matmul of the STORED bf16 dX (one bf16 rounding of
+    the result + fp32 summation order); twice the same call bit-identical (split-K partials reduced in a fixed order, no
+    atomics).  Shapes: layer3 of ResNet-101 at batch 256, ragged row counts (a partial last stage, a last workgroup with one
+    stage), other channel counts."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import ctypes
+    from creamfl_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    P = 256
+    assert lib.cfl_bn_bwd_wgrad_supported(R, C, P) == 1
+    assert lib.cfl_bn_bwd_wgrad_supported(R, C, 128) == 0 and lib.cfl_bn_bwd_wgrad_supported(100, C, P) == 0
+    g = torch.Generator(device=dev).manual_seed(R + C)
+    dy = torch.randn(R, C, generator=g, device=dev).to(torch.bfloat16)
+    x = (torch.randn(R, C, generator=g, device=dev) * 1.4 + 0.2).to(torch.bfloat16)
+    a = torch.relu(torch.randn(R, P, generator=g, device=dev)).to(torch.bfloat16)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g, device=dev)
+    mean = x.float().mean(0)
+    invstd = torch.rsqrt(x.float().var(0, unbiased=False) + 1e-5)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def plain():
+        dx = torch.empty_like(x); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
+        ws = torch.empty(lib.cfl_bn_ws_bytes(R, C), dtype=torch.uint8, device=dev)
+        _lib.check(lib.cfl_bn_bwd(P_(dy), None, P_(x), None, None, P_(gamma), None, P_(mean), P_(invstd), R, C, 0, 0, P_(dx), None, P_(dg),
+                                  P_(db), P_(ws), st), 'cfl_bn_bwd')
+        return dx, dg, db
+
+    def fused():
+        dx = torch.empty_like(x); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
+        dw = torch.empty(C, P, dtype=torch.bfloat16, device=dev)
+        ws = torch.empty(lib.cfl_bn_bwd_wgrad_ws_bytes(R, C, P), dtype=torch.uint8, device=dev)
+        _lib.check(lib.cfl_bn_bwd_wgrad(P_(dy), P_(x), P_(a), P, P_(gamma), P_(mean), P_(invstd), R, C, P_(dx), P_(dg), P_(db), P_(dw),
+                                        P_(ws), st), 'cfl_bn_bwd_wgrad')
+        return dx, dg, db, dw
+    ref = plain()
+    got = fused()
+    torch.cuda.synchronize()
+    for name, r_, g_ in zip(('dx', 'dgamma', 'dbeta'), ref, got):
+        assert torch.equal(r_, g_), name
+    want = ref[0].float().t() @ a.float()
+    scale = float(want.abs().max())
+    err = (got[3].float() - want).abs()
+    assert float(err.max()) <= 2.0 ** -7 * scale, (float(err.max()), scale)
+    assert float((err / (want.abs() + 1e-3 * scale)).mean()) < 4e-3
+    again = fused()
+    torch.cuda.synchronize()
+    for a_, b_ in zip(got, again):
+        assert torch.equal(a_, b_)
+
+
+def test_conv3_weight_gradient_rides_in_the_bn_backward_of_a_bottleneck_stack(monkeypatch):
+    """The same through the modules: three layer3-shaped bottlenecks (planes = 256), backward run the way TrainerEngine.backward
+    runs it.  With the fusion on, conv3 of the two blocks whose output gradient arrives pre-joined get their weight gradient from
+    the BatchNorm backward (2 launches taken, their library weight gradient skipped); every gradient agrees with the fusion off
+    (library weight gradients: bf16-level), and the data path is untouched (input gradient bit-equal)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops, streams
+    from creamfl_amd.networks.backbones import Bottleneck
+    dev = torch.device('cuda:0')
+    planes, n, hw = 256, 8, 14
+
+    def run(fuse):
+        monkeypatch.setitem(ops.WGRAD_FUSE, 0, fuse)
+        torch.manual_seed(7)
+        blocks = torch.nn.Sequential(*[Bottleneck(4 * planes, planes) for _ in range(3)]).to(dev).to(torch.bfloat16)
+        blocks = blocks.to(memory_format=torch.channels_last).train()
+        for m in blocks.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.float()
+        x = torch.randn(n, 4 * planes, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        w = torch.randn(n, 4 * planes, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        taken0 = ops.WGRAD_FUSED[0]
+        with ops.join_scope():
+            out = blocks(x)
+            out = out[0] if isinstance(out, tuple) else out
+            loss = (out.float() * w.float()).sum()
+            ops.prepare_weight_transposes([m.weight for m in blocks.modules() if isinstance(m, torch.nn.Conv2d)])
+            ops._join_reset(True)
+            try:
+                loss.backward()
+                streams.flush(dev)
+                streams.join_into_current(dev)
+            finally:
+                ops.release_weight_transposes()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().float().cpu() for k, p in blocks.named_parameters()}
+        grads['input'] = x.grad.detach().float().cpu()
+        return grads, ops.WGRAD_FUSED[0] - taken0
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == 2, (n_ref, n_got)
+    assert torch.equal(ref['input'], got['input'])
+    for k in ref:
+        a, b = got[k].numpy(), ref[k].numpy()
+        scale = float(np.abs(b).max())
+        assert np.isfinite(a).all(), k
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-2 * scale, err_msg=k)
+        if 'conv3' in k:
+            assert float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)) < 1e-2, k

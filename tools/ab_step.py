@@ -6,6 +6,7 @@ pool's boxes differ by several per cent from run to run, more than most of the e
 
 knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming kernel (default) vs the tile kernel
         join   the gradient join of the residual blocks in the data-gradient GEMM's epilogue (default) vs in the BatchNorm backward
+        wgfuse   conv3's weight gradient inside the BatchNorm backward-apply pass (default) vs the library's kernel on the side stream
         bnslice  the BatchNorm passes on the channel-sliced block map (no `final` launches, default) vs the whole-row map
 """
 import argparse
@@ -55,6 +56,9 @@ def main():
         elif args.knob == 'convstats':
             from creamfl_amd import ops
             ops.CONV_STATS[0] = bool(on)
+        elif args.knob == 'wgfuse':
+            from creamfl_amd import ops
+            ops.WGRAD_FUSE[0] = bool(on)
         elif args.knob == 'bnslice':
             lib.cfl_bn_sliced(1 if on else 0)
         elif args.knob == 'join':
