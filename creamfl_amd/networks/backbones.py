@@ -87,6 +87,16 @@ class TrunkConv(nn.Conv2d):
             if x.dtype == self.weight.dtype:
                 return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD,
                                       bn_follows=self.bn_follows and self.training)
+        if (x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype and self.stride[0] == self.stride[1]
+                and self.padding[0] == self.padding[1] and isinstance(self.padding[0], int)):
+            from .. import ops
+            if ops.conv_gate_worthwhile(x, self.weight, self.stride[0], self.padding[0]):
+                # every other case (the fp32 NCHW client encoders; forward-only passes: representation extraction, evaluation):
+                # the library's kernels, but answered from the shipped find-db per call where it holds the problem instead of a
+                # timed search per process and shape
+                if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+                    return ops.conv_gated(x, self.weight, self.stride[0], self.padding[0])
+                return ops._conv_fwd(x, self.weight, self.stride[0], self.padding[0])
         return super().forward(x)
 
 

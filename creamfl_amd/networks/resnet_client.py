@@ -8,7 +8,7 @@ import math
 import torch.nn as nn
 
 from .. import ops
-from .backbones import BasicBlock, BNAct, Bottleneck, MaxPool3s2, first_of
+from .backbones import BasicBlock, BNAct, Bottleneck, MaxPool3s2, TrunkConv, first_of
 from .language_model import clamped_head, local_projection_head
 
 STAGE_WIDTHS = (64, 128, 256, 512)
@@ -23,7 +23,7 @@ class ResNet(nn.Module):
         self.phase = str(kwargs.get('phase', 'none'))
         self.mlp_local = kwargs.get('mlp_local', False)
         # stem
-        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.conv1 = TrunkConv(3, 64, 7, stride=2, padding=3)        # (an nn.Conv2d: same parameter name, same state_dict)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=False)
         self.maxpool = MaxPool3s2()
@@ -54,7 +54,7 @@ class ResNet(nn.Module):
         out_planes = planes * block.expansion
         shortcut = None
         if stride != 1 or self.inplanes != out_planes:
-            shortcut = nn.Sequential(nn.Conv2d(self.inplanes, out_planes, kernel_size=1, stride=stride, bias=False),
+            shortcut = nn.Sequential(TrunkConv(self.inplanes, out_planes, 1, stride=stride),
                                      BNAct(out_planes))
         stage = [block(self.inplanes, planes, stride, shortcut)] + [block(out_planes, planes) for _ in range(blocks - 1)]
         self.inplanes = out_planes

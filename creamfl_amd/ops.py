@@ -1181,26 +1181,33 @@ def _fdb_keys():
     return _FDB['keys']
 
 
-def fdb_key(direction, xs, ws, os_, stride, padding):
-    """The find-db key of a bf16 NHWC convolution problem: xs = input [N, Ci, H, W], ws = weight [Co, Ci, kh, kw], os_ = output
-    [N, Co, Ho, Wo]; direction 'F' (forward), 'B' (data gradient), 'W' (weight gradient)."""
+def fdb_key(direction, xs, ws, os_, stride, padding, nhwc=True, dtype='BF16'):
+    """The find-db key of a convolution problem: xs = input [N, Ci, H, W], ws = weight [Co, Ci, kh, kw], os_ = output
+    [N, Co, Ho, Wo]; direction 'F' (forward), 'B' (data gradient), 'W' (weight gradient); channels_last problems spell the three
+    layouts out (`NHWC-NHWC-NHWC`), NCHW ones a single `NCHW`; dtype BF16 / FP32 / FP16."""
     N, Ci, H, W = xs
     Co, _, kh, kw = ws
     Ho, Wo = os_[2], os_[3]
     a = (Ci, H, W, Co, Ho, Wo) if direction == 'F' else (Co, Ho, Wo, Ci, H, W)
-    return '%d-%d-%d-%dx%d-%d-%d-%d-%d-%dx%d-%dx%d-1x1-0-NHWC-NHWC-NHWC-BF16-%s' % (
-        a[0], a[1], a[2], kh, kw, a[3], a[4], a[5], N, padding, padding, stride, stride, direction)
+    return '%d-%d-%d-%dx%d-%d-%d-%d-%d-%dx%d-%dx%d-1x1-0-%s-%s-%s' % (
+        a[0], a[1], a[2], kh, kw, a[3], a[4], a[5], N, padding, padding, stride, stride,
+        'NHWC-NHWC-NHWC' if nhwc else 'NCHW', dtype, direction)
+
+
+_FDB_DTYPES = {torch.bfloat16: 'BF16', torch.float32: 'FP32', torch.float16: 'FP16'}
 
 
 def _fdb_covered(direction, x, w, out_shape, stride, padding):
-    if not _FDB['on'] or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+    dt = _FDB_DTYPES.get(x.dtype)
+    if not _FDB['on'] or dt is None or w.dtype != x.dtype:
         return False
-    nhwc = x.is_contiguous(memory_format=torch.channels_last)      # part of the problem: the db's records are NHWC ones
-    k = (direction, x.shape, w.shape, stride, padding, nhwc)
+    nhwc = x.is_contiguous(memory_format=torch.channels_last) and not (x.shape[1] > 1 and x.is_contiguous())
+    if not nhwc and not x.is_contiguous():
+        return False
+    k = (direction, x.shape, w.shape, stride, padding, nhwc, dt)   # layout and dtype are part of the problem
     hit = _FDB['known'].get(k)
     if hit is None:
-        hit = (nhwc
-               and fdb_key(direction, tuple(x.shape), tuple(w.shape), tuple(out_shape), stride, padding) in _fdb_keys())
+        hit = fdb_key(direction, tuple(x.shape), tuple(w.shape), tuple(out_shape), stride, padding, nhwc, dt) in _fdb_keys()
         _FDB['known'][k] = hit
         _FDB['hits' if hit else 'misses'] += 1
     return hit
@@ -1279,7 +1286,8 @@ class _ConvSplitFn(torch.autograd.Function):
         Co = weight.shape[0]
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        dy = dy.contiguous(memory_format=torch.channels_last)
+        nhwc = x.is_contiguous(memory_format=torch.channels_last) and not (x.shape[1] > 1 and x.is_contiguous())
+        dy = dy.contiguous(memory_format=torch.channels_last) if nhwc else dy.contiguous()
         args = (dy, x, weight, None, [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1)
         dx = dw = None
         if ctx.wg is not None:
@@ -1342,7 +1350,7 @@ class _ConvSplitFn(torch.autograd.Function):
                     dx = torch.nn.functional.conv2d(dy, wt.view(Ci, Co, 1, 1))
                 else:
                     gemm_bf16_nt(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt, out=dx.permute(0, 2, 3, 1).reshape(N * H * W, Ci))
-            elif (stride == 1 and padding == weight.shape[2] // 2 and weight.dtype == torch.bfloat16 and _rot_ok(weight)
+            elif (nhwc and stride == 1 and padding == weight.shape[2] // 2 and weight.dtype == torch.bfloat16 and _rot_ok(weight)
                   and not _NO_FWD_DGRAD):
                 # k x k / stride 1 / same padding: dX = conv2d(dY, W') with the rotated, transposed weight -- MIOpen's FORWARD
                 # kernels run this 1.3-1.6x faster than its backward-data kernels on every ResNet-101 shape (3x3, batch 256:
@@ -1391,6 +1399,23 @@ def conv_split(x, weight, stride=1, padding=0, side_wgrad=True, bn_follows=False
             y._cfl_wg = _LAST_WG[0]                       # bn_act_train picks it up; anything in between drops the fusion
         _LAST_WG[0] = None
     return y
+
+
+def conv_gated(x, weight, stride=1, padding=0):
+    """A plain convolution (any layout / dtype the library takes; no bias, groups 1) whose three library calls -- forward, data
+    gradient, weight gradient -- each answer from the shipped find-db where it holds the problem (MIOpen immediate mode for that
+    call only) instead of PyTorch's timed search: the client encoders' fp32 NCHW convolutions and every other convolution outside
+    the channels_last bf16 trunk path (round 5; the first round of a configs[2] federation spent 704 s in those searches)."""
+    return _ConvSplitFn.apply(x, weight, int(stride), int(padding), False, False, 0)
+
+
+def conv_gate_worthwhile(x, weight, stride, padding):
+    """True when at least the FORWARD problem of this convolution is in the shipped find-db (else the plain library call)."""
+    if not (_FDB['on'] and x.is_cuda and x.dim() == 4 and weight.dim() == 4):
+        return False
+    out_shape = (x.shape[0], weight.shape[0], (x.shape[2] + 2 * padding - weight.shape[2]) // stride + 1,
+                 (x.shape[3] + 2 * padding - weight.shape[3]) // stride + 1)
+    return _fdb_covered('F', x, weight, out_shape, stride, padding)
 
 
 def conv1x1(x, weight):

@@ -703,26 +703,29 @@ def test_bench_forward_flops_counts_both_towers(dev):
 @pytest.mark.gpu
 def test_training_outcome_bf16_fused_equals_fp32(dev):
     """VERDICT r4 missing #4 / next #3b: does the bf16 path TRAIN like the fp32 path?  A synthetic retrieval task with signal
-    (tests/learnable_task.py: identity prototypes <-> caption signatures, chance R@1 = 0.1 %), the same PCME (ResNet-18 + BERT-mini,
-    d = 64) trained by `TrainerEngine.train_step` (retrieval_trainer.py:185-214) from ONE initial state -- once with bf16 trunks and
-    every fusion of the bench's code path on, once with fp32 trunks -- then `COCOEvaluator.evaluate` (eval_coco.py:392-448) on
-    held-out samples of 1000 identities x 5 captions.  Both runs must have learned the task and agree in retrieval quality."""
+    (tests/learnable_task.py: 200 identity prototypes <-> caption signatures; a model that learns it retrieves ~all of them, an
+    untrained one 0.5 %), the same PCME (ResNet-18 + BERT-mini, d = 64) trained by `TrainerEngine.train_step`
+    (retrieval_trainer.py:185-214) from ONE initial state -- once with bf16 trunks and every fusion of the bench's code path on,
+    once with fp32 trunks -- then `COCOEvaluator.evaluate` (eval_coco.py:392-448) on held-out samples (fresh noise, fresh filler
+    words) of the 200 identities x 5 captions.  Both runs must have learned the task and agree in retrieval quality.  (Settings
+    calibrated with tools/train_outcome_probe.py and, for learnability, the CPU oracle port: the loss leaves its plateau at
+    ~step 100 and R@1 passes 95 % by step 400.)"""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     from learnable_task import LearnableTask
     from train_outcome_probe import train_and_eval
-    task = LearnableTask(n_id=1000, img=64, seed=0, device=dev)
+    o = OUTCOME
+    task = LearnableTask(n_id=o['n_id'], img=64, seed=0, noise=o['noise'], device=dev)
     with torch.backends.cudnn.flags(enabled=True, benchmark=False):
-        bf16, state = train_and_eval(task, OUTCOME['steps'], OUTCOME['batch'], OUTCOME['lr'], False, None, dev)
-        fp32, _ = train_and_eval(task, OUTCOME['steps'], OUTCOME['batch'], OUTCOME['lr'], True, state, dev)
+        bf16, state = train_and_eval(task, o['steps'], o['batch'], o['lr'], False, None, dev, n_eval=o['n_id'])
+        fp32, _ = train_and_eval(task, o['steps'], o['batch'], o['lr'], True, state, dev, n_eval=o['n_id'])
     for run in (bf16, fp32):
-        assert run['losses'][-1] < 0.5 * run['losses'][0], run                     # the loss went down
-        assert run['i2t_r1'] >= OUTCOME['min_r1'] and run['t2i_r1'] >= OUTCOME['min_r1'], run      # far above chance (0.1)
-    assert abs(bf16['i2t_r1'] - fp32['i2t_r1']) <= OUTCOME['band'], (bf16, fp32)
-    assert abs(bf16['t2i_r1'] - fp32['t2i_r1']) <= OUTCOME['band'], (bf16, fp32)
-    assert abs(bf16['fold_i2t_r1'] - fp32['fold_i2t_r1']) <= OUTCOME['band'], (bf16, fp32)
+        assert run['losses'][-1] < 0.25 * run['losses'][0], run                     # the loss left its plateau
+        assert run['i2t_r1'] >= o['min_r1'] and run['t2i_r1'] >= o['min_r1'], run    # learned (chance: 0.5)
+    for k in ('i2t_r1', 't2i_r1', 'fold_i2t_r1', 'fold_t2i_r1'):
+        assert abs(bf16[k] - fp32[k]) <= o['band'], (k, bf16, fp32)
 
 
-# steps / batch / learning rate of the training-outcome test and its acceptance band (R@1 points), calibrated with
+# the training-outcome test: task size, steps / batch / learning rate, and its acceptance (R@1 points), calibrated with
 # tools/train_outcome_probe.py on an MI355X (profiles/r5_train_outcome.jsonl)
-OUTCOME = {'steps': 150, 'batch': 64, 'lr': 1e-3, 'min_r1': 5.0, 'band': 1.0}
+OUTCOME = {'n_id': 200, 'noise': 0.3, 'steps': 400, 'batch': 32, 'lr': 2e-4, 'min_r1': 80.0, 'band': 3.0}
