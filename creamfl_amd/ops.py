@@ -1373,7 +1373,12 @@ class _ConvSplitFn(torch.autograd.Function):
 # object; bn_act_train hands it to the BatchNorm node; in the backward, when the BatchNorm's gradient arrives pre-joined (ops.JOIN)
 # and the shape is taken, ONE launch sequence writes dY, dgamma, dbeta AND dW, accumulates dW into weight.grad (as the deferred
 # weight gradients do) and marks the holder done -- the convolution's own backward then skips its library weight gradient.
-WGRAD_FUSE = [_os.environ.get('CFL_NO_WGRAD_FUSE', '0') != '1']      # switch (tools/ab_step.py --knob wgfuse)
+# MEASURED AND NOT SHIPPED (off by default, CFL_WGRAD_FUSE=1 / tools/ab_step.py --knob wgfuse switch it on): stand-alone the fused
+# pass costs +19 us per layer3 block for a weight gradient the library takes 63 us for (tools/hip/bnwg_probe.hip), but inside the
+# server step it LOSES: 44.47 vs 43.93 ms (six alternating rounds, profiles/r5_ab_wgfuse.json) -- the BatchNorm apply pass is on
+# the main stream, i.e. on the step's critical path, and every microsecond added there shows, while the library kernel it replaces
+# runs on the side stream, which only costs the step through contention (the data-gradient GEMMs did speed up, 100 -> 88 us).
+WGRAD_FUSE = [_os.environ.get('CFL_WGRAD_FUSE', '0') == '1']
 WGRAD_FUSED = [0]                                                   # launches taken (tests / benches read it)
 _LAST_WG = [None]
 CONV_STATS = [_os.environ.get('CFL_NO_CONV_STATS', '0') != '1']     # switch (also flipped by tools/ab_step.py --knob convstats)

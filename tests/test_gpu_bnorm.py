@@ -683,7 +683,7 @@ def test_bn_bwd_with_the_conv3_weight_gradient_in_its_apply_pass(R, C):
 
 def test_conv3_weight_gradient_rides_in_the_bn_backward_of_a_bottleneck_stack(monkeypatch):
     """The same through the modules: three layer3-shaped bottlenecks (planes = 256), backward run the way TrainerEngine.backward
-    runs it.  With the fusion on, conv3 of the two blocks whose output gradient arrives pre-joined get their weight gradient from
+    runs it.  With the fusion on (it is OFF by default: it lost its A/B inside the server step, ops.WGRAD_FUSE), conv3 of the two blocks whose output gradient arrives pre-joined get their weight gradient from
     the BatchNorm backward (2 launches taken, their library weight gradient skipped); every gradient agrees with the fusion off
     (library weight gradients: bf16-level), and the data path is untouched (input gradient bit-equal)."""
     if not torch.cuda.is_available():
@@ -694,7 +694,7 @@ def test_conv3_weight_gradient_rides_in_the_bn_backward_of_a_bottleneck_stack(mo
     planes, n, hw = 256, 8, 14
 
     def run(fuse):
-        monkeypatch.setitem(ops.WGRAD_FUSE, 0, fuse)
+        ops.WGRAD_FUSE[0] = fuse
         torch.manual_seed(7)
         blocks = torch.nn.Sequential(*[Bottleneck(4 * planes, planes) for _ in range(3)]).to(dev).to(torch.bfloat16)
         blocks = blocks.to(memory_format=torch.channels_last).train()
@@ -722,8 +722,12 @@ def test_conv3_weight_gradient_rides_in_the_bn_backward_of_a_bottleneck_stack(mo
         grads['input'] = x.grad.detach().float().cpu()
         return grads, ops.WGRAD_FUSED[0] - taken0
 
-    ref, n_ref = run(False)
-    got, n_got = run(True)
+    was = ops.WGRAD_FUSE[0]
+    try:
+        ref, n_ref = run(False)
+        got, n_got = run(True)
+    finally:
+        ops.WGRAD_FUSE[0] = was
     assert n_ref == 0 and n_got == 2, (n_ref, n_got)
     assert torch.equal(ref['input'], got['input'])
     for k in ref:
