@@ -718,6 +718,8 @@ def test_training_outcome_bf16_fused_equals_fp32(dev):
     task = LearnableTask(n_id=o['n_id'], img=64, seed=0, noise=o['noise'], device=dev)
     with torch.backends.cudnn.flags(enabled=True, benchmark=False):
         bf16, state = train_and_eval(task, o['steps'], o['batch'], o['lr'], False, None, dev, n_eval=o['n_id'])
+    with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+        # (fp32 convolutions in immediate mode run on fallback kernels, ~0.4 s per step here: the timed search pays for itself)
         fp32, _ = train_and_eval(task, o['steps'], o['batch'], o['lr'], True, state, dev, n_eval=o['n_id'])
     for run in (bf16, fp32):
         assert run['losses'][-1] < 0.25 * run['losses'][0], run                     # the loss left its plateau
@@ -728,4 +730,4 @@ def test_training_outcome_bf16_fused_equals_fp32(dev):
 
 # the training-outcome test: task size, steps / batch / learning rate, and its acceptance (R@1 points), calibrated with
 # tools/train_outcome_probe.py on an MI355X (profiles/r5_train_outcome.jsonl)
-OUTCOME = {'n_id': 200, 'noise': 0.3, 'steps': 400, 'batch': 32, 'lr': 2e-4, 'min_r1': 80.0, 'band': 3.0}
+OUTCOME = {'n_id': 200, 'noise': 0.3, 'steps': 400, 'batch': 32, 'lr': 2e-4, 'min_r1': 90.0, 'band': 2.5}     # measured: 98.0 / 98.2 vs 99.0 / 99.0

@@ -75,6 +75,7 @@ def main():
     with torch.backends.cudnn.flags(enabled=True, benchmark=False):
         a, state = train_and_eval(task, args.steps, args.batch, args.lr, False, None, dev, cnn=args.cnn, n_eval=args.n_id)
         print(json.dumps(dict(a, **vars(args))), flush=True)
+    with torch.backends.cudnn.flags(enabled=True, benchmark=True):       # fp32 immediate mode = fallback kernels (~0.4 s per step)
         b, _ = train_and_eval(task, args.steps, args.batch, args.lr, True, state, dev, cnn=args.cnn, n_eval=args.n_id)
         print(json.dumps(dict(b, **vars(args))), flush=True)
 
