@@ -27,6 +27,11 @@ def _init(rank, world, path):
     # in a search) must show WHERE, the parent's join() only sees a missing exit code
     faulthandler.dump_traceback_later(540, exit=True)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
+    # MIOpen immediate mode in the workers (the product's own switch, creamfl_amd/runtime.py): two processes that share one GPU
+    # and both let the library time every solver of every new problem is where a round-5 run of this file sat for nine minutes
+    # (one rank inside a convolution's search, the other waiting in the bucket all-reduce); which library kernel runs is not what
+    # these tests are about
+    os.environ['CFL_MIOPEN_IMMEDIATE'] = '1'
     os.environ.setdefault('MIOPEN_FIND_MODE', '2')
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', init_method=f'file://{path}', rank=rank, world_size=world)

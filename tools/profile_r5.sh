@@ -47,3 +47,6 @@ rocprofv3 --kernel-trace -d $OUT/trace_bench -o bench --output-format csv -- pyt
 python3 $ROOT/tools/trace_stats.py $(ls $OUT/trace_bench/*kernel_trace.csv $OUT/trace_bench/*/*kernel_trace.csv 2>/dev/null | head -1) > $OUT/${TAG}_bench_kernel_stats.csv
 rm -rf $OUT/trace_a3one $OUT/trace_client $OUT/trace_bench
 ls -la $OUT
+cd $ROOT
+( time python -m pytest tests/test_gpu_multirank.py -m gpu -x -q ) > $OUT/multirank_tests.log 2>&1
+tail -5 $OUT/multirank_tests.log
