@@ -13,7 +13,7 @@
 // (max, sum, O) partials of the S bank splits into lse + the unit gradient, does the exact-fp32 positive dot and the intra /
 // MOON term (A4) per row, and -- last block to finish -- the means and the loss combination.
 // History: round 2's pass over the fp32 bank (128-row groups, D <= 256, conversion while staging: cfl_bank_attn_kernel /
-// cfl_client_contrast_fwd) was kept through round 3 as an A/B reference and removed in round 4 (DESIGN.md section 4.3 has its
+// cfl_client_contrast_fwd) was kept through round 3 as an A/B reference and removed in round 4 (docs/history/DESIGN_r1-r4.md section 4.3 has its
 // measurements); the exact-fp32 two-pass kernels of csrc/bank.hip remain as the one reference path.
 //
 // Workspace layout (floats): part_m[RG][S][128] part_l[RG][S][128] rowbuf[2][Bp] part_o[Bp][S][DP]; `sync` is a

@@ -16,7 +16,7 @@
 //   * 32 feature rows per workgroup => 4 row groups for a batch of 128 => 64 bank splits: 64 x [128, D] partials = 8.4 MB
 //     (was 33.5).  The row groups of a split are neighbours on one XCD (block ids 8 apart), so HBM sees the image once and
 //     the others hit that XCD's L2 (PMC: 51.2 MB fetched for a 51.2 MB image with 4 row groups).
-// Measured and dropped on the way (B = 128, M = 50 000, D = 256): 32 rows per WAVE (F and O = D/2
+// Measured and dropped on the way (B = 128, M = 50 000, D = 256; docs/history/DESIGN_r1-r4.md section 4.3): 32 rows per WAVE (F and O = D/2
 // registers each, 4 waves, one per SIMD, private slots, 32x32x16 MFMA for the gradient with the probabilities moved between
 // the two accumulator layouts by v_permlane16_swap) -- correct, but 46 us: with 256 registers gone there is room for half a
 // slot of prefetch, and every slot waited twice for a load issued half an iteration earlier (3.3 us per slot, 0.7 of MFMA).

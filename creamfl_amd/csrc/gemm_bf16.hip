@@ -8,7 +8,7 @@
 //       beats its BACKWARD-DATA kernels on every ResNet-101 shape (14x14 1024->256: 78 -> 48 us; 56x56 256->64:
 //       184 -> 110 us)  => the product routes the data gradient of the 1x1 convolutions here (ops.conv1x1).
 //   (A TN kernel for the weight gradient C[N1,N2] = A[M,N1]^T B[M,N2] -- transposing register loader, split-K -- measured on
-//   par with MIOpen alone and +0.8 ms inside the step (its 32 MB of split-K partials); removed in round 4)
+//   par with MIOpen alone and +0.8 ms inside the step (its 32 MB of split-K partials); removed in round 4, docs/history/DESIGN_r1-r4.md section 7.)
 // Why the forward stalls: with 128x128 workgroup tiles the LDS pipe (fragment reads 128 KB + direct-to-LDS writes 64 KB
 // per CU per K step vs 1024 MFMA cycles) caps the matrix pipe at ~1/3; 256x256 tiles lift that cap but leave one
 // workgroup per CU and 1-16 K steps per tile, where prologue / epilogue latency dominates.  A 3-stage LDS ring with the

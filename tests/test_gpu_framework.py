@@ -420,7 +420,7 @@ def test_device_prefetcher_on_the_gpu(dev):
 
 # ------------------------------------------------------------------------------------------ the bench's own code path, whole model
 class _Knobs:
-    """Every measurement switch of DESIGN 6.2 flipped to the UNFUSED / single-stream / library form inside this process (they are
+    """Every measurement switch of DESIGN 6.1 flipped to the UNFUSED / single-stream / library form inside this process (they are
     module attributes read at call time), restored on exit."""
 
     def __init__(self, off):

@@ -1,5 +1,5 @@
 // slice_stream_probe.hip -- does a BatchNorm-style streaming pass keep its bandwidth when a block owns a 64-CHANNEL SLICE of the
-// [R, C] bf16 activation (128-byte row segments, rows C * 2 bytes apart) instead of whole rows?  (a channel-
+// [R, C] bf16 activation (128-byte row segments, rows C * 2 bytes apart) instead of whole rows?  (docs/history/DESIGN_r1-r4.md section 7: a channel-
 // sliced block map would let the apply pass sum the few partials of its own slice and drop the 208 `final` launches of a step.)
 //   hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/slice_probe tools/hip/slice_stream_probe.hip && /tmp/slice_probe
 // Two passes per map: read-only column sums (the statistics / reduce pass) and read + write (the apply pass).
