@@ -63,6 +63,11 @@ def add_arguments(ap):
     ap.add_argument('--client-train-n', default='5000,12000,5800',
                     help='config 2: private samples per image / text / multi-modal client (CIFAR-100 / 10, AG_NEWS / 10, Flickr30k / 5)')
     ap.add_argument('--rep-wire', default='fp32', choices=['fp32', 'bf16'])
+    ap.add_argument('--client-layout', default='channels_last', choices=['channels_last', 'nchw'],
+                    help='config 2: memory format of the clients\' image encoders (fp32 either way; nchw = as the reference lays them out)')
+    ap.add_argument('--client-bf16', type=int, default=0, choices=[0, 1],
+                    help='config 2: bf16 autocast for the clients\' image encoders -- BELOW the reference\'s fp32 client precision: the '
+                         'line then says dtype bf16 and is a companion number, not the configs[2] measurement')
     ap.add_argument('--cpu-client-child', action='store_true', help='(internal)')
 
 
@@ -75,7 +80,8 @@ def reference_namespace(a, dev_index, M):
         client_num_per_round=a.clients_per_round, agg_method='con_w', contrast_local_intra=True, contrast_local_inter=True,
         interintra_weight=0.5, loss_scale=False, kd_weight=0.3, disable_distill=False, save_client=False, device=dev_index,
         cnn_type=a.server_cnn, bert_name=a.server_bert, image_size=a.image_size, test_pairs=5000 if M >= 5000 else max(100, M // 2),
-        quiet=True, save_checkpoints=False, server_dp=0, rep_wire=a.rep_wire, client_graph=1)
+        quiet=True, save_checkpoints=False, server_dp=0, rep_wire=a.rep_wire, client_graph=1,
+        client_channels_last=int(a.client_layout == 'channels_last'), client_bf16=int(a.client_bf16))
 
 
 def build_federation(a, dev, M, mini=False):
@@ -145,9 +151,8 @@ class StepHarness:
         idx = torch.randperm(g_img.shape[0], generator=gen)[:B]
         self.d_idx_host, self.d_idx_dev = tuple(idx.tolist()), idx.to(dev)
         t = trainer
-        t.model.to(dev)
+        t._to_device()                                   # device + the layout / precision the build flags ask for, as run() does
         if kind == 'mm':
-            t.criterion.to(dev)
             t.model.train()
             t.old_model = copy.deepcopy(t.model).eval()
             step = t.contrast_step_fn(g_img, g_txt, True, True)
@@ -501,14 +506,15 @@ def run(a, world, rank, dev, use_dist, json_out):
         out = {
             'metric': 'image-text pairs/sec (contrastive step)', 'value': round(value, 2), 'unit': 'pairs/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 (opt-in, below the reference\'s fp32 clients)' if a.client_bf16 else 'f32',
+            'data': 'synthetic',
             'config': {'workload': 'client contrast step (BASELINE.json configs[2]): %s client(s), public batch %d of %dx%d images / '
                                    'COCO-shaped captions resident in HBM, banks M = %d, D = %d, inter + intra (weight 0.5), encoder '
                                    'forward + old-model forward + A3/A4 + backward + optimizer; value = %s'
                                    % ('one image / text / multi-modal' if world == 1 else 'one per rank, kinds ' + ','.join(KINDS8[r % 8] for r in range(world)),
                                       B, S, S, M, D, 'the image client replayed from its HIP graph (product default)' if world == 1
                                       else 'pairs of all ranks / slowest rank'),
-                       'global_batch': B * world, 'parallelism': 'clients%d' % world,
+                       'global_batch': B * world, 'parallelism': 'clients%d' % world, 'client_image_layout': a.client_layout,
                        'client_nets': {'img': 'resnet18_client', 'txt': 'bi-GRU + PIE (language_model.EncoderText)',
                                        'mm': 'PCME small: ResNet-18 + GRU, AdamP'}},
             'ranks': {'world_size': world, 'backend': None if not use_dist else ('rccl' if a.backend == 'nccl' else

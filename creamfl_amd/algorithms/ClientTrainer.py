@@ -104,6 +104,12 @@ class ClientTrainer:
         self.global_test_set = global_test_set
         self.train_loader = None
         self.client_idx = -1
+        # image encoders: channels_last by default (same fp32 arithmetic, the library's NHWC kernels), bf16 autocast as an opt-in
+        is_cuda = torch.device(gpuid).type == 'cuda'
+        self._cl = bool(self.dset_name in IMAGE_SETS and is_cuda and int(flags.get(args, 'client_channels_last')))
+        self._bf16 = bool(self.dset_name in IMAGE_SETS and is_cuda and int(flags.get(args, 'client_bf16')))
+        if self._bf16:
+            self._cl = True
 
     def _log(self, msg):
         if self.logger is not None:
@@ -141,8 +147,20 @@ class ClientTrainer:
             for g in self.optimizer.param_groups:
                 g['lr'] = self.init_lr * self.decay_rate * self.decay_rate
 
-    def run(self, global_img_feature, global_txt_feature, distill_index, global_train_loader):
+    def _to_device(self):
         self.model.to(self.gpuid)
+        if self._cl:
+            self.model.to(memory_format=torch.channels_last)
+
+    def _images(self, images):
+        images = images.to(self.gpuid)
+        return images.contiguous(memory_format=torch.channels_last) if self._cl else images
+
+    def _autocast(self):
+        return torch.autocast('cuda', dtype=torch.bfloat16, enabled=self._bf16)
+
+    def run(self, global_img_feature, global_txt_feature, distill_index, global_train_loader):
+        self._to_device()
         self.old_model = copy.deepcopy(self.model)
         self.old_model.eval()
         self.lr_scheduler(self.cur_epoch)
@@ -163,7 +181,9 @@ class ClientTrainer:
     # -- step 3: learning ----------------------------------------------------------------------------------------
     def _features(self, model, images, captions, caption_lens):
         if self.dset_name in IMAGE_SETS:
-            return model(images.to(self.gpuid))
+            with self._autocast():
+                out = model(self._images(images))
+            return out.float() if self._bf16 else out
         out = model(captions.to(self.gpuid), caption_lens.to(self.gpuid))
         return out.squeeze() if out.dim() > 2 else out
 
@@ -175,7 +195,10 @@ class ClientTrainer:
             if self.dset_name in IMAGE_SETS:
                 inputs_bt, labels_bt = data
                 labels_var = labels_bt.to(self.gpuid)
-                fvec, _, class_weight, _ = self.model(inputs_bt.to(self.gpuid))
+                with self._autocast():
+                    fvec, _, class_weight, _ = self.model(self._images(inputs_bt))
+                if self._bf16:
+                    fvec, class_weight = fvec.float(), class_weight.float()
             else:
                 inputs_bt, labels_bt, caplens = data
                 labels_var = labels_bt.to(self.gpuid)
@@ -276,7 +299,8 @@ class ClientTrainer:
             for i, data in enumerate(self.global_test_set):
                 if self.dset_name in IMAGE_SETS:
                     inputs_bt, labels_bt = data
-                    fvec, _, _, _ = self.model(inputs_bt.to(self.gpuid))
+                    with self._autocast():
+                        fvec, _, _, _ = self.model(self._images(inputs_bt))
                 else:
                     inputs_bt, labels_bt, caplens = data
                     fvec, _, _, _ = self.model(inputs_bt.to(self.gpuid), caplens.to(self.gpuid))
@@ -305,7 +329,7 @@ class ClientTrainer:
 
     def extract_pub_feature(self, dataloader, out=None):
         """ClientTrainer.py:631-664, device-resident."""
-        self.model.to(self.gpuid)
+        self._to_device()
         self.model.phase = 'extract_conv_feature'
         self.model.is_train = False
         was_training = self.model.training

@@ -18,8 +18,7 @@ is_test = False
 class MMClientTrainer(EngineBase):
 
     def run(self, global_img_feature, global_txt_feature, distill_index, global_train_loader, prefix=''):
-        self.model.to(self.device)
-        self.criterion.to(self.device)
+        self._to_device()
         self.old_model = copy.deepcopy(self.model)
         self.old_model.eval()
         if self.local_epoch == 0 and self.config.train.get('use_fp16'):
@@ -37,7 +36,21 @@ class MMClientTrainer(EngineBase):
         del self.old_model
         self.old_model = None
 
+    def _to_device(self):
+        """Model and criterion on the device, the image tower in the layout / precision the build flags ask for."""
+        from .. import flags
+        self.model.to(self.device)
+        self.criterion.to(self.device)
+        if torch.device(self.device).type == 'cuda':
+            if int(flags.get(self.args, 'client_bf16')) and self.autocast_dtype is None:
+                self.to_half()                                    # opt-in, below the reference's fp32 clients (flags.py)
+            elif int(flags.get(self.args, 'client_channels_last')):
+                self.model.to(memory_format=torch.channels_last)  # same fp32 arithmetic on the library's NHWC kernels
+                self._cl = True
+
     def _forward(self, model, images, captions, captions_word, caption_lens):
+        if (getattr(self, '_cl', False) or self.autocast_dtype is not None) and images.is_cuda:
+            images = images.contiguous(memory_format=torch.channels_last)
         with torch.autocast('cuda', dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
             return model(images, captions, captions_word, caption_lens)
 
@@ -103,7 +116,7 @@ class MMClientTrainer(EngineBase):
     def generate_logits(self, dataloader, out=None):
         """MMClientTrainer.py:326-359.  `out` = {'img': [M, D], 'txt': [M, D]}: write the representations straight into these
         (the rank's slices of the round's all-gather buffer, section 8f-3) instead of concatenating fresh tensors."""
-        self.model.to(self.device)
+        self._to_device()
         was_training = self.model.training
         self.model.eval()
         img_vec, txt_vec, distill_index, off = [], [], [], 0

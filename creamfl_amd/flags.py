@@ -32,6 +32,13 @@ BUILD_FLAGS = {
     'quiet': (dict(action='store_true'), 'no console logging'),
     'client_graph': (dict(type=int, default=1, choices=[0, 1]),
                      'capture the client contrast step (fixed B, M, D) in a HIP graph'),
+    'client_channels_last': (dict(type=int, default=1, choices=[0, 1]),
+                             'image encoders of the clients (ResNet client net, the multi-modal client\'s image tower) in channels_last '
+                             'memory format: the reference\'s fp32 arithmetic on the library\'s NHWC kernels (-16 % per contrast step '
+                             'on an MI355X); 0 = NCHW as the reference lays them out'),
+    'client_bf16': (dict(type=int, default=0, choices=[0, 1]),
+                    '1 = bf16 autocast for the clients\' image encoders (3.3 x faster contrast steps); BELOW the reference\'s client '
+                    'precision (fp32, src/algorithms/ClientTrainer.py has no mixed precision), hence opt-in'),
     'miopen_immediate': (dict(type=int, default=0, choices=[0, 1]),
                          '1 = MIOpen immediate mode (no solver timing in the first step of every process: seconds instead of ~1 min); '
                          'only for the convolution shapes the shipped / recorded find-db holds -- other shapes silently get a '

@@ -731,3 +731,47 @@ def test_training_outcome_bf16_fused_equals_fp32(dev):
 # the training-outcome test: task size, steps / batch / learning rate, and its acceptance (R@1 points), calibrated with
 # tools/train_outcome_probe.py on an MI355X (profiles/r5_train_outcome.jsonl)
 OUTCOME = {'n_id': 200, 'noise': 0.3, 'steps': 400, 'batch': 32, 'lr': 2e-4, 'min_r1': 90.0, 'band': 2.5}     # measured: 98.0 / 98.2 vs 99.0 / 99.0
+
+
+@pytest.mark.gpu
+def test_image_client_layouts_train_the_same(dev):
+    """Round 5: the clients' image encoders run channels_last by default (`--client_channels_last 1`: the reference's fp32
+    arithmetic, ClientTrainer.py:369-429, on the library's NHWC kernels: 28.6 -> 23.9 ms per contrast step at B = 128) and can run
+    under bf16 autocast as an opt-in (`--client_bf16 1`: 8.5 ms, BELOW the reference's client precision).  The same client, the same
+    batches, 8 eager contrast steps: channels_last must end where NCHW ends to fp32 / algorithm-choice noise; bf16 stays within
+    bf16 noise of it and is never the default."""
+    from creamfl_amd import flags
+    from creamfl_amd.algorithms.ClientTrainer import ClientTrainer
+    from creamfl_amd.utils.synthetic import SyntheticCocoLoader
+    assert flags.BUILD_FLAGS['client_channels_last'][0]['default'] == 1 and flags.BUILD_FLAGS['client_bf16'][0]['default'] == 0
+    M, D, bs = 128, 64, 16
+    batches = list(SyntheticCocoLoader(M, bs, seed=9, img=64))
+    gen = torch.Generator().manual_seed(5)
+    g_img = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
+    g_txt = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
+
+    def run(cl, bf16):
+        args = SimpleNamespace(feature_dim=D, mlp_local=False, local_epochs=1, contrast_local_intra=True, contrast_local_inter=True,
+                               interintra_weight=0.5, loss_scale=False, save_client=False, client_graph=0, client_channels_last=cl,
+                               client_bf16=bf16)
+        t = ClientTrainer(args, 'Cifar100', None, None, None, None, None, global_test_set=None, client_id=0, gpuid=str(dev))
+        t.train_loader = None
+        t.cur_epoch = 0
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            t.run(g_img, g_txt, list(range(M)), batches)
+            vec, _ = t.generate_logits(batches)
+        torch.cuda.synchronize()
+        first = next(t.model.parameters())
+        assert first.is_contiguous(memory_format=torch.channels_last) == bool(cl or bf16) or first.dim() != 4
+        return {k: v.detach().float().cpu() for k, v in t.model.state_dict().items() if v.is_floating_point()}, \\
+            float(t.last_contrast_loss), vec['img'].float().cpu()
+    ref, loss_ref, rep_ref = run(0, 0)
+    cl, loss_cl, rep_cl = run(1, 0)
+    bf, loss_bf, rep_bf = run(0, 1)
+    assert abs(loss_cl - loss_ref) <= 1e-4 * abs(loss_ref) + 1e-5, (loss_cl, loss_ref)
+    assert float((rep_cl - rep_ref).abs().max()) <= 2e-4                       # unit-norm representations
+    for k, v in ref.items():
+        scale = float(v.abs().max()) + 1e-12
+        assert float((cl[k] - v).abs().max()) <= 1e-4 * scale + 1e-6, k
+    assert abs(loss_bf - loss_ref) <= 3e-2 * abs(loss_ref) and np.isfinite(loss_bf), (loss_bf, loss_ref)
+    assert float((rep_bf - rep_ref).abs().max()) <= 5e-2
