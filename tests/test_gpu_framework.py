@@ -763,8 +763,8 @@ def test_image_client_layouts_train_the_same(dev):
         torch.cuda.synchronize()
         first = next(t.model.parameters())
         assert first.is_contiguous(memory_format=torch.channels_last) == bool(cl or bf16) or first.dim() != 4
-        return {k: v.detach().float().cpu() for k, v in t.model.state_dict().items() if v.is_floating_point()}, \\
-            float(t.last_contrast_loss), vec['img'].float().cpu()
+        sd = {k: v.detach().float().cpu() for k, v in t.model.state_dict().items() if v.is_floating_point()}
+        return sd, float(t.last_contrast_loss), vec['img'].float().cpu()
     ref, loss_ref, rep_ref = run(0, 0)
     cl, loss_cl, rep_cl = run(1, 0)
     bf, loss_bf, rep_bf = run(0, 1)
