@@ -90,6 +90,9 @@ SIGNATURES = {
     'cfl_bn_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_fwd_pre': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     'cfl_bn_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, _P]),
+    'cfl_bn_fwd_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
+    'cfl_bn_apply_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, _P]),
+    'cfl_bn_bwd_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_pool_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_pool_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

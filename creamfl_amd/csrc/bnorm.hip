@@ -21,7 +21,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void cfl_bn_stats_kernel(const U4* __restrict__ x, long long R, int C, int rows_per_block,
+template <class G>
+__global__ __launch_bounds__(256) void cfl_bn_stats_kernel(const G* __restrict__ x, long long R, int C, int rows_per_block,
                                                            float* psum, float* psq) {
     __shared__ float lds[4096];
     const Map m = make_map(C);
@@ -30,10 +31,10 @@ __global__ __launch_bounds__(256) void cfl_bn_stats_kernel(const U4* __restrict_
     const long long re = min(R, rb + rows_per_block);
     if (m.active) {
         const long long stride = (long long)m.rpp * (C >> 3);
-        const U4* p = x + (rb + m.rsub) * (C >> 3) + (m.c0 >> 3);
+        const G* p = x + (rb + m.rsub) * (C >> 3) + (m.c0 >> 3);
         long long r = rb + m.rsub;
         for (; r + 3 * m.rpp < re; r += 4 * m.rpp, p += 4 * stride) {
-            const U4 u0 = p[0], u1 = p[stride], u2 = p[2 * stride], u3 = p[3 * stride];
+            const G u0 = p[0], u1 = p[stride], u2 = p[2 * stride], u3 = p[3 * stride];
             float f[8];
             unpack8(u0, f);
 #pragma unroll
@@ -80,11 +81,11 @@ __global__ __launch_bounds__(1024) void cfl_bn_final_kernel(const float* __restr
     }
 }
 
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const U4* __restrict__ x, const U4* __restrict__ res,
+template <class G, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const G* __restrict__ x, const G* __restrict__ res,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           long long R, int C, int rows_per_block, U4* y,
+                                                           long long R, int C, int rows_per_block, G* y,
                                                            unsigned char* __restrict__ relu_mask) {
     const Map m = make_map(C);
     if (!m.active) return;
@@ -111,15 +112,10 @@ __global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const U4* __restrict_
             if (RELU) v = fmaxf(v, 0.f);
             f[k] = v;
         }
-        const U4 o = pack8(f);
+        const G o = pack8g<G>(f);
         y[off] = o;
         if (RELU && relu_mask) {                           // bit k = (y_k > 0) of the STORED bf16 value: the backward reads
-            unsigned b = 0;                                // one byte per 8 outputs instead of the 16 bytes of y
-            b |= (o.x & 0xffffu) ? 1u : 0u;  b |= (o.x >> 16) ? 2u : 0u;
-            b |= (o.y & 0xffffu) ? 4u : 0u;  b |= (o.y >> 16) ? 8u : 0u;
-            b |= (o.z & 0xffffu) ? 16u : 0u; b |= (o.z >> 16) ? 32u : 0u;
-            b |= (o.w & 0xffffu) ? 64u : 0u; b |= (o.w >> 16) ? 128u : 0u;
-            relu_mask[off] = (unsigned char)b;
+            relu_mask[off] = (unsigned char)relu_bits(o);
         }
     }
 }
@@ -221,9 +217,9 @@ __device__ __forceinline__ void pool_grad8(const U4* __restrict__ g, const B8* _
 // exactly the forward's sc/sh, so (x*sc + sh > 0) == (y > 0).  dy2 (may be NULL) is a second upstream gradient that is
 // added on the fly: the block output feeds the next convolution AND the next residual add, and autograd would
 // otherwise spend a separate read-read-write kernel on summing the two gradients.
-template <bool RELU, bool XMASK, bool POOL = false>
-__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
-                                                                const U4* __restrict__ x, const U4* __restrict__ y,
+template <class G, bool RELU, bool XMASK, bool POOL = false>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const G* __restrict__ dy, const G* __restrict__ dy2,
+                                                                const G* __restrict__ x, const G* __restrict__ y,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 long long R, int C, int rows_per_block, float* pdb, float* pdg,
@@ -246,7 +242,7 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_kernel(const U4* __rest
 #pragma unroll 2
         for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
             float d[8], f[8], o[8];
-            if (POOL) {                                                  // dy = the pooling's gradient at this pixel, never stored
+            if constexpr (POOL) {                                        // dy = the pooling's gradient at this pixel, never stored
                 const int pw = (int)(r % PW);
                 const long long t_ = r / PW;
                 pool_grad8(dy, pidx, (int)(t_ / PH), (int)(t_ % PH), pw, m.c0 >> 3, C >> 3, (PH - 1) / 2 + 1, (PW - 1) / 2 + 1, d);
@@ -286,13 +282,13 @@ __global__ __launch_bounds__(1024) void cfl_bn_bwd_final_kernel(const float* __r
     if (grp == 0 && c < C) { dbeta[c] = a; dgamma[c] = b; }
 }
 
-template <bool RES, bool RELU, bool XMASK, bool POOL = false>
-__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
-                                                               const U4* __restrict__ x, const U4* __restrict__ y,
+template <class G, bool RES, bool RELU, bool XMASK, bool POOL = false>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const G* __restrict__ dy, const G* __restrict__ dy2,
+                                                               const G* __restrict__ x, const G* __restrict__ y,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ dbeta, const float* __restrict__ dgamma,
-                                                               long long R, int C, int rows_per_block, U4* dx, U4* dres,
+                                                               long long R, int C, int rows_per_block, G* dx, G* dres,
                                                                const unsigned char* __restrict__ relu_mask,
                                                                const B8* __restrict__ pidx = nullptr, int PH = 0, int PW = 0) {
     const Map m = make_map(C);
@@ -314,7 +310,7 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
 #pragma unroll 2
     for (long long r = rb + m.rsub; r < re; r += m.rpp, off += stride) {
         float d[8], f[8], o[8];
-        if (POOL) {
+        if constexpr (POOL) {
             const int pw = (int)(r % PW);
             const long long t_ = r / PW;
             pool_grad8(dy, pidx, (int)(t_ / PH), (int)(t_ % PH), pw, m.c0 >> 3, C >> 3, (PH - 1) / 2 + 1, (PW - 1) / 2 + 1, d);
@@ -340,8 +336,8 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const U4* __restr
             d[k] = dd;
             f[k] = a[k] * (dd - b[k] - (f[k] - mu[k]) * is[k] * c[k]);
         }
-        dx[off] = pack8(f);
-        if (RES) dres[off] = pack8(d);
+        dx[off] = pack8g<G>(f);
+        if (RES) dres[off] = pack8g<G>(d);
     }
 }
 
@@ -398,7 +394,8 @@ __device__ __forceinline__ void slice_totals(const float* __restrict__ pa, const
     }
 }
 
-__global__ __launch_bounds__(256) void cfl_bn_stats_sl_kernel(const U4* __restrict__ x, long long R, int C, int rows_per_block,
+template <class G>
+__global__ __launch_bounds__(256) void cfl_bn_stats_sl_kernel(const G* __restrict__ x, long long R, int C, int rows_per_block,
                                                               float* psum, float* psq) {
     __shared__ float lds[2 * SL_RL * 64];
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -406,9 +403,9 @@ __global__ __launch_bounds__(256) void cfl_bn_stats_sl_kernel(const U4* __restri
     const long long re = min(R, rb + rows_per_block);
     const long long stride = (long long)SL_RL * (C >> 3);
     long long r = rb + (threadIdx.x >> 3);
-    const U4* p = x + r * (C >> 3) + blockIdx.y * 8 + (threadIdx.x & 7);
+    const G* p = x + r * (C >> 3) + blockIdx.y * 8 + (threadIdx.x & 7);
     for (; r + 3 * SL_RL < re; r += 4 * SL_RL, p += 4 * stride) {
-        const U4 u0 = p[0], u1 = p[stride], u2 = p[2 * stride], u3 = p[3 * stride];
+        const G u0 = p[0], u1 = p[stride], u2 = p[2 * stride], u3 = p[3 * stride];
         float f[8];
         unpack8(u0, f);
 #pragma unroll
@@ -434,11 +431,11 @@ __global__ __launch_bounds__(256) void cfl_bn_stats_sl_kernel(const U4* __restri
 
 // apply pass of the forward on the sliced map; its prologue is the old `final` kernel for this slice (workgroup 0 of a slice
 // also stores mean / invstd for the backward and updates the running statistics)
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void cfl_bn_apply_sl_kernel(const U4* __restrict__ x, const U4* __restrict__ res,
+template <class G, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void cfl_bn_apply_sl_kernel(const G* __restrict__ x, const G* __restrict__ res,
                                                               const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              long long R, int C, int rows_per_block, float eps, float momentum, U4* y,
+                                                              long long R, int C, int rows_per_block, float eps, float momentum, G* y,
                                                               unsigned char* __restrict__ relu_mask, float* mean, float* invstd,
                                                               float* rmean, float* rvar) {
     __shared__ float lds[512];
@@ -480,22 +477,17 @@ __global__ __launch_bounds__(256) void cfl_bn_apply_sl_kernel(const U4* __restri
             if (RELU) v = fmaxf(v, 0.f);
             f[k] = v;
         }
-        const U4 o = pack8(f);
+        const G o = pack8g<G>(f);
         y[off] = o;
         if (RELU && relu_mask) {
-            unsigned b = 0;
-            b |= (o.x & 0xffffu) ? 1u : 0u;  b |= (o.x >> 16) ? 2u : 0u;
-            b |= (o.y & 0xffffu) ? 4u : 0u;  b |= (o.y >> 16) ? 8u : 0u;
-            b |= (o.z & 0xffffu) ? 16u : 0u; b |= (o.z >> 16) ? 32u : 0u;
-            b |= (o.w & 0xffffu) ? 64u : 0u; b |= (o.w >> 16) ? 128u : 0u;
-            relu_mask[off] = (unsigned char)b;
+            relu_mask[off] = (unsigned char)relu_bits(o);
         }
     }
 }
 
-template <bool RELU, bool XMASK>
-__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_sl_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
-                                                                   const U4* __restrict__ x, const U4* __restrict__ y,
+template <class G, bool RELU, bool XMASK>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_sl_kernel(const G* __restrict__ dy, const G* __restrict__ dy2,
+                                                                   const G* __restrict__ x, const G* __restrict__ y,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    long long R, int C, int rows_per_block, float* pdb, float* pdg,
@@ -540,14 +532,14 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_reduce_sl_kernel(const U4* __r
     slice_col_reduce(db, dg, C, pdb, pdg, lds);
 }
 
-template <bool RES, bool RELU, bool XMASK>
-__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_sl_kernel(const U4* __restrict__ dy, const U4* __restrict__ dy2,
-                                                                  const U4* __restrict__ x, const U4* __restrict__ y,
+template <class G, bool RES, bool RELU, bool XMASK>
+__global__ __launch_bounds__(256) void cfl_bn_bwd_apply_sl_kernel(const G* __restrict__ dy, const G* __restrict__ dy2,
+                                                                  const G* __restrict__ x, const G* __restrict__ y,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ pdb, const float* __restrict__ pdg, int nparts,
                                                                   float* dbeta, float* dgamma, long long R, int C, int rows_per_block,
-                                                                  U4* dx, U4* dres, const unsigned char* __restrict__ relu_mask) {
+                                                                  G* dx, G* dres, const unsigned char* __restrict__ relu_mask) {
     __shared__ float lds[512];
     float tdb[8], tdg[8];
     slice_totals(pdb, pdg, nparts, C, lds, tdb, tdg);
@@ -591,8 +583,8 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_sl_kernel(const U4* __re
             d[k] = dd;
             f[k] = a[k] * (dd - b[k] - (f[k] - mu[k]) * is[k] * c[k]);
         }
-        dx[off] = pack8(f);
-        if (RES) dres[off] = pack8(d);
+        dx[off] = pack8g<G>(f);
+        if (RES) dres[off] = pack8g<G>(d);
     }
 }
 
@@ -856,6 +848,122 @@ static Plan bn_plan(long long R, int C) {
     return p;
 }
 
+template <class G>
+static int bn_fwd_t(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
+               float* save_mean, float* save_invstd, unsigned char* relu_mask, void* ws, void* stream_) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (bn_use_sliced(R, C)) {
+        // two launches: statistics and apply on the same 64-channel slices; the apply pass sums its slice's partials itself
+        const SPlan sp = bn_splan(R, C);
+        float* qsum = (float*)ws;
+        float* qsq = qsum + (size_t)sp.parts * C;
+        const dim3 sg(sp.parts, sp.slices);
+        const G* xs = (const G*)x; const G* rs = (const G*)residual; G* ys = (G*)y;
+        CFL_LAUNCH(K_BN_STATS, (cfl_bn_stats_sl_kernel<G>), sg, dim3(256), 0, stream, xs, R, C, sp.rows_per_block, qsum, qsq);
+#define BN_APPLY_SL(RES_, RELU_) CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_sl_kernel<G, RES_, RELU_>), sg, dim3(256), 0, stream, xs, rs, qsum, qsq, \
+                                            sp.parts, gamma, beta, R, C, sp.rows_per_block, eps, momentum, ys, relu_mask, save_mean,      \
+                                            save_invstd, running_mean, running_var)
+        if (residual && relu) BN_APPLY_SL(true, true);
+        else if (residual) BN_APPLY_SL(true, false);
+        else if (relu) BN_APPLY_SL(false, true);
+        else BN_APPLY_SL(false, false);
+#undef BN_APPLY_SL
+        return 0;
+    }
+    const Plan p = bn_plan(R, C);
+    float* psum = (float*)ws;
+    float* psq = psum + (size_t)p.nblk * C;
+    const dim3 grid(p.nblk, p.gy);
+    CFL_LAUNCH(K_BN_STATS, (cfl_bn_stats_kernel<G>), grid, dim3(256), 0, stream, (const G*)x, R, C, p.rows_per_block, psum, psq);
+    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, p.nblk, C, R, eps,
+               momentum, save_mean, save_invstd, running_mean, running_var);
+    const G* xr = (const G*)x; const G* rr = (const G*)residual; G* yy = (G*)y;
+    if (residual && relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else if (residual)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else if (relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    return 0;
+}
+
+template <class G>
+static int bn_apply_t(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, long long R, int C, int relu, void* y, void* stream_) {
+    unsigned char* relu_mask = nullptr;
+    if (!x || !mean || !invstd || !gamma || !beta || !y || R <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Plan p = bn_plan(R, C);
+    const dim3 grid(p.nblk, p.gy);
+    const G* xr = (const G*)x; const G* rr = (const G*)residual; G* yy = (G*)y;
+    if (residual && relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, true, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else if (residual)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, true, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else if (relu)
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, false, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    else
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<G, false, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+    return 0;
+}
+
+template <class G>
+static int bn_bwd_t(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,
+               const float* beta, const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual,
+               void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream_) {
+    if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
+    const bool xmask = relu && !y && !relu_mask;         // ReLU mask recomputed from x: needs beta, and no residual
+    if ((xmask && (has_residual || !beta)) || (has_residual && !dres)) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const G *d = (const G*)dy, *d2 = (const G*)dy2, *xx = (const G*)x, *yy = (const G*)y;
+    if (bn_use_sliced(R, C)) {
+        const SPlan sp = bn_splan(R, C);
+        float* qdb = (float*)ws;
+        float* qdg = qdb + (size_t)sp.parts * C;
+        const dim3 sg(sp.parts, sp.slices);
+#define BN_REDUCE_SL(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_sl_kernel<G, RELU_, XM_>), sg, dim3(256), 0, stream, d, d2, xx, yy, \
+                                            save_mean, save_invstd, gamma, beta, R, C, sp.rows_per_block, qdb, qdg, relu_mask)
+        if (xmask) BN_REDUCE_SL(true, true); else if (relu) BN_REDUCE_SL(true, false); else BN_REDUCE_SL(false, false);
+#undef BN_REDUCE_SL
+        G *sx = (G*)dx, *sr = (G*)dres;
+#define BN_APPLY_SL(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_sl_kernel<G, RES_, RELU_, XM_>), sg, dim3(256), 0, stream, d, d2, \
+                                                 xx, yy, save_mean, save_invstd, gamma, beta, qdb, qdg, sp.parts, dbeta, dgamma, R, C,       \
+                                                 sp.rows_per_block, sx, sr, relu_mask)
+        if (xmask) BN_APPLY_SL(false, true, true);
+        else if (has_residual && relu) BN_APPLY_SL(true, true, false);
+        else if (has_residual) BN_APPLY_SL(true, false, false);
+        else if (relu) BN_APPLY_SL(false, true, false);
+        else BN_APPLY_SL(false, false, false);
+#undef BN_APPLY_SL
+        return 0;
+    }
+    const Plan p = bn_plan(R, C);
+    float* pdb = (float*)ws;
+    float* pdg = pdb + (size_t)p.nblk * C;
+    const dim3 grid(p.nblk, p.gy);
+#define BN_REDUCE(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<G, RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, xx, yy, \
+                                         save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, relu_mask, (const B8*)nullptr, 0, 0)
+    if (xmask) BN_REDUCE(true, true); else if (relu) BN_REDUCE(true, false); else BN_REDUCE(false, false);
+#undef BN_REDUCE
+    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
+    G *ox = (G*)dx, *orr = (G*)dres;
+#define BN_APPLY(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<G, RES_, RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, \
+                                              xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr, relu_mask, (const B8*)nullptr, 0, 0)
+    if (xmask) BN_APPLY(false, true, true);
+    else if (has_residual && relu) BN_APPLY(true, true, false);
+    else if (has_residual) BN_APPLY(true, false, false);
+    else if (relu) BN_APPLY(false, true, false);
+    else BN_APPLY(false, false, false);
+#undef BN_APPLY
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -879,44 +987,14 @@ int cfl_bn_sliced(int on) {
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
                float* save_mean, float* save_invstd, unsigned char* relu_mask, void* ws, void* stream_) {
-    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
-    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    if (bn_use_sliced(R, C)) {
-        // two launches: statistics and apply on the same 64-channel slices; the apply pass sums its slice's partials itself
-        const SPlan sp = bn_splan(R, C);
-        float* qsum = (float*)ws;
-        float* qsq = qsum + (size_t)sp.parts * C;
-        const dim3 sg(sp.parts, sp.slices);
-        const U4* xs = (const U4*)x; const U4* rs = (const U4*)residual; U4* ys = (U4*)y;
-        CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_sl_kernel, sg, dim3(256), 0, stream, xs, R, C, sp.rows_per_block, qsum, qsq);
-#define BN_APPLY_SL(RES_, RELU_) CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_sl_kernel<RES_, RELU_>), sg, dim3(256), 0, stream, xs, rs, qsum, qsq, \
-                                            sp.parts, gamma, beta, R, C, sp.rows_per_block, eps, momentum, ys, relu_mask, save_mean,      \
-                                            save_invstd, running_mean, running_var)
-        if (residual && relu) BN_APPLY_SL(true, true);
-        else if (residual) BN_APPLY_SL(true, false);
-        else if (relu) BN_APPLY_SL(false, true);
-        else BN_APPLY_SL(false, false);
-#undef BN_APPLY_SL
-        return 0;
-    }
-    const Plan p = bn_plan(R, C);
-    float* psum = (float*)ws;
-    float* psq = psum + (size_t)p.nblk * C;
-    const dim3 grid(p.nblk, p.gy);
-    CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_kernel, grid, dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
-    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, p.nblk, C, R, eps,
-               momentum, save_mean, save_invstd, running_mean, running_var);
-    const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
-    if (residual && relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    else if (residual)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    else if (relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    else
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    return 0;
+    return bn_fwd_t<U4>(x, residual, gamma, beta, running_mean, running_var, R, C, eps, momentum, relu, y, save_mean, save_invstd, relu_mask, ws, stream_);
+}
+
+// the same for fp32 activations (channels_last [R, C] floats): the clients' fp32 encoders
+int cfl_bn_fwd_f32(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,
+               float* save_mean, float* save_invstd, unsigned char* relu_mask, void* ws, void* stream_) {
+    return bn_fwd_t<F8>(x, residual, gamma, beta, running_mean, running_var, R, C, eps, momentum, relu, y, save_mean, save_invstd, relu_mask, ws, stream_);
 }
 
 // cfl_bn_fwd without its statistics pass: psum / psq [nblk, C] were written by the producer of x (the statistics epilogue of
@@ -934,85 +1012,38 @@ int cfl_bn_fwd_pre(const void* x, const void* residual, const float* gamma, cons
                momentum, save_mean, save_invstd, running_mean, running_var);
     const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
     if (residual && relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<U4, true, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else if (residual)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<U4, true, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else if (relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<U4, false, true>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     else
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
+        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<U4, false, false>), grid, dim3(256), 0, stream, xr, rr, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
     return 0;
 }
 
 int cfl_bn_apply(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
                  const float* beta, long long R, int C, int relu, void* y, void* stream_) {
-    unsigned char* relu_mask = nullptr;
-    if (!x || !mean || !invstd || !gamma || !beta || !y || R <= 0 || C <= 0) return CFL_EINVAL;
-    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    const Plan p = bn_plan(R, C);
-    const dim3 grid(p.nblk, p.gy);
-    const U4* xr = (const U4*)x; const U4* rr = (const U4*)residual; U4* yy = (U4*)y;
-    if (residual && relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    else if (residual)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    else if (relu)
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    else
-        CFL_LAUNCH(K_BN_APPLY, (cfl_bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, xr, rr, mean, invstd, gamma, beta, R, C, p.rows_per_block, yy, relu_mask);
-    return 0;
+    return bn_apply_t<U4>(x, residual, mean, invstd, gamma, beta, R, C, relu, y, stream_);
+}
+
+// the same for fp32 activations (channels_last [R, C] floats): the clients' fp32 encoders
+int cfl_bn_apply_f32(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, long long R, int C, int relu, void* y, void* stream_) {
+    return bn_apply_t<F8>(x, residual, mean, invstd, gamma, beta, R, C, relu, y, stream_);
 }
 
 int cfl_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,
                const float* beta, const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual,
                void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream_) {
-    if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || R <= 0 || C <= 0) return CFL_EINVAL;
-    const bool xmask = relu && !y && !relu_mask;         // ReLU mask recomputed from x: needs beta, and no residual
-    if ((xmask && (has_residual || !beta)) || (has_residual && !dres)) return CFL_EINVAL;
-    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    const U4 *d = (const U4*)dy, *d2 = (const U4*)dy2, *xx = (const U4*)x, *yy = (const U4*)y;
-    if (bn_use_sliced(R, C)) {
-        const SPlan sp = bn_splan(R, C);
-        float* qdb = (float*)ws;
-        float* qdg = qdb + (size_t)sp.parts * C;
-        const dim3 sg(sp.parts, sp.slices);
-#define BN_REDUCE_SL(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_sl_kernel<RELU_, XM_>), sg, dim3(256), 0, stream, d, d2, xx, yy, \
-                                            save_mean, save_invstd, gamma, beta, R, C, sp.rows_per_block, qdb, qdg, relu_mask)
-        if (xmask) BN_REDUCE_SL(true, true); else if (relu) BN_REDUCE_SL(true, false); else BN_REDUCE_SL(false, false);
-#undef BN_REDUCE_SL
-        U4 *sx = (U4*)dx, *sr = (U4*)dres;
-#define BN_APPLY_SL(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_sl_kernel<RES_, RELU_, XM_>), sg, dim3(256), 0, stream, d, d2, \
-                                                 xx, yy, save_mean, save_invstd, gamma, beta, qdb, qdg, sp.parts, dbeta, dgamma, R, C,       \
-                                                 sp.rows_per_block, sx, sr, relu_mask)
-        if (xmask) BN_APPLY_SL(false, true, true);
-        else if (has_residual && relu) BN_APPLY_SL(true, true, false);
-        else if (has_residual) BN_APPLY_SL(true, false, false);
-        else if (relu) BN_APPLY_SL(false, true, false);
-        else BN_APPLY_SL(false, false, false);
-#undef BN_APPLY_SL
-        return 0;
-    }
-    const Plan p = bn_plan(R, C);
-    float* pdb = (float*)ws;
-    float* pdg = pdb + (size_t)p.nblk * C;
-    const dim3 grid(p.nblk, p.gy);
-#define BN_REDUCE(RELU_, XM_) CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, xx, yy, \
-                                         save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, relu_mask, (const B8*)nullptr, 0, 0)
-    if (xmask) BN_REDUCE(true, true); else if (relu) BN_REDUCE(true, false); else BN_REDUCE(false, false);
-#undef BN_REDUCE
-    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
-    U4 *ox = (U4*)dx, *orr = (U4*)dres;
-#define BN_APPLY(RES_, RELU_, XM_) CFL_LAUNCH(K_BN_BWD_APPLY, (cfl_bn_bwd_apply_kernel<RES_, RELU_, XM_>), grid, dim3(256), 0, stream, d, d2, \
-                                              xx, yy, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, ox, orr, relu_mask, (const B8*)nullptr, 0, 0)
-    if (xmask) BN_APPLY(false, true, true);
-    else if (has_residual && relu) BN_APPLY(true, true, false);
-    else if (has_residual) BN_APPLY(true, false, false);
-    else if (relu) BN_APPLY(false, true, false);
-    else BN_APPLY(false, false, false);
-#undef BN_APPLY
-    return 0;
+    return bn_bwd_t<U4>(dy, dy2, x, y, relu_mask, gamma, beta, save_mean, save_invstd, R, C, relu, has_residual, dx, dres, dgamma, dbeta, ws, stream_);
+}
+
+// the same for fp32 activations (channels_last [R, C] floats): the clients' fp32 encoders
+int cfl_bn_bwd_f32(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,
+               const float* beta, const float* save_mean, const float* save_invstd, long long R, int C, int relu, int has_residual,
+               void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream_) {
+    return bn_bwd_t<F8>(dy, dy2, x, y, relu_mask, gamma, beta, save_mean, save_invstd, R, C, relu, has_residual, dx, dres, dgamma, dbeta, ws, stream_);
 }
 
 // cfl_bn_bwd for a pre-joined gradient (no ReLU mask, no residual, one upstream gradient) whose apply pass also produces the
@@ -1039,7 +1070,7 @@ int cfl_bn_bwd_wgrad(const void* dy, const void* x, const void* a_in, int P, con
     float* qdg = qdb + (size_t)sp.parts * C;
     float* part = (float*)((char*)ws + cfl_align256((size_t)2 * sp.parts * C * sizeof(float)));
     const U4 *d = (const U4*)dy, *xx = (const U4*)x, *none = nullptr;
-    CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_sl_kernel<false, false>), dim3(sp.parts, sp.slices), dim3(256), 0, stream, d, none, xx, none,
+    CFL_LAUNCH(K_BN_BWD_REDUCE, (cfl_bn_bwd_reduce_sl_kernel<U4, false, false>), dim3(sp.parts, sp.slices), dim3(256), 0, stream, d, none, xx, none,
                save_mean, save_invstd, gamma, (const float*)nullptr, R, C, sp.rows_per_block, qdb, qdg, (const unsigned char*)nullptr);
     constexpr size_t LDS = (size_t)2 * WG_TILE_A + 2 * WG_TILE_B + 4096;
     CFL_SET_LDS(cfl_bn_bwd_apply_wgrad_kernel, LDS);
@@ -1064,7 +1095,7 @@ int cfl_bn_pool_fwd(const void* x, const float* gamma, const float* beta, float*
     const Plan p = bn_plan(R, C);
     float* psum = (float*)ws;
     float* psq = psum + (size_t)p.nblk * C;
-    CFL_LAUNCH(K_BN_STATS, cfl_bn_stats_kernel, dim3(p.nblk, p.gy), dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
+    CFL_LAUNCH(K_BN_STATS, (cfl_bn_stats_kernel<U4>), dim3(p.nblk, p.gy), dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
     CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, p.nblk, C, R, eps,
                momentum, save_mean, save_invstd, running_mean, running_var);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -1088,11 +1119,11 @@ int cfl_bn_pool_bwd(const void* g_pool, const void* idx, const void* x, const fl
     float* pdg = pdb + (size_t)p.nblk * C;
     const dim3 grid(p.nblk, p.gy);
     const U4* none = nullptr;
-    CFL_LAUNCH(K_BN_POOL_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
+    CFL_LAUNCH(K_BN_POOL_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<U4, true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
                (const U4*)x, none, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, (const unsigned char*)nullptr,
                (const B8*)idx, H, W);
     CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
-    CFL_LAUNCH(K_BN_POOL_BWD_APPLY, (cfl_bn_bwd_apply_kernel<false, true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
+    CFL_LAUNCH(K_BN_POOL_BWD_APPLY, (cfl_bn_bwd_apply_kernel<U4, false, true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
                (const U4*)x, none, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, (U4*)dx, (U4*)nullptr,
                (const unsigned char*)nullptr, (const B8*)idx, H, W);
     return 0;

@@ -28,11 +28,50 @@ __device__ __forceinline__ U4 pack8(const float (&f)[8]) {
     return u;
 }
 
+// fp32 activations (round 5: the clients' fp32 channels_last encoders): the same 8-channel group per thread, 32 bytes wide
+struct __attribute__((aligned(16))) F8 { float v[8]; };
+__device__ __forceinline__ void unpack8(const F8& u, float (&f)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = u.v[k];
+}
+template <class G> __device__ __forceinline__ G pack8g(const float (&f)[8]);
+template <> __device__ __forceinline__ U4 pack8g<U4>(const float (&f)[8]) { return pack8(f); }
+template <> __device__ __forceinline__ F8 pack8g<F8>(const float (&f)[8]) {
+    F8 u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u.v[k] = f[k];
+    return u;
+}
+// bit k = (stored value k > 0): what the 1-bit ReLU mask keeps of an output group
+__device__ __forceinline__ unsigned relu_bits(const U4& o) {
+    unsigned b = 0;
+    b |= (o.x & 0xffffu) ? 1u : 0u;  b |= (o.x >> 16) ? 2u : 0u;
+    b |= (o.y & 0xffffu) ? 4u : 0u;  b |= (o.y >> 16) ? 8u : 0u;
+    b |= (o.z & 0xffffu) ? 16u : 0u; b |= (o.z >> 16) ? 32u : 0u;
+    b |= (o.w & 0xffffu) ? 64u : 0u; b |= (o.w >> 16) ? 128u : 0u;
+    return b;
+}
+__device__ __forceinline__ unsigned relu_bits(const F8& o) {
+    unsigned b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b |= (o.v[k] != 0.f) ? (1u << k) : 0u;
+    return b;
+}
+
 // last-use streams (activations that are dead after this kernel) bypass the caches
 __device__ __forceinline__ U4 ld_nt(const U4* p) {
     typedef u32 v4u __attribute__((ext_vector_type(4)));
     const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
     U4 u; u.x = v[0]; u.y = v[1]; u.z = v[2]; u.w = v[3];
+    return u;
+}
+
+__device__ __forceinline__ F8 ld_nt(const F8* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    const v4f b = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p) + 1);
+    F8 u;
+    u.v[0] = a[0]; u.v[1] = a[1]; u.v[2] = a[2]; u.v[3] = a[3]; u.v[4] = b[0]; u.v[5] = b[1]; u.v[6] = b[2]; u.v[7] = b[3];
     return u;
 }
 

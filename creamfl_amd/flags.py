@@ -33,7 +33,7 @@ BUILD_FLAGS = {
     'client_graph': (dict(type=int, default=1, choices=[0, 1]),
                      'capture the client contrast step (fixed B, M, D) in a HIP graph'),
     'client_channels_last': (dict(type=int, default=1, choices=[0, 1]),
-                             'image encoders of the clients (ResNet client net, the multi-modal client\'s image tower) in channels_last '
+                             'image encoder of the uni-modal image clients (ResNet client net) in channels_last '
                              'memory format: the reference\'s fp32 arithmetic on the library\'s NHWC kernels (-16 % per contrast step '
                              'on an MI355X); 0 = NCHW as the reference lays them out'),
     'client_bf16': (dict(type=int, default=0, choices=[0, 1]),

@@ -114,7 +114,7 @@ class MaxPool3s2(nn.MaxPool2d):
 
     def forward(self, x):
         from .. import ops
-        if ops.bn_act_supported(x, x.shape[1]):
+        if x.dtype == torch.bfloat16 and ops.bn_act_supported(x, x.shape[1]):
             return ops.maxpool3s2(x)
         return super().forward(x)
 

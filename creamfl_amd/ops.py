@@ -745,10 +745,15 @@ def l2_normalize(tensor, axis=-1):
 
 
 # --------------------------------------------------------------------------- trunk glue: fused BN (+add) (+ReLU)
+BN_FP32 = [_os.environ.get('CFL_NO_BN_FP32', '0') != '1']      # switch: fp32 channels_last activations on the fused kernels too
+
+
 def bn_act_supported(x, num_features):
-    """True when the fused NHWC bf16 BatchNorm kernels apply to `x` ([N, C, H, W] bf16, channels_last)."""
+    """True when the fused NHWC BatchNorm kernels apply to `x`: [N, C, H, W] channels_last, bf16 (the server's trunks) or -- round
+    5, the clients' fp32 encoders -- fp32 (the same kernels instantiated on 32-byte channel groups: cfl_bn_*_f32)."""
     c8 = num_features // 8
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and num_features % 8 == 0
+    return (x.is_cuda and (x.dtype == torch.bfloat16 or (x.dtype == torch.float32 and BN_FP32[0])) and x.dim() == 4
+            and num_features % 8 == 0
             and (256 % c8 == 0 if c8 < 256 else num_features % 2048 == 0)
             and x.is_contiguous(memory_format=torch.channels_last))
 
@@ -839,7 +844,8 @@ class _BNActFn(torch.autograd.Function):
                                           ctypes.c_void_p(pstat.data_ptr()), ctypes.c_void_p(pstat.data_ptr() + 4 * pstat_nblk * C),
                                           pstat_nblk, _stream(x)), 'cfl_bn_fwd_pre')
         else:
-            _lib.check(lib.cfl_bn_fwd(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+            _lib.check((lib.cfl_bn_fwd_f32 if x.dtype == torch.float32 else lib.cfl_bn_fwd)(
+                _ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                                       R, C, eps, momentum, int(relu), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(mask), _ptr(ws),
                                       _stream(x)), 'cfl_bn_fwd')
         ctx.save_for_backward(x, mask if need_mask else x, weight, bias, mean, invstd)
@@ -887,9 +893,11 @@ class _BNActFn(torch.autograd.Function):
         if dy2 is not None:
             BN_COUNTERS['bwd_two'] += R * C
 
+        bn_bwd = lib.cfl_bn_bwd_f32 if x.dtype == torch.float32 else lib.cfl_bn_bwd
+
         def prep(t):
-            if t.dtype != torch.bfloat16:
-                t = t.to(torch.bfloat16)
+            if t.dtype != x.dtype:
+                t = t.to(x.dtype)
             return t.contiguous(memory_format=torch.channels_last)
         dy = prep(dy)
         dy2 = prep(dy2) if dy2 is not None else None
@@ -899,7 +907,7 @@ class _BNActFn(torch.autograd.Function):
         dbeta = torch.empty_like(weight)
         ws = _ws(lib.cfl_bn_ws_bytes(R, C), x.device)
         wg = ctx.wg
-        if pre and wg is not None and WGRAD_FUSE[0] and wg['x'] is not None and not wg['done'] and \
+        if pre and wg is not None and WGRAD_FUSE[0] and x.dtype == torch.bfloat16 and wg['x'] is not None and not wg['done'] and \
                 lib.cfl_bn_bwd_wgrad_supported(R, C, wg['w'].shape[1]) and wg['x'].is_contiguous(memory_format=torch.channels_last):
             # ... and the weight gradient of the convolution that made x, from the dY tile while it is on the chip
             w = wg['w']
@@ -921,11 +929,11 @@ class _BNActFn(torch.autograd.Function):
             if _st.GRAD_READY[0] is not None:
                 _st.GRAD_READY[0](w)                      # multi-GPU: this gradient may now be bucketed
         elif pre:          # plain BatchNorm backward of an already masked, already summed gradient
-            _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(None), _ptr(x), _ptr(None), _ptr(None), _ptr(weight), _ptr(bias), _ptr(mean),
+            _lib.check(bn_bwd(_ptr(dy), _ptr(None), _ptr(x), _ptr(None), _ptr(None), _ptr(weight), _ptr(bias), _ptr(mean),
                                       _ptr(invstd), R, C, 0, 0, _ptr(dx), _ptr(None), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)),
                        'cfl_bn_bwd')
         else:
-            _lib.check(lib.cfl_bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(None), _ptr(mask) if (ctx.relu and ctx.has_res) else _ptr(None),
+            _lib.check(bn_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(None), _ptr(mask) if (ctx.relu and ctx.has_res) else _ptr(None),
                                       _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), R, C, int(ctx.relu), int(ctx.has_res),
                                       _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_bwd')
         if JOIN['on'] and ctx.has_res and ctx.res_tok and ctx.res_tok in JOIN['consumer'] and ctx.res_tok in JOIN['mask']:
@@ -941,14 +949,14 @@ def bn_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu
     `two=True` returns the output as two tensor objects on one buffer: give one to the next convolution and the other
     to the next residual add, and their two gradients are summed inside the fused backward (no autograd add kernel)."""
     res_tok = getattr(residual, '_cfl_tok', 0) if residual is not None else 0
-    if residual is not None and not (residual.shape == x.shape and bn_act_supported(residual, x.shape[1])):
-        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if residual is not None and not (residual.shape == x.shape and residual.dtype == x.dtype and bn_act_supported(residual, x.shape[1])):
+        residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
         res_tok = 0
     tok = 0
     if JOIN['armed']:
         JOIN['serial'] += 1
         tok = JOIN['serial']
-    pre = getattr(x, '_cfl_bnstats', None)
+    pre = getattr(x, '_cfl_bnstats', None) if x.dtype == torch.bfloat16 else None
     if pre is not None and not (CONV_STATS[0] and pre[2] == x.shape[0] * x.shape[2] * x.shape[3] and pre[3] == x.shape[1]):
         pre = None
     y, y2 = _BNActFn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), tok, res_tok,
@@ -1002,7 +1010,7 @@ _NO_STEM_TAIL = _os.environ.get('CFL_NO_STEM_TAIL', '0') == '1'     # measuremen
 
 
 def bn_relu_maxpool_supported(x, num_features):
-    return (not _NO_STEM_TAIL and bn_act_supported(x, num_features) and num_features <= 2048 and x.shape[2] >= 2 and x.shape[3] >= 2
+    return (not _NO_STEM_TAIL and x.dtype == torch.bfloat16 and bn_act_supported(x, num_features) and num_features <= 2048 and x.shape[2] >= 2 and x.shape[3] >= 2
             and torch.is_grad_enabled())
 
 
@@ -1017,9 +1025,9 @@ def bn_act_eval(x, weight, bias, running_mean, running_var, eps, relu=False, res
     N, C, H, W = x.shape
     y = torch.empty_like(x)
     invstd = torch.rsqrt(running_var.float() + eps)
-    if residual is not None and not (residual.shape == x.shape and bn_act_supported(residual, C)):
-        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    _lib.check(lib.cfl_bn_apply(_ptr(x), _ptr(residual), _ptr(running_mean), _ptr(invstd), _ptr(weight), _ptr(bias),
+    if residual is not None and not (residual.shape == x.shape and residual.dtype == x.dtype and bn_act_supported(residual, C)):
+        residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    _lib.check((lib.cfl_bn_apply_f32 if x.dtype == torch.float32 else lib.cfl_bn_apply)(_ptr(x), _ptr(residual), _ptr(running_mean), _ptr(invstd), _ptr(weight), _ptr(bias),
                                 N * H * W, C, int(relu), _ptr(y), _stream(x)), 'cfl_bn_apply')
     return y
 
@@ -1538,7 +1546,7 @@ class _MaxPool3s2Fn(torch.autograd.Function):
 
 def maxpool3s2(x):
     """3x3 / stride 2 / pad 1 max pooling of a channels_last bf16 activation (the ResNet stem pool)."""
-    if not bn_act_supported(x, x.shape[1]):
+    if x.dtype != torch.bfloat16 or not bn_act_supported(x, x.shape[1]):
         raise _lib.CreamflHipError('maxpool3s2: expected a channels_last bf16 HIP tensor with C % 8 == 0')
     return _MaxPool3s2Fn.apply(x)
 

@@ -379,6 +379,18 @@ size_t cfl_bn_bwd_wgrad_ws_bytes(long long R, int C, int P);
 int cfl_bn_bwd_wgrad(const void* dy, const void* x, const void* a_in, int P, const float* gamma, const float* save_mean,
                      const float* save_invstd, long long R, int C, void* dx, float* dgamma, float* dbeta, void* dw, void* ws,
                      void* stream);
+/* cfl_bn_fwd / cfl_bn_apply / cfl_bn_bwd for FP32 activations (channels_last rows of C floats; every other argument as in the bf16
+ * entries below, same kernels instantiated on 32-byte channel groups): BatchNorm2d (+ residual add) (+ ReLU) of the clients' fp32
+ * encoders (src/networks/resnet_client.py:33-66,162-201 BasicBlock / stem; the reference runs them in fp32, ClientTrainer.py has no
+ * mixed precision).  fp32 statistics and arithmetic: results equal torch's fp32 BatchNorm to summation order. */
+int cfl_bn_fwd_f32(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, long long R, int C, float eps, float momentum, int relu, void* y, float* save_mean,
+                   float* save_invstd, unsigned char* relu_mask, void* ws, void* stream);
+int cfl_bn_apply_f32(const void* x, const void* residual, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, long long R, int C, int relu, void* y, void* stream);
+int cfl_bn_bwd_f32(const void* dy, const void* dy2, const void* x, const void* y, const unsigned char* relu_mask, const float* gamma,
+                   const float* beta, const float* save_mean, const float* save_invstd, long long R, int C, int relu,
+                   int has_residual, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream);
 size_t cfl_bn_ws_bytes(long long R, int C);
 int cfl_bn_fwd(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                float* running_var, long long R, int C, float eps, float momentum, int relu, void* y,

@@ -808,3 +808,64 @@ def test_bottleneck_data_path_bf16_fused_vs_fp32_autograd(hw, planes, n):
         rel = float((a - b).norm() / b.norm())
         print('bottleneck data path', hw, planes, name, 'cos %.6f rel %.5f' % (cos, rel))
         assert cos >= 0.999 and rel <= tol, (name, cos, rel)
+
+
+@pytest.mark.parametrize('n,c,h,w', [(16, 64, 56, 56), (8, 128, 28, 28), (8, 256, 14, 14), (4, 512, 7, 7), (3, 64, 9, 11), (2, 1024, 5, 3)])
+@pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])
+def test_bn_act_fp32_channels_last_matches_torch(n, c, h, w, relu, res):
+    """Round 5: the fused BatchNorm (+ add) (+ ReLU) kernels instantiated for fp32 channels_last activations (cfl_bn_*_f32: the
+    clients' fp32 encoders, resnet_client.py:33-66) against torch's fp32 BatchNorm2d on the same values: output, input / residual
+    gradients, dgamma / dbeta, running statistics at fp32 tolerance (summation order only), training and evaluation mode; both
+    block maps (C = 64 / 128: whole rows + `final`; C >= 256: channel slices)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    from creamfl_amd.networks.backbones import BNAct
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(c + h + n)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.3)
+    r = torch.randn(n, c, h, w, generator=g) if res else None
+    gy = torch.randn(n, c, h, w, generator=g)
+    bn = BNAct(c)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(c, generator=g))
+        bn.bias.copy_(0.3 * torch.randn(c, generator=g))
+    ref = torch.nn.BatchNorm2d(c)
+    ref.load_state_dict(bn.state_dict())
+    ref = ref.to(dev).train()
+    bn = bn.to(dev).train()
+
+    def run(mod, fused):
+        xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        rg = r.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
+        if fused:
+            assert ops.bn_act_supported(xg, c)
+            y = mod(xg, residual=rg, relu=relu)
+        else:
+            y = mod(xg)
+            y = y + rg if res else y
+            y = F.relu(y) if relu else y
+        (y * gy.to(dev)).sum().backward()
+        return y.detach(), xg.grad, (rg.grad if res else None), mod.weight.grad.clone(), mod.bias.grad.clone(), mod.running_mean.clone(), mod.running_var.clone()
+    pre = {k: ops.BN_COUNTERS[k] for k in ('fwd', 'bwd')}
+    got = run(bn, True)
+    assert ops.BN_COUNTERS['fwd'] > pre['fwd'] and ops.BN_COUNTERS['bwd'] > pre['bwd']      # the fused kernels really ran
+    want = run(ref, False)
+    for name, a, b in zip(('y', 'dx', 'dres', 'dgamma', 'dbeta', 'running_mean', 'running_var'), got, want):
+        if a is None:
+            continue
+        assert a.dtype == torch.float32
+        scale = float(b.abs().max()) + 1e-12
+        # (a ReLU output that is ~0 can fall on the other side of zero under another summation order: a handful of elements)
+        far = (a - b).abs() > 2e-5 * scale + 1e-6
+        assert float(far.float().mean()) <= (1e-5 if relu and name in ('dx', 'dres', 'y') else 0.0) + (2e-2 if relu and name in ('dgamma', 'dbeta') else 0.0), \
+            (name, int(far.sum()), float((a - b).abs().max()), scale)
+    bn.eval(); ref.eval()
+    with torch.no_grad():
+        xe = x.to(dev).contiguous(memory_format=torch.channels_last)
+        re_ = r.to(dev).contiguous(memory_format=torch.channels_last) if res else None
+        ye = bn(xe, residual=re_, relu=relu)
+        yr = ref(xe)
+        yr = yr + re_ if res else yr
+        yr = F.relu(yr) if relu else yr
+    np.testing.assert_allclose(ye.cpu().numpy(), yr.cpu().numpy(), rtol=1e-5, atol=1e-5)
