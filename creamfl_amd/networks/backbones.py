@@ -49,7 +49,14 @@ class BNAct(nn.BatchNorm2d):
         from .. import ops
         if self.track_running_stats and self.momentum is not None and self.affine and ops.bn_act_supported(x, self.num_features):
             if self.training:
-                self._nbt_pending += 1
+                if torch.cuda.is_current_stream_capturing():
+                    # inside a HIP-graph capture (the clients' contrast step, creamfl_amd/graphs.py) the count must live on the
+                    # device: a replay runs no Python, and a host counter would stand still while the graph trains
+                    # (the host's pending count stays pending: folding it in HERE would be captured and replayed too)
+                    if self.num_batches_tracked is not None:
+                        self.num_batches_tracked.add_(1)
+                else:
+                    self._nbt_pending += 1
                 return ops.bn_act_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
                                         self.eps, relu=relu, residual=residual, two=two)
             if not torch.is_grad_enabled():
@@ -85,7 +92,11 @@ class TrunkConv(nn.Conv2d):
             if self.in_channels == 3 and ops.stem_conv_supported(x, self.weight, self.stride[0], self.padding[0]):
                 return ops.stem_conv(x, self.weight, side_wgrad=not _NO_SIDE_WGRAD)      # 3-channel 7x7 stem: space-to-depth form
             if x.dtype == self.weight.dtype:
-                return ops.conv_split(x, self.weight, self.stride[0], self.padding[0], side_wgrad=not _NO_SIDE_WGRAD,
+                # the weight-gradient side stream belongs to the bf16 trunks of the server step; for the clients' fp32 encoders it
+                # buys nothing eager (21.6 vs 21.4 ms per contrast step) and costs their HIP graph 7 ms (28.6 vs 21.1: the
+                # fork / join pattern of the flushes serialises in the replay)
+                return ops.conv_split(x, self.weight, self.stride[0], self.padding[0],
+                                      side_wgrad=not _NO_SIDE_WGRAD and x.dtype == torch.bfloat16,
                                       bn_follows=self.bn_follows and self.training)
         if (x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype and self.stride[0] == self.stride[1]
                 and self.padding[0] == self.padding[1] and isinstance(self.padding[0], int)):
