@@ -730,7 +730,9 @@ def test_training_outcome_bf16_fused_equals_fp32(dev):
 
 # the training-outcome test: task size, steps / batch / learning rate, and its acceptance (R@1 points), calibrated with
 # tools/train_outcome_probe.py on an MI355X (profiles/r5_train_outcome.jsonl)
-OUTCOME = {'n_id': 200, 'noise': 0.3, 'steps': 400, 'batch': 32, 'lr': 2e-4, 'min_r1': 90.0, 'band': 2.5}     # measured: 98.0 / 98.2 vs 99.0 / 99.0
+OUTCOME = {'n_id': 200, 'noise': 0.3, 'steps': 400, 'batch': 32, 'lr': 2e-4, 'min_r1': 90.0, 'band': 6.0}
+# measured on four leases (i2t / t2i): bf16 fused 98.0 / 98.2, 99.5 / 99.5, 99.5 / 99.5, 96.5 / 96.1; fp32 99.0 / 99.0, 99.0 / 99.5,
+# 99.0 / 99.5, 99.0 / 100.0 -- the bf16 run's spread from run to run (library atomics in its weight gradients) is what sets the band
 
 
 @pytest.mark.gpu
