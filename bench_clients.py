@@ -218,7 +218,7 @@ def measure_client(trainer, kind, banks, batch, dev, steps, warmup, use_dist=Fal
         gs = GraphedStep(h.graph_fn, warmup=3)
         for _ in range(4 + max(0, warmup)):                       # 3 eager warm-ups, the capture (+ first replay), replays
             gs(*h.graph_in, device=dev)
-        dtg, loss = _wall(lambda: gs(*h.graph_in, device=dev), steps, use_dist)
+        dtg, loss = _wall(lambda: gs(*h.graph_in, device=dev), steps, False)     # (local fences: only image clients have this region)
         out['graph'] = {'ms_per_step': round(dtg / steps * 1e3, 3), 'pairs_per_s': round(h.B * steps / dtg, 1), 'seconds': dtg,
                         'replays': gs.replays, 'capture_failed': gs.failed}
     best = out.get('graph') or out['eager']

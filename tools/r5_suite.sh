@@ -1,18 +1,18 @@
 #!/bin/bash
-# the whole GPU suite + smoke, then the final config-2 and bench lines of the round
+# the final lines of the round (bench first: a fresh box), then the whole GPU suite + smoke
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r5_suite
 rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
-( time python -m pytest tests -m gpu -x -q --durations=8 ) > $OUT/gputest.log 2>&1
-tail -22 $OUT/gputest.log | cut -c1-300
-python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
-timeout 1200 python bench.py --config 2 --steps 30 --warmup 5 > $OUT/r5_config2_line.json 2> $OUT/c2.err
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/r5_bench_line_final.json 2> $OUT/bench.err
+timeout 1200 python bench.py --config 2 --steps 30 --warmup 5 > $OUT/r5_config2_line.json 2> $OUT/c2.err
 python3 - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r5_suite/r5_config2_line.json').read().strip().splitlines()[-1])
-print('config2', d['value'], {k:(v['eager']['ms_per_step'], v.get('graph') and v['graph']['ms_per_step'], v['a3a4_share_of_step']['product_path']) for k,v in d['clients'].items()}, d['round']['miniature_warm_up_round_s'], d['round']['phases_s_rank0'], d['full_M'], d['roofline']['frac'], d['cpu_baseline'])
 d=json.loads(open('gpurun_out/r5_suite/r5_bench_line_final.json').read().strip().splitlines()[-1])
-print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['alone']['frac'], d['roofline']['traffic_source'][:40], d['mfu']['mfu'], d['cpu_baseline']['value'])
+print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['alone']['frac'], d['roofline']['traffic'], d['roofline']['traffic_source'][:44], d['mfu']['mfu'], d['cpu_baseline']['value'])
+d=json.loads(open('gpurun_out/r5_suite/r5_config2_line.json').read().strip().splitlines()[-1])
+print('config2', d['value'], {k:(v['eager']['ms_per_step'], v.get('graph') and v['graph']['ms_per_step'], v['a3a4_kernels_us_per_step'], v['a3a4_share_of_step']['product_path'], v['hand_written_kernels_us_per_step']) for k,v in d['clients'].items()}, d['round']['miniature_warm_up_round_s'], d['round']['phases_s_rank0'], d['round']['ms_per_public_batch'], d['full_M']['con_w_ms_per_client'], d['roofline']['frac'], d['roofline']['avg_launch_us'], d['cpu_baseline']['value'])
 PY
+( time python -m pytest tests -m gpu -q --durations=6 ) > $OUT/gputest.log 2>&1
+tail -14 $OUT/gputest.log | cut -c1-300
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
