@@ -64,6 +64,11 @@ SIGNATURES = {
     'cfl_sup_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_sup_glue_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P]),
     'cfl_sup_glue_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
+    'cfl_gru_supported': (c_int, [c_int]),
+    'cfl_gru_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'cfl_gru_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'cfl_gru_cell0_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    'cfl_gru_cell0_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     'cfl_conw_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cfl_conw_logprob': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_conw_combine': (c_int, [POINTER(c_void_p), _P, c_int, c_int, c_int, _P, _P, _P]),

@@ -32,6 +32,7 @@ enum CflKernel {
     K_BN_POOL_FWD, K_BN_POOL_BWD_REDUCE, K_BN_POOL_BWD_APPLY,
     K_BANK_IMAGE, K_BANK_STREAM,
     K_BN_BWD_APPLY_WG, K_BN_WGRAD_REDUCE,
+    K_GRU_FWD, K_GRU_BWD, K_GRU_CELL0,
     K_NUM
 };
 

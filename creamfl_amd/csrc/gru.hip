@@ -1,0 +1,275 @@
+// gru.hip -- row A2c, the text towers' recurrence (src/networks/language_model.py:93-107, src/networks/models/caption_encoder.py:87-101).
+//
+// The reference runs a packed bidirectional GRU over every caption and then keeps ONE vector per caption: the output at the last
+// valid step, `gather(padded, 1, lengths - 1)`.  At that position the forward direction holds its final state (len steps of the
+// recurrence) and the backward direction -- which walks from the last word to the first -- holds its FIRST step: one GRU cell on the
+// last word from a zero state.  Nothing else of the [B, L, 2H] output is read (the PIE head pools the word embeddings, not the
+// states).  The library's GRU computes all of it, both directions, as ~50 small launches per time step (its element-wise tensor
+// ops were 52 000 launches = 5 % of the clients' kernel time and most of the text client's host time), and the packed form needs
+// the lengths on the host.
+//
+// Here:  xp = words W_ih^T + b_ih for all (b, t) is ONE library GEMM (the caller's); the recurrence
+//     g   = h W_hh^T + b_hh
+//     r   = sigmoid(xp_r + g_r),  z = sigmoid(xp_z + g_z),  n = tanh(xp_n + r * g_n),  h' = (1 - z) n + z h        (torch.nn.GRU)
+// runs as ONE launch per direction of autograd: batch rows are independent, so a workgroup owns R = 3 rows for all their time
+// steps and never talks to another.  3H threads; thread j keeps row j of W_hh (H floats) in registers for the whole launch and
+// forms g[., j] for the workgroup's rows from the state in LDS (broadcast reads); then thread (r, i) = (j / H, j % H) does the
+// gate arithmetic of one state element.  Lengths are read on the device: no packing, no host copy of the lengths, rows simply
+// stop at their own length.  fp32 FMA chains in k order, expf / tanhf of the device library: the reference's client precision.
+// The backward launch walks t downwards with W_hh^T columns in registers, writes the pre-activation gradients for every (b, t)
+// (zeros beyond a row's length) and leaves the four weight / input gradients to library GEMMs over those buffers.
+// The backward direction's single cell is an element-wise kernel pair (cfl_gru_cell0_*).
+// This is latency work (T dependent steps of a 3 x H x 3H product): ~2 us per step, ~40 workgroups.
+#include "common.h"
+
+namespace {
+
+template <int H, int R>
+__global__ __launch_bounds__(3 * H) void cfl_gru_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ w_hh,
+                                                            const float* __restrict__ b_hh, const int* __restrict__ lens,
+                                                            float* __restrict__ out, float* __restrict__ hs,
+                                                            float* __restrict__ gates, int B, int T) {
+    static_assert(R == 3, "one state element per thread: R * H == 3 * H");
+    __shared__ __attribute__((aligned(16))) float h[R][H];
+    __shared__ float g[R][3 * H];
+    __shared__ int slen[R];
+    const int j = threadIdx.x, b0 = blockIdx.x * R;
+    const int r = j / H, i = j % H, b = b0 + r;
+    float w[H];
+    {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(w_hh + (size_t)j * H);
+#pragma unroll
+        for (int k = 0; k < H / 4; ++k) {
+            const f32x4 v = wr[k];
+            w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
+        }
+    }
+    const float bj = b_hh[j];
+    if (j < R) slen[j] = b0 + j < B ? min(max(lens[b0 + j], 0), T) : 0;
+    h[r][i] = 0.f;
+    __syncthreads();
+    const int len = slen[r];
+    int tmax = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) tmax = max(tmax, slen[q]);
+    const bool live = b < B;
+    // hs is time-major [T + 1, B, H]: hs[t] = state BEFORE step t (hs[0] = 0), so hs[:T] is the contiguous "previous state"
+    // operand of the weight-gradient GEMM
+    if (hs && live) hs[(size_t)b * H + i] = 0.f;
+    const float* xrow = xp + (size_t)(live ? b : 0) * T * 3 * H;
+    float hv = 0.f;
+    float xr = 0.f, xz = 0.f, xn = 0.f;
+    if (len > 0) { xr = xrow[i]; xz = xrow[H + i]; xn = xrow[2 * H + i]; }
+    for (int t = 0; t < tmax; ++t) {
+        float acc[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = bj;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const f32x4 s = *reinterpret_cast<const f32x4*>(&h[q][k]);
+                acc[q] = fmaf(w[k], s[0], acc[q]);
+                acc[q] = fmaf(w[k + 1], s[1], acc[q]);
+                acc[q] = fmaf(w[k + 2], s[2], acc[q]);
+                acc[q] = fmaf(w[k + 3], s[3], acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) g[q][j] = acc[q];
+        __syncthreads();
+        const bool act = t < len;
+        float nxr = 0.f, nxz = 0.f, nxn = 0.f;
+        if (t + 1 < len) {                                           // next step's input projections: in flight over the gate math
+            const float* xq = xrow + (size_t)(t + 1) * 3 * H;
+            nxr = xq[i]; nxz = xq[H + i]; nxn = xq[2 * H + i];
+        }
+        if (act) {
+            const float gr = g[r][i], gz = g[r][H + i], gn = g[r][2 * H + i];
+            const float rr = sigmoidf(xr + gr), zz = sigmoidf(xz + gz);
+            const float nn = tanhf(xn + rr * gn);
+            hv = (1.f - zz) * nn + zz * hv;
+            h[r][i] = hv;
+            if (gates) {
+                float* gp = gates + ((size_t)b * T + t) * 4 * H;
+                gp[i] = rr; gp[H + i] = zz; gp[2 * H + i] = nn; gp[3 * H + i] = gn;
+            }
+        }
+        if (hs && live) hs[((size_t)(t + 1) * B + b) * H + i] = hv;
+        xr = nxr; xz = nxz; xn = nxn;
+        __syncthreads();
+    }
+    if (live) {
+        out[(size_t)b * H + i] = hv;
+        if (hs)
+            for (int t = tmax; t < T; ++t) hs[((size_t)(t + 1) * B + b) * H + i] = hv;     // finite beyond the length (times a zero gradient)
+    }
+}
+
+template <int H, int R>
+__global__ __launch_bounds__(3 * H) void cfl_gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
+                                                            const int* __restrict__ lens, const float* __restrict__ hs,
+                                                            const float* __restrict__ gates, float* __restrict__ dxp,
+                                                            float* __restrict__ dg, int B, int T) {
+    static_assert(R == 3, "one state element per thread");
+    __shared__ __attribute__((aligned(16))) float sg[R][3 * H];       // gradients of the hidden-side pre-activations of this step
+    __shared__ float part[R][3][H];
+    __shared__ int slen[R];
+    const int j = threadIdx.x, b0 = blockIdx.x * R;
+    const int r = j / H, i = j % H, b = b0 + r;                        // as item: row r, state element i; as product thread: gate block r
+    float w[H];                                                        // w[k] = W_hh[r * H + k][i]: column i of gate block r
+#pragma unroll
+    for (int k = 0; k < H; ++k) w[k] = w_hh[((size_t)r * H + k) * H + i];
+    if (j < R) slen[j] = b0 + j < B ? min(max(lens[b0 + j], 0), T) : 0;
+    __syncthreads();
+    const int len = slen[r];
+    int tmax = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) tmax = max(tmax, slen[q]);
+    const bool live = b < B;
+    float dh = live ? dout[(size_t)b * H + i] : 0.f;
+    const float* grow = gates + (size_t)(live ? b : 0) * T * 4 * H;
+    float* dxrow = dxp + (size_t)(live ? b : 0) * T * 3 * H;           // batch-major [B, T, 3H] (meets the batch-major word embeddings)
+    float rr = 0.f, zz = 0.f, nn = 0.f, gn = 0.f, hp = 0.f;
+    auto fetch = [&](int t) {
+        const float* gp = grow + (size_t)t * 4 * H;
+        rr = gp[i]; zz = gp[H + i]; nn = gp[2 * H + i]; gn = gp[3 * H + i];
+        hp = hs[((size_t)t * B + b) * H + i];
+    };
+    if (tmax > 0 && tmax - 1 < len) fetch(tmax - 1);
+    for (int t = tmax - 1; t >= 0; --t) {
+        const bool act = t < len;
+        float keep = dh;
+        if (act) {
+            const float dn = dh * (1.f - zz), dz = dh * (hp - nn);
+            const float dan = dn * (1.f - nn * nn);
+            const float daz = dz * zz * (1.f - zz);
+            const float dar = dan * gn * rr * (1.f - rr);
+            const float dgn = dan * rr;
+            keep = dh * zz;
+            sg[r][i] = dar; sg[r][H + i] = daz; sg[r][2 * H + i] = dgn;
+            float* dx = dxrow + (size_t)t * 3 * H;
+            dx[i] = dar; dx[H + i] = daz; dx[2 * H + i] = dan;
+            float* dq = dg + ((size_t)t * B + b) * 3 * H;              // time-major [T, B, 3H] (meets hs[:T])
+            dq[i] = dar; dq[H + i] = daz; dq[2 * H + i] = dgn;
+        } else {
+            sg[r][i] = 0.f; sg[r][H + i] = 0.f; sg[r][2 * H + i] = 0.f;
+        }
+        __syncthreads();
+        if (t > 0 && t - 1 < len) fetch(t - 1);                        // in flight over the product
+        float acc[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const f32x4 s = *reinterpret_cast<const f32x4*>(&sg[q][r * H + k]);
+                acc[q] = fmaf(w[k], s[0], acc[q]);
+                acc[q] = fmaf(w[k + 1], s[1], acc[q]);
+                acc[q] = fmaf(w[k + 2], s[2], acc[q]);
+                acc[q] = fmaf(w[k + 3], s[3], acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) part[q][r][i] = acc[q];
+        __syncthreads();
+        dh = keep + (part[r][0][i] + part[r][1][i] + part[r][2][i]);
+    }
+    if (live) {
+        for (int t = len; t < T; ++t) {
+            float* dx = dxrow + (size_t)t * 3 * H;
+            dx[i] = 0.f; dx[H + i] = 0.f; dx[2 * H + i] = 0.f;
+            float* dq = dg + ((size_t)t * B + b) * 3 * H;
+            dq[i] = 0.f; dq[H + i] = 0.f; dq[2 * H + i] = 0.f;
+        }
+    }
+}
+
+// One GRU cell from a zero state (the backward direction's output at the last valid position): gx = x W_ih^T + b_ih [B, 3H].
+__global__ __launch_bounds__(256) void cfl_gru_cell0_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ b_hh,
+                                                                float* __restrict__ out, float* __restrict__ saved, int B, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, i = idx % H;
+    const float* x = gx + (size_t)b * 3 * H;
+    const float rr = sigmoidf(x[i] + b_hh[i]), zz = sigmoidf(x[H + i] + b_hh[H + i]);
+    const float nn = tanhf(x[2 * H + i] + rr * b_hh[2 * H + i]);
+    out[idx] = (1.f - zz) * nn;
+    if (saved) {
+        float* s = saved + (size_t)b * 3 * H;
+        s[i] = rr; s[H + i] = zz; s[2 * H + i] = nn;
+    }
+}
+
+// dgx [B, 3H] = gradient of gx (and of b_ih once summed over b); dgh [B, 3H] = gradient of the hidden-side bias b_hh per row.
+__global__ __launch_bounds__(256) void cfl_gru_cell0_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ saved,
+                                                                const float* __restrict__ b_hh, float* __restrict__ dgx,
+                                                                float* __restrict__ dgh, int B, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, i = idx % H;
+    const float* s = saved + (size_t)b * 3 * H;
+    const float rr = s[i], zz = s[H + i], nn = s[2 * H + i], dh = dout[idx];
+    const float dan = dh * (1.f - zz) * (1.f - nn * nn);
+    const float daz = -dh * nn * zz * (1.f - zz);
+    const float dar = dan * b_hh[2 * H + i] * rr * (1.f - rr);
+    float* x = dgx + (size_t)b * 3 * H;
+    float* q = dgh + (size_t)b * 3 * H;
+    x[i] = dar; x[H + i] = daz; x[2 * H + i] = dan;
+    q[i] = dar; q[H + i] = daz; q[2 * H + i] = dan * rr;
+}
+
+constexpr int GRU_R = 3;
+
+}  // namespace
+
+extern "C" {
+
+int cfl_gru_supported(int H) { return H == 32 || H == 64 || H == 128; }
+
+int cfl_gru_fwd(const float* xp, const float* w_hh, const float* b_hh, const int* lens, float* out, float* hs, float* gates, int B,
+                int T, int H, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!cfl_gru_supported(H)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cfl_cdiv(B, GRU_R));
+    if (H == 128)
+        CFL_LAUNCH(K_GRU_FWD, (cfl_gru_fwd_kernel<128, GRU_R>), grid, dim3(384), 0, st, xp, w_hh, b_hh, lens, out, hs, gates, B, T);
+    else if (H == 64)
+        CFL_LAUNCH(K_GRU_FWD, (cfl_gru_fwd_kernel<64, GRU_R>), grid, dim3(192), 0, st, xp, w_hh, b_hh, lens, out, hs, gates, B, T);
+    else
+        CFL_LAUNCH(K_GRU_FWD, (cfl_gru_fwd_kernel<32, GRU_R>), grid, dim3(96), 0, st, xp, w_hh, b_hh, lens, out, hs, gates, B, T);
+    return 0;
+}
+
+int cfl_gru_bwd(const float* dout, const float* w_hh, const int* lens, const float* hs, const float* gates, float* dxp, float* dg,
+                int B, int T, int H, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!cfl_gru_supported(H)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cfl_cdiv(B, GRU_R));
+    if (H == 128)
+        CFL_LAUNCH(K_GRU_BWD, (cfl_gru_bwd_kernel<128, GRU_R>), grid, dim3(384), 0, st, dout, w_hh, lens, hs, gates, dxp, dg, B, T);
+    else if (H == 64)
+        CFL_LAUNCH(K_GRU_BWD, (cfl_gru_bwd_kernel<64, GRU_R>), grid, dim3(192), 0, st, dout, w_hh, lens, hs, gates, dxp, dg, B, T);
+    else
+        CFL_LAUNCH(K_GRU_BWD, (cfl_gru_bwd_kernel<32, GRU_R>), grid, dim3(96), 0, st, dout, w_hh, lens, hs, gates, dxp, dg, B, T);
+    return 0;
+}
+
+int cfl_gru_cell0_fwd(const float* gx, const float* b_hh, float* out, float* saved, int B, int H, void* stream) {
+    if (B <= 0 || H <= 0) return 0;
+    CFL_LAUNCH(K_GRU_CELL0, cfl_gru_cell0_fwd_kernel, dim3(cfl_cdiv(B * H, 256)), dim3(256), 0, (hipStream_t)stream, gx, b_hh, out,
+               saved, B, H);
+    return 0;
+}
+
+int cfl_gru_cell0_bwd(const float* dout, const float* saved, const float* b_hh, float* dgx, float* dgh, int B, int H, void* stream) {
+    if (B <= 0 || H <= 0) return 0;
+    CFL_LAUNCH(K_GRU_CELL0, cfl_gru_cell0_bwd_kernel, dim3(cfl_cdiv(B * H, 256)), dim3(256), 0, (hipStream_t)stream, dout, saved,
+               b_hh, dgx, dgh, B, H);
+    return 0;
+}
+
+}  // extern "C"

@@ -20,6 +20,7 @@ static const char* const g_kernel_names[K_NUM] = {
     "cfl_bn_pool_fwd_kernel", "cfl_bn_pool_bwd_reduce_kernel", "cfl_bn_pool_bwd_apply_kernel",
     "cfl_bank_image_kernel", "cfl_bank_stream_kernel",
     "cfl_bn_bwd_apply_wgrad_kernel", "cfl_bn_wgrad_reduce_kernel",
+    "cfl_gru_fwd_kernel", "cfl_gru_bwd_kernel", "cfl_gru_cell0_kernel",
 };
 
 namespace {

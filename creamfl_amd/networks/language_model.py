@@ -51,14 +51,18 @@ class EncoderText(nn.Module):
     def sentence_states(self, tokens, lengths):
         """(GRU output at each sentence's last valid step [B, embed_dim], word embeddings [B, L, word_dim])."""
         words = self.embed(tokens)
+        if ops.gru_last_supported(self.rnn, words):
+            # gru.hip: the forward direction's final state and the backward direction's first step are all the reference keeps
+            # of the packed bi-GRU's output; lengths may stay on the device (no host round trip, capturable)
+            return ops.bigru_last_states(self.rnn, words, lengths), words
+        lengths = lengths.cpu()
         states, _ = pad_packed_sequence(self.rnn(pack_padded_sequence(words, lengths, batch_first=True))[0], batch_first=True)
         last = (lengths.to(tokens.device) - 1).view(-1, 1, 1).expand(-1, 1, self.embed_dim)
         return states.gather(1, last).squeeze(1), words
 
     def forward(self, x, lengths):
-        lengths = lengths.cpu()
         final, words = self.sentence_states(x, lengths)
-        pooled, _, _ = self.pie_net(final, words, get_pad_mask(words.shape[1], lengths, True).to(final.device))
+        pooled, _, _ = self.pie_net(final, words, get_pad_mask(words.shape[1], lengths.to(final.device), True))
         feat = self.relu(pooled * self.scale)
         if self.is_train:
             logits, w = clamped_head(self.class_fc, feat)

@@ -39,14 +39,19 @@ class EncoderText(nn.Module):
                                       'construct with wemb_type=None and load embed.weight yourself')
 
     def forward(self, x, lengths):
-        lengths = lengths.cpu()
         wemb_out = self.embed(x)
-        packed = pack_padded_sequence(wemb_out, lengths, batch_first=True)
-        rnn_out, _ = self.rnn(packed)
-        padded = pad_packed_sequence(rnn_out, batch_first=True)
-        I = lengths.expand(self.embed_dim, 1, -1).permute(2, 1, 0) - 1
-        out = torch.gather(padded[0], 1, I.to(x.device)).squeeze(1)
-        pad_mask = get_pad_mask(wemb_out.shape[1], lengths, True).to(out.device)
+        if ops.gru_last_supported(self.rnn, wemb_out):
+            # gru.hip: [forward direction's final state | backward direction's first step] = the gather below, lengths on the device
+            out = ops.bigru_last_states(self.rnn, wemb_out, lengths)
+            pad_mask = get_pad_mask(wemb_out.shape[1], lengths.to(out.device), True)
+        else:
+            lengths = lengths.cpu()
+            packed = pack_padded_sequence(wemb_out, lengths, batch_first=True)
+            rnn_out, _ = self.rnn(packed)
+            padded = pad_packed_sequence(rnn_out, batch_first=True)
+            I = lengths.expand(self.embed_dim, 1, -1).permute(2, 1, 0) - 1
+            out = torch.gather(padded[0], 1, I.to(x.device)).squeeze(1)
+            pad_mask = get_pad_mask(wemb_out.shape[1], lengths, True).to(out.device)
         output = {}
         if not self.mlp_local:
             out, _, attn, residual = self.pie_net.forward_fused(out, wemb_out, pad_mask, l2norm=True)

@@ -480,6 +480,118 @@ def kd_mse(output, aggregate, d_idx, kd_weight=1.0):
     return _KdMseFn.apply(out, agg, _idx(d_idx, out.device), float(kd_weight))
 
 
+# ---- A2c: the text towers' GRU, last valid step only (gru.hip) ---------------------------------------------------------------
+# The reference keeps ONE vector per caption of its packed bidirectional GRU: gather(output, lengths - 1) = [the forward
+# direction's final state | the backward direction's FIRST step (a cell on the last word from a zero state)]
+# (language_model.py:93-107, caption_encoder.py:87-101).  The recurrence is one launch per autograd direction, the lengths stay
+# on the device, and the four weight / input gradients are library GEMMs over the pre-activation gradients the kernel writes.
+GRU_FUSED = [_os.environ.get('CFL_NO_GRU_FUSED', '0') != '1']
+
+
+class _GruLastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, words, lens, w_ih, w_hh, b_ih, b_hh):
+        lib = _lib.load()
+        B, T, E = words.shape
+        H = w_hh.shape[1]
+        x2 = words.reshape(B * T, E)
+        xp = torch.addmm(b_ih, x2, w_ih.t())                               # [B * T, 3H]: the input side of every step at once
+        need = any(ctx.needs_input_grad)
+        out = torch.empty(B, H, dtype=torch.float32, device=words.device)
+        hs = torch.empty(T + 1, B, H, dtype=torch.float32, device=words.device) if need else None
+        gates = torch.empty(B, T, 4 * H, dtype=torch.float32, device=words.device) if need else None
+        _lib.check(lib.cfl_gru_fwd(_ptr(xp), _ptr(w_hh), _ptr(b_hh), _ptr(lens), _ptr(out), _ptr(hs), _ptr(gates), B, T, H,
+                                   _stream(words)), 'cfl_gru_fwd')
+        if need:
+            ctx.save_for_backward(x2, lens, w_ih, w_hh, hs, gates)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x2, lens, w_ih, w_hh, hs, gates = ctx.saved_tensors
+        T, B, H = hs.shape[0] - 1, hs.shape[1], hs.shape[2]
+        dxp = torch.empty(B * T, 3 * H, dtype=torch.float32, device=x2.device)
+        dg = torch.empty(T * B, 3 * H, dtype=torch.float32, device=x2.device)
+        _lib.check(lib.cfl_gru_bwd(_ptr(dout.contiguous()), _ptr(w_hh), _ptr(lens), _ptr(hs), _ptr(gates), _ptr(dxp), _ptr(dg),
+                                   B, T, H, _stream(x2)), 'cfl_gru_bwd')
+        need = ctx.needs_input_grad
+        dwords = (dxp @ w_ih).view(B, T, -1) if need[0] else None
+        dw_ih = dxp.t() @ x2 if need[2] else None
+        dw_hh = dg.t() @ hs[:T].view(T * B, H) if need[3] else None
+        db_ih = dxp.sum(0) if need[4] else None
+        db_hh = dg.sum(0) if need[5] else None
+        return dwords, None, dw_ih, dw_hh, db_ih, db_hh
+
+
+class _GruCell0Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_last, w_ih, w_hh, b_ih, b_hh):
+        lib = _lib.load()
+        B, H = x_last.shape[0], w_hh.shape[1]
+        gx = torch.addmm(b_ih, x_last, w_ih.t())
+        need = any(ctx.needs_input_grad)
+        out = torch.empty(B, H, dtype=torch.float32, device=x_last.device)
+        saved = torch.empty(B, 3 * H, dtype=torch.float32, device=x_last.device) if need else None
+        _lib.check(lib.cfl_gru_cell0_fwd(_ptr(gx), _ptr(b_hh), _ptr(out), _ptr(saved), B, H, _stream(x_last)), 'cfl_gru_cell0_fwd')
+        if need:
+            ctx.save_for_backward(x_last, w_ih, w_hh, b_hh, saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x_last, w_ih, w_hh, b_hh, saved = ctx.saved_tensors
+        B, H = x_last.shape[0], w_hh.shape[1]
+        dgx = torch.empty(B, 3 * H, dtype=torch.float32, device=x_last.device)
+        dgh = torch.empty(B, 3 * H, dtype=torch.float32, device=x_last.device)
+        _lib.check(lib.cfl_gru_cell0_bwd(_ptr(dout.contiguous()), _ptr(saved), _ptr(b_hh), _ptr(dgx), _ptr(dgh), B, H,
+                                         _stream(x_last)), 'cfl_gru_cell0_bwd')
+        need = ctx.needs_input_grad
+        dx = dgx @ w_ih if need[0] else None
+        dw_ih = dgx.t() @ x_last if need[1] else None
+        # the state this cell's W_hh multiplies is zero: its gradient is a zero TENSOR, not None (the reference's packed GRU returns
+        # zeros too, and an optimizer with weight decay treats the two differently)
+        dw_hh = torch.zeros_like(w_hh) if need[2] else None
+        db_ih = dgx.sum(0) if need[3] else None
+        db_hh = dgh.sum(0) if need[4] else None
+        return dx, dw_ih, dw_hh, db_ih, db_hh
+
+
+def gru_last_supported(rnn, words):
+    """True when `bigru_last_states` covers this nn.GRU call: one bidirectional batch_first layer with biases, fp32 on the GPU,
+    hidden width built into gru.hip; anything else stays on the library's GRU."""
+    return (GRU_FUSED[0] and isinstance(rnn, torch.nn.GRU) and rnn.num_layers == 1 and rnn.bidirectional and rnn.batch_first
+            and rnn.bias and float(rnn.dropout) == 0.0 and words.is_cuda and words.dtype == torch.float32 and words.dim() == 3
+            and rnn.weight_hh_l0.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and bool(_lib.load().cfl_gru_supported(rnn.hidden_size)))
+
+
+def bigru_last_states(rnn, words, lengths):
+    """`pad_packed_sequence(rnn(pack_padded_sequence(words, lengths)))[0].gather(1, lengths - 1)` of the reference's text towers
+    (language_model.py:93-107, caption_encoder.py:87-101) without the packing and without the rest of the output: [B, 2H] =
+    [forward direction after lengths[b] steps | backward direction's cell on word lengths[b] - 1].  `lengths` may live on the
+    host (then it is checked like pack_padded_sequence checks it: sorted, positive) or on the device (no host round trip: the
+    form the captured client step uses)."""
+    B, T, _ = words.shape
+    if not lengths.is_cuda:
+        ll = lengths.tolist()
+        if any(v <= 0 for v in ll):
+            raise RuntimeError('Length of all samples has to be greater than 0, but found an element in \'lengths\' that is <= 0')
+        if any(a < b for a, b in zip(ll, ll[1:])):
+            raise RuntimeError('`lengths` array must be sorted in decreasing order when `enforce_sorted` is True.')
+        if ll and ll[0] > T:
+            raise RuntimeError(f'length {ll[0]} exceeds the padded width {T}')
+    lens = lengths.to(device=words.device, dtype=torch.int32, non_blocking=True).contiguous()
+    words = words.contiguous()
+    fwd = _GruLastFn.apply(words, lens, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+    last = (lens.to(torch.int64) - 1).clamp_(0, T - 1)
+    x_last = words.gather(1, last.view(B, 1, 1).expand(B, 1, words.shape[2])).squeeze(1)
+    bwd = _GruCell0Fn.apply(x_last, rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse,
+                            rnn.bias_hh_l0_reverse)
+    return torch.cat([fwd, bwd], 1)
+
+
 class _SupGlueFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fvec, labels, class_weight, margin, topk, center_weight):

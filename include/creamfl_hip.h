@@ -258,6 +258,30 @@ int cfl_sup_glue_bwd(const float* fvec, const long long* labels, const float* cl
                      float inter_distance, float center_weight, const float* gout, const void* ws, float* dfvec,
                      float* dclass_weight, void* stream);
 
+/* ---- A2c: the text towers' GRU recurrence, last valid step only ------------------------------------------
+ * Replaces nn.GRU(bidirectional) over packed captions + gather at lengths - 1
+ * (src/networks/language_model.py:93-107 EncoderText.forward; src/networks/models/caption_encoder.py:87-101):
+ * the reference keeps, per caption, the forward direction's final state and the backward direction's first step.
+ *   cfl_gru_fwd:  xp [B, T, 3H] = words W_ih^T + b_ih (gate order r | z | n, torch.nn.GRU), w_hh [3H, H], b_hh [3H], lens int32 [B] ON
+ *                 THE DEVICE (clamped to [0, T]); out [B, H] = state after lens[b] steps from a zero state.  hs [T + 1, B, H]
+ *                 (time-major; hs[t] = state before step t) and gates [B, T, 4H] (r | z | n | hidden-side n pre-activation) are
+ *                 written when non-NULL (training) -- positions beyond a row's length: hs carries the final state, gates are
+ *                 not written (never read).
+ *   cfl_gru_bwd:  dout [B, H] -> dxp [B, T, 3H] (gradient of xp, batch-major) and dg [T, B, 3H] (gradient of the hidden-side
+ *                 pre-activations h W_hh^T + b_hh, time-major); zeros beyond a row's length.  The caller forms
+ *                 dW_ih = dxp^T words, db_ih = sum dxp, dwords = dxp W_ih, dW_hh = dg^T hs[:T], db_hh = sum dg with library GEMMs.
+ *   cfl_gru_cell0_fwd / _bwd: one GRU cell from a zero state (the backward direction at the last valid word): gx [B, 3H] =
+ *                 x_last W_ih^T + b_ih -> out [B, H], saved [B, 3H] (r | z | n, may be NULL); bwd: dgx [B, 3H], dgh [B, 3H]
+ *                 (per-row gradient of b_hh; the gradient of W_hh is identically zero: the state it multiplies is zero).
+ * fp32 throughout, FMA chains in k order.  H in {32, 64, 128} (cfl_gru_supported); other widths stay on the library's GRU. */
+int cfl_gru_supported(int H);
+int cfl_gru_fwd(const float* xp, const float* w_hh, const float* b_hh, const int* lens, float* out, float* hs, float* gates, int B,
+                int T, int H, void* stream);
+int cfl_gru_bwd(const float* dout, const float* w_hh, const int* lens, const float* hs, const float* gates, float* dxp, float* dg,
+                int B, int T, int H, void* stream);
+int cfl_gru_cell0_fwd(const float* gx, const float* b_hh, float* out, float* saved, int B, int H, void* stream);
+int cfl_gru_cell0_bwd(const float* dout, const float* saved, const float* b_hh, float* dgx, float* dgh, int B, int H, void* stream);
+
 /* ---- A5: con_w aggregation ----------------------------------------------------------------
  * Replaces the closure `aggregation` in MMFL.distill (src/algorithms/MMFL.py:298-335).
  * logprob: out_l[n - row0] = V_n.G_n - log sum_m exp(V_n.G_m)  for n in [row0, row0+rows)

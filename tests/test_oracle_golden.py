@@ -316,3 +316,26 @@ def test_f1_kd_terms(fname):
     np.testing.assert_allclose(loss.item(), float(z['loss']), rtol=1e-6)
     _scale_close((oi.grad if oi.grad is not None else torch.zeros_like(oi)).numpy(), z['d_out_img'], 1e-6)
     _scale_close((ot.grad if ot.grad is not None else torch.zeros_like(ot)).numpy(), z['d_out_txt'], 1e-6)
+
+
+# ---- A2c: the text towers' recurrence, last valid step only (oracle/gru.py) -----------------------------------------------------
+@pytest.mark.parametrize('hidden,B,T', [(16, 5, 7), (128, 9, 12)])
+def test_gru_last_states_restatement_matches_the_reference_lines(hidden, B, T):
+    """The numpy restatement of torch.nn.GRU (oracle/gru.py) against the reference's own three lines run through torch on the CPU
+    (pack -> bi-GRU -> pad -> gather at lengths - 1, language_model.py:99-107): pins the oracle AND the property gru.hip is built
+    on -- at the gathered position the backward direction has taken exactly one step from a zero state."""
+    import torch
+    from oracle import gru as ogru
+    torch.manual_seed(3)
+    rnn = torch.nn.GRU(20, hidden, bidirectional=True, batch_first=True)
+    words = torch.randn(B, T, 20)
+    lengths = torch.tensor(sorted(np.random.RandomState(1).randint(1, T + 1, size=B).tolist(), reverse=True))
+    lengths[0] = T
+    lengths[-1] = 1
+    want = ogru.reference_formulation(rnn, words, lengths).detach().numpy()
+    got = ogru.bigru_last_states(words.numpy(), lengths.numpy(), ogru.gru_params(rnn))
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    # the gradient of the backward direction's hidden-side weight is identically zero (and a tensor, not None)
+    ogru.reference_formulation(rnn, words, lengths).square().sum().backward()
+    assert rnn.weight_hh_l0_reverse.grad is not None and float(rnn.weight_hh_l0_reverse.grad.abs().max()) == 0.0
+    assert float(rnn.weight_hh_l0.grad.abs().max()) > 0.0
