@@ -172,6 +172,13 @@ class StepHarness:
             else:
                 self.eager = lambda: step(None, captions, lens, self.d_idx_host)
                 self.graph_fn, self.graph_in = None, None
+                from creamfl_amd import ops
+                from creamfl_amd.algorithms.ClientTrainer import caption_graph_width, pad_captions
+                if ops.gru_last_supported(getattr(t.model, 'rnn', None)):
+                    # the product path of a text client since gru.hip: lengths on the device, every batch padded to one width
+                    width = caption_graph_width(captions.shape[1])
+                    self.graph_fn = lambda cap, ln, di: step(None, cap, ln, di)
+                    self.graph_in = (pad_captions(captions, width), torch.as_tensor(lens, dtype=torch.int64), self.d_idx_dev)
         self.B = B
 
     def close(self):
@@ -182,7 +189,7 @@ class StepHarness:
 
 
 def measure_client(trainer, kind, banks, batch, dev, steps, warmup, use_dist=False, profile_steps=5):
-    """Eager (+ graphed, image clients) wall time of the contrast step, the hand-written kernels' table from a profiled eager
+    """Eager (+ graphed: image and text clients) wall time of the contrast step, the hand-written kernels' table from a profiled eager
     pass, and the bank pass HIP-event timed INSIDE the eager timed region (prof_select: only that kernel carries events)."""
     from creamfl_amd import _lib
     from creamfl_amd.graphs import GraphedStep
@@ -218,7 +225,7 @@ def measure_client(trainer, kind, banks, batch, dev, steps, warmup, use_dist=Fal
         gs = GraphedStep(h.graph_fn, warmup=3)
         for _ in range(4 + max(0, warmup)):                       # 3 eager warm-ups, the capture (+ first replay), replays
             gs(*h.graph_in, device=dev)
-        dtg, loss = _wall(lambda: gs(*h.graph_in, device=dev), steps, False)     # (local fences: only image clients have this region)
+        dtg, loss = _wall(lambda: gs(*h.graph_in, device=dev), steps, False)     # (local fences: the multi-modal client has no such region)
         out['graph'] = {'ms_per_step': round(dtg / steps * 1e3, 3), 'pairs_per_s': round(h.B * steps / dtg, 1), 'seconds': dtg,
                         'replays': gs.replays, 'capture_failed': gs.failed}
     best = out.get('graph') or out['eager']

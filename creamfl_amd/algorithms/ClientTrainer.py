@@ -57,6 +57,19 @@ TEXT_SETS = ('AG_NEWS', 'YelpReviewPolarity')
 CLASSES = {'Cifar100': 100, 'Cifar10': 10, 'AG_NEWS': 4, 'YelpReviewPolarity': 2}
 
 
+def caption_graph_width(first_width):
+    """Padded caption width of a text client's captured contrast step: the first batch's width plus headroom, a multiple of 8, at
+    least 32 (COCO captions: the batch maximum is rarely above 30 words).  Wider batches run eagerly."""
+    return max(32, (int(first_width) + 8 + 7) // 8 * 8)
+
+
+def pad_captions(captions, width):
+    """[B, L] token ids -> [B, width] with the pad token 0 (the loaders' own padding); unchanged when already that wide or wider."""
+    if captions.shape[1] >= width:
+        return captions
+    return torch.nn.functional.pad(captions, (0, width - captions.shape[1]))
+
+
 class ClientTrainer:
     def __init__(self, args, dataset, dst, RGBmean, RGBstdv, data_dict, logger, global_test_set, inter_distance=4,
                  loss='softmax', gpuid='cuda:0', num_epochs=30, init_lr=0.0001, decay=0.1, batch_size=512,
@@ -263,25 +276,35 @@ class ClientTrainer:
 
         contrast_step = self.contrast_step_fn(g_same, g_other, use_intra, use_inter)
 
-        # Image clients have fixed batch shapes: the whole step replays from one HIP graph, re-captured every round (the banks,
-        # the old model and the learning rate are constants of a round).  Text clients' caption lengths vary per batch (packed
-        # GRU sequences): they stay eager.  --client_graph 0 switches it off.
+        # The whole step replays from one HIP graph, re-captured every round (the banks, the old model and the learning rate are
+        # constants of a round).  Image clients have fixed batch shapes.  Text clients: with the recurrence of gru.hip the caption
+        # lengths stay on the device (no packed sequences), so the step is capturable once every batch is padded to ONE width
+        # (`caption_graph_width`: padded words are masked out of the PIE head and never reached by the recurrence -- same values,
+        # zero gradient); a batch wider than the captured width runs eagerly.  --client_graph 0 switches it off.
         graphed = None
-        if is_img and bool(int(flags.get(self.args, 'client_graph'))) and not is_test and torch.device(self.gpuid).type == 'cuda':
+        can_graph = is_img or ops.gru_last_supported(getattr(self.model, 'rnn', None))
+        if can_graph and bool(int(flags.get(self.args, 'client_graph'))) and not is_test and torch.device(self.gpuid).type == 'cuda':
             # ONE capture per round: the local epochs of a round see the same banks, the same old model and the same learning
             # rate, so the later epochs replay the first one's graph (the closure it captured holds exactly those objects)
             key = (self.cur_epoch, g_same.data_ptr(), g_other.data_ptr(), id(self.old_model), use_intra, use_inter,
                    tuple(g['lr'] for g in self.optimizer.param_groups))
             graphed = getattr(self, '_graphed_contrast', None)
             if graphed is None or getattr(self, '_graphed_key', None) != key:
-                graphed = self._graphed_contrast = GraphedStep(lambda images, d_idx: contrast_step(images, None, None, d_idx),
-                                                               warmup=3, log=self._log)
+                fn = (lambda images, d_idx: contrast_step(images, None, None, d_idx)) if is_img else \
+                    (lambda captions, caption_lens, d_idx: contrast_step(None, captions, caption_lens, d_idx))
+                graphed = self._graphed_contrast = GraphedStep(fn, warmup=3, log=self._log)
+                graphed.caption_width = None
                 self._graphed_key = key
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
-            if graphed is not None:
+            if graphed is not None and is_img:
                 loss = graphed(images, torch.as_tensor(d_idx, dtype=torch.int64), device=torch.device(self.gpuid))
+            elif graphed is not None:
+                if graphed.caption_width is None:
+                    graphed.caption_width = caption_graph_width(captions.shape[1])
+                loss = graphed(pad_captions(captions, graphed.caption_width), torch.as_tensor(caption_lens, dtype=torch.int64),
+                               torch.as_tensor(d_idx, dtype=torch.int64), device=torch.device(self.gpuid))
             else:
                 loss = contrast_step(images, captions, caption_lens, d_idx)
             self.last_contrast_loss = loss

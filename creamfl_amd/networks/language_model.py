@@ -50,7 +50,7 @@ class EncoderText(nn.Module):
 
     def sentence_states(self, tokens, lengths):
         """(GRU output at each sentence's last valid step [B, embed_dim], word embeddings [B, L, word_dim])."""
-        words = self.embed(tokens)
+        words = ops.embedding_lookup(self.embed, tokens)
         if ops.gru_last_supported(self.rnn, words):
             # gru.hip: the forward direction's final state and the backward direction's first step are all the reference keeps
             # of the packed bi-GRU's output; lengths may stay on the device (no host round trip, capturable)

@@ -10,7 +10,7 @@ from .pie_model import PIENet
 
 
 def get_pad_mask(max_length, lengths, set_pad_to_one=True):
-    ind = torch.arange(0, max_length).unsqueeze(0).to(lengths.device)
+    ind = torch.arange(0, max_length, device=lengths.device).unsqueeze(0)       # (born on the lengths' device: capturable)
     mask = (ind >= lengths.unsqueeze(1)) if set_pad_to_one else (ind < lengths.unsqueeze(1))
     return mask.to(lengths.device)
 
@@ -39,7 +39,7 @@ class EncoderText(nn.Module):
                                       'construct with wemb_type=None and load embed.weight yourself')
 
     def forward(self, x, lengths):
-        wemb_out = self.embed(x)
+        wemb_out = ops.embedding_lookup(self.embed, x)
         if ops.gru_last_supported(self.rnn, wemb_out):
             # gru.hip: [forward direction's final state | backward direction's first step] = the gather below, lengths on the device
             out = ops.bigru_last_states(self.rnn, wemb_out, lengths)

@@ -24,7 +24,7 @@ class ResNet(nn.Module):
         self.mlp_local = kwargs.get('mlp_local', False)
         # stem
         self.conv1 = TrunkConv(3, 64, 7, stride=2, padding=3)        # (an nn.Conv2d: same parameter name, same state_dict)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BNAct(64)                                         # (an nn.BatchNorm2d: same state_dict; ReLU fused where the fused kernels apply)
         self.relu = nn.ReLU(inplace=False)
         self.maxpool = MaxPool3s2()
         # four stages; only the first keeps the resolution
@@ -61,7 +61,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*stage)
 
     def extract_conv_feature(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         for i in range(1, 5):
             x = getattr(self, f'layer{i}')(x)
         return first_of(x)

@@ -558,13 +558,47 @@ class _GruCell0Fn(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db_ih, db_hh
 
 
-def gru_last_supported(rnn, words):
-    """True when `bigru_last_states` covers this nn.GRU call: one bidirectional batch_first layer with biases, fp32 on the GPU,
-    hidden width built into gru.hip; anything else stays on the library's GRU."""
-    return (GRU_FUSED[0] and isinstance(rnn, torch.nn.GRU) and rnn.num_layers == 1 and rnn.bidirectional and rnn.batch_first
-            and rnn.bias and float(rnn.dropout) == 0.0 and words.is_cuda and words.dtype == torch.float32 and words.dim() == 3
-            and rnn.weight_hh_l0.dtype == torch.float32 and not torch.is_autocast_enabled()
-            and bool(_lib.load().cfl_gru_supported(rnn.hidden_size)))
+class _EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding's lookup with a backward that stays on the device: one index_add_ (atomic adds into the zeroed table).
+    torch's dense embedding backward switches, above 3072 indices, to a sort / unique-by-key path that reads a count back to the
+    host -- a host synchronisation per step in the eager text loops, and inside a HIP-graph capture a count read at capture time
+    and baked into the replays' launch sizes (seen as a memory fault in the replay of a text client's step padded to 128 x 32)."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight):
+        ctx.save_for_backward(tokens)
+        ctx.table = weight.shape
+        return weight.index_select(0, tokens.reshape(-1)).view(*tokens.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (tokens,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.table, dtype=g.dtype, device=g.device)
+        dw.index_add_(0, tokens.reshape(-1), g.reshape(-1, g.shape[-1]))
+        return None, dw
+
+
+def embedding_lookup(embed, tokens):
+    """`embed(tokens)` for a plain nn.Embedding on the GPU (no padding_idx / max_norm / sparse gradients / frequency scaling: the
+    reference's text towers, language_model.py:39, caption_encoder.py:39) with the sync-free backward above; anything else goes to
+    the module itself."""
+    w = embed.weight
+    if (w.is_cuda and tokens.is_cuda and embed.padding_idx is None and embed.max_norm is None and not embed.sparse
+            and not embed.scale_grad_by_freq and tokens.dtype == torch.int64):
+        return _EmbeddingFn.apply(tokens, w)
+    return embed(tokens)
+
+
+def gru_last_supported(rnn, words=None):
+    """True when `bigru_last_states` covers this nn.GRU (and, when given, this input): one bidirectional batch_first layer with
+    biases, fp32 on the GPU, hidden width built into gru.hip; anything else stays on the library's GRU."""
+    if not (GRU_FUSED[0] and isinstance(rnn, torch.nn.GRU) and rnn.num_layers == 1 and rnn.bidirectional and rnn.batch_first
+            and rnn.bias and float(rnn.dropout) == 0.0 and rnn.weight_hh_l0.is_cuda and rnn.weight_hh_l0.dtype == torch.float32
+            and not torch.is_autocast_enabled()):
+        return False
+    if words is not None and not (words.is_cuda and words.dtype == torch.float32 and words.dim() == 3):
+        return False
+    return bool(_lib.load().cfl_gru_supported(rnn.hidden_size))
 
 
 def bigru_last_states(rnn, words, lengths):

@@ -629,6 +629,58 @@ def test_client_contrast_step_in_a_hip_graph_equals_eager(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,D,bs', [(136, 64, 16), (1088, 256, 128)])      # (the second: 128 x 32 = 4096 embedding indices per step)
+def test_text_client_contrast_step_in_a_hip_graph_equals_eager(dev, M, D, bs):
+    """A TEXT client's contrast loop replayed from one HIP graph (possible since gru.hip keeps the caption lengths on the device:
+    no packed sequences): every batch padded to one caption width, three eager steps, one capture, replays; against the same loop
+    run eagerly on the unpadded batches (--client_graph 0).  Same parameters after 9 steps (1e-4 of scale), the ragged last batch
+    runs eagerly, the graph was really replayed, and a batch WIDER than the captured width runs eagerly too."""
+    from creamfl_amd.algorithms.ClientTrainer import ClientTrainer, caption_graph_width, pad_captions
+    from creamfl_amd.utils.synthetic import SyntheticCocoLoader
+    batches = list(SyntheticCocoLoader(M, bs, seed=7, img=8, bert=False))         # 8 full batches + one ragged batch of bs / 2
+    widths = {b[1].shape[1] for b in batches}
+    assert (len(widths) > 1 or bs > 16) and max(widths) <= 32          # (small batches differ in width;) all fit the captured one
+    assert caption_graph_width(max(widths)) == 32 and pad_captions(batches[0][1], 32).shape[1] == 32
+    gen = torch.Generator().manual_seed(3)
+    g_img = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
+    g_txt = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
+
+    def run(graph, data):
+        args = SimpleNamespace(feature_dim=D, mlp_local=False, local_epochs=1, contrast_local_intra=True, contrast_local_inter=True,
+                               interintra_weight=0.5, loss_scale=False, save_client=False, client_graph=graph)
+        t = ClientTrainer(args, 'AG_NEWS', None, None, None, None, None, global_test_set=None, client_id=0, gpuid=str(dev))
+        t.train_loader = None
+        t.cur_epoch = 0
+        t.run(g_img, g_txt, list(range(M)), data)
+        torch.cuda.synchronize()
+        return t, {k: v.detach().float().cpu() for k, v in t.model.state_dict().items()}
+
+    t_eager, sd_eager = run(0, batches)
+    t_graph, sd_graph = run(1, batches)
+    gs = t_graph.graph_stats
+    assert gs['failed'] is None, gs['failed']
+    assert gs['calls'] == 9 and gs['replays'] == 5                     # 3 eager warm-up steps, 5 replays, the ragged batch eager
+    assert t_eager.graph_stats is None
+    assert bool(torch.isfinite(t_graph.last_contrast_loss))
+    for k, v in sd_eager.items():
+        scale = float(v.abs().max()) + 1e-12
+        assert float((v - sd_graph[k]).abs().max()) <= 1e-4 * scale + 1e-6, k
+    ref = ClientTrainer(SimpleNamespace(feature_dim=D, mlp_local=False, local_epochs=1), 'AG_NEWS', None, None, None, None, None,
+                        global_test_set=None, client_id=0, gpuid=str(dev)).model.state_dict()
+    assert max(float((sd_graph[k] - ref[k].float().cpu()).abs().max()) for k in sd_graph) > 1e-6      # the steps did train
+    # a batch wider than the captured width: that call is eager, the loop goes on
+    wide = list(batches[:8])
+    b5 = list(wide[5])
+    b5[1] = pad_captions(b5[1], 40)
+    wide[5] = tuple(b5)
+    t_wide, sd_wide = run(1, wide)
+    assert t_wide.graph_stats['failed'] is None and t_wide.graph_stats['calls'] == 8 and t_wide.graph_stats['replays'] == 4
+    t_ref, sd_ref = run(0, batches[:8])
+    for k, v in sd_ref.items():
+        assert float((v - sd_wide[k]).abs().max()) <= 1e-4 * (float(v.abs().max()) + 1e-12) + 1e-6, k
+
+
+@pytest.mark.gpu
 def test_first_server_step_answers_from_the_find_db(dev):
     """Every process used to spend ~56 s of its first server step letting MIOpen time solvers whose answers the shipped find-db
     already holds (PyTorch's cudnn.benchmark asks for an exhaustive search).  The trunk's convolution calls now use immediate mode

@@ -161,3 +161,26 @@ def test_text_client_encoder_trains_the_same_on_both_recurrences():
     for k in a:
         scale = float(b[k].abs().max())
         assert float((a[k] - b[k]).abs().max()) <= 2e-4 * max(scale, 1e-3), k
+
+
+@pytest.mark.parametrize('shape', [(16, 12), (128, 32)])                # 192 and 4096 indices: both sides of torch's 3072 switch
+def test_embedding_lookup_matches_nn_embedding(shape):
+    """ops.embedding_lookup (index_select forward, index_add_ backward: no host read-back) against nn.Embedding."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(shape[0])
+    emb = torch.nn.Embedding(11755, 300).to(dev)
+    tokens = torch.randint(0, 40, shape, generator=g).to(dev)          # few distinct tokens: many rows collide
+    gy = torch.randn(*shape, 300, generator=g).to(dev)
+    a = ops.embedding_lookup(emb, tokens)
+    (a * gy).sum().backward()
+    ga = emb.weight.grad.clone()
+    emb.weight.grad = None
+    b = emb(tokens)
+    (b * gy).sum().backward()
+    assert torch.equal(a, b)
+    scale = float(emb.weight.grad.abs().max())
+    assert float((ga - emb.weight.grad).abs().max()) <= 1e-5 * scale        # (atomic adds: the order of the colliding rows differs)
+    assert not ops.embedding_lookup(torch.nn.Embedding(10, 4, padding_idx=0).to(dev), tokens[:1] % 10).grad_fn.__class__.__name__.startswith('_EmbeddingFn')
