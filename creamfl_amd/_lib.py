@@ -65,7 +65,8 @@ SIGNATURES = {
     'cfl_sup_glue_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P]),
     'cfl_sup_glue_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     'cfl_gru_supported': (c_int, [c_int]),
-    'cfl_gru_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'cfl_gru_streams_weights': (c_int, [c_int]),
+    'cfl_gru_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'cfl_gru_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'cfl_gru_cell0_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'cfl_gru_cell0_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),

@@ -186,6 +186,181 @@ __global__ __launch_bounds__(3 * H) void cfl_gru_bwd_kernel(const float* __restr
     }
 }
 
+// ---- any width (H % 4 == 0): W_hh streamed from L2 every step -------------------------------------------------------------------
+// Beyond H = 128 a row of W_hh no longer fits a thread's registers (H = 256: 786 KB per matrix, more than a CU's register file).
+// Same block structure (a workgroup owns R rows for all their steps), 256 threads, thread t forms the columns t, t + 256, ... of
+// g from W_hh^T [H, 3H] (k-major: for a fixed k the lanes read consecutive columns, coalesced) -- 3H * H * 4 bytes through L2 -> CU
+// per step and workgroup (~5 us at H = 256), which bounds the step; the state is read from LDS once per 4 k for all the thread's
+// columns.  The library's GRU at these widths is the same ~50 launches per time step.
+constexpr int GS_T = 256, GS_R = 4, GS_C = 6;                         // threads, rows per workgroup, columns per thread (3H <= 1536)
+
+__global__ __launch_bounds__(GS_T) void cfl_gru_fwd_stream_kernel(const float* __restrict__ xp, const float* __restrict__ w_hh_t,
+                                                                  const float* __restrict__ b_hh, const int* __restrict__ lens,
+                                                                  float* __restrict__ out, float* __restrict__ hs,
+                                                                  float* __restrict__ gates, int B, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* h = sm;                                                    // [R][H]
+    float* g = sm + GS_R * H;                                         // [R][3H]
+    __shared__ int slen[GS_R];
+    const int tid = threadIdx.x, b0 = blockIdx.x * GS_R, N = 3 * H;
+    if (tid < GS_R) slen[tid] = b0 + tid < B ? min(max(lens[b0 + tid], 0), T) : 0;
+    for (int e = tid; e < GS_R * H; e += GS_T) {
+        h[e] = 0.f;
+        const int b = b0 + e / H;
+        if (hs && b < B) hs[(size_t)b * H + e % H] = 0.f;
+    }
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int q = 0; q < GS_R; ++q) tmax = max(tmax, slen[q]);
+    float bj[GS_C];
+#pragma unroll
+    for (int c = 0; c < GS_C; ++c) bj[c] = tid + c * GS_T < N ? b_hh[tid + c * GS_T] : 0.f;
+    for (int t = 0; t < tmax; ++t) {
+        float acc[GS_R][GS_C];
+#pragma unroll
+        for (int q = 0; q < GS_R; ++q)
+#pragma unroll
+            for (int c = 0; c < GS_C; ++c) acc[q][c] = bj[c];
+        for (int k0 = 0; k0 < H; k0 += 4) {
+            f32x4 hq[GS_R];
+#pragma unroll
+            for (int q = 0; q < GS_R; ++q) hq[q] = *reinterpret_cast<const f32x4*>(h + q * H + k0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float* wr = w_hh_t + (size_t)(k0 + kk) * N + tid;
+#pragma unroll
+                for (int c = 0; c < GS_C; ++c) {
+                    if (c * GS_T < N) {                                // (uniform)
+                        const float w = tid + c * GS_T < N ? wr[c * GS_T] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < GS_R; ++q) acc[q][c] = fmaf(w, hq[q][kk], acc[q][c]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < GS_C; ++c)
+            if (tid + c * GS_T < N)
+#pragma unroll
+                for (int q = 0; q < GS_R; ++q) g[q * N + tid + c * GS_T] = acc[q][c];
+        __syncthreads();
+        for (int e = tid; e < GS_R * H; e += GS_T) {
+            const int q = e / H, i = e % H, b = b0 + q;
+            if (b >= B) continue;
+            float hv = h[e];
+            if (t < slen[q]) {
+                const float* xq = xp + ((size_t)b * T + t) * N;
+                const float gn = g[q * N + 2 * H + i];
+                const float rr = sigmoidf(xq[i] + g[q * N + i]), zz = sigmoidf(xq[H + i] + g[q * N + H + i]);
+                const float nn = tanhf(xq[2 * H + i] + rr * gn);
+                hv = (1.f - zz) * nn + zz * hv;
+                h[e] = hv;
+                if (gates) {
+                    float* gp = gates + ((size_t)b * T + t) * 4 * H;
+                    gp[i] = rr; gp[H + i] = zz; gp[2 * H + i] = nn; gp[3 * H + i] = gn;
+                }
+            }
+            if (hs) hs[((size_t)(t + 1) * B + b) * H + i] = hv;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < GS_R * H; e += GS_T) {
+        const int i = e % H, b = b0 + e / H;
+        if (b >= B) continue;
+        out[(size_t)b * H + i] = h[e];
+        if (hs)
+            for (int t = tmax; t < T; ++t) hs[((size_t)(t + 1) * B + b) * H + i] = h[e];
+    }
+}
+
+// backward: thread t forms the state-gradient elements t, t + 256, ... from W_hh [3H, H] (for a fixed j the lanes read consecutive
+// elements of row j: coalesced); the state gradient lives in LDS between steps.
+constexpr int GS_C2 = 2;                                              // state elements per thread (H <= 512)
+
+__global__ __launch_bounds__(GS_T) void cfl_gru_bwd_stream_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
+                                                                  const int* __restrict__ lens, const float* __restrict__ hs,
+                                                                  const float* __restrict__ gates, float* __restrict__ dxp,
+                                                                  float* __restrict__ dg, int B, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sg = sm;                                                   // [R][3H] hidden-side pre-activation gradients of this step
+    float* dh = sm + GS_R * 3 * H;                                    // [R][H]  gradient of the state after step t
+    float* keep = dh + GS_R * H;                                      // [R][H]  dh * z (what the state before step t keeps directly)
+    __shared__ int slen[GS_R];
+    const int tid = threadIdx.x, b0 = blockIdx.x * GS_R, N = 3 * H;
+    if (tid < GS_R) slen[tid] = b0 + tid < B ? min(max(lens[b0 + tid], 0), T) : 0;
+    for (int e = tid; e < GS_R * H; e += GS_T) {
+        const int b = b0 + e / H;
+        dh[e] = b < B ? dout[(size_t)b * H + e % H] : 0.f;
+    }
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int q = 0; q < GS_R; ++q) tmax = max(tmax, slen[q]);
+    for (int t = tmax - 1; t >= 0; --t) {
+        for (int e = tid; e < GS_R * H; e += GS_T) {
+            const int q = e / H, i = e % H, b = b0 + q;
+            float dar = 0.f, daz = 0.f, dgn = 0.f, kp = dh[e];
+            if (b < B && t < slen[q]) {
+                const float* gp = gates + ((size_t)b * T + t) * 4 * H;
+                const float rr = gp[i], zz = gp[H + i], nn = gp[2 * H + i], gn = gp[3 * H + i];
+                const float hp = hs[((size_t)t * B + b) * H + i], d = dh[e];
+                const float dan = d * (1.f - zz) * (1.f - nn * nn);
+                daz = d * (hp - nn) * zz * (1.f - zz);
+                dar = dan * gn * rr * (1.f - rr);
+                dgn = dan * rr;
+                kp = d * zz;
+                float* dx = dxp + ((size_t)b * T + t) * N;
+                dx[i] = dar; dx[H + i] = daz; dx[2 * H + i] = dan;
+                float* dq = dg + ((size_t)t * B + b) * N;
+                dq[i] = dar; dq[H + i] = daz; dq[2 * H + i] = dgn;
+            }
+            sg[q * N + i] = dar; sg[q * N + H + i] = daz; sg[q * N + 2 * H + i] = dgn;
+            keep[e] = kp;
+        }
+        __syncthreads();
+        float acc[GS_R][GS_C2];
+#pragma unroll
+        for (int q = 0; q < GS_R; ++q)
+#pragma unroll
+            for (int c = 0; c < GS_C2; ++c) acc[q][c] = 0.f;
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            f32x4 sq[GS_R];
+#pragma unroll
+            for (int q = 0; q < GS_R; ++q) sq[q] = *reinterpret_cast<const f32x4*>(sg + q * N + j0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float* wr = w_hh + (size_t)(j0 + jj) * H + tid;
+#pragma unroll
+                for (int c = 0; c < GS_C2; ++c) {
+                    if (c * GS_T < H) {
+                        const float w = tid + c * GS_T < H ? wr[c * GS_T] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < GS_R; ++q) acc[q][c] = fmaf(w, sq[q][jj], acc[q][c]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < GS_C2; ++c)
+            if (tid + c * GS_T < H)
+#pragma unroll
+                for (int q = 0; q < GS_R; ++q)
+                    if (t < slen[q]) dh[q * H + tid + c * GS_T] = keep[q * H + tid + c * GS_T] + acc[q][c];
+        __syncthreads();
+    }
+    for (int e = tid; e < GS_R * H; e += GS_T) {
+        const int q = e / H, i = e % H, b = b0 + q;
+        if (b >= B) continue;
+        for (int t = slen[q]; t < T; ++t) {
+            float* dx = dxp + ((size_t)b * T + t) * N;
+            dx[i] = 0.f; dx[H + i] = 0.f; dx[2 * H + i] = 0.f;
+            float* dq = dg + ((size_t)t * B + b) * N;
+            dq[i] = 0.f; dq[H + i] = 0.f; dq[2 * H + i] = 0.f;
+        }
+    }
+}
+
 // One GRU cell from a zero state (the backward direction's output at the last valid position): gx = x W_ih^T + b_ih [B, 3H].
 __global__ __launch_bounds__(256) void cfl_gru_cell0_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ b_hh,
                                                                 float* __restrict__ out, float* __restrict__ saved, int B, int H) {
@@ -226,13 +401,21 @@ constexpr int GRU_R = 3;
 
 extern "C" {
 
-int cfl_gru_supported(int H) { return H == 32 || H == 64 || H == 128; }
+static bool gru_in_registers(int H) { return H == 32 || H == 64 || H == 128; }
+int cfl_gru_supported(int H) { return gru_in_registers(H) || (H > 0 && H % 4 == 0 && H <= 512); }
+int cfl_gru_streams_weights(int H) { return cfl_gru_supported(H) && !gru_in_registers(H); }
 
-int cfl_gru_fwd(const float* xp, const float* w_hh, const float* b_hh, const int* lens, float* out, float* hs, float* gates, int B,
-                int T, int H, void* stream) {
+int cfl_gru_fwd(const float* xp, const float* w_hh, const float* w_hh_t, const float* b_hh, const int* lens, float* out, float* hs,
+                float* gates, int B, int T, int H, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (!cfl_gru_supported(H)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    if (!gru_in_registers(H)) {
+        if (!w_hh_t) return (int)hipErrorInvalidValue;
+        CFL_LAUNCH(K_GRU_FWD, cfl_gru_fwd_stream_kernel, dim3(cfl_cdiv(B, GS_R)), dim3(GS_T), (size_t)GS_R * 4 * H * sizeof(float), st, xp,
+                   w_hh_t, b_hh, lens, out, hs, gates, B, T, H);
+        return 0;
+    }
     const dim3 grid(cfl_cdiv(B, GRU_R));
     if (H == 128)
         CFL_LAUNCH(K_GRU_FWD, (cfl_gru_fwd_kernel<128, GRU_R>), grid, dim3(384), 0, st, xp, w_hh, b_hh, lens, out, hs, gates, B, T);
@@ -248,6 +431,11 @@ int cfl_gru_bwd(const float* dout, const float* w_hh, const int* lens, const flo
     if (B <= 0 || T <= 0) return 0;
     if (!cfl_gru_supported(H)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    if (!gru_in_registers(H)) {
+        CFL_LAUNCH(K_GRU_BWD, cfl_gru_bwd_stream_kernel, dim3(cfl_cdiv(B, GS_R)), dim3(GS_T), (size_t)GS_R * 5 * H * sizeof(float), st, dout,
+                   w_hh, lens, hs, gates, dxp, dg, B, T, H);
+        return 0;
+    }
     const dim3 grid(cfl_cdiv(B, GRU_R));
     if (H == 128)
         CFL_LAUNCH(K_GRU_BWD, (cfl_gru_bwd_kernel<128, GRU_R>), grid, dim3(384), 0, st, dout, w_hh, lens, hs, gates, dxp, dg, B, T);

@@ -500,8 +500,10 @@ class _GruLastFn(torch.autograd.Function):
         out = torch.empty(B, H, dtype=torch.float32, device=words.device)
         hs = torch.empty(T + 1, B, H, dtype=torch.float32, device=words.device) if need else None
         gates = torch.empty(B, T, 4 * H, dtype=torch.float32, device=words.device) if need else None
-        _lib.check(lib.cfl_gru_fwd(_ptr(xp), _ptr(w_hh), _ptr(b_hh), _ptr(lens), _ptr(out), _ptr(hs), _ptr(gates), B, T, H,
-                                   _stream(words)), 'cfl_gru_fwd')
+        # widths beyond the register-resident kernels stream W_hh from L2 every step: k-major copy for coalesced column reads
+        w_hh_t = w_hh.t().contiguous() if lib.cfl_gru_streams_weights(H) else None
+        _lib.check(lib.cfl_gru_fwd(_ptr(xp), _ptr(w_hh), _ptr(w_hh_t), _ptr(b_hh), _ptr(lens), _ptr(out), _ptr(hs), _ptr(gates),
+                                   B, T, H, _stream(words)), 'cfl_gru_fwd')
         if need:
             ctx.save_for_backward(x2, lens, w_ih, w_hh, hs, gates)
         return out

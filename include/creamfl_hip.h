@@ -273,10 +273,13 @@ int cfl_sup_glue_bwd(const float* fvec, const long long* labels, const float* cl
  *   cfl_gru_cell0_fwd / _bwd: one GRU cell from a zero state (the backward direction at the last valid word): gx [B, 3H] =
  *                 x_last W_ih^T + b_ih -> out [B, H], saved [B, 3H] (r | z | n, may be NULL); bwd: dgx [B, 3H], dgh [B, 3H]
  *                 (per-row gradient of b_hh; the gradient of W_hh is identically zero: the state it multiplies is zero).
- * fp32 throughout, FMA chains in k order.  H in {32, 64, 128} (cfl_gru_supported); other widths stay on the library's GRU. */
+ * fp32 throughout, FMA chains in k order.  H in {32, 64, 128}: a row of W_hh per thread in registers for the whole launch; any
+ * other H % 4 == 0 up to 512 (cfl_gru_streams_weights): W_hh streamed from L2 every step, and cfl_gru_fwd then needs
+ * w_hh_t = W_hh^T [H, 3H] (k-major, coalesced; NULL otherwise).  Other widths stay on the library's GRU (cfl_gru_supported). */
 int cfl_gru_supported(int H);
-int cfl_gru_fwd(const float* xp, const float* w_hh, const float* b_hh, const int* lens, float* out, float* hs, float* gates, int B,
-                int T, int H, void* stream);
+int cfl_gru_streams_weights(int H);
+int cfl_gru_fwd(const float* xp, const float* w_hh, const float* w_hh_t, const float* b_hh, const int* lens, float* out, float* hs,
+                float* gates, int B, int T, int H, void* stream);
 int cfl_gru_bwd(const float* dout, const float* w_hh, const int* lens, const float* hs, const float* gates, float* dxp, float* dg,
                 int B, int T, int H, void* stream);
 int cfl_gru_cell0_fwd(const float* gx, const float* b_hh, float* out, float* saved, int B, int H, void* stream);

@@ -29,7 +29,10 @@ def _case(hidden, B, T, E, seed, full=False):
 
 
 @pytest.mark.parametrize('hidden,B,T,E', [(128, 128, 31, 300), (128, 7, 12, 300), (64, 10, 9, 40), (32, 5, 12, 300), (128, 1, 5, 16),
-                                         (128, 32, 57, 300)])
+                                         (128, 32, 57, 300),
+                                         # widths beyond the register-resident kernels: W_hh streamed from L2 (d = 512 / 768 text towers)
+                                         (256, 20, 14, 300), (384, 9, 11, 300), (16, 5, 7, 20), (100, 6, 9, 24), (512, 3, 6, 32),
+                                         (256, 128, 24, 300)])
 @pytest.mark.parametrize('lengths_on', ['host', 'device'])
 def test_bigru_last_states_match_the_reference_lines(hidden, B, T, E, lengths_on):
     if not torch.cuda.is_available():
@@ -118,7 +121,9 @@ def test_unsupported_gru_stays_on_the_library():
     from creamfl_amd import ops
     dev = torch.device('cuda:0')
     x = torch.randn(2, 3, 300, device=dev)
-    assert not ops.gru_last_supported(torch.nn.GRU(300, 256, bidirectional=True, batch_first=True).to(dev), x)     # width not built
+    assert not ops.gru_last_supported(torch.nn.GRU(300, 1024, bidirectional=True, batch_first=True).to(dev), x)    # width not built
+    assert not ops.gru_last_supported(torch.nn.GRU(300, 130, bidirectional=True, batch_first=True).to(dev), x)     # not a multiple of 4
+    assert ops.gru_last_supported(torch.nn.GRU(300, 256, bidirectional=True, batch_first=True).to(dev), x)         # streamed weights
     assert not ops.gru_last_supported(torch.nn.GRU(300, 128, bidirectional=False, batch_first=True).to(dev), x)
     assert not ops.gru_last_supported(torch.nn.GRU(300, 128, bidirectional=True, batch_first=True), x.cpu())
     assert ops.gru_last_supported(torch.nn.GRU(300, 128, bidirectional=True, batch_first=True).to(dev), x)

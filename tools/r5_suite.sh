@@ -16,3 +16,16 @@ PY
 ( time python -m pytest tests -m gpu -q --durations=6 ) > $OUT/gputest.log 2>&1
 tail -14 $OUT/gputest.log | cut -c1-300
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+# every kernel of the three clients' contrast steps at the final code
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/trace_client -o cl --output-format csv -- python $ROOT/bench.py --config 2 --round none --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace_client.log 2>&1
+python3 - $OUT <<'PY'
+import csv, sys, glob
+f = (glob.glob(sys.argv[1]+'/trace_client/*kernel_stats.csv')+glob.glob(sys.argv[1]+'/trace_client/*/*kernel_stats.csv'))[0]
+rows = list(csv.DictReader(open(f)))
+w = csv.writer(open(sys.argv[1]+'/r5_client_step_kernel_stats.csv','w'))
+w.writerow(['Name','Calls','TotalDurationNs','AverageNs','Percentage','MinNs','MaxNs'])
+for r in rows: w.writerow([r['Name'][:140], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+PY
+rm -rf $OUT/trace_client
+head -12 $OUT/r5_client_step_kernel_stats.csv | cut -c1-160
