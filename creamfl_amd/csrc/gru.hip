@@ -21,6 +21,7 @@
 // The backward direction's single cell is an element-wise kernel pair (cfl_gru_cell0_*).
 // This is latency work (T dependent steps of a 3 x H x 3H product): ~2 us per step, ~40 workgroups.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -186,23 +187,29 @@ __global__ __launch_bounds__(3 * H) void cfl_gru_bwd_kernel(const float* __restr
     }
 }
 
-// ---- any width (H % 4 == 0): W_hh streamed from L2 every step -------------------------------------------------------------------
+// ---- any width (H % 4 == 0, H <= 512): W_hh streamed from L2 every step ----------------------------------------------------------
 // Beyond H = 128 a row of W_hh no longer fits a thread's registers (H = 256: 786 KB per matrix, more than a CU's register file).
-// Same block structure (a workgroup owns R rows for all their steps), 256 threads, thread t forms the columns t, t + 256, ... of
-// g from W_hh^T [H, 3H] (k-major: for a fixed k the lanes read consecutive columns, coalesced) -- 3H * H * 4 bytes through L2 -> CU
-// per step and workgroup (~5 us at H = 256), which bounds the step; the state is read from LDS once per 4 k for all the thread's
-// columns.  The library's GRU at these widths is the same ~50 launches per time step.
-constexpr int GS_T = 256, GS_R = 4, GS_C = 6;                         // threads, rows per workgroup, columns per thread (3H <= 1536)
+// Same block structure (a workgroup owns R = 2 rows for all their steps), but the matrix passes L2 -> CU once per step and
+// workgroup (3H * H * 4 bytes: ~5 us at H = 256 at the ~64 B/clk a CU pulls), which bounds the step.  To keep that stream busy
+// the CONTRACTION is split over the 8 waves: wave w owns k in [w K/8, (w + 1) K/8), lane l the output columns 4l .. 4l + 3 (+ 256 c)
+// -- one 16-byte load per lane, 1 KB contiguous per wave and k (forward: W_hh^T [H, 3H]; backward: W_hh [3H, H] itself) -- with a
+// two-stage register ring so that 6 KB per wave are in flight while the previous stage is multiplied; the 8 partial sums meet
+// in LDS and are added in wave order (deterministic).  First version of these kernels (contraction not split, 4-byte loads,
+// no ring): 70 us per step at H = 256.
+constexpr int GS_T = 512, GS_W = 8, GS_R = 2;
 
+template <int C>                                                    // 16-byte column groups per lane: 3H <= 1024 C
 __global__ __launch_bounds__(GS_T) void cfl_gru_fwd_stream_kernel(const float* __restrict__ xp, const float* __restrict__ w_hh_t,
                                                                   const float* __restrict__ b_hh, const int* __restrict__ lens,
                                                                   float* __restrict__ out, float* __restrict__ hs,
                                                                   float* __restrict__ gates, int B, int T, int H) {
+    constexpr int KS = C <= 3 ? 2 : 1;                                // k per ring stage: 6 loads of 16 bytes per lane and stage
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = 3 * H;
     float* h = sm;                                                    // [R][H]
-    float* g = sm + GS_R * H;                                         // [R][3H]
+    float* part = sm + GS_R * H;                                      // [W][R][N]
     __shared__ int slen[GS_R];
-    const int tid = threadIdx.x, b0 = blockIdx.x * GS_R, N = 3 * H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b0 = blockIdx.x * GS_R;
     if (tid < GS_R) slen[tid] = b0 + tid < B ? min(max(lens[b0 + tid], 0), T) : 0;
     for (int e = tid; e < GS_R * H; e += GS_T) {
         h[e] = 0.f;
@@ -213,46 +220,68 @@ __global__ __launch_bounds__(GS_T) void cfl_gru_fwd_stream_kernel(const float* _
     int tmax = 0;
 #pragma unroll
     for (int q = 0; q < GS_R; ++q) tmax = max(tmax, slen[q]);
-    float bj[GS_C];
+    const int kper = (H + GS_W - 1) / GS_W, k_lo = min(w * kper, H), k_hi = min(k_lo + kper, H);
+    const int nst = (k_hi - k_lo + KS - 1) / KS;
+    bool colok[C];
 #pragma unroll
-    for (int c = 0; c < GS_C; ++c) bj[c] = tid + c * GS_T < N ? b_hh[tid + c * GS_T] : 0.f;
+    for (int c = 0; c < C; ++c) colok[c] = 4 * lane + 256 * c < N;
     for (int t = 0; t < tmax; ++t) {
-        float acc[GS_R][GS_C];
+        f32x4 acc[GS_R][C];
 #pragma unroll
         for (int q = 0; q < GS_R; ++q)
 #pragma unroll
-            for (int c = 0; c < GS_C; ++c) acc[q][c] = bj[c];
-        for (int k0 = 0; k0 < H; k0 += 4) {
-            f32x4 hq[GS_R];
+            for (int c = 0; c < C; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ring0[KS][C], ring1[KS][C];                                // (two named stages: the slot must be a compile-time index)
+        auto issue = [&](int st, f32x4 (&ring)[KS][C]) {
 #pragma unroll
-            for (int q = 0; q < GS_R; ++q) hq[q] = *reinterpret_cast<const f32x4*>(h + q * H + k0);
+            for (int kk = 0; kk < KS; ++kk) {
+                const int k = min(k_lo + st * KS + kk, H - 1);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float* wr = w_hh_t + (size_t)(k0 + kk) * N + tid;
+                for (int c = 0; c < C; ++c)
+                    ring[kk][c] = colok[c] ? *reinterpret_cast<const f32x4*>(w_hh_t + (size_t)k * N + 4 * lane + 256 * c)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto mult = [&](int st, const f32x4 (&ring)[KS][C]) {
 #pragma unroll
-                for (int c = 0; c < GS_C; ++c) {
-                    if (c * GS_T < N) {                                // (uniform)
-                        const float w = tid + c * GS_T < N ? wr[c * GS_T] : 0.f;
+            for (int kk = 0; kk < KS; ++kk) {
+                const int k = k_lo + st * KS + kk;
+                if (k < k_hi) {
 #pragma unroll
-                        for (int q = 0; q < GS_R; ++q) acc[q][c] = fmaf(w, hq[q][kk], acc[q][c]);
+                    for (int q = 0; q < GS_R; ++q) {
+                        const float hv = h[q * H + k];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[q][c] += ring[kk][c] * hv;
                     }
                 }
             }
+        };
+        if (nst > 0) issue(0, ring0);
+        for (int st = 0; st < nst; st += 2) {
+            if (st + 1 < nst) issue(st + 1, ring1);
+            mult(st, ring0);
+            if (st + 2 < nst) issue(st + 2, ring0);
+            if (st + 1 < nst) mult(st + 1, ring1);
         }
 #pragma unroll
-        for (int c = 0; c < GS_C; ++c)
-            if (tid + c * GS_T < N)
+        for (int q = 0; q < GS_R; ++q)
 #pragma unroll
-                for (int q = 0; q < GS_R; ++q) g[q * N + tid + c * GS_T] = acc[q][c];
+            for (int c = 0; c < C; ++c)
+                if (colok[c]) *reinterpret_cast<f32x4*>(part + ((size_t)w * GS_R + q) * N + 4 * lane + 256 * c) = acc[q][c];
         __syncthreads();
         for (int e = tid; e < GS_R * H; e += GS_T) {
             const int q = e / H, i = e % H, b = b0 + q;
             if (b >= B) continue;
             float hv = h[e];
             if (t < slen[q]) {
+                float gr = b_hh[i], gz = b_hh[H + i], gn = b_hh[2 * H + i];
+#pragma unroll
+                for (int ww = 0; ww < GS_W; ++ww) {
+                    const float* pp = part + ((size_t)ww * GS_R + q) * N;
+                    gr += pp[i]; gz += pp[H + i]; gn += pp[2 * H + i];
+                }
                 const float* xq = xp + ((size_t)b * T + t) * N;
-                const float gn = g[q * N + 2 * H + i];
-                const float rr = sigmoidf(xq[i] + g[q * N + i]), zz = sigmoidf(xq[H + i] + g[q * N + H + i]);
+                const float rr = sigmoidf(xq[i] + gr), zz = sigmoidf(xq[H + i] + gz);
                 const float nn = tanhf(xq[2 * H + i] + rr * gn);
                 hv = (1.f - zz) * nn + zz * hv;
                 h[e] = hv;
@@ -274,20 +303,22 @@ __global__ __launch_bounds__(GS_T) void cfl_gru_fwd_stream_kernel(const float* _
     }
 }
 
-// backward: thread t forms the state-gradient elements t, t + 256, ... from W_hh [3H, H] (for a fixed j the lanes read consecutive
-// elements of row j: coalesced); the state gradient lives in LDS between steps.
-constexpr int GS_C2 = 2;                                              // state elements per thread (H <= 512)
-
+// backward: the contraction runs over the 3H hidden-side pre-activation gradients, the outputs are the H state-gradient elements:
+// lane l owns elements 4l .. 4l + 3 (+ 256 c) of W_hh's rows, wave w the rows j in its eighth of [0, 3H).
+template <int C>                                                    // H <= 256 C
 __global__ __launch_bounds__(GS_T) void cfl_gru_bwd_stream_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
                                                                   const int* __restrict__ lens, const float* __restrict__ hs,
                                                                   const float* __restrict__ gates, float* __restrict__ dxp,
                                                                   float* __restrict__ dg, int B, int T, int H) {
+    constexpr int KS = C == 1 ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = 3 * H;
     float* sg = sm;                                                   // [R][3H] hidden-side pre-activation gradients of this step
-    float* dh = sm + GS_R * 3 * H;                                    // [R][H]  gradient of the state after step t
-    float* keep = dh + GS_R * H;                                      // [R][H]  dh * z (what the state before step t keeps directly)
+    float* dh = sm + GS_R * N;                                        // [R][H]  gradient of the state after step t
+    float* keep = dh + GS_R * H;                                      // [R][H]  dh * z
+    float* part = keep + GS_R * H;                                    // [W][R][H]
     __shared__ int slen[GS_R];
-    const int tid = threadIdx.x, b0 = blockIdx.x * GS_R, N = 3 * H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b0 = blockIdx.x * GS_R;
     if (tid < GS_R) slen[tid] = b0 + tid < B ? min(max(lens[b0 + tid], 0), T) : 0;
     for (int e = tid; e < GS_R * H; e += GS_T) {
         const int b = b0 + e / H;
@@ -297,6 +328,11 @@ __global__ __launch_bounds__(GS_T) void cfl_gru_bwd_stream_kernel(const float* _
     int tmax = 0;
 #pragma unroll
     for (int q = 0; q < GS_R; ++q) tmax = max(tmax, slen[q]);
+    const int jper = (N + GS_W - 1) / GS_W, j_lo = min(w * jper, N), j_hi = min(j_lo + jper, N);
+    const int nst = (j_hi - j_lo + KS - 1) / KS;
+    bool colok[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) colok[c] = 4 * lane + 256 * c < H;
     for (int t = tmax - 1; t >= 0; --t) {
         for (int e = tid; e < GS_R * H; e += GS_T) {
             const int q = e / H, i = e % H, b = b0 + q;
@@ -319,34 +355,58 @@ __global__ __launch_bounds__(GS_T) void cfl_gru_bwd_stream_kernel(const float* _
             keep[e] = kp;
         }
         __syncthreads();
-        float acc[GS_R][GS_C2];
+        f32x4 acc[GS_R][C];
 #pragma unroll
         for (int q = 0; q < GS_R; ++q)
 #pragma unroll
-            for (int c = 0; c < GS_C2; ++c) acc[q][c] = 0.f;
-        for (int j0 = 0; j0 < N; j0 += 4) {
-            f32x4 sq[GS_R];
+            for (int c = 0; c < C; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ring0[KS][C], ring1[KS][C];
+        auto issue = [&](int st, f32x4 (&ring)[KS][C]) {
 #pragma unroll
-            for (int q = 0; q < GS_R; ++q) sq[q] = *reinterpret_cast<const f32x4*>(sg + q * N + j0);
+            for (int kk = 0; kk < KS; ++kk) {
+                const int j = min(j_lo + st * KS + kk, N - 1);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float* wr = w_hh + (size_t)(j0 + jj) * H + tid;
+                for (int c = 0; c < C; ++c)
+                    ring[kk][c] = colok[c] ? *reinterpret_cast<const f32x4*>(w_hh + (size_t)j * H + 4 * lane + 256 * c)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto mult = [&](int st, const f32x4 (&ring)[KS][C]) {
 #pragma unroll
-                for (int c = 0; c < GS_C2; ++c) {
-                    if (c * GS_T < H) {
-                        const float w = tid + c * GS_T < H ? wr[c * GS_T] : 0.f;
+            for (int kk = 0; kk < KS; ++kk) {
+                const int j = j_lo + st * KS + kk;
+                if (j < j_hi) {
 #pragma unroll
-                        for (int q = 0; q < GS_R; ++q) acc[q][c] = fmaf(w, sq[q][jj], acc[q][c]);
+                    for (int q = 0; q < GS_R; ++q) {
+                        const float sv = sg[q * N + j];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[q][c] += ring[kk][c] * sv;
                     }
                 }
             }
+        };
+        if (nst > 0) issue(0, ring0);
+        for (int st = 0; st < nst; st += 2) {
+            if (st + 1 < nst) issue(st + 1, ring1);
+            mult(st, ring0);
+            if (st + 2 < nst) issue(st + 2, ring0);
+            if (st + 1 < nst) mult(st + 1, ring1);
         }
 #pragma unroll
-        for (int c = 0; c < GS_C2; ++c)
-            if (tid + c * GS_T < H)
+        for (int q = 0; q < GS_R; ++q)
 #pragma unroll
-                for (int q = 0; q < GS_R; ++q)
-                    if (t < slen[q]) dh[q * H + tid + c * GS_T] = keep[q * H + tid + c * GS_T] + acc[q][c];
+            for (int c = 0; c < C; ++c)
+                if (colok[c]) *reinterpret_cast<f32x4*>(part + ((size_t)w * GS_R + q) * H + 4 * lane + 256 * c) = acc[q][c];
+        __syncthreads();
+        for (int e = tid; e < GS_R * H; e += GS_T) {
+            const int q = e / H;
+            if (t < slen[q]) {
+                float a = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < GS_W; ++ww) a += part[((size_t)ww * GS_R + q) * H + e % H];
+                dh[e] = keep[e] + a;
+            }
+        }
         __syncthreads();
     }
     for (int e = tid; e < GS_R * H; e += GS_T) {
@@ -401,7 +461,10 @@ constexpr int GRU_R = 3;
 
 extern "C" {
 
-static bool gru_in_registers(int H) { return H == 32 || H == 64 || H == 128; }
+static bool gru_in_registers(int H) {
+    static const bool force_stream = [] { const char* e = getenv("CFL_GRU_STREAM"); return e && e[0] == '1'; }();   // (A/B switch)
+    return !force_stream && (H == 32 || H == 64 || H == 128);
+}
 int cfl_gru_supported(int H) { return gru_in_registers(H) || (H > 0 && H % 4 == 0 && H <= 512); }
 int cfl_gru_streams_weights(int H) { return cfl_gru_supported(H) && !gru_in_registers(H); }
 
@@ -412,8 +475,15 @@ int cfl_gru_fwd(const float* xp, const float* w_hh, const float* w_hh_t, const f
     hipStream_t st = (hipStream_t)stream;
     if (!gru_in_registers(H)) {
         if (!w_hh_t) return (int)hipErrorInvalidValue;
-        CFL_LAUNCH(K_GRU_FWD, cfl_gru_fwd_stream_kernel, dim3(cfl_cdiv(B, GS_R)), dim3(GS_T), (size_t)GS_R * 4 * H * sizeof(float), st, xp,
-                   w_hh_t, b_hh, lens, out, hs, gates, B, T, H);
+        const size_t lds = ((size_t)GS_R * H + (size_t)GS_W * GS_R * 3 * H) * sizeof(float);        // H = 512: 102 KB
+        const dim3 grid(cfl_cdiv(B, GS_R));
+        if (3 * H <= 768) {
+            CFL_SET_LDS(cfl_gru_fwd_stream_kernel<3>, 100 * 1024);
+            CFL_LAUNCH(K_GRU_FWD, cfl_gru_fwd_stream_kernel<3>, grid, dim3(GS_T), lds, st, xp, w_hh_t, b_hh, lens, out, hs, gates, B, T, H);
+        } else {
+            CFL_SET_LDS(cfl_gru_fwd_stream_kernel<6>, 104 * 1024);
+            CFL_LAUNCH(K_GRU_FWD, cfl_gru_fwd_stream_kernel<6>, grid, dim3(GS_T), lds, st, xp, w_hh_t, b_hh, lens, out, hs, gates, B, T, H);
+        }
         return 0;
     }
     const dim3 grid(cfl_cdiv(B, GRU_R));
@@ -432,8 +502,12 @@ int cfl_gru_bwd(const float* dout, const float* w_hh, const int* lens, const flo
     if (!cfl_gru_supported(H)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     if (!gru_in_registers(H)) {
-        CFL_LAUNCH(K_GRU_BWD, cfl_gru_bwd_stream_kernel, dim3(cfl_cdiv(B, GS_R)), dim3(GS_T), (size_t)GS_R * 5 * H * sizeof(float), st, dout,
-                   w_hh, lens, hs, gates, dxp, dg, B, T, H);
+        const size_t lds = ((size_t)GS_R * 3 * H + 2 * (size_t)GS_R * H + (size_t)GS_W * GS_R * H) * sizeof(float);   // H = 512: 53 KB
+        const dim3 grid(cfl_cdiv(B, GS_R));
+        if (H <= 256)
+            CFL_LAUNCH(K_GRU_BWD, cfl_gru_bwd_stream_kernel<1>, grid, dim3(GS_T), lds, st, dout, w_hh, lens, hs, gates, dxp, dg, B, T, H);
+        else
+            CFL_LAUNCH(K_GRU_BWD, cfl_gru_bwd_stream_kernel<2>, grid, dim3(GS_T), lds, st, dout, w_hh, lens, hs, gates, dxp, dg, B, T, H);
         return 0;
     }
     const dim3 grid(cfl_cdiv(B, GRU_R));
