@@ -367,3 +367,34 @@ def test_device_prefetcher_passes_cpu_loaders_through_and_keeps_the_contract():
     assert len(pf) == len(loader) == 3 and pf.dataset is loader.dataset
     for a, b in zip(pf, loader):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[6] == b[6]
+
+
+def test_caption_padding_of_the_captured_text_step_and_the_cpu_text_path():
+    """Host logic around gru.hip: the one caption width a text client's captured step pads to; padding with the pad token;
+    EncoderText's sentence states on the CPU (no HIP): the library formulation = the reference's lines, unchanged by extra
+    padding (the packed recurrence never reaches padded words)."""
+    import torch
+    from creamfl_amd import ops
+    from creamfl_amd.algorithms.ClientTrainer import caption_graph_width, pad_captions
+    assert caption_graph_width(24) == 32 and caption_graph_width(21) == 32 and caption_graph_width(25) == 40
+    assert caption_graph_width(3) == 32 and caption_graph_width(32) == 40 and caption_graph_width(57) % 8 == 0
+    cap = torch.arange(12).view(2, 6) + 1
+    p = pad_captions(cap, 9)
+    assert p.shape == (2, 9) and torch.equal(p[:, :6], cap) and int(p[:, 6:].abs().sum()) == 0
+    assert pad_captions(cap, 6) is cap and pad_captions(cap, 4) is cap
+    # the CPU path never claims the HIP recurrence
+    rnn = torch.nn.GRU(8, 128, bidirectional=True, batch_first=True)
+    assert not ops.gru_last_supported(rnn) and not ops.gru_last_supported(rnn, torch.zeros(2, 3, 8))
+    assert not ops.gru_last_supported(None)
+    emb = torch.nn.Embedding(20, 8)
+    tok = torch.randint(0, 20, (3, 5))
+    assert torch.equal(ops.embedding_lookup(emb, tok), emb(tok))           # CPU: the module itself
+    from creamfl_amd.networks.language_model import EncoderText
+    torch.manual_seed(0)
+    m = EncoderText(embed_dim=64, vocab_size=50)
+    tokens = torch.randint(1, 50, (4, 7))
+    lengths = torch.tensor([7, 5, 2, 1])
+    tokens[torch.arange(7)[None] >= lengths[:, None]] = 0
+    a, words = m.sentence_states(tokens, lengths)                          # (the PIE head behind it has no CPU path, by design)
+    b, words_b = m.sentence_states(pad_captions(tokens, 12), lengths)
+    assert a.shape == (4, 64) and words_b.shape == (4, 12, 300) and float((a - b).abs().max()) <= 1e-6
