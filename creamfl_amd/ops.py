@@ -561,10 +561,11 @@ class _GruCell0Fn(torch.autograd.Function):
 
 
 class _EmbeddingFn(torch.autograd.Function):
-    """nn.Embedding's lookup with a backward that stays on the device: one index_add_ (atomic adds into the zeroed table).
-    torch's dense embedding backward switches, above 3072 indices, to a sort / unique-by-key path that reads a count back to the
-    host -- a host synchronisation per step in the eager text loops, and inside a HIP-graph capture a count read at capture time
-    and baked into the replays' launch sizes (seen as a memory fault in the replay of a text client's step padded to 128 x 32)."""
+    """nn.Embedding's lookup with the backward as ONE index_add_ (atomic adds into the zeroed table).  torch's dense embedding
+    backward switches, above 3072 indices, to a sort / unique-by-key path: ~10 launches and 70-180 us of host time per call
+    where this one takes 10 (tools/embed_sync_probe.py; neither waits for the device), and on this stack that path does not
+    survive a HIP-graph capture -- the replay of a text client's step padded to 128 x 32 = 4096 indices died with a memory
+    fault (profiles/r5_embed_backward_probe.json), the same step with this backward replays."""
 
     @staticmethod
     def forward(ctx, tokens, weight):
@@ -582,7 +583,7 @@ class _EmbeddingFn(torch.autograd.Function):
 
 def embedding_lookup(embed, tokens):
     """`embed(tokens)` for a plain nn.Embedding on the GPU (no padding_idx / max_norm / sparse gradients / frequency scaling: the
-    reference's text towers, language_model.py:39, caption_encoder.py:39) with the sync-free backward above; anything else goes to
+    reference's text towers, language_model.py:39, caption_encoder.py:39) with the capturable backward above; anything else goes to
     the module itself."""
     w = embed.weight
     if (w.is_cuda and tokens.is_cuda and embed.padding_idx is None and embed.max_norm is None and not embed.sparse

@@ -170,7 +170,7 @@ def test_text_client_encoder_trains_the_same_on_both_recurrences():
 
 @pytest.mark.parametrize('shape', [(16, 12), (128, 32)])                # 192 and 4096 indices: both sides of torch's 3072 switch
 def test_embedding_lookup_matches_nn_embedding(shape):
-    """ops.embedding_lookup (index_select forward, index_add_ backward: no host read-back) against nn.Embedding."""
+    """ops.embedding_lookup (index_select forward, index_add_ backward: one launch, capturable) against nn.Embedding."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from creamfl_amd import ops
