@@ -270,7 +270,7 @@ class PhaseClock:
         self._undo = []
 
 
-def timed_round(algo, use_dist):
+def timed_round(algo, use_dist, round_n=0):
     from creamfl_amd import dist as cdist
     clk = PhaseClock()
     clk.wrap(algo.engine, 'train', 'global_train')
@@ -318,7 +318,7 @@ def timed_round(algo, use_dist):
             finally:
                 cdist.all_gather_cat = orig_agc
         algo.aggregation = aggregation
-        algo.train(0)
+        algo.train(round_n)
     finally:
         cdist.RepGatherBuffer.gather = orig_gather
         cdist.all_gather_cat = orig_agc
@@ -477,7 +477,11 @@ def run(a, world, rank, dev, use_dist, json_out):
             warm_s = round(time.perf_counter() - t0, 1)
             del mini
             torch.cuda.empty_cache()
-        ph, counts, comm, sampled = timed_round(algo, use_dist)
+        # the federation's FIRST round starts on an empty allocator and a fresh server engine (its first steps allocate their
+        # gigabytes: 44 ms per public batch where the same loop runs 28-35 ms warm, tools/server_phase_probe.py); every later round
+        # of a real run is the steady state, so the SECOND round is the one reported phase by phase, the first one beside it
+        ph0, _, _, _ = timed_round(algo, use_dist, 0)
+        ph, counts, comm, sampled = timed_round(algo, use_dist, 1)
         if use_dist:
             keys = sorted(ph)
             t = torch.tensor([ph[k] for k in keys], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
@@ -490,6 +494,9 @@ def run(a, world, rank, dev, use_dist, json_out):
         per_batch = {k: round(ph_max[k] / n_pub_batches * 1e3, 2) for k in ('global_train', 'global_reps', 'kd') if k in ph_max}
         rnd = {'pub_data_num': Mr, 'public_batches': n_pub_batches, 'clients_sampled': sampled,
                'miniature_warm_up_round_s': warm_s, 'ms_per_public_batch': per_batch,
+               'timed_round': 'the second round of the federation (steady state: warm allocator, warm server engine); the first '
+                              'round is in first_round_phases_s_rank0',
+               'first_round_phases_s_rank0': {k: round(v, 3) for k, v in sorted(ph0.items())},
                'scaling_note': 'every loop of the round is linear in the public batches (391 at the full M = 50 000); con_w '
                                '(quadratic in M) and the representation all-gather are in `full_M` at the full size',
                'clients_trained_by_this_rank': counts.get('clients_train', 0),

@@ -222,7 +222,8 @@ class ClientTrainer:
             self.top1.update(stats[3], inputs_bt.size(0))
             self.top5.update(stats[4], inputs_bt.size(0))
             self.losses.update(total_loss.detach(), inputs_bt.size(0))
-            total_loss.backward()
+            with runtime.backward_here():
+                total_loss.backward()
             self.optimizer.step()
             if is_test:
                 break
@@ -251,7 +252,8 @@ class ClientTrainer:
                                               interintra_weight=self.args.interintra_weight,
                                               loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
                                               use_intra=use_intra)
-            loss.backward()
+            with runtime.backward_here():
+                loss.backward()
             self.optimizer.step()
             return loss.detach()
         return step

@@ -7,6 +7,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import runtime
 from ..utils.prefetch import DevicePrefetcher
 from .base import EngineBase
 from .contrast import mm_client_contrast_loss
@@ -59,7 +60,8 @@ class MMClientTrainer(EngineBase):
 
     def _step(self, loss):
         self.optimizer.zero_grad()
-        loss.backward()
+        with runtime.backward_here():
+            loss.backward()
         clip = self.config.train.grad_clip
         if isinstance(self.optimizer, AdamP):
             self.optimizer.step(clip=(self.model.parameters(), clip) if clip > 0 else None)

@@ -195,6 +195,13 @@ class MMFL(object):
     def train(self, round_n):
         self.cur_epoch = round_n
         self.cur_trainers = self.total_local_trainers
+        if not getattr(self, '_gc_frozen', False) and os.environ.get('CFL_NO_GC_FREEZE', '0') != '1':
+            # a federation is ~27 models' worth of long-lived Python objects; every step of the host-bound loops allocates
+            # thousands of short-lived ones (autograd nodes, Function contexts), so the cyclic collector keeps re-walking the
+            # permanent ones.  Move what exists now out of its reach, once (objects are still freed by reference count).
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
         # multi-rank: the server phases (global contrastive training, KD) are REPLICATED by default -- every rank does the whole
         # public batch: bit-for-bit the single-process round, full-batch BatchNorm statistics (the reference's semantics).
         # `--server_dp 1` (creamfl_amd/flags.py) makes them DATA-PARALLEL: every rank encodes 1/W of each public batch, features

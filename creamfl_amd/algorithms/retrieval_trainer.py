@@ -50,6 +50,7 @@ class EngineBase(object):
         self.dp = None                       # creamfl_amd.dist.DataParallelContext when enabled
         self.shard_batches = False           # multi-rank: train() / the KD loop give every rank 1/W of each batch (MMFL --server_dp)
         self._conv1x1_weights = None         # weights whose transposes are prepared in one launch before backward
+        self._clip_params = None             # (id(model), its parameter list) for the gradient clip
 
     def create(self, config, word2idx, evaluator, mlp_local):
         runtime.configure()                  # MIOpen find mode / recorded find-db / cudnn.benchmark before the first convolution
@@ -305,7 +306,8 @@ class TrainerEngine(EngineBase):
                                      and (m.kernel_size == (1, 1) or m.padding == (m.kernel_size[0] // 2,) * 2)]
         ops.prepare_weight_transposes(self._conv1x1_weights)
         try:
-            loss.backward()
+            with runtime.backward_here():            # (no hand-over to autograd's worker thread: the step is host-bound at batch 128)
+                loss.backward()
         finally:
             ops.release_weight_transposes()
 
@@ -313,11 +315,16 @@ class TrainerEngine(EngineBase):
         """clip_grad_norm_(model.parameters(), grad_clip) + optimizer.step() (:211-214); fused into the
         multi-tensor HIP kernels when the optimizer is creamfl_amd's AdamP."""
         clip = self.config.train.grad_clip
+        if clip > 0:
+            # the module tree is walked once, not every step (500 modules: 1.3 ms of a 29 ms host-bound step); a model swapped in
+            # later (load_models / set_model) shows up as another id
+            if getattr(self, '_clip_params', None) is None or self._clip_params[0] != id(self.model):
+                self._clip_params = (id(self.model), list(self.model.parameters()))
         if isinstance(self.optimizer, AdamP):
-            self.optimizer.step(clip=(self.model.parameters(), clip) if clip > 0 else None)
+            self.optimizer.step(clip=(self._clip_params[1], clip) if clip > 0 else None)
         else:
             if clip > 0:
-                nn.utils.clip_grad.clip_grad_norm_(self.model.parameters(), clip)
+                nn.utils.clip_grad.clip_grad_norm_(self._clip_params[1], clip)
             self.optimizer.step()
 
     def train(self, tr_loader, pub_data_ratio=1.):

@@ -1,6 +1,10 @@
 set -x
-mkdir -p gpurun_out/gru
-for h in 64 128; do python tools/gru_probe.py --hidden $h >> gpurun_out/gru/probe.jsonl 2>> gpurun_out/gru/probe.err; CFL_GRU_STREAM=1 python tools/gru_probe.py --hidden $h >> gpurun_out/gru/probe.jsonl 2>> gpurun_out/gru/probe.err; done
-CFL_GRU_STREAM=1 python -m pytest tests/test_gpu_gru.py -x -q 2>&1 | tail -3
-CFL_GRU_STREAM=1 python bench.py --config 2 --round none --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/gru/c2_stream.json 2> gpurun_out/gru/c2_stream.err
-cat gpurun_out/gru/probe.jsonl
+mkdir -p gpurun_out/bh
+python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bh/c2_freeze.json 2> gpurun_out/bh/c2_freeze.err
+CFL_NO_GC_FREEZE=1 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bh/c2_nofreeze.json 2> gpurun_out/bh/c2_nofreeze.err
+python - <<'PY'
+import json
+for f in ('c2_freeze','c2_nofreeze'):
+    d=json.loads(open('gpurun_out/bh/%s.json'%f).read().strip().splitlines()[-1])
+    print(f, d['round']['phases_s_rank0'], d['round']['ms_per_public_batch']); print('   first', d['round']['first_round_phases_s_rank0'])
+PY
