@@ -157,7 +157,17 @@ class StepHarness:
             t.old_model = copy.deepcopy(t.model).eval()
             step = t.contrast_step_fn(g_img, g_txt, True, True)
             self.eager = lambda: step(images, captions, None, lens, self.d_idx_host)
-            self.graph_fn, self.graph_in = None, None
+            self.graph_fn, self.graph_in, self.graph_opt = None, None, None
+            from creamfl_amd import flags, ops
+            from creamfl_amd.algorithms.ClientTrainer import caption_graph_width, pad_captions
+            from creamfl_amd.algorithms.optimizers import AdamP
+            if (isinstance(t.optimizer, AdamP) and int(flags.get(t.args, 'mm_client_graph')) and t.model.config.not_bert
+                    and ops.gru_last_supported(getattr(t.model.txt_enc, 'rnn', None))):
+                # the product path since the fused AdamP reads its step count on the device (MMClientTrainer._graphed_for_round)
+                width = caption_graph_width(captions.shape[1])
+                self.graph_fn = lambda im, cap, ln, di: step(im, cap, None, ln, di)
+                self.graph_in = (images, pad_captions(captions, width), torch.as_tensor(lens, dtype=torch.int64), self.d_idx_dev)
+                self.graph_opt = t.optimizer
         else:
             t.model.train()
             t.old_model = copy.deepcopy(t.model).eval()
@@ -222,7 +232,7 @@ def measure_client(trainer, kind, banks, batch, dev, steps, warmup, use_dist=Fal
     out['eager'] = {'ms_per_step': round(dt / steps * 1e3, 3), 'pairs_per_s': round(h.B * steps / dt, 1), 'seconds': dt}
     out['bank_pass'] = None if not bank else {'launches': bank[0], 'avg_launch_us': round(bank[1] / bank[0] * 1e3, 2)}
     if h.graph_fn is not None:
-        gs = GraphedStep(h.graph_fn, warmup=3)
+        gs = GraphedStep(h.graph_fn, warmup=3, optimizer=getattr(h, 'graph_opt', None))
         for _ in range(4 + max(0, warmup)):                       # 3 eager warm-ups, the capture (+ first replay), replays
             gs(*h.graph_in, device=dev)
         dtg, loss = _wall(lambda: gs(*h.graph_in, device=dev), steps, False)     # (local fences: the multi-modal client has no such region)

@@ -105,6 +105,8 @@ SIGNATURES = {
     'cfl_grad_clip_coef': (c_int, [_P, _P, c_int, c_float, _P, _P, _P]),
     'cfl_adamp_step': (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P, c_float, c_float, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int, _P, _P]),
+    'cfl_adamp_step_counted': (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P, c_float, c_float, c_float, c_float, c_float,
+                                       c_float, c_float, c_int, _P, _P, _P]),
 }
 
 _lib = None

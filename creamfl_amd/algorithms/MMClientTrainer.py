@@ -8,8 +8,10 @@ import torch
 import torch.nn as nn
 
 from .. import runtime
+from ..graphs import GraphedStep
 from ..utils.prefetch import DevicePrefetcher
 from .base import EngineBase
+from .ClientTrainer import caption_graph_width, pad_captions
 from .contrast import mm_client_contrast_loss
 from .optimizers import AdamP
 
@@ -37,6 +39,9 @@ class MMClientTrainer(EngineBase):
             os.makedirs('./saved_clients/Flicker30K', exist_ok=True)
             torch.save(self.model.state_dict(),
                        f'./saved_clients/Flicker30K/Client{self.client}-model_{self.local_epoch}.pth')
+        gs = getattr(self, '_graphed_contrast', None)
+        self.graph_stats = None if gs is None else {'calls': gs.calls, 'replays': gs.replays, 'failed': gs.failed}
+        self._graphed_contrast = self._graphed_key = None       # the round's graph (and its private pool) goes with the old model
         del self.old_model
         self.old_model = None
 
@@ -87,12 +92,46 @@ class MMClientTrainer(EngineBase):
         distill_dict = {b: a for a, b in enumerate(distill_index)}
         self.last_contrast_loss = None
         contrast_step = self.contrast_step_fn(g_img, g_txt, use_intra, use_inter)
+        graphed = self._graphed_for_round(contrast_step, g_img, g_txt, use_intra, use_inter)
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(DevicePrefetcher(global_train_loader, self.device)):
             d_idx = operator.itemgetter(*index)(distill_dict)
             d_idx = d_idx if isinstance(d_idx, tuple) else (d_idx,)
-            self.last_contrast_loss = contrast_step(images, captions, captions_word, caption_lens, d_idx)
+            if graphed is not None:
+                if graphed.caption_width is None:
+                    graphed.caption_width = caption_graph_width(captions.shape[1])
+                self.last_contrast_loss = graphed(images, pad_captions(captions, graphed.caption_width),
+                                                  torch.as_tensor(caption_lens, dtype=torch.int64),
+                                                  torch.as_tensor(d_idx, dtype=torch.int64), device=torch.device(self.device))
+            else:
+                self.last_contrast_loss = contrast_step(images, captions, captions_word, caption_lens, d_idx)
             if is_test:
                 break
+
+    def _graphed_for_round(self, contrast_step, g_img, g_txt, use_intra, use_inter):
+        """The contrast step as ONE HIP graph per round (banks, old model and learning rate are constants of a round; the local
+        epochs of a round replay the first one's graph), like the uni-modal clients (ClientTrainer.tra): GRU text tower with the
+        caption lengths on the device (gru.hip), captions padded to one width, and the fused AdamP with its step count on the
+        device (AdamP.prepare_capture).  None when the step is not capturable (BERT text tower with a tokenizer, another
+        optimizer, the CPU) or switched off (--client_graph 0 / --mm_client_graph 0)."""
+        from .. import flags, ops
+        if is_test or torch.device(self.device).type != 'cuda' or not isinstance(self.optimizer, AdamP):
+            return None
+        if not (int(flags.get(self.args, 'client_graph')) and int(flags.get(self.args, 'mm_client_graph'))):
+            return None
+        if not (self.model.config.not_bert and ops.gru_last_supported(getattr(self.model.txt_enc, 'rnn', None))):
+            return None
+        key = (id(self.old_model), g_img.data_ptr(), g_txt.data_ptr(), use_intra, use_inter,
+               tuple(g['lr'] for g in self.optimizer.param_groups))
+        graphed = getattr(self, '_graphed_contrast', None)
+        if graphed is None or getattr(self, '_graphed_key', None) != key:
+            self._graphed_contrast = None                                    # (the old graph first: its pinned tables return)
+            log = (lambda m: self.logger.log(m)) if self.logger is not None else None
+            graphed = self._graphed_contrast = GraphedStep(
+                lambda images, captions, lens, d_idx: contrast_step(images, captions, None, lens, d_idx),
+                warmup=3, log=log, optimizer=self.optimizer)
+            graphed.caption_width = None
+            self._graphed_key = key
+        return graphed
 
     def contrast_step_fn(self, g_img, g_txt, use_intra, use_inter):
         """The multi-modal client's contrast step against the round's frozen banks (MMClientTrainer.py:150-224) as a function

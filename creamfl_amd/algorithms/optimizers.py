@@ -9,6 +9,7 @@ issues no host synchronisation (the package syncs once or twice per parameter te
 """
 import ctypes
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -34,6 +35,12 @@ class AdamP(Optimizer):
         self._plans = {}
         self.grad_override = None        # {parameter: tensor to read its gradient from} (multi-GPU: dist.GradBuckets views)
         self.grad_override_consume = None   # callable: raises unless those views hold THIS backward pass's averages
+        # steps replayed from a HIP graph (graphs.GraphedStep): see prepare_capture()
+        self._gstep_host = 0             # step() calls + replays so far ...
+        self._gstep_dev = None           # ... and the same count on the device once a capture was prepared
+        self._capture = None             # the CaptureHandle of the capture in progress
+        self._handles = []               # handles with replays not yet folded into state[p]['step']
+        self._live = weakref.WeakSet()   # handles of captured steps that are still valid
 
     META_DTYPE = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64), ('p16', np.uint64),
                            ('numel', np.int64), ('inner', np.int64), ('row_base', np.int64),
@@ -52,6 +59,8 @@ class AdamP(Optimizer):
         as fp32, would write past the buffers.  Restore them from the incoming state dict as fp32, in the parameter's
         memory layout."""
         from itertools import chain
+        self._flush_replays()
+        self._void_captures()            # step counts change under any captured step
         incoming = {pid: {k: v for k, v in st.items() if k in self.FP32_STATE and torch.is_tensor(v)}
                     for pid, st in state_dict['state'].items()}
         saved_ids = list(chain.from_iterable(g['params'] for g in state_dict['param_groups']))
@@ -104,8 +113,10 @@ class AdamP(Optimizer):
         `src`'s.  Broadcasting the bf16 weights alone is not enough: the next step rewrites each weight from the
         rank's own master."""
         import torch.distributed as dist
+        self._flush_replays()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
+        self._void_captures()            # the step counts are about to change under any captured step
         # Which parameters carry which state is identical on every rank (same model, same history of None gradients), so the
         # whole state travels as ONE flat fp32 tensor per device plus one int64 vector of step counts -- not ~4 small
         # broadcasts and a host sync per parameter (~2000 collectives for ResNet-101 + BERT-base).
@@ -169,6 +180,85 @@ class AdamP(Optimizer):
         for (p, st), n in zip(held, steps.tolist()):
             st['step'] = int(n)
         self._plans = {}
+
+    # ---- steps inside a HIP graph -------------------------------------------------------------------------------------
+    # A captured step cannot carry the step count (the bias corrections) or this call's gradient pointers as host values.
+    # Inside a stream capture step() therefore (a) uploads the tensor table from a pinned buffer of its own -- the copy is a
+    # node of the graph, so every replay restores the CAPTURED gradient addresses (the graph's private pool: static) after
+    # whatever an eager step in between uploaded -- and (b) launches cfl_adamp_step_counted, which reads the optimizer's step
+    # counter on the device; the table's `step` fields hold every tensor's offset from that counter.  The counter is
+    # incremented on the stream by every step (captured `add_`, or eagerly once a capture was prepared).  The host's
+    # state[p]['step'] of replayed steps is folded in lazily (CaptureHandle.replayed -> _flush_replays at the next step(),
+    # state_dict() or broadcast_state()).  A captured step stays valid while every step in between updates AT LEAST the
+    # parameters it updates (its offsets are differences of step counts: a step that skips one of its parameters -- the KD step
+    # and the criterion's scalars -- moves the counter without it); CaptureHandle.valid() says so, GraphedStep asks before a replay.
+
+    class CaptureHandle:
+        def __init__(self, opt):
+            self.opt = opt
+            self.plans = []              # the plans of the captured step (kept alive with the graph that addresses their buffers)
+            self.params = []             # the parameters it updates
+            self.pending = 0             # replays not yet counted in state[p]['step']
+            self.ids = frozenset()
+            self.stale = False
+
+        def replayed(self):
+            o = self.opt
+            o._gstep_host += 1
+            self.pending += 1
+            if self not in o._handles:
+                o._handles.append(self)
+            if len(o._live) > 1:         # another captured step whose parameters this one does not all update
+                for h in list(o._live):
+                    if h is not self and not h.ids <= self.ids:
+                        h.stale = True
+                        o._live.discard(h)
+
+        def valid(self):
+            return not self.stale
+
+        def __del__(self):               # the graph is gone: its pinned tables go back to their plans
+            for plan, pin in self.plans:
+                plan['cap_pins'].append(pin)
+
+    def prepare_capture(self, device=None):
+        """Call BEFORE the warm-up steps of a step that will be captured: creates the device-side step counter (an
+        allocation + a fill cannot happen inside the capture: they would be replayed)."""
+        if self._gstep_dev is None:
+            if device is None:
+                device = next(p.device for g in self.param_groups for p in g['params'])
+            self._gstep_dev = torch.tensor([self._gstep_host], dtype=torch.int32, device=device)
+
+    def capture_begin(self):
+        if self._gstep_dev is None:
+            raise _lib.CreamflHipError('AdamP.capture_begin() without prepare_capture()')
+        self._flush_replays()
+        self._capture = AdamP.CaptureHandle(self)
+        return self._capture
+
+    def capture_end(self, handle):
+        if self._capture is handle:
+            self._capture = None
+        handle.ids = frozenset(id(p) for p in handle.params)
+        self._live.add(handle)
+        return handle
+
+    def _void_captures(self):
+        for h in list(self._live):
+            h.stale = True
+        self._live.clear()
+
+    def _flush_replays(self):
+        for h in self._handles:
+            if h.pending:
+                for p in h.params:
+                    self.state[p]['step'] += h.pending
+                h.pending = 0
+        del self._handles[:]
+
+    def state_dict(self):
+        self._flush_replays()
+        return super().state_dict()
 
     PIN_SLOTS = 4
 
@@ -245,6 +335,7 @@ class AdamP(Optimizer):
             'partial': torch.empty(len(items), dtype=torch.float32, device=dev),
             'clip': torch.ones(2, dtype=torch.float32, device=dev),
             'gptrs': None,
+            'cap_pins': [torch.empty(meta.nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)],
         }
         self._plans[gi] = plan
         return plan
@@ -263,6 +354,16 @@ class AdamP(Optimizer):
         if clip is not None:
             clip_ids, max_norm = {id(p) for p in clip[0]}, float(clip[1])
         self.last_grad_norm = None
+        capturing = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
+        if capturing and self._capture is None:
+            raise _lib.CreamflHipError('AdamP.step() inside a stream capture needs prepare_capture() before the warm-up steps and '
+                                       'capture_begin() / capture_end() around the capture (graphs.GraphedStep(optimizer=...))')
+        if self._handles:
+            self._flush_replays()
+        self._gstep_host += 1
+        if self._gstep_dev is not None:
+            self._gstep_dev.add_(1)          # (a node of the graph when capturing)
+        stepped = set()
         if self.grad_override is not None and self.grad_override_consume is not None:
             self.grad_override_consume()
         work = []
@@ -281,6 +382,8 @@ class AdamP(Optimizer):
                     if p.dtype == torch.bfloat16 and 'master' not in st:
                         st['master'] = p.detach().to(torch.float32, memory_format=torch.preserve_format)
                 st['step'] += 1
+            if self._live:
+                stepped.update(id(p) for p in params)
             plan = self._plan(gi, params, clip_ids)
             grads = []
             ov = self.grad_override
@@ -297,7 +400,22 @@ class AdamP(Optimizer):
             # travel as the launch argument; otherwise every tensor's own count goes into its meta record.
             steps = [int(self.state[p]['step']) for p in params]
             tsteps = np.zeros(len(params), dtype=np.int32) if min(steps) == max(steps) else np.asarray(steps, dtype=np.int32)
-            if gptrs != plan['gptrs'] or not np.array_equal(plan['meta']['step'], tsteps):
+            if capturing:
+                # the table of THIS graph: captured gradient addresses, step offsets from the device counter; uploaded by a node
+                # of the graph from a pinned buffer nothing else writes
+                cap = plan['meta'].copy()
+                cap['g'] = np.asarray(gptrs, dtype=np.uint64)
+                cap['step'] = np.asarray(steps, dtype=np.int64) - self._gstep_host
+                if not plan['cap_pins']:
+                    raise _lib.CreamflHipError('AdamP: no pinned table left for another capture of this step (two live graphs '
+                                               'already address it; drop the old GraphedStep first)')
+                pin = plan['cap_pins'].pop()     # (pinned memory cannot be allocated inside a capture: a pool made with the plan)
+                pin.numpy().view(self.META_DTYPE)[:] = cap
+                plan['meta_dev'].copy_(pin, non_blocking=True)
+                plan['captured'] = True          # the device table is the graph's after every replay: eager steps re-upload
+                self._capture.plans.append((plan, pin))
+                self._capture.params.extend(params)
+            elif plan.get('captured') or gptrs != plan['gptrs'] or not np.array_equal(plan['meta']['step'], tsteps):
                 plan['meta']['g'] = np.asarray(gptrs, dtype=np.uint64)
                 plan['meta']['step'] = tsteps
                 self._upload_meta(plan)
@@ -310,6 +428,10 @@ class AdamP(Optimizer):
                                                   plan['partial'].data_ptr(), plan['clip'].data_ptr(), stream),
                            'cfl_grad_clip_coef')
             work.append((group, params, plan, grads, steps, stream, n_items, clipped))
+        for h in list(self._live):           # (an eager step between replays, or another captured step being recorded)
+            if not h.ids <= stepped:
+                h.stale = True
+                self._live.discard(h)
         clipped_plans = [w[2] for w in work if w[7]]
         if len(clipped_plans) > 1:
             # clip_grad_norm_ is ONE norm over every clipped parameter, whatever group it sits in: combine the groups' norms
@@ -324,6 +446,14 @@ class AdamP(Optimizer):
         for group, params, plan, grads, steps, stream, n_items, clipped in work:
             clip_ptr = ctypes.c_void_p(plan['clip'].data_ptr()) if clipped else ctypes.c_void_p(0)
             beta1, beta2 = group['betas']
+            if capturing:
+                _lib.check(lib.cfl_adamp_step_counted(
+                    plan['meta_dev'].data_ptr(), len(params), plan['items'].data_ptr(), n_items, plan['matrix_ids'].data_ptr(),
+                    plan['n_matrix'], plan['rowstats'].data_ptr(), plan['tstats'].data_ptr(), float(group['lr']), float(beta1),
+                    float(beta2), float(group['eps']), float(group['weight_decay']), float(group['delta']),
+                    float(group['wd_ratio']), int(bool(group['nesterov'])), self._gstep_dev.data_ptr(), clip_ptr, stream),
+                    'cfl_adamp_step_counted')
+                continue
             _lib.check(lib.cfl_adamp_step(plan['meta_dev'].data_ptr(), len(params), plan['items'].data_ptr(), n_items,
                                           plan['matrix_ids'].data_ptr(), plan['n_matrix'], plan['rowstats'].data_ptr(),
                                           plan['tstats'].data_ptr(), float(group['lr']), float(beta1), float(beta2),

@@ -19,6 +19,8 @@ namespace {
 struct Hyper {
     float beta1, beta2, eps, lr, wd, delta, wd_ratio, bc1, bc2, max_norm;
     int nesterov;
+    const int* gstep;       // cfl_adamp_step_counted: the optimizer's step counter on the device (a replayed HIP graph cannot carry a
+                            // host count as a launch argument); CflTensorMeta.step is then every tensor's OFFSET from it
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -97,9 +99,13 @@ __global__ __launch_bounds__(256) void cfl_gradnorm_final_kernel(const float* pa
 }
 
 // bias corrections of ONE tensor: its own step count when the host filled it in (steps differ inside the group), else the
-// launch-wide one
+// launch-wide one; with a device counter, counter + the tensor's offset
 __device__ __forceinline__ void bias_corr(const CflTensorMeta& tm, const Hyper& h, float& bc1, float& bc2) {
-    if (tm.step > 0) {
+    if (h.gstep) {
+        const int s = max(1, *h.gstep + tm.step);
+        bc1 = 1.f - powf(h.beta1, (float)s);
+        bc2 = 1.f - powf(h.beta2, (float)s);
+    } else if (tm.step > 0) {
         bc1 = 1.f - powf(h.beta1, (float)tm.step);
         bc2 = 1.f - powf(h.beta2, (float)tm.step);
     } else {
@@ -273,6 +279,30 @@ __global__ __launch_bounds__(256) void cfl_adamp_pass3_kernel(const CflTensorMet
 
 }  // namespace
 
+static int adamp_launch(const CflTensorMeta* meta_dev, int n_tensors, const int* items_dev, int n_items,
+                        const int* matrix_ids_dev, int n_matrix, float* rowstats_ws, float* tstats_ws,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, float delta,
+                        float wd_ratio, int nesterov, int step, const int* gstep_dev, const float* clip_dev, void* stream_) {
+    if (!meta_dev || !items_dev || n_tensors <= 0 || n_items <= 0 || step <= 0) return CFL_EINVAL;
+    if (n_matrix > 0 && (!matrix_ids_dev || !rowstats_ws || !tstats_ws)) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    Hyper h;
+    h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.lr = lr; h.wd = weight_decay; h.delta = delta;
+    h.wd_ratio = wd_ratio; h.nesterov = nesterov; h.max_norm = 0.f; h.gstep = gstep_dev;
+    h.bc1 = 1.f - powf(beta1, (float)step);
+    h.bc2 = 1.f - powf(beta2, (float)step);
+    CFL_LAUNCH(K_ADAMP_PASS1, cfl_adamp_pass1_kernel, dim3(n_items), dim3(256), 0, stream, meta_dev, items_dev, h, clip_dev,
+               rowstats_ws);
+    if (n_matrix > 0) {
+        CFL_LAUNCH(K_ADAMP_DECIDE, cfl_adamp_decide_kernel, dim3(n_matrix), dim3(256), 0, stream, meta_dev, matrix_ids_dev, h,
+                   rowstats_ws, tstats_ws);
+        CFL_LAUNCH(K_ADAMP_PASS3, cfl_adamp_pass3_kernel, dim3(n_items), dim3(256), 0, stream, meta_dev, items_dev, h, clip_dev,
+                   rowstats_ws, tstats_ws);
+    }
+    return 0;
+}
+
+
 extern "C" {
 
 int cfl_grad_clip_coef(const CflTensorMeta* meta_dev, const int* items_dev, int n_items, float max_norm,
@@ -288,23 +318,17 @@ int cfl_adamp_step(const CflTensorMeta* meta_dev, int n_tensors, const int* item
                    const int* matrix_ids_dev, int n_matrix, float* rowstats_ws, float* tstats_ws,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float delta,
                    float wd_ratio, int nesterov, int step, const float* clip_dev, void* stream_) {
-    if (!meta_dev || !items_dev || n_tensors <= 0 || n_items <= 0 || step <= 0) return CFL_EINVAL;
-    if (n_matrix > 0 && (!matrix_ids_dev || !rowstats_ws || !tstats_ws)) return CFL_EINVAL;
-    hipStream_t stream = (hipStream_t)stream_;
-    Hyper h;
-    h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.lr = lr; h.wd = weight_decay; h.delta = delta;
-    h.wd_ratio = wd_ratio; h.nesterov = nesterov; h.max_norm = 0.f;
-    h.bc1 = 1.f - powf(beta1, (float)step);
-    h.bc2 = 1.f - powf(beta2, (float)step);
-    CFL_LAUNCH(K_ADAMP_PASS1, cfl_adamp_pass1_kernel, dim3(n_items), dim3(256), 0, stream, meta_dev, items_dev, h, clip_dev,
-               rowstats_ws);
-    if (n_matrix > 0) {
-        CFL_LAUNCH(K_ADAMP_DECIDE, cfl_adamp_decide_kernel, dim3(n_matrix), dim3(256), 0, stream, meta_dev, matrix_ids_dev, h,
-                   rowstats_ws, tstats_ws);
-        CFL_LAUNCH(K_ADAMP_PASS3, cfl_adamp_pass3_kernel, dim3(n_items), dim3(256), 0, stream, meta_dev, items_dev, h, clip_dev,
-                   rowstats_ws, tstats_ws);
-    }
-    return 0;
+    return adamp_launch(meta_dev, n_tensors, items_dev, n_items, matrix_ids_dev, n_matrix, rowstats_ws, tstats_ws, lr, beta1, beta2,
+                        eps, weight_decay, delta, wd_ratio, nesterov, step, nullptr, clip_dev, stream_);
+}
+
+int cfl_adamp_step_counted(const CflTensorMeta* meta_dev, int n_tensors, const int* items_dev, int n_items,
+                           const int* matrix_ids_dev, int n_matrix, float* rowstats_ws, float* tstats_ws,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, float delta,
+                           float wd_ratio, int nesterov, const int* gstep_dev, const float* clip_dev, void* stream_) {
+    if (!gstep_dev) return CFL_EINVAL;
+    return adamp_launch(meta_dev, n_tensors, items_dev, n_items, matrix_ids_dev, n_matrix, rowstats_ws, tstats_ws, lr, beta1, beta2,
+                        eps, weight_decay, delta, wd_ratio, nesterov, 1, gstep_dev, clip_dev, stream_);
 }
 
 }  // extern "C"

@@ -32,6 +32,12 @@ BUILD_FLAGS = {
     'quiet': (dict(action='store_true'), 'no console logging'),
     'client_graph': (dict(type=int, default=1, choices=[0, 1]),
                      'capture the client contrast step (fixed B, M, D) in a HIP graph'),
+    'mm_client_graph': (dict(type=int, default=1, choices=[0, 1]),
+                        'the multi-modal client\'s contrast step (both towers, old model, A3 + A4, backward, clip + fused AdamP) in a HIP '
+                        'graph too (needs --client_graph 1; the AdamP step count lives on the device inside the graph)'),
+    'server_graph': (dict(type=int, default=0, choices=[0, 1]),
+                     'single process only: the server\'s contrastive step and KD step (retrieval_trainer.py:192-214, MMFL.py:346-391) '
+                     'replayed from HIP graphs, captured once per phase and round (the step is host-bound at the public batch 128)'),
     'client_channels_last': (dict(type=int, default=1, choices=[0, 1]),
                              'image encoders of the clients (ResNet client net, the multi-modal client\'s image tower) in channels_last '
                              'memory format: the reference\'s fp32 arithmetic on the library\'s NHWC convolutions and the fused fp32 BatchNorm '

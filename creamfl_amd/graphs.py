@@ -18,11 +18,18 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, fn, warmup=3, enabled=True, log=None):
+    def __init__(self, fn, warmup=3, enabled=True, log=None, optimizer=None):
         """log: callable(str) that is told ONCE why a capture failed (default: warnings.warn) -- a step that silently stays eager
-        looks like a performance regression with no trace."""
+        looks like a performance regression with no trace.
+        optimizer: an optimizer whose step needs to know about captures and replays (creamfl_amd's fused AdamP: the step count of
+        its bias corrections lives on the device inside a graph, `prepare_capture` / `capture_begin` / `capture_end`, and the
+        host's counts follow through the handle's `replayed()`; the handle's `valid()` is asked before every replay)."""
         self.fn = fn
         self.log = log
+        self.optimizer = optimizer if hasattr(optimizer, 'capture_begin') else None
+        self._opt_handle = None
+        if self.optimizer is not None and bool(enabled) and torch.cuda.is_available():
+            self.optimizer.prepare_capture()
         self._side = None
         self.warmup = max(1, int(warmup))
         self.enabled = bool(enabled) and torch.cuda.is_available()
@@ -48,18 +55,27 @@ class GraphedStep:
         self._copy_in(inputs)
         self.sig = self._signature(inputs)
         graph = torch.cuda.CUDAGraph()
+        handle = self.optimizer.capture_begin() if self.optimizer is not None else None
         try:
             with torch.cuda.graph(graph):
                 out = self.fn(*self.static_in)
         except Exception as e:                                    # noqa: BLE001  (capture not possible: stay eager, say why once)
-            self.failed = repr(e)[:300]
-            self.enabled = False
-            torch.cuda.synchronize()
-            msg = 'GraphedStep: HIP-graph capture failed, the step stays eager: %s' % self.failed
-            (self.log or warnings.warn)(msg)
+            if handle is not None:
+                self.optimizer.capture_end(handle)
+            self._stay_eager(repr(e)[:300])
             return False
-        self.graph, self.static_out = graph, out
+        if handle is not None:
+            self.optimizer.capture_end(handle)
+        self.graph, self.static_out, self._opt_handle = graph, out, handle
         return True
+
+    def _stay_eager(self, why):
+        self.failed = why
+        self.enabled = False
+        self.graph = self.static_out = self._opt_handle = None
+        torch.cuda.synchronize()
+        msg = 'GraphedStep: no HIP graph (capture failed or went stale), the step stays eager: %s' % self.failed
+        (self.log or warnings.warn)(msg)
 
     def _warm(self, inputs):
         """An eager warm-up step on a SIDE stream (the capture recipe: the libraries bind their handles and workspaces, and the
@@ -93,6 +109,12 @@ class GraphedStep:
             return self.static_out
         if self._signature(inputs) != self.sig:
             return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])               # ragged batch: eager
+        if self._opt_handle is not None:
+            if not self._opt_handle.valid():
+                # another step updated a different set of parameters since the capture: the captured step-count offsets are void
+                self._stay_eager('the optimizer stepped a different parameter set since the capture')
+                return self.fn(*[t.to(self._device, non_blocking=True) for t in inputs])
+            self._opt_handle.replayed()
         self._copy_in(inputs)
         self.graph.replay()
         self.replays += 1

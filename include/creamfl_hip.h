@@ -451,6 +451,11 @@ int cfl_bn_pool_bwd(const void* g_pool, const void* idx, const void* x, const fl
  *                     partial_ws >= n_items floats.
  * cfl_adamp_step:     rowstats_ws >= 4 * (total rows of matrix tensors) floats, tstats_ws >= n_tensors floats;
  *                     clip_dev = out2 of cfl_grad_clip_coef or NULL; `step` is the 1-based step count.
+ * cfl_adamp_step_counted: the same step with the count read ON THE DEVICE: a tensor's step = *gstep_dev + its
+ *                     CflTensorMeta.step (then a signed offset, clamped to >= 1).  For steps replayed from a HIP graph (the
+ *                     clients' contrast loops, MMClientTrainer.py:150-224; the server loop, retrieval_trainer.py:192-214):
+ *                     a captured launch cannot carry the host's count as an argument; the caller increments the counter on
+ *                     the same stream before each step.
  * Mixed precision (the reference trains with apex O2: fp16 model weights, fp32 master weights,
  * retrieval_trainer.py:107-111): p is the fp32 master, p16 the bf16 model weight rewritten by pass 3, and g may be
  * bf16 (CFL_OPT_GRAD_BF16); moments are always fp32.
@@ -467,7 +472,8 @@ typedef struct CflTensorMeta {
     int n0;
     int flags;
     int step;               /* this tensor's own 1-based step count for the bias corrections (adamp.AdamP keeps `step` per
-                             * parameter: tensors whose gradient was None in some steps lag behind); 0 = use the `step` argument */
+                             * parameter: tensors whose gradient was None in some steps lag behind); 0 = use the `step` argument.
+                             * cfl_adamp_step_counted: the tensor's signed offset from the device counter */
     int reserved;
 } CflTensorMeta;
 int cfl_grad_clip_coef(const CflTensorMeta* meta_dev, const int* items_dev, int n_items, float max_norm,
@@ -476,6 +482,10 @@ int cfl_adamp_step(const CflTensorMeta* meta_dev, int n_tensors, const int* item
                    const int* matrix_ids_dev, int n_matrix, float* rowstats_ws, float* tstats_ws,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float delta,
                    float wd_ratio, int nesterov, int step, const float* clip_dev, void* stream);
+int cfl_adamp_step_counted(const CflTensorMeta* meta_dev, int n_tensors, const int* items_dev, int n_items,
+                           const int* matrix_ids_dev, int n_matrix, float* rowstats_ws, float* tstats_ws,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, float delta,
+                           float wd_ratio, int nesterov, const int* gstep_dev, const float* clip_dev, void* stream);
 
 #ifdef __cplusplus
 }

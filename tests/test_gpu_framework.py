@@ -830,3 +830,57 @@ def test_image_client_layouts_train_the_same(dev):
         assert float((cl[k] - v).abs().max()) <= 1e-3 * scale + 1e-6, k
     assert abs(loss_bf - loss_ref) <= 3e-2 * abs(loss_ref) and np.isfinite(loss_bf), (loss_bf, loss_ref)
     assert float((rep_bf - rep_ref).abs().max()) <= 5e-2
+
+
+@pytest.mark.gpu
+def test_mm_client_contrast_step_in_a_hip_graph_equals_eager(dev):
+    """The MULTI-MODAL client's contrast loop (MMClientTrainer.py:150-224: both towers, the old model's forward, stacked intra +
+    summed inter terms, backward, clip + AdamP) replayed from one HIP graph per round -- possible since the fused AdamP reads its
+    step count from the device inside a graph (cfl_adamp_step_counted) -- against the same loop run eagerly (--mm_client_graph 0).
+    Two local epochs: the local PCME steps on the client's own pairs (eager, they also update the criterion's scalars) sit
+    between the two epochs' replays of ONE graph.  Same parameters (AdamP's first steps move a weight by ~lr whatever the size of
+    its gradient, so a library convolution's reordered sum can flip single elements: all but a sliver equal to 1e-4 of scale, the
+    sliver within 2 lr per step), same step counts, the ragged last batch eager, the graph really replayed."""
+    from creamfl_amd.algorithms.MMClientTrainer import MMClientTrainer
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import SyntheticCocoLoader
+    M, D, bs = 136, 64, 16                                             # 8 full batches + one ragged batch of 8
+    pub = list(SyntheticCocoLoader(M, bs, seed=7, img=64, bert=False))
+    own = list(SyntheticCocoLoader(32, bs, seed=9, img=64, bert=False))
+    gen = torch.Generator().manual_seed(3)
+    g_img = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
+    g_txt = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
+
+    def run(graph):
+        torch.manual_seed(11)
+        args = SimpleNamespace(feature_dim=D, mlp_local=False, local_epochs=2, contrast_local_intra=True, contrast_local_inter=True,
+                               interintra_weight=0.5, loss_scale=False, save_client=False, client_graph=1, mm_client_graph=graph)
+        cfg = default_config(embed_dim=D, cnn_type='resnet18', not_bert=True)
+        cfg.train.use_fp16 = False
+        msgs = []
+        t = MMClientTrainer(args, cfg, SimpleNamespace(log=msgs.append), client=0, device=str(dev), train_loader=own)
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            t.run(g_img, g_txt, list(range(M)), pub)
+        torch.cuda.synchronize()
+        osd = t.optimizer.state_dict()
+        steps = sorted(set(int(st['step']) for st in osd['state'].values()))
+        return t, {k: v.detach().float().cpu() for k, v in t.model.state_dict().items()}, steps, msgs
+
+    t_e, sd_e, steps_e, _ = run(0)
+    t_g, sd_g, steps_g, msgs = run(1)
+    gs = t_g.graph_stats
+    assert gs is not None and gs['failed'] is None, (gs, msgs)
+    assert gs['calls'] == 18 and gs['replays'] == 5 + 8                # epoch 1: 3 warm-ups, capture + 4 replays, ragged; epoch 2: 8 + ragged
+    assert t_e.graph_stats is None and t_g._graphed_contrast is None
+    assert steps_e == steps_g and max(steps_g) == 2 * (2 + 9)          # model: local + contrast steps; the criterion's scalars: 4
+    assert bool(torch.isfinite(t_g.last_contrast_loss))
+    lr = float(t_g.optimizer.param_groups[0]['lr'])
+    for k, v in sd_e.items():
+        if not v.is_floating_point():
+            assert torch.equal(v, sd_g[k]), k
+            continue
+        d = (v - sd_g[k]).abs()
+        off = d > 1e-4 * (float(v.abs().max()) + 1e-12) + 1e-6
+        assert float(off.float().mean()) < 5e-3, (k, float(off.float().mean()), float(d.max()))
+        if bool(off.any()) and 'running' not in k:
+            assert float(d[off].max()) <= 2.2 * lr * max(steps_g), (k, float(d[off].max()))

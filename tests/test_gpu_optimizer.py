@@ -227,3 +227,100 @@ def test_fused_adamp_checkpoint_round_trip_is_bit_exact():
             if key in opt_a.state[pa]:
                 assert torch.equal(opt_a.state[pa][key], opt_b.state[pb][key]), (k, key)
         assert opt_a.state[pa]['step'] == opt_b.state[pb]['step'] == 3
+
+
+def _graph_toy(dev, seed=0):
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(24, 48), torch.nn.Tanh(), torch.nn.Linear(48, 8)).to(dev)
+    scal = torch.nn.Parameter(torch.tensor([0.7], device=dev))          # plays the criterion's scalars: skipped by some steps
+    return net, scal
+
+
+def test_fused_adamp_step_inside_a_hip_graph_equals_eager():
+    """The fused AdamP inside a replayed HIP graph (graphs.GraphedStep(optimizer=...), the multi-modal client's contrast step,
+    MMClientTrainer.py:150-224): the step count of the bias corrections is read from the device (cfl_adamp_step_counted: counter +
+    per-tensor offset), the tensor table with the captured gradient addresses is re-uploaded by a node of the graph.  Against the
+    same 12 steps run eagerly: 3 eager warm-ups, the capture, replays, ONE eager step on a ragged batch in between (it uploads its
+    own table and moves the counter), more replays.  Before them 2 steps that skip the scalar parameter, so the tensors' step
+    counts differ (per-tensor offsets).  Weights equal to 1e-6, and state_dict() reports the same step counts."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from creamfl_amd.graphs import GraphedStep
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(5)
+    xs = [torch.randn(16, 24, generator=gen).to(dev) for _ in range(12)]
+    ragged = torch.randn(5, 24, generator=gen).to(dev)
+
+    def run(graph):
+        net, scal = _graph_toy(dev)
+        opt = AdamP(list(net.parameters()) + [scal], lr=1e-2, weight_decay=0.01)
+
+        def step(x, with_scalar=True):
+            opt.zero_grad(set_to_none=True)
+            y = net(x)
+            loss = (y * y).mean() * (scal.sum() if with_scalar else 1.0)
+            loss.backward()
+            opt.step(clip=(net.parameters(), 0.5))
+            return loss.detach()
+        for x in xs[:2]:
+            step(x, with_scalar=False)                                  # the scalar lags two steps behind from here on
+        gs = GraphedStep(step, warmup=3, enabled=graph, optimizer=opt)
+        losses = []
+        for i, x in enumerate(xs[2:]):
+            losses.append(float(gs(x)))
+            if i == 6:
+                losses.append(float(gs(ragged)))                        # another shape: eager, between two replays
+        torch.cuda.synchronize()
+        sd = opt.state_dict()
+        steps = [sd['state'][k]['step'] for k in sorted(sd['state'])]
+        return gs, [p.detach().cpu() for p in list(net.parameters()) + [scal]], steps, losses
+
+    gs_e, w_e, steps_e, loss_e = run(False)
+    gs_g, w_g, steps_g, loss_g = run(True)
+    assert gs_g.failed is None, gs_g.failed
+    assert gs_g.replays == 7 and gs_g.calls == 11 and gs_e.replays == 0   # 3 warm-ups, capture + 6 replays, one ragged call
+    assert steps_e == steps_g == [13, 13, 13, 13, 11]
+    np.testing.assert_allclose(loss_g, loss_e, rtol=1e-5)
+    for a, b in zip(w_e, w_g):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_adamp_captured_step_goes_stale_when_its_parameters_are_skipped():
+    """A captured step's table holds step-count OFFSETS from the device counter.  An eager step that skips one of its parameters
+    (the KD step skips the criterion's scalars, MMFL.py:346-391) moves the counter without that parameter: the handle reports
+    stale, GraphedStep drops the graph and the calls go on eagerly -- with the same weights as an all-eager run."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from creamfl_amd.graphs import GraphedStep
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(6)
+    xs = [torch.randn(16, 24, generator=gen).to(dev) for _ in range(9)]
+
+    def run(graph):
+        net, scal = _graph_toy(dev, 1)
+        opt = AdamP(list(net.parameters()) + [scal], lr=1e-2)
+
+        def step(x, with_scalar=True):
+            opt.zero_grad(set_to_none=True)
+            loss = (net(x) ** 2).mean() * (scal.sum() if with_scalar else 1.0)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        msgs = []
+        gs = GraphedStep(step, warmup=2, enabled=graph, optimizer=opt, log=msgs.append)
+        for x in xs[:5]:
+            gs(x)                                                       # 2 warm-ups, capture, 2 replays
+        step(xs[5], with_scalar=False)                                  # skips the scalar
+        for x in xs[6:]:
+            gs(x)
+        torch.cuda.synchronize()
+        return gs, msgs, [p.detach().cpu() for p in list(net.parameters()) + [scal]], opt.state_dict()
+
+    gs_e, _, w_e, sd_e = run(False)
+    gs_g, msgs, w_g, sd_g = run(True)
+    assert gs_g.replays == 3 and gs_g.graph is None and len(msgs) == 1 and 'parameter set' in msgs[0]
+    assert [sd_g['state'][k]['step'] for k in sorted(sd_g['state'])] == [9, 9, 9, 9, 8]
+    for a, b in zip(w_e, w_g):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-5, atol=1e-6)

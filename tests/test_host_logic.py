@@ -398,3 +398,36 @@ def test_caption_padding_of_the_captured_text_step_and_the_cpu_text_path():
     a, words = m.sentence_states(tokens, lengths)                          # (the PIE head behind it has no CPU path, by design)
     b, words_b = m.sentence_states(pad_captions(tokens, 12), lengths)
     assert a.shape == (4, 64) and words_b.shape == (4, 12, 300) and float((a - b).abs().max()) <= 1e-6
+
+
+def test_adamp_capture_handles_count_replays_and_go_stale_on_the_host():
+    """Host bookkeeping of AdamP steps replayed from a HIP graph (no kernel runs here): replays are folded into state[p]['step']
+    lazily (state_dict / the next step), a handle goes stale when another captured step that skips one of its parameters is
+    replayed, when a state dict is loaded, and capture_begin() refuses without prepare_capture()."""
+    from creamfl_amd._lib import CreamflHipError
+    from creamfl_amd.algorithms.optimizers import AdamP
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(3)]
+    opt = AdamP(ps, lr=1e-3)
+    with pytest.raises(CreamflHipError):
+        opt.capture_begin()
+    opt.prepare_capture()
+    assert int(opt._gstep_dev) == 0
+    for p in ps:
+        opt.state[p]['step'] = 5
+
+    def captured(params):
+        h = opt.capture_begin()
+        h.params.extend(params)              # (what step() records while capturing)
+        return opt.capture_end(h)
+    train, kd = captured(ps), captured(ps[:2])          # the contrastive step updates all three, the KD step skips the last
+    assert train.valid() and kd.valid()
+    train.replayed(); train.replayed()
+    assert kd.valid()                        # a superset was stepped: the KD step's offsets still hold
+    assert [opt.state[p]['step'] for p in ps] == [5, 5, 5] and opt._gstep_host == 2
+    steps = [st['step'] for st in opt.state_dict()['state'].values()]
+    assert steps == [7, 7, 7] and train.pending == 0
+    kd.replayed()
+    assert not train.valid() and kd.valid()  # the third parameter fell behind the counter
+    assert [st['step'] for st in opt.state_dict()['state'].values()] == [8, 8, 7]
+    opt.load_state_dict(opt.state_dict())
+    assert not kd.valid()
