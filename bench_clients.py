@@ -69,6 +69,10 @@ def add_arguments(ap):
                     help='config 2: bf16 autocast for the clients\' image encoders -- BELOW the reference\'s fp32 client precision: the '
                          'line then says dtype bf16 and is a companion number, not the configs[2] measurement')
     ap.add_argument('--cpu-client-child', action='store_true', help='(internal)')
+    ap.add_argument('--server-graph', type=int, default=0, choices=[0, 1],
+                    help='config 2: --server_graph of the federation (the server\'s contrastive and KD steps replayed from HIP graphs)')
+    ap.add_argument('--mm-client-graph', type=int, default=1, choices=[0, 1],
+                    help='config 2: --mm_client_graph of the federation (the multi-modal client\'s contrast step from a HIP graph)')
 
 
 def reference_namespace(a, dev_index, M):
@@ -81,7 +85,8 @@ def reference_namespace(a, dev_index, M):
         interintra_weight=0.5, loss_scale=False, kd_weight=0.3, disable_distill=False, save_client=False, device=dev_index,
         cnn_type=a.server_cnn, bert_name=a.server_bert, image_size=a.image_size, test_pairs=5000 if M >= 5000 else max(100, M // 2),
         quiet=True, save_checkpoints=False, server_dp=0, rep_wire=a.rep_wire, client_graph=1,
-        client_channels_last=int(a.client_layout == 'channels_last'), client_bf16=int(a.client_bf16))
+        client_channels_last=int(a.client_layout == 'channels_last'), client_bf16=int(a.client_bf16),
+        server_graph=int(a.server_graph), mm_client_graph=int(a.mm_client_graph))
 
 
 def build_federation(a, dev, M, mini=False):
@@ -517,6 +522,9 @@ def run(a, world, rank, dev, use_dist, json_out):
                         'agg_all_gather_ms': round(comm['agg_all_gather_s'] * 1e3, 3),
                         'con_w_ms': round(ph.get('con_w', 0.0) * 1e3, 3), 'rep_wire': a.rep_wire},
                'private_samples_per_client': fed['private_samples'],
+               'graphs': {'server_graph': int(a.server_graph), 'mm_client_graph': int(a.mm_client_graph),
+                          'server': dict(getattr(algo.engine, 'graph_stats', {}) or {}),
+                          'mm_clients': [getattr(t, 'graph_stats', None) for t in algo.mm_local_trainers][:2]},
                'recall_1_after_round': None}
         try:
             sc = algo.best_scores['test']

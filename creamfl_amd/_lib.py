@@ -55,6 +55,7 @@ SIGNATURES = {
     'cfl_bias_gelu_fwd': (c_int, [_P, _P, c_int, c_longlong, c_int, _P, _P]),
     'cfl_bias_gelu_bwd': (c_int, [_P, _P, c_int, _P, c_longlong, c_int, _P, _P, c_int, _P, _P]),
     'cfl_dropout_mask': (c_int, [c_uint, c_float, c_longlong, _P, _P]),
+    'cfl_set_dropout_tick': (c_int, [_P]),
     'cfl_attn_small_fwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong, _P]),
     'cfl_attn_small_bwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong,
                                    _P, _P, _P, c_longlong, c_longlong, _P]),

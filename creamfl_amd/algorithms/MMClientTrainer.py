@@ -128,7 +128,7 @@ class MMClientTrainer(EngineBase):
             log = (lambda m: self.logger.log(m)) if self.logger is not None else None
             graphed = self._graphed_contrast = GraphedStep(
                 lambda images, captions, lens, d_idx: contrast_step(images, captions, None, lens, d_idx),
-                warmup=3, log=log, optimizer=self.optimizer)
+                warmup=3, log=log, optimizer=self.optimizer, other_threads=True)
             graphed.caption_width = None
             self._graphed_key = key
         return graphed

@@ -120,6 +120,7 @@ class MMFL(object):
         self.vocab = vocab
         word2idx = vocab.word2idx if vocab is not None else {i: i for i in range(11755)}
         self.engine = TrainerEngine(device=self.device or 'cuda')
+        self.engine.server_graph = bool(int(flags.get(args, 'server_graph')))
         self.engine.set_logger(self.logger)
         self.config.optimizer.learning_rate = self.args.server_lr
         self._dataloaders = dict(self.dataloaders_global)
@@ -337,6 +338,26 @@ class MMFL(object):
                 loss = loss + code_sim(output['caption_features'], self.txt_vec)
         return loss
 
+    def _kd_has_terms(self):
+        has_img = self.img_vec is not None and len(self.img_vec)
+        has_txt = self.txt_vec is not None and len(self.txt_vec)
+        a = self.args
+        return bool(((a.num_img_clients > 0 or a.num_mm_clients > 0) and has_img)
+                    or ((a.num_txt_clients > 0 or a.num_mm_clients > 0) and has_txt))
+
+    def _kd_graph_fn(self, model):
+        eng = self.engine
+
+        def fn(images, captions, caption_lens, d_idx):
+            ops.dropout_tick(images.device).add_(1)
+            with ops.join_scope():
+                with torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
+                    output = model(images, captions, None, caption_lens)
+                loss = self.kd_terms(output, d_idx)
+                eng.backward_and_step(loss)
+            return loss.detach()
+        return fn
+
     def distill(self, round_n, img_vec, txt_vec, img_num, txt_num, distill_index):
         # Multi-rank: the server phases are replicated, and the replicas stay identical only if their dropout draws are --
         # but the ranks have just trained DIFFERENT clients and consumed the generators differently.  Rank 0 draws a seed,
@@ -361,12 +382,21 @@ class MMFL(object):
                 captions_word = captions_word[r0:r1] if captions_word is not None else None
             if eng.autocast_dtype is not None:
                 images = images.contiguous(memory_format=torch.channels_last)
+            d_idx = operator.itemgetter(*index)(distill_dict)
+            d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
+            if sh is None and self._kd_has_terms() and eng.graph_capable(captions_word):
+                # --server_graph 1: the KD step from a HIP graph, one capture per round (the aggregated representations and the
+                # learning rate are constants of a round)
+                key = (id(eng.model), tuple(g['lr'] for g in eng.optimizer.param_groups),
+                       tuple(v.data_ptr() if torch.is_tensor(v) else None for v in (self.img_vec, self.txt_vec)))
+                gs = eng.graphed_step('kd', key, self._kd_graph_fn(model))
+                gs(*eng.graph_inputs(gs, images, captions, caption_lens), d_idx, device=images.device)
+                continue
             with ops.join_scope():                # the same backward path as the contrastive step (gradient joins fused)
                 with torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
                     output = model(images, captions, captions_word, caption_lens)
-                d_idx = operator.itemgetter(*index)(distill_dict)
-                d_idx = torch.as_tensor(d_idx if isinstance(d_idx, tuple) else (d_idx,), device=eng.device)
                 loss = self.kd_terms(output, d_idx)
                 if not torch.is_tensor(loss):
                     continue
                 eng.backward_and_step(loss)       # incl. the bucketed gradient averaging when data parallel is on
+        eng.drop_graph('kd')

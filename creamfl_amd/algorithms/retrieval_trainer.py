@@ -51,6 +51,9 @@ class EngineBase(object):
         self.shard_batches = False           # multi-rank: train() / the KD loop give every rank 1/W of each batch (MMFL --server_dp)
         self._conv1x1_weights = None         # weights whose transposes are prepared in one launch before backward
         self._clip_params = None             # (id(model), its parameter list) for the gradient clip
+        self.server_graph = False            # --server_graph: the contrastive / KD steps replayed from HIP graphs (graphed_step)
+        self._graphs = {}                    # name -> (key, GraphedStep)
+        self.graph_stats = {}                # name -> {'calls', 'replays', 'failed'} of the last graph of that name
 
     def create(self, config, word2idx, evaluator, mlp_local):
         runtime.configure()                  # MIOpen find mode / recorded find-db / cudnn.benchmark before the first convolution
@@ -257,6 +260,62 @@ class TrainerEngine(EngineBase):
         per = n // self.dp.world
         return self.dp.rank * per, (self.dp.rank + 1) * per
 
+    # ---- the server's steps from HIP graphs (--server_graph 1) ---------------------------------------------------------------
+    # At the reference's public batch (128) the server step is host-bound: ~1 600 launches issued in 27-35 ms of Python for ~24 ms
+    # of GPU work, 782 times per round (global training + KD).  A step is capturable once nothing in it travels as a host value:
+    # the fused AdamP's step count (cfl_adamp_step_counted), the fused BERT dropout's seeds (ops.dropout_tick), the BatchNorm batch
+    # counters (on the device since the clients' graphs), captions padded to ONE width (the attention mask comes from the lengths
+    # on the device).  One capture per phase and round: the learning rate is a constant of a round (MMFL.py:286), and the KD step
+    # skips the criterion's scalars, which voids the contrastive step's captured step-count offsets (AdamP.CaptureHandle).
+    def graph_capable(self, captions_word=None):
+        return bool(self.server_graph and self.dp is None and isinstance(self.optimizer, AdamP)
+                    and torch.device(self.device).type == 'cuda' and torch.cuda.is_available()
+                    and (captions_word is None or getattr(self.model, 'tokenizer', None) is None))
+
+    def graphed_step(self, name, key, fn):
+        """The GraphedStep of phase `name`, re-made (the old one dropped first: its pool and pinned tables return) when `key`
+        changes."""
+        from ..graphs import GraphedStep
+        slot = self._graphs.get(name)
+        if slot is None or slot[0] != key:
+            self.drop_graph(name)
+            log = self.logger.log if self.logger is not None else None
+            gs = GraphedStep(fn, warmup=3, log=log, optimizer=self.optimizer, other_threads=True)
+            gs.caption_width = None
+            self._graphs[name] = (key, gs)
+        return self._graphs[name][1]
+
+    def drop_graph(self, name):
+        slot = self._graphs.pop(name, None)
+        if slot is not None:
+            gs = slot[1]
+            self.graph_stats[name] = {'calls': gs.calls, 'replays': gs.replays, 'failed': gs.failed}
+
+    @staticmethod
+    def graph_caption_width(first_width):
+        """Padded caption width of a captured server step: the first batch's, rounded up to a multiple of 8 (a public batch of 128
+        captions nearly always contains one of the maximum length); a wider batch runs eagerly."""
+        return (int(first_width) + 7) // 8 * 8
+
+    def graph_inputs(self, gs, images, captions, caption_lens):
+        """(images, captions, lengths) in the form the captured step takes them: channels_last images when the trunk computes in
+        that layout, captions zero-padded to the graph's width, int64 lengths."""
+        from .ClientTrainer import pad_captions
+        if gs.caption_width is None:
+            gs.caption_width = self.graph_caption_width(captions.shape[1])
+        if self.autocast_dtype is not None and images.dim() == 4:
+            images = images.contiguous(memory_format=torch.channels_last)
+        return images, pad_captions(captions, gs.caption_width), caption_lens.to(torch.int64)
+
+    def _train_graph_fn(self):
+        from .. import ops
+
+        def fn(images, captions, caption_lens):
+            ops.dropout_tick(images.device).add_(1)
+            loss, _ = self.train_step(images, captions, None, caption_lens, gather=False)
+            return loss.detach()
+        return fn
+
     def backward_and_step(self, loss):
         """zero_grad -> backward -> (multi-rank: bucketed gradient averaging) -> clip -> optimizer step: the tail every
         server-side step shares (the contrastive step, retrieval_trainer.py:208-214, and the KD step, MMFL.py:385-391)."""
@@ -345,8 +404,13 @@ class TrainerEngine(EngineBase):
                 r0, r1 = sh
                 cw = captions_word[r0:r1] if captions_word is not None else None
                 self.train_step(images[r0:r1], captions[r0:r1], cw, caption_lens[r0:r1])
+            elif self.graph_capable(captions_word):
+                gs = self.graphed_step('train', (id(self.model), tuple(g['lr'] for g in self.optimizer.param_groups)),
+                                       self._train_graph_fn())
+                gs(*self.graph_inputs(gs, images, captions, caption_lens), device=images.device)
             else:
                 self.train_step(images, captions, captions_word, caption_lens, gather=False)
+        self.drop_graph('train')        # (the KD steps that follow void its step-count offsets; its activations' pool returns)
 
     def report_scores(self, step, scores, metadata, prefix=''):
         report_dict = {data_key: flatten_dict(_scores, sep='_') for data_key, _scores in scores.items()}

@@ -38,6 +38,12 @@ __device__ __forceinline__ u32 mix32(u32 seed, u32 i) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
+// Steps replayed from a HIP graph: the host's per-call seed is a constant of the graph, so the masks would repeat every step.  With a
+// step tick on the device (cfl_set_dropout_tick; the caller increments it on the stream once per step) the effective seed of a launch is
+// seed + tick * odd constant: forward and backward of one step read the same tick, successive replays different ones.
+__device__ __forceinline__ u32 tick_seed(u32 seed, const u32* __restrict__ tick) {
+    return tick ? seed + *tick * 0x85EBCA6Bu : seed;
+}
 // keep flags of the 4 consecutive elements starting at element index e (e % 4 == 0): 16 random bits per element
 __device__ __forceinline__ void keep4(u32 seed, long long e, u32 thr16, bool (&k)[4]) {
     const u32 i = (u32)(e >> 1);
@@ -67,10 +73,12 @@ __global__ __launch_bounds__(256) void cfl_daln_fwd_kernel(const U2* __restrict_
                                                            const U2* __restrict__ res, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int T, int H, float eps, u32 thr16,
                                                            float scale, u32 seed, U2* __restrict__ z, U2* __restrict__ s_out,
-                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           const u32* __restrict__ tick) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
     if (row >= T) return;
+    seed = tick_seed(seed, tick);
     const long long base = (long long)row * H;
     float s[NJ][4];
     float sum = 0.f;
@@ -127,9 +135,11 @@ __global__ __launch_bounds__(256) void cfl_daln_bwd_kernel(const U2* __restrict_
                                                            const U2* __restrict__ dz_b, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int T,
                                                            int H, u32 thr16, float scale, u32 seed, int rows_per_block,
-                                                           U2* __restrict__ ds_out, U2* __restrict__ dy_out, float* __restrict__ partials) {
+                                                           U2* __restrict__ ds_out, U2* __restrict__ dy_out, float* __restrict__ partials,
+                                                           const u32* __restrict__ tick) {
     __shared__ float red[4][NJ * 256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    seed = tick_seed(seed, tick);
     float dgam[NJ][4], dbet[NJ][4], dbia[NJ][4], gam[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -291,9 +301,11 @@ __global__ __launch_bounds__(256) void cfl_bias_gelu_bwd_kernel(const U4* __rest
 }
 
 // test helper: the keep mask of n elements (n % 4 == 0)
-__global__ __launch_bounds__(256) void cfl_dropout_mask_kernel(u32 seed, u32 thr16, long long n4, unsigned char* keep) {
+__global__ __launch_bounds__(256) void cfl_dropout_mask_kernel(u32 seed, u32 thr16, long long n4, unsigned char* keep,
+                                                               const u32* __restrict__ tick) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    seed = tick_seed(seed, tick);
     bool k[4];
     keep4(seed, i * 4, thr16, k);
 #pragma unroll
@@ -328,6 +340,8 @@ inline GPlan gelu_plan(long long R, int C) {
 
 }  // namespace
 
+static const unsigned* g_dropout_tick = nullptr;     // cfl_set_dropout_tick: device word added (x odd constant) to every dropout seed
+
 extern "C" {
 
 size_t cfl_daln_ws_bytes(int T, int H) {
@@ -344,7 +358,7 @@ int cfl_daln_fwd(const void* g, const void* bias, int bias_bf16, const void* res
     const float sc = scale_of(thr);
     const dim3 grid(cfl_cdiv(T, 4));
 #define DALN_FWD(NJ) CFL_LAUNCH(K_BERT_DALN, (cfl_daln_fwd_kernel<NJ>), grid, dim3(256), 0, stream, (const U2*)g, bias, bias_bf16, \
-                                (const U2*)residual, gamma, beta, T, H, eps, thr, sc, seed, (U2*)z, (U2*)s, mean, rstd)
+                                (const U2*)residual, gamma, beta, T, H, eps, thr, sc, seed, (U2*)z, (U2*)s, mean, rstd, g_dropout_tick)
     const int nj = cfl_cdiv(H, 256);
     if (nj <= 1) DALN_FWD(1); else if (nj <= 2) DALN_FWD(2); else if (nj <= 3) DALN_FWD(3); else if (nj <= 4) DALN_FWD(4); else DALN_FWD(8);
 #undef DALN_FWD
@@ -362,7 +376,7 @@ int cfl_daln_bwd(const void* s, const void* dz_a, const void* dz_b, const float*
     const int rpb = daln_rows_per_block(T), nblk = cfl_cdiv(T, rpb);
     float* partials = (float*)ws;
 #define DALN_BWD(NJ) CFL_LAUNCH(K_BERT_DALN, (cfl_daln_bwd_kernel<NJ>), dim3(nblk), dim3(256), 0, stream, (const U2*)s, (const U2*)dz_a, \
-                                (const U2*)dz_b, gamma, mean, rstd, T, H, thr, sc, seed, rpb, (U2*)ds, (U2*)dy, partials)
+                                (const U2*)dz_b, gamma, mean, rstd, T, H, thr, sc, seed, rpb, (U2*)ds, (U2*)dy, partials, g_dropout_tick)
     const int nj = cfl_cdiv(H, 256);
     if (nj <= 1) DALN_BWD(1); else if (nj <= 2) DALN_BWD(2); else if (nj <= 3) DALN_BWD(3); else if (nj <= 4) DALN_BWD(4); else DALN_BWD(8);
 #undef DALN_BWD
@@ -402,11 +416,16 @@ int cfl_bias_gelu_bwd(const void* g, const void* bias, int bias_bf16, const void
     return 0;
 }
 
+int cfl_set_dropout_tick(const unsigned* tick_dev) {
+    g_dropout_tick = tick_dev;
+    return 0;
+}
+
 int cfl_dropout_mask(unsigned seed, float p, long long n, unsigned char* keep, void* stream_) {
     if (!keep || n <= 0 || n % 4 != 0 || p < 0.f || p >= 1.f) return CFL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     CFL_LAUNCH(K_BERT_DALN, cfl_dropout_mask_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, seed, thr_of(p),
-               n / 4, keep);
+               n / 4, keep, g_dropout_tick);
     return 0;
 }
 

@@ -18,7 +18,7 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, fn, warmup=3, enabled=True, log=None, optimizer=None):
+    def __init__(self, fn, warmup=3, enabled=True, log=None, optimizer=None, other_threads=False):
         """log: callable(str) that is told ONCE why a capture failed (default: warnings.warn) -- a step that silently stays eager
         looks like a performance regression with no trace.
         optimizer: an optimizer whose step needs to know about captures and replays (creamfl_amd's fused AdamP: the step count of
@@ -26,6 +26,10 @@ class GraphedStep:
         host's counts follow through the handle's `replayed()`; the handle's `valid()` is asked before every replay)."""
         self.fn = fn
         self.log = log
+        # other_threads: another thread of the process issues HIP work while this step is captured (utils.prefetch's copy thread
+        # stages or generates the next batches): capture in thread-local mode -- the default global mode fails ANY thread's
+        # allocation for the duration of the capture
+        self.capture_mode = 'thread_local' if other_threads else 'global'
         self.optimizer = optimizer if hasattr(optimizer, 'capture_begin') else None
         self._opt_handle = None
         if self.optimizer is not None and bool(enabled) and torch.cuda.is_available():
@@ -57,7 +61,7 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph()
         handle = self.optimizer.capture_begin() if self.optimizer is not None else None
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=self.capture_mode):
                 out = self.fn(*self.static_in)
         except Exception as e:                                    # noqa: BLE001  (capture not possible: stay eager, say why once)
             if handle is not None:

@@ -1712,6 +1712,20 @@ def _next_dropout_seed():
     return (torch.initial_seed() * 0x9E3779B1 + _DROPOUT_CALLS[0] * 0x85EBCA6B) & 0xFFFFFFFF
 
 
+_DROPOUT_TICK = [None]
+
+
+def dropout_tick(device):
+    """The device word that varies the fused dropout masks between replays of a captured step (cfl_set_dropout_tick): created and
+    registered with the library on first use -- from then on every fused dropout launch of the process adds it to its seed, eager
+    steps included.  A step that is (or will be) captured calls `dropout_tick(device).add_(1)` once at its start."""
+    if _DROPOUT_TICK[0] is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _lib.check(_lib.load().cfl_set_dropout_tick(t.data_ptr()), 'cfl_set_dropout_tick')
+        _DROPOUT_TICK[0] = t
+    return _DROPOUT_TICK[0]
+
+
 def _bf16c(t, name):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise _lib.CreamflHipError(f'{name}: expected a CUDA/HIP tensor (no CPU fallback in creamfl_amd)')

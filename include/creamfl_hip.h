@@ -174,6 +174,11 @@ int cfl_bias_gelu_fwd(const void* g, const void* bias, int bias_bf16, long long 
 int cfl_bias_gelu_bwd(const void* g, const void* bias, int bias_bf16, const void* dh, long long T, int I, void* du, void* dbias,
                       int dbias_bf16, void* ws, void* stream);
 int cfl_dropout_mask(unsigned seed, float p, long long n, unsigned char* keep, void* stream);
+/* Steps replayed from a HIP graph (the server loop, retrieval_trainer.py:192-214, whose BERT tower draws dropout masks): the `seed`
+ * arguments above are constants of a captured launch.  With a tick word registered here (device memory the caller increments on the
+ * stream once per step; NULL = off, the default) every launch of cfl_daln_fwd / cfl_daln_bwd / cfl_dropout_mask uses
+ * seed + *tick * 0x85EBCA6B.  Process-wide; the pointer is read when a launch is issued (or captured). */
+int cfl_set_dropout_tick(const unsigned* tick_dev);
 
 /* ---- BERT self-attention for short sequences (L <= 32 tokens, head_dim 64) -------------------------------------
  * softmax(Q K^T / sqrt(64) + key-padding mask) V per (batch, head): BertSelfAttention of the BertModel built at

@@ -884,3 +884,131 @@ def test_mm_client_contrast_step_in_a_hip_graph_equals_eager(dev):
         assert float(off.float().mean()) < 5e-3, (k, float(off.float().mean()), float(d.max()))
         if bool(off.any()) and 'running' not in k:
             assert float(d[off].max()) <= 2.2 * lr * max(steps_g), (k, float(d[off].max()))
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('half', [False, True])
+def test_server_contrastive_step_in_a_hip_graph(dev, half):
+    """--server_graph 1: TrainerEngine.train (retrieval_trainer.py:192-214) replays its step from ONE HIP graph -- two towers on two
+    streams, MCSoftContrastiveLoss, clip + fused AdamP with the step count on the device, captions padded to one width.
+    fp32 trunks (deterministic up to the library's atomics), dropout off: the weights after 9 steps equal the eager loop's for
+    all but a sliver of elements, the sliver within 2 lr per step (AdamP's first steps move a weight by ~lr whatever its
+    gradient's size, so a reordered sum flips single elements), same step counts.  bf16 trunks (the bench's code path: fused
+    BatchNorm / GEMM / join kernels, fused BERT glue with dropout ON): the capture succeeds, the graph is replayed, everything
+    stays finite, and the loss of the replayed steps stays in the eager loop's range."""
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import coco_batch
+    batches = [coco_batch(16 if i < 8 else 8, 'cpu', seed=70 + i, bert=True, img=64, min_len=18, max_len=24, index0=16 * i)
+               for i in range(9)]
+    assert max(b[1].shape[1] for b in batches) <= 24
+
+    def run(graph):
+        torch.manual_seed(0)
+        cfg = default_config(embed_dim=64, cnn_type='resnet18', not_bert=False)
+        cfg.model.bert_name = 'bert-mini'
+        eng = TrainerEngine(device=dev)
+        msgs = []
+        eng.set_logger(SimpleNamespace(log=msgs.append, update_tracker=lambda *a, **k: None))
+        eng.create(cfg, {'<pad>': 0}, None, False)
+        eng.model_to_device()
+        if half:
+            eng.to_half()
+        else:
+            _no_dropout(eng.model)
+        eng.server_graph = bool(graph)
+        losses = []
+        orig = eng.train_step
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            losses.append(out[0].detach())
+            return out
+        if not graph:
+            eng.train_step = spy
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            eng.train(batches)
+        torch.cuda.synchronize()
+        sd = eng.optimizer.state_dict()
+        steps = sorted(set(int(st['step']) for st in sd['state'].values()))
+        named = {k: v.detach().float().cpu() for k, v in eng.model.named_parameters()}
+        return eng, named, steps, [float(x) for x in losses], msgs
+
+    e_e, w_e, steps_e, loss_e, _ = run(0)
+    e_g, w_g, steps_g, _, msgs = run(1)
+    gs = e_g.graph_stats.get('train')
+    assert gs is not None and gs['failed'] is None, (gs, msgs)
+    assert gs['calls'] == 9 and gs['replays'] == 5                     # 3 warm-ups, capture + 4 replays, the ragged batch eager
+    assert e_e.graph_stats == {} and e_g._graphs == {}
+    assert steps_e == steps_g == [9]
+    assert all(bool(torch.isfinite(v).all()) for v in w_g.values())
+    lr = float(e_g.optimizer.param_groups[0]['lr'])
+    if half:
+        return
+    for k, v in w_e.items():
+        d = (v - w_g[k]).abs()
+        off = d > 1e-4 * (float(v.abs().max()) + 1e-12) + 1e-6
+        assert float(off.float().mean()) < 5e-3, (k, float(off.float().mean()), float(d.max()))
+        if bool(off.any()):
+            assert float(d[off].max()) <= 2.2 * lr * 9, (k, float(d[off].max()))
+
+
+@pytest.mark.gpu
+def test_fused_dropout_masks_follow_the_device_tick(dev):
+    """A captured step's dropout seeds are constants of the graph; the masks vary between replays through a device word the step
+    increments (cfl_set_dropout_tick): same seed + same tick = same mask, another tick = another mask, tick 0 = the mask the seed
+    alone gives."""
+    from creamfl_amd import ops
+    base = ops.dropout_keep_mask(1234, 0.3, (64, 256), dev).clone()
+    tick = ops.dropout_tick(dev)
+    was = int(tick)
+    try:
+        tick.zero_()
+        k0 = ops.dropout_keep_mask(1234, 0.3, (64, 256), dev).clone()
+        tick.add_(1)
+        k1 = ops.dropout_keep_mask(1234, 0.3, (64, 256), dev).clone()
+        k1b = ops.dropout_keep_mask(1234, 0.3, (64, 256), dev).clone()
+        assert torch.equal(k1, k1b) and not torch.equal(k0, k1)
+        assert abs(float(k1.float().mean()) - 0.7) < 0.02
+        if was == 0:
+            assert torch.equal(base, k0)
+    finally:
+        tick.fill_(was)
+
+
+@pytest.mark.gpu
+def test_one_communication_round_with_server_graphs(dev):
+    """The round of test_one_communication_round with --server_graph 1 and the bf16 server: the global-training steps and the KD
+    steps (MMFL.py:346-391) each replay from a graph captured in their phase, the multi-modal client replays its contrast step
+    too; step counts of the server's optimizer = steps taken, everything finite."""
+    from creamfl_amd.algorithms.MMFL import MMFL
+    torch.manual_seed(2)
+    M = 144
+    args = SimpleNamespace(name='/tmp/creamfl_test', feature_dim=64, pub_data_num=M, not_bert=False, mlp_local=False,
+                           server_lr=2e-4, local_epochs=1, comm_rounds=1, num_img_clients=1, num_txt_clients=1,
+                           num_mm_clients=1, client_num_per_round=3, agg_method='con_w', contrast_local_intra=True,
+                           contrast_local_inter=True, interintra_weight=0.5, loss_scale=False, kd_weight=0.3,
+                           disable_distill=False, save_client=False, device=0, cnn_type='resnet18', bert_name='bert-mini',
+                           image_size=64, test_pairs=100, quiet=True, save_checkpoints=False, server_graph=1)
+    algo = MMFL(args, None)
+    algo.config.dataloader.batch_size = 16
+    algo.create_model(args)
+    algo.load_dataset(args)
+    algo.train(0)
+    st = algo.engine.graph_stats
+    assert set(st) == {'train', 'kd'}, st
+    for name in ('train', 'kd'):
+        assert st[name]['failed'] is None and st[name]['replays'] >= 4, (name, st[name])
+    mm = algo.mm_local_trainers[0].graph_stats
+    assert mm is not None and mm['failed'] is None and mm['replays'] >= 4, mm
+    sd = algo.engine.optimizer.state_dict()
+    steps = sorted(set(int(s['step']) for s in sd['state'].values()))
+    assert steps == [9, 18], steps                                     # the criterion's scalars skip the 9 KD steps
+    assert all(torch.isfinite(p).all() for p in algo.engine.model.parameters())
+    assert np.isfinite(algo.best_scores['test']['rsum'])

@@ -275,6 +275,8 @@ def main():
         out += [case_a3(128, 50000, 256)]
     if 'a5' in cases:
         out += [case_a5(args.conw_m, 256)]
+    if 'a5wide' in cases:            # D = 512 (configs[1]) / 768 (configs[4]): the 128 x 128 tile GEMM of bank.hip (no wide bank kernel)
+        out += [case_a5(args.conw_m, 512), case_a5(args.conw_m, 768)]
     if 'a2' in cases:
         out += [case_a2(256, 49, 2048, 1024, 512), case_a2(256, 49, 2048, 1024, 512, torch.bfloat16), case_a2(128, 49, 512, 256, 256)]
     if 'a6' in cases:
