@@ -75,8 +75,12 @@ class MMClientTrainer(EngineBase):
                 nn.utils.clip_grad.clip_grad_norm_(self.model.parameters(), clip)
             self.optimizer.step()
 
-    def train_epoch(self, global_img_feature, global_txt_feature, distill_index, global_train_loader, prefix=''):
-        # local PCME training on the client's own pairs (MMClientTrainer.py:118-143)
+    def _local_epoch(self):
+        """Local PCME training on the client's own pairs (MMClientTrainer.py:118-143).  A method of its own on purpose: its last
+        `loss` / `output` must be dead before the contrast step is captured -- a live loss keeps its autograd graph's AccumulateGrad
+        nodes alive, those are bound to the stream they were made on (here the default stream), the captured backward would make
+        THAT stream wait for the capturing one, and the HIP runtime faults in hipStreamEndCapture when the legacy default stream
+        is pulled into a capture (tools/mm_graph_probe.py)."""
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(self.train_loader or []):
             images, captions, caption_lens = images.to(self.device), captions.to(self.device), caption_lens.to(self.device)
             output = self._forward(self.model, images, captions, captions_word, caption_lens)
@@ -84,6 +88,9 @@ class MMClientTrainer(EngineBase):
             self._step(loss)
             if is_test:
                 break
+
+    def train_epoch(self, global_img_feature, global_txt_feature, distill_index, global_train_loader, prefix=''):
+        self._local_epoch()
         use_intra = bool(self.args.contrast_local_intra)
         use_inter = bool(self.args.contrast_local_inter)
         if not (use_intra or use_inter):

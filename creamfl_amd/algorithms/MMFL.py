@@ -399,4 +399,5 @@ class MMFL(object):
                 if not torch.is_tensor(loss):
                     continue
                 eng.backward_and_step(loss)       # incl. the bucketed gradient averaging when data parallel is on
+            del output, loss                      # (no live autograd graph across iterations: see MMClientTrainer._local_epoch)
         eng.drop_graph('kd')

@@ -12,6 +12,7 @@ synchronisation and no data-dependent Python control flow inside, outputs = tens
 valid until the next call).  A call whose input shapes differ from the captured ones (the ragged last batch of an epoch) runs
 eagerly.
 """
+import os
 import warnings
 
 import torch
@@ -29,7 +30,7 @@ class GraphedStep:
         # other_threads: another thread of the process issues HIP work while this step is captured (utils.prefetch's copy thread
         # stages or generates the next batches): capture in thread-local mode -- the default global mode fails ANY thread's
         # allocation for the duration of the capture
-        self.capture_mode = 'thread_local' if other_threads else 'global'
+        self.capture_mode = os.environ.get('CFL_GRAPH_CAPTURE_MODE') or ('thread_local' if other_threads else 'global')
         self.optimizer = optimizer if hasattr(optimizer, 'capture_begin') else None
         self._opt_handle = None
         if self.optimizer is not None and bool(enabled) and torch.cuda.is_available():

@@ -838,9 +838,8 @@ def test_mm_client_contrast_step_in_a_hip_graph_equals_eager(dev):
     summed inter terms, backward, clip + AdamP) replayed from one HIP graph per round -- possible since the fused AdamP reads its
     step count from the device inside a graph (cfl_adamp_step_counted) -- against the same loop run eagerly (--mm_client_graph 0).
     Two local epochs: the local PCME steps on the client's own pairs (eager, they also update the criterion's scalars) sit
-    between the two epochs' replays of ONE graph.  Same parameters (AdamP's first steps move a weight by ~lr whatever the size of
-    its gradient, so a library convolution's reordered sum can flip single elements: all but a sliver equal to 1e-4 of scale, the
-    sliver within 2 lr per step), same step counts, the ragged last batch eager, the graph really replayed."""
+    between the two epochs' replays of ONE graph.  Weights as close to the eager run's as a second eager run is
+    (_assert_same_training), same step counts, the ragged last batch eager, the graph really replayed."""
     from creamfl_amd.algorithms.MMClientTrainer import MMClientTrainer
     from creamfl_amd.utils.config import default_config
     from creamfl_amd.utils.synthetic import SyntheticCocoLoader
@@ -859,31 +858,52 @@ def test_mm_client_contrast_step_in_a_hip_graph_equals_eager(dev):
         cfg.train.use_fp16 = False
         msgs = []
         t = MMClientTrainer(args, cfg, SimpleNamespace(log=msgs.append), client=0, device=str(dev), train_loader=own)
+        w0 = {k: v.detach().float().cpu().clone() for k, v in t.model.state_dict().items()}
         with torch.backends.cudnn.flags(enabled=True, benchmark=False):
             t.run(g_img, g_txt, list(range(M)), pub)
         torch.cuda.synchronize()
         osd = t.optimizer.state_dict()
         steps = sorted(set(int(st['step']) for st in osd['state'].values()))
-        return t, {k: v.detach().float().cpu() for k, v in t.model.state_dict().items()}, steps, msgs
+        return t, {k: v.detach().float().cpu() for k, v in t.model.state_dict().items()}, steps, msgs, w0
 
-    t_e, sd_e, steps_e, _ = run(0)
-    t_g, sd_g, steps_g, msgs = run(1)
+    t_e, sd_e, steps_e, _, w0 = run(0)
+    _, sd_e2, _, _, _ = run(0)
+    t_g, sd_g, steps_g, msgs, _ = run(1)
     gs = t_g.graph_stats
     assert gs is not None and gs['failed'] is None, (gs, msgs)
     assert gs['calls'] == 18 and gs['replays'] == 5 + 8                # epoch 1: 3 warm-ups, capture + 4 replays, ragged; epoch 2: 8 + ragged
     assert t_e.graph_stats is None and t_g._graphed_contrast is None
     assert steps_e == steps_g and max(steps_g) == 2 * (2 + 9)          # model: local + contrast steps; the criterion's scalars: 4
     assert bool(torch.isfinite(t_g.last_contrast_loss))
-    lr = float(t_g.optimizer.param_groups[0]['lr'])
     for k, v in sd_e.items():
         if not v.is_floating_point():
-            assert torch.equal(v, sd_g[k]), k
+            assert torch.equal(v, sd_g[k]), k                          # BatchNorm batch counters advance inside the graph too
+    fl = [k for k, v in sd_e.items() if v.is_floating_point()]
+    _assert_same_training({k: w0[k] for k in fl}, {k: sd_e[k] for k in fl}, {k: sd_e2[k] for k in fl}, {k: sd_g[k] for k in fl},
+                          'mm client graph')
+
+
+def _assert_same_training(w0, w_ref, w_ref2, w_new, what):
+    """Do two training runs from one initial state end in the same weights, as far as the run itself is reproducible?  AdamP moves a
+    weight by ~lr per step whatever the size of its gradient, so the library convolutions' reordered sums (atomics) decorrelate the
+    noise-dominated elements of two IDENTICAL eager runs; the yardstick is therefore measured, not assumed: per parameter
+    d(a, b) = |a - b| / |a - initial| (distance relative to the distance trained), and the run under test must be as close to
+    the reference run as a second reference run is (x 3 + 0.05 per parameter; x 2 + 0.02 over all parameters together).  A capture
+    that replays stale inputs, wrong step counts or constant dropout masks is off by O(1) in EVERY parameter."""
+    num_n = num_r = den = 0.0
+    for k in w_ref:
+        moved = float((w_ref[k] - w0[k]).norm())
+        if moved == 0.0:
+            assert torch.equal(w_new[k], w_ref[k]), (what, k)
             continue
-        d = (v - sd_g[k]).abs()
-        off = d > 1e-4 * (float(v.abs().max()) + 1e-12) + 1e-6
-        assert float(off.float().mean()) < 5e-3, (k, float(off.float().mean()), float(d.max()))
-        if bool(off.any()) and 'running' not in k:
-            assert float(d[off].max()) <= 2.2 * lr * max(steps_g), (k, float(d[off].max()))
+        d_new = float((w_new[k] - w_ref[k]).norm()) / moved
+        d_ref = float((w_ref2[k] - w_ref[k]).norm()) / moved
+        assert d_new <= 3.0 * d_ref + 0.05, (what, k, d_new, d_ref)
+        num_n += float((w_new[k] - w_ref[k]).norm()) ** 2
+        num_r += float((w_ref2[k] - w_ref[k]).norm()) ** 2
+        den += moved ** 2
+    assert den > 0.0, what
+    assert (num_n / den) ** 0.5 <= 2.0 * (num_r / den) ** 0.5 + 0.02, (what, (num_n / den) ** 0.5, (num_r / den) ** 0.5)
 
 
 def _no_dropout(model):
@@ -897,9 +917,8 @@ def _no_dropout(model):
 def test_server_contrastive_step_in_a_hip_graph(dev, half):
     """--server_graph 1: TrainerEngine.train (retrieval_trainer.py:192-214) replays its step from ONE HIP graph -- two towers on two
     streams, MCSoftContrastiveLoss, clip + fused AdamP with the step count on the device, captions padded to one width.
-    fp32 trunks (deterministic up to the library's atomics), dropout off: the weights after 9 steps equal the eager loop's for
-    all but a sliver of elements, the sliver within 2 lr per step (AdamP's first steps move a weight by ~lr whatever its
-    gradient's size, so a reordered sum flips single elements), same step counts.  bf16 trunks (the bench's code path: fused
+    fp32 trunks, dropout off: the weights after 9 steps are as close to the eager loop's as a second eager run is
+    (_assert_same_training), same step counts.  bf16 trunks (the bench's code path: fused
     BatchNorm / GEMM / join kernels, fused BERT glue with dropout ON): the capture succeeds, the graph is replayed, everything
     stays finite, and the loss of the replayed steps stays in the eager loop's range."""
     from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
@@ -940,6 +959,14 @@ def test_server_contrastive_step_in_a_hip_graph(dev, half):
         named = {k: v.detach().float().cpu() for k, v in eng.model.named_parameters()}
         return eng, named, steps, [float(x) for x in losses], msgs
 
+    def initial():
+        torch.manual_seed(0)
+        cfg = default_config(embed_dim=64, cnn_type='resnet18', not_bert=False)
+        cfg.model.bert_name = 'bert-mini'
+        eng = TrainerEngine(device='cpu')
+        eng.create(cfg, {'<pad>': 0}, None, False)
+        return {k: v.detach().float().clone() for k, v in eng.model.named_parameters()}
+
     e_e, w_e, steps_e, loss_e, _ = run(0)
     e_g, w_g, steps_g, _, msgs = run(1)
     gs = e_g.graph_stats.get('train')
@@ -948,15 +975,10 @@ def test_server_contrastive_step_in_a_hip_graph(dev, half):
     assert e_e.graph_stats == {} and e_g._graphs == {}
     assert steps_e == steps_g == [9]
     assert all(bool(torch.isfinite(v).all()) for v in w_g.values())
-    lr = float(e_g.optimizer.param_groups[0]['lr'])
     if half:
         return
-    for k, v in w_e.items():
-        d = (v - w_g[k]).abs()
-        off = d > 1e-4 * (float(v.abs().max()) + 1e-12) + 1e-6
-        assert float(off.float().mean()) < 5e-3, (k, float(off.float().mean()), float(d.max()))
-        if bool(off.any()):
-            assert float(d[off].max()) <= 2.2 * lr * 9, (k, float(d[off].max()))
+    _, w_e2, _, _, _ = run(0)
+    _assert_same_training(initial(), w_e, w_e2, w_g, 'server graph')
 
 
 @pytest.mark.gpu
