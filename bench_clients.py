@@ -15,8 +15,8 @@ Two measurements, one JSON line (rank 0):
      trainer's own `contrast_step_fn` -- the function `tra()` / `train_epoch()` iterate -- on a device-resident public batch
      (B = 128, 224 x 224 images, COCO-shaped captions) against M = 50 000 random unit banks, D = 256, inter + intra,
      interintra_weight 0.5.  N = 1: one image client (ResNet-18 client net; replayed from a HIP graph, the product default, and
-     eager), one text client (bi-GRU + PIE; eager: packed sequences), one multi-modal client (PCME small: ResNet-18 + GRU,
-     AdamP; eager); `value` = the image client's graphed step.  N > 1: rank r times the step of the client KIND it would own
+     eager), one text client (bi-GRU + PIE; graph and eager), one multi-modal client (PCME small: ResNet-18 + GRU,
+     AdamP; graph and eager); `value` = the image client's graphed step.  N > 1: rank r times the step of the client KIND it would own
      (KINDS8), `value` = pairs of all ranks / slowest rank's time.
   2. ONE ROUND (`MMFL.train(0)`, product code, untouched: phases are timed by wrapping its methods from outside): global
      contrastive training, global representations, the sampled clients (local training + contrast loop + representations), the
@@ -524,7 +524,7 @@ def run(a, world, rank, dev, use_dist, json_out):
                'private_samples_per_client': fed['private_samples'],
                'graphs': {'server_graph': int(a.server_graph), 'mm_client_graph': int(a.mm_client_graph),
                           'server': dict(getattr(algo.engine, 'graph_stats', {}) or {}),
-                          'mm_clients': [getattr(t, 'graph_stats', None) for t in algo.mm_local_trainers][:2]},
+                          'mm_clients': [g for g in (getattr(t, 'graph_stats', None) for t in algo.mm_local_trainers) if g][:2]},
                'recall_1_after_round': None}
         try:
             sc = algo.best_scores['test']
