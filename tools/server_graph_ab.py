@@ -17,6 +17,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--dim', type=int, default=512)
+    ap.add_argument('--passes', type=int, default=2)
+    ap.add_argument('--tag', default='')
     a = ap.parse_args()
     from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
     from creamfl_amd.utils.config import default_config
@@ -42,8 +44,8 @@ def main():
         return time.perf_counter() - t0
 
     phase(20, 0)                                   # libraries, allocator
-    out = {'batch': a.batch, 'dim': a.dim}
-    for rep in range(2):
+    out = {'batch': a.batch, 'dim': a.dim, 'tag': a.tag}
+    for rep in range(a.passes):
         e20, e60 = phase(20, 0), phase(60, 0)
         g20, g60 = phase(20, 1), phase(60, 1)
         out[f'pass{rep}'] = {'eager_ms_per_batch': round(e60 / 60 * 1e3, 2), 'eager_slope_ms': round((e60 - e20) / 40 * 1e3, 2),
