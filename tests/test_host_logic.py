@@ -431,3 +431,41 @@ def test_adamp_capture_handles_count_replays_and_go_stale_on_the_host():
     assert [st['step'] for st in opt.state_dict()['state'].values()] == [8, 8, 7]
     opt.load_state_dict(opt.state_dict())
     assert not kd.valid()
+
+
+def test_server_graph_host_logic_on_the_cpu():
+    """--server_graph host logic without a GPU: the engine refuses graphs on the CPU / with data parallel on / with a tokenizer that
+    wants the caption strings; captions are padded to the graph's width (multiple of 8, fixed by the first batch) and lengths
+    become int64; GraphedStep keys re-make the step when the learning rate changes and keep statistics of the dropped one."""
+    from types import SimpleNamespace
+    from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
+    eng = TrainerEngine(device='cpu')
+    eng.server_graph = True
+    assert not eng.graph_capable()                                     # CPU: never
+    assert TrainerEngine.graph_caption_width(17) == 24 and TrainerEngine.graph_caption_width(24) == 24
+    gs = SimpleNamespace(caption_width=None)
+    im, cap, ln = eng.graph_inputs(gs, torch.zeros(2, 3, 4, 4), torch.ones(2, 19, dtype=torch.int64), torch.tensor([19, 7], dtype=torch.int32))
+    assert gs.caption_width == 24 and cap.shape == (2, 24) and int(cap[:, 19:].abs().sum()) == 0 and ln.dtype == torch.int64
+    _, cap2, _ = eng.graph_inputs(gs, torch.zeros(2, 3, 4, 4), torch.ones(2, 30, dtype=torch.int64), ln)
+    assert cap2.shape == (2, 30)                                       # wider than the graph: handed through (that call runs eagerly)
+    eng.drop_graph('train')                                            # nothing to drop: no statistics appear
+    assert eng.graph_stats == {}
+    made = []
+
+    class FakeStep:
+        def __init__(self, fn, **kw):
+            made.append(kw)
+            self.calls = self.replays = 0
+            self.failed = None
+    import creamfl_amd.graphs as graphs
+    real, graphs.GraphedStep = graphs.GraphedStep, FakeStep
+    try:
+        eng.optimizer = object()
+        a = eng.graphed_step('kd', ('lr', 1e-3), lambda: None)
+        assert eng.graphed_step('kd', ('lr', 1e-3), lambda: None) is a and len(made) == 1
+        a.calls, a.replays = 9, 5
+        b = eng.graphed_step('kd', ('lr', 5e-4), lambda: None)         # another round's learning rate: a new step, the old one counted
+        assert b is not a and eng.graph_stats['kd'] == {'calls': 9, 'replays': 5, 'failed': None}
+        assert made[0]['other_threads'] is True and made[0]['optimizer'] is eng.optimizer
+    finally:
+        graphs.GraphedStep = real
