@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--batches', type=int, default=50)
     ap.add_argument('--rounds', type=int, default=2)
     ap.add_argument('--sync-every', type=int, default=0, help='> 0: synchronise after every n-th step (GPU time per step, perturbs the loop)')
+    ap.add_argument('--mini-first', type=int, default=0, help='the miniature warm-up federation of the bench first')
+    ap.add_argument('--measure-first', type=int, default=0, help='the three client step measurements of the bench first')
     a = ap.parse_args()
     import bench_clients
     p2 = argparse.ArgumentParser()
@@ -29,6 +31,21 @@ def main():
     dev = torch.device('cuda', 0)
     torch.manual_seed(1234)
     algo, _ = bench_clients.build_federation(fa, dev, 128 * a.batches)
+    if a.measure_first:
+        from creamfl_amd.utils.synthetic import coco_batch_on_device
+        g = torch.Generator(device=dev).manual_seed(4321)
+        unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=g, device=dev), dim=-1)
+        banks = (unit(50000, 256), unit(50000, 256))
+        batch = coco_batch_on_device(128, dev, seed=1234, img=224)
+        for kind in ('img', 'txt', 'mm'):
+            bench_clients.measure_client(bench_clients.first_of_kind(algo, kind), kind, banks, batch, dev, 10, 3, False)
+    if a.mini_first:
+        mini, _ = bench_clients.build_federation(fa, dev, 4 * 128, mini=True)
+        random.seed(4321)
+        mini.train(0)
+        torch.cuda.synchronize()
+        del mini
+        torch.cuda.empty_cache()
     eng = algo.engine
     stamps, phases = [], []
     orig_step, orig_train = eng.train_step, eng.train
@@ -61,7 +78,7 @@ def main():
     for r in range(a.rounds):
         random.seed(1234)
         algo.train(r)
-    print(json.dumps({'sync_every': a.sync_every, 'phases': phases}), flush=True)
+    print(json.dumps({'mini_first': a.mini_first, 'measure_first': a.measure_first, 'threads': __import__('threading').active_count(), 'sync_every': a.sync_every, 'phases': phases}), flush=True)
 
 
 if __name__ == '__main__':
