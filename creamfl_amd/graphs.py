@@ -84,7 +84,7 @@ class GraphedStep:
     def _stay_eager(self, why):
         self.failed = why
         self.enabled = False
-        self.graph = self.static_out = self._opt_handle = None
+        self.graph = self.static_out = self.static_in = self._opt_handle = None    # (the graph's pool and its inputs return)
         torch.cuda.synchronize()
         msg = 'GraphedStep: no HIP graph (capture failed or went stale), the step stays eager: %s' % self.failed
         (self.log or warnings.warn)(msg)
