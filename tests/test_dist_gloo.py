@@ -265,8 +265,19 @@ def _worker_adamp_broadcast_state(rank, world, path, out):
         st['exp_avg_sq'] = torch.rand_like(p, memory_format=torch.preserve_format)
         if p.dim() == 4:
             st['master'] = torch.randn_like(p, memory_format=torch.preserve_format)
+    # a captured step with replays the host has not folded into the counts yet (AdamP.CaptureHandle): broadcast_state folds them
+    # in BEFORE the counts travel (rank 0's 3 + i + 2 reach everybody) and voids the capture (its offsets are differences of counts)
+    opt.prepare_capture()
+    handle = opt.capture_begin()
+    handle.params.extend(opt.param_groups[0]['params'])
+    opt.capture_end(handle)
+    handle.replayed()
+    handle.replayed()
     opt.broadcast_state(0)
     ok = True
+    ok &= handle.pending == 0 and not handle.valid()
+    for i, p in enumerate(opt.param_groups[0]['params']):
+        opt.state[p]['step'] -= 2                                 # (the rest of the test checks the fabricated counts)
     torch.manual_seed(100)                                        # rank 0's draws, replayed
     conv0 = torch.nn.Conv2d(4, 6, 3).to(memory_format=torch.channels_last)
     lin0 = torch.nn.Linear(5, 7)
