@@ -176,6 +176,7 @@ class ClientTrainer:
         self._to_device()
         self.old_model = copy.deepcopy(self.model)
         self.old_model.eval()
+        self.old_model.requires_grad_(False)                 # frozen for the round: its forwards save nothing for a backward
         self.lr_scheduler(self.cur_epoch)
         for i in range(self.local_epochs):
             self.local_epoch += 1
@@ -294,7 +295,7 @@ class ClientTrainer:
             if graphed is None or getattr(self, '_graphed_key', None) != key:
                 fn = (lambda images, d_idx: contrast_step(images, None, None, d_idx)) if is_img else \
                     (lambda captions, caption_lens, d_idx: contrast_step(None, captions, caption_lens, d_idx))
-                graphed = self._graphed_contrast = GraphedStep(fn, warmup=3, log=self._log)
+                graphed = self._graphed_contrast = GraphedStep(fn, warmup=3, log=self._log, guard_params=[p for g in self.optimizer.param_groups for p in g['params']])
                 graphed.caption_width = None
                 self._graphed_key = key
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(global_train_loader):

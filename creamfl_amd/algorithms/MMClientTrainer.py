@@ -27,6 +27,7 @@ class MMClientTrainer(EngineBase):
         self._to_device()
         self.old_model = copy.deepcopy(self.model)
         self.old_model.eval()
+        self.old_model.requires_grad_(False)                 # frozen for the round: its forwards save nothing for a backward
         if self.local_epoch == 0 and self.config.train.get('use_fp16'):
             self.to_half()
         self.model.train()

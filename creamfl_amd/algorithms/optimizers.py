@@ -199,6 +199,7 @@ class AdamP(Optimizer):
             self.plans = []              # the plans of the captured step (kept alive with the graph that addresses their buffers)
             self.params = []             # the parameters it updates
             self.pending = 0             # replays not yet counted in state[p]['step']
+            self.nsteps = 0              # step() calls recorded while this capture was open (rolled back if the capture fails)
             self.ids = frozenset()
             self.stale = False
 
@@ -236,9 +237,24 @@ class AdamP(Optimizer):
         self._capture = AdamP.CaptureHandle(self)
         return self._capture
 
-    def capture_end(self, handle):
+    def capture_end(self, handle, ok=True):
+        """ok=False: the capture FAILED after step() had been recorded (an exception inside the captured function, or from
+        hipStreamEndCapture).  Nothing that was recorded ever ran -- no update, no captured `add_` on the device counter -- but the
+        host has counted the step: state[p]['step'] and the host's running count are taken back, so that the eager re-run of the
+        same step is counted once and later graphs of this optimizer compute their offsets from a count that equals the device's."""
         if self._capture is handle:
             self._capture = None
+        if not ok:
+            for p in handle.params:                  # (a parameter stepped twice inside the capture is listed twice)
+                st = self.state.get(p)
+                if st is not None and 'step' in st:
+                    st['step'] -= 1
+            self._gstep_host -= handle.nsteps
+            for plan, pin in handle.plans:           # the pinned tables go back now; the device table is re-uploaded by the next step
+                plan['cap_pins'].append(pin)
+            handle.plans, handle.params, handle.nsteps = [], [], 0
+            handle.stale = True
+            return handle
         handle.ids = frozenset(id(p) for p in handle.params)
         self._live.add(handle)
         return handle
@@ -361,6 +377,8 @@ class AdamP(Optimizer):
         if self._handles:
             self._flush_replays()
         self._gstep_host += 1
+        if capturing:
+            self._capture.nsteps += 1        # (taken back by capture_end(handle, ok=False) if the capture fails)
         if self._gstep_dev is not None:
             self._gstep_dev.add_(1)          # (a node of the graph when capturing)
         stepped = set()

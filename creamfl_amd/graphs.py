@@ -18,16 +18,44 @@ stream it was made on; the captured backward makes that stream wait for the capt
 default stream's event record into a capture node, so the fork is never joined and hipStreamEndCapture faults (a segmentation
 fault, not an error code: the fallback below cannot catch it).  Trainers keep such steps in functions of their own
 (MMClientTrainer._local_epoch) so that their locals are dead; nodes made on any other stream are joined properly.
+The condition is ENFORCED, not only documented: before a capture `live_grad_nodes` probes the AccumulateGrad node of every parameter
+the step updates (`guard_params`, by default the optimizer's); if one is alive -- after a `gc.collect()` -- the step stays eager and
+says so.  (A node's stream cannot be read from Python, so the check is conservative: any live node refuses the capture.  The wrapped
+functions return detached losses, so nothing of a well-formed caller is alive here.)
 """
+import gc
 import os
 import warnings
 
 import torch
 
 
+def live_grad_nodes(params):
+    """How many of `params` have an AccumulateGrad node that some autograd graph (a loss that is still referenced, with or
+    without its buffers) keeps alive.  A tensor holds its accumulator weakly: asking for the gradient edge creates a node that dies
+    with the handle unless a graph owns it.  So: tag the node's metadata, drop the handle, ask again -- the tag survives only on a
+    node that something else holds."""
+    tok = object()
+    n_live = 0
+    for p in params:
+        if not (torch.is_tensor(p) and p.requires_grad and p.is_leaf):
+            continue
+        node = torch.autograd.graph.get_gradient_edge(p).node
+        node.metadata['_cfl_probe'] = tok
+        del node
+        node = torch.autograd.graph.get_gradient_edge(p).node
+        if node.metadata.get('_cfl_probe') is tok:
+            n_live += 1
+            del node.metadata['_cfl_probe']
+        del node
+    return n_live
+
+
 class GraphedStep:
-    def __init__(self, fn, warmup=3, enabled=True, log=None, optimizer=None, other_threads=False):
-        """log: callable(str) that is told ONCE why a capture failed (default: warnings.warn) -- a step that silently stays eager
+    def __init__(self, fn, warmup=3, enabled=True, log=None, optimizer=None, other_threads=False, guard_params=None):
+        """guard_params: the parameters the step updates (default: those of `optimizer`, any torch optimizer): no AccumulateGrad node
+        of theirs may be alive when the capture starts (module docstring) -- checked, the step stays eager otherwise.
+        log: callable(str) that is told ONCE why a capture failed (default: warnings.warn) -- a step that silently stays eager
         looks like a performance regression with no trace.
         optimizer: an optimizer whose step needs to know about captures and replays (creamfl_amd's fused AdamP: the step count of
         its bias corrections lives on the device inside a graph, `prepare_capture` / `capture_begin` / `capture_end`, and the
@@ -38,6 +66,9 @@ class GraphedStep:
         # stages or generates the next batches): capture in thread-local mode -- the default global mode fails ANY thread's
         # allocation for the duration of the capture
         self.capture_mode = os.environ.get('CFL_GRAPH_CAPTURE_MODE') or ('thread_local' if other_threads else 'global')
+        if guard_params is None and hasattr(optimizer, 'param_groups'):
+            guard_params = [p for g in optimizer.param_groups for p in g['params']]
+        self.guard_params = list(guard_params) if guard_params is not None else []
         self.optimizer = optimizer if hasattr(optimizer, 'capture_begin') else None
         self._opt_handle = None
         if self.optimizer is not None and bool(enabled) and torch.cuda.is_available():
@@ -63,6 +94,16 @@ class GraphedStep:
                 s.copy_(t, non_blocking=True)
 
     def _capture(self, inputs):
+        if self.guard_params:
+            n_live = live_grad_nodes(self.guard_params)
+            if n_live:
+                gc.collect()                                      # (a loss that only a reference cycle holds)
+                n_live = live_grad_nodes(self.guard_params)
+            if n_live:
+                # hipStreamEndCapture would FAULT (not raise) if such a node was made on the legacy default stream: never try
+                self._stay_eager('%d parameter(s) of the step still have a live AccumulateGrad node -- a loss of an earlier eager step is '
+                                 'referenced somewhere (return detached losses, keep eager steps in functions of their own)' % n_live)
+                return False
         self.static_in = [torch.empty_like(t) if t.is_cuda else torch.empty(t.shape, dtype=t.dtype, device=self._device) for t in inputs]
         self._copy_in(inputs)
         self.sig = self._signature(inputs)
@@ -73,7 +114,7 @@ class GraphedStep:
                 out = self.fn(*self.static_in)
         except Exception as e:                                    # noqa: BLE001  (capture not possible: stay eager, say why once)
             if handle is not None:
-                self.optimizer.capture_end(handle)
+                self.optimizer.capture_end(handle, ok=False)     # the recorded step never ran: the host's step counts go back
             self._stay_eager(repr(e)[:300])
             return False
         if handle is not None:

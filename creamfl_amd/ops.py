@@ -6,6 +6,7 @@ contiguous fp32 device tensor -- there is no CPU fallback (the CPU oracle lives 
 test infrastructure only).
 """
 import contextlib
+import threading as _threading
 import ctypes
 from collections.abc import Mapping
 
@@ -498,7 +499,9 @@ class _GruLastFn(torch.autograd.Function):
         H = w_hh.shape[1]
         x2 = words.reshape(B * T, E)
         xp = torch.addmm(b_ih, x2, w_ih.t())                               # [B * T, 3H]: the input side of every step at once
-        need = any(ctx.needs_input_grad)
+        # (needs_input_grad is True under no_grad() too whenever a weight has requires_grad: the frozen old model's forward of the
+        # intra contrast must not write and keep the [T+1, B, H] states and [B, T, 4H] gates)
+        need = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         out = torch.empty(B, H, dtype=torch.float32, device=words.device)
         hs = torch.empty(T + 1, B, H, dtype=torch.float32, device=words.device) if need else None
         gates = torch.empty(B, T, 4 * H, dtype=torch.float32, device=words.device) if need else None
@@ -534,7 +537,7 @@ class _GruCell0Fn(torch.autograd.Function):
         lib = _lib.load()
         B, H = x_last.shape[0], w_hh.shape[1]
         gx = torch.addmm(b_ih, x_last, w_ih.t())
-        need = any(ctx.needs_input_grad)
+        need = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         out = torch.empty(B, H, dtype=torch.float32, device=x_last.device)
         saved = torch.empty(B, 3 * H, dtype=torch.float32, device=x_last.device) if need else None
         _lib.check(lib.cfl_gru_cell0_fwd(_ptr(gx), _ptr(b_hh), _ptr(out), _ptr(saved), B, H, _stream(x_last)), 'cfl_gru_cell0_fwd')
@@ -563,11 +566,16 @@ class _GruCell0Fn(torch.autograd.Function):
 
 
 class _EmbeddingFn(torch.autograd.Function):
-    """nn.Embedding's lookup with the backward as ONE index_add_ (atomic adds into the zeroed table).  torch's dense embedding
-    backward switches, above 3072 indices, to a sort / unique-by-key path: ~10 launches and 70-180 us of host time per call
-    where this one takes 10 (tools/embed_sync_probe.py; neither waits for the device), and on this stack that path does not
-    survive a HIP-graph capture -- the replay of a text client's step padded to 128 x 32 = 4096 indices died with a memory
-    fault (profiles/r5_embed_backward_probe.json), the same step with this backward replays."""
+    """nn.Embedding's lookup whose backward is, INSIDE a HIP-graph capture, ONE index_add_ (atomic adds into the zeroed table).
+    torch's dense embedding backward switches, above 3072 indices, to a sort / unique-by-key path: ~10 launches and 70-180 us of
+    host time per call where this one takes 10 (tools/embed_sync_probe.py; neither waits for the device), and on this stack that
+    path does not survive a HIP-graph capture -- the replay of a text client's step padded to 128 x 32 = 4096 indices died with a
+    memory fault (profiles/r5_embed_backward_probe.json), the same step with this backward replays.
+    The atomic adds make the fp32 sum order-dependent, so the index_add_ form is used ONLY while a stream is capturing (or with
+    EMBED_INDEX_ADD[0] set: measurements); an eager step -- the replicated multi-rank server phases that are documented as bit-for-bit
+    equal on every rank, and anything under torch.use_deterministic_algorithms(True) -- runs torch's own deterministic dense backward,
+    i.e. exactly what the reference's nn.Embedding does.  A REPLAYED text / multi-modal client step is therefore deterministic only up
+    to fp32 summation order in its embedding gradient (rows of repeated words)."""
 
     @staticmethod
     def forward(ctx, tokens, weight):
@@ -578,9 +586,14 @@ class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (tokens,) = ctx.saved_tensors
+        if not (EMBED_INDEX_ADD[0] or torch.cuda.is_current_stream_capturing()):
+            return None, torch.ops.aten.embedding_dense_backward(g.contiguous(), tokens, ctx.table[0], -1, False)
         dw = torch.zeros(ctx.table, dtype=g.dtype, device=g.device)
         dw.index_add_(0, tokens.reshape(-1), g.reshape(-1, g.shape[-1]))
         return None, dw
+
+
+EMBED_INDEX_ADD = [_os.environ.get('CFL_EMBED_INDEX_ADD', '0') == '1']
 
 
 def embedding_lookup(embed, tokens):
@@ -1372,19 +1385,62 @@ def _fdb_covered(direction, x, w, out_shape, stride, padding):
     return hit
 
 
+_MIOPEN_MODE_LOCK = _threading.RLock()
+
+
 def _miopen(covered, fn, *args):
     """fn(*args) in MIOpen immediate mode when the find-db covers the problem, else as the process is configured."""
     if not covered or not torch.backends.cudnn.benchmark:
         return fn(*args)
-    torch._C._set_cudnn_benchmark(False)
-    try:
-        return fn(*args)
-    finally:
-        torch._C._set_cudnn_benchmark(True)
+    # the benchmark flag is process-global: flipping it is safe only while no other thread issues a convolution.  Convolutions are
+    # issued by the thread that runs the step (forward, and -- runtime.backward_here -- backward); the lock makes a second issuing
+    # thread (autograd's worker with CFL_AUTOGRAD_THREAD=1, a user's own thread) wait instead of seeing the flag half-flipped.
+    with _MIOPEN_MODE_LOCK:
+        torch._C._set_cudnn_benchmark(False)
+        try:
+            return fn(*args)
+        finally:
+            torch._C._set_cudnn_benchmark(True)
+
+
+# Round 6: the 3 x 3 / stride 1 weight gradients of layers 3 and 4 (14 x 14 and 7 x 7 maps: 25 of the 33 bottlenecks of a ResNet-101)
+# on the hand-written kernel of csrc/wgrad3x3.hip instead of MIOpen's igemm_wrw -- it moves the operands once and runs at several times
+# the library kernel's MFMA rate, and what the side stream does not ask of HBM and of the matrix pipes the main stream gets
+# (profiles/r6_bound_wgrad.json: the weight gradients cost the step 6.5 ms).  CFL_NO_WGRAD3=1 / tools/ab_step.py --knob wgrad3 is the A/B.
+WGRAD3 = [_os.environ.get('CFL_NO_WGRAD3', '0') != '1']
+WGRAD3_TAKEN = [0]
+
+
+def conv3x3_wgrad(dy, x, weight):
+    """dW of y = conv2d(x, weight, stride 1, padding 1) for a 3 x 3 weight, all bf16 channels_last: the kernel of csrc/wgrad3x3.hip.
+    None when the shape / layout is not taken (the caller goes to the library)."""
+    if not (weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3 and x.dim() == 4 and dy.dim() == 4):
+        return None
+    if not (dy.dtype == x.dtype == weight.dtype == torch.bfloat16 and x.is_cuda):
+        return None
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    if tuple(dy.shape) != (N, Co, H, W) or weight.shape[1] != Ci:
+        return None
+    lib = _lib.load()
+    if not lib.cfl_conv3x3_wgrad_supported(N, H, W, Ci, Co):
+        return None
+    cl = torch.channels_last
+    if not (x.is_contiguous(memory_format=cl) and dy.is_contiguous(memory_format=cl) and weight.is_contiguous(memory_format=cl)):
+        return None
+    dw = torch.empty_like(weight)                                        # [Co][3][3][Ci] in memory, as the weight
+    ws = _ws(lib.cfl_conv3x3_wgrad_ws_bytes(N, H, W, Ci, Co), x.device)
+    _lib.check(lib.cfl_conv3x3_wgrad(_ptr(dy), _ptr(x), N, H, W, Ci, Co, _ptr(dw), _ptr(ws), _stream(x)), 'cfl_conv3x3_wgrad')
+    WGRAD3_TAKEN[0] += 1
+    return dw
 
 
 def _conv_wgrad(args):
     dy, x, w = args[0], args[1], args[2]
+    if WGRAD3[0] and w.shape[2] == 3 and args[4][0] == 1 and args[5][0] == 1:
+        g = conv3x3_wgrad(dy, x, w)
+        if g is not None:
+            return g
     cov = _fdb_covered('W', x, w, dy.shape, args[4][0], args[5][0])
     return _miopen(cov, torch.ops.aten.convolution_backward, *args, [False, True, False])[1]
 
@@ -1719,10 +1775,18 @@ def dropout_tick(device):
     """The device word that varies the fused dropout masks between replays of a captured step (cfl_set_dropout_tick): created and
     registered with the library on first use -- from then on every fused dropout launch of the process adds it to its seed, eager
     steps included.  A step that is (or will be) captured calls `dropout_tick(device).add_(1)` once at its start."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
     if _DROPOUT_TICK[0] is None:
-        t = torch.zeros(1, dtype=torch.int32, device=device)
+        t = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.check(_lib.load().cfl_set_dropout_tick(t.data_ptr()), 'cfl_set_dropout_tick')
         _DROPOUT_TICK[0] = t
+    elif _DROPOUT_TICK[0].device != dev:
+        # the library holds ONE registered pointer per process (one process drives one GPU: DESIGN section 6); a second device's
+        # kernels would dereference the first device's word
+        raise _lib.CreamflHipError('dropout_tick: registered on %s, asked for %s -- one process drives one GPU (launch one rank per '
+                                   'device); the fused dropout tick is a per-process word' % (_DROPOUT_TICK[0].device, dev))
     return _DROPOUT_TICK[0]
 
 

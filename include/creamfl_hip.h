@@ -411,6 +411,19 @@ size_t cfl_bn_bwd_wgrad_ws_bytes(long long R, int C, int P);
 int cfl_bn_bwd_wgrad(const void* dy, const void* x, const void* a_in, int P, const float* gamma, const float* save_mean,
                      const float* save_invstd, long long R, int C, void* dx, float* dgamma, float* dbeta, void* dw, void* ws,
                      void* stream);
+/* Weight gradient of a 3 x 3 / stride 1 / padding 1 convolution on channels_last bf16 activations (torchvision Bottleneck.conv2 inside
+ * src/networks/models/image_encoder.py:27-36; the reference leaves it to cuDNN, this build's fallback is MIOpen's igemm_wrw kernel):
+ *   dw[co][kh][kw][ci] (bf16, the channels_last weight's own memory order) = sum_{n,h,w} dy[n,h,w,co] x[n,h+kh-1,w+kw-1,ci]
+ * dy [N,H,W,Co], x [N,H,W,Ci] bf16 rows.  One MFMA K step per zero-padded image row, both operands read transposed from LDS, the nine
+ * taps share operands through a rolling window of rows and modular w-shifts; split-K over image ranges (one range per XCD at a time)
+ * with fp32 partials and a fixed-order reduce: deterministic.  `supported`: (H, W) = (14, 14) or (7, 7), Ci % 64 == 0,
+ * Co % 128 == 0 (layers 3 and 4 of ResNet-50 / -101).  ws: cfl_conv3x3_wgrad_ws_bytes (splits x Co x 9 x Ci floats).
+ * cfl_conv3x3_wgrad_splits(n): n > 0 forces the number of image ranges (rounded down to a multiple of 8; measurements: 16 runs the
+ * layer3 shape on half of the chip), 0 restores the default (256 workgroups), negative only queries; returns the previous value. */
+int cfl_conv3x3_wgrad_supported(int N, int H, int W, int Ci, int Co);
+size_t cfl_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
+int cfl_conv3x3_wgrad(const void* dy, const void* x, int N, int H, int W, int Ci, int Co, void* dw, void* ws, void* stream);
+int cfl_conv3x3_wgrad_splits(int splits);
 /* cfl_bn_fwd / cfl_bn_apply / cfl_bn_bwd for FP32 activations (channels_last rows of C floats; every other argument as in the bf16
  * entries below, same kernels instantiated on 32-byte channel groups): BatchNorm2d (+ residual add) (+ ReLU) of the clients' fp32
  * encoders (src/networks/resnet_client.py:33-66,162-201 BasicBlock / stem; the reference runs them in fp32, ClientTrainer.py has no

@@ -324,3 +324,88 @@ def test_fused_adamp_captured_step_goes_stale_when_its_parameters_are_skipped():
     assert [sd_g['state'][k]['step'] for k in sorted(sd_g['state'])] == [9, 9, 9, 9, 8]
     for a, b in zip(w_e, w_g):
         np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_adamp_failed_capture_rolls_the_step_counts_back():
+    """a capture that fails AFTER optimizer.step() was recorded (here: the captured function raises behind it) must not
+    leave the host's counts one ahead of the device counter -- nothing recorded ever ran.  The step is re-run eagerly by GraphedStep,
+    counted once; the run ends with the weights and step counts of an all-eager run, and a LATER graph on the same optimizer (next
+    round's client graph, the server's KD graph) computes its offsets from a host count that equals the device's."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.algorithms.optimizers import AdamP
+    from creamfl_amd.graphs import GraphedStep
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(8)
+    xs = [torch.randn(16, 24, generator=gen).to(dev) for _ in range(10)]
+
+    def run(mode):
+        net, scal = _graph_toy(dev, 2)
+        opt = AdamP(list(net.parameters()) + [scal], lr=1e-2, weight_decay=0.01)
+        state = {'boom': mode == 'fail'}
+
+        def step(x):
+            opt.zero_grad(set_to_none=True)
+            loss = (net(x) ** 2).mean() * scal.sum()
+            loss.backward()
+            opt.step(clip=(net.parameters(), 0.5))
+            if state['boom'] and torch.cuda.is_current_stream_capturing():
+                state['boom'] = False
+                raise RuntimeError('injected: the capture fails behind optimizer.step()')
+            return loss.detach()
+        msgs = []
+        gs = GraphedStep(step, warmup=2, enabled=mode != 'eager', optimizer=opt, log=msgs.append)
+        for x in xs[:5]:
+            gs(x)
+        if mode == 'fail':
+            assert gs.failed is not None and 'injected' in gs.failed and len(msgs) == 1 and gs.replays == 0
+            assert opt._gstep_host == int(opt._gstep_dev) == 5
+        gs2 = GraphedStep(step, warmup=1, enabled=mode != 'eager', optimizer=opt)       # a later graph on the same optimizer
+        for x in xs[5:]:
+            gs2(x)
+        torch.cuda.synchronize()
+        if mode == 'fail':
+            assert gs2.failed is None and gs2.replays == 4
+            assert opt._gstep_host == int(opt._gstep_dev) == 10
+        sd = opt.state_dict()
+        return [p.detach().cpu() for p in list(net.parameters()) + [scal]], [sd['state'][k]['step'] for k in sorted(sd['state'])]
+
+    w_e, steps_e = run('eager')
+    w_f, steps_f = run('fail')
+    assert steps_e == steps_f == [10] * 5
+    for a, b in zip(w_e, w_f):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_graphed_step_refuses_a_capture_while_a_loss_is_alive():
+    """a loss of an earlier eager step that is still referenced keeps the AccumulateGrad nodes of the step's parameters
+    alive; capturing then can FAULT inside hipStreamEndCapture (graphs.py).  The precondition is checked: the step stays eager and
+    says why, instead of relying on the callers' discipline."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd.graphs import GraphedStep, live_grad_nodes
+    dev = torch.device('cuda:0')
+    net, _ = _graph_toy(dev, 3)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+    x = torch.randn(16, 24, device=dev)
+
+    def step(x):
+        opt.zero_grad(set_to_none=True)
+        loss = (net(x) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    kept = (net(x) ** 2).mean()                       # what a logging line / a closure / a debugger would hold on to
+    assert live_grad_nodes(net.parameters()) == 4
+    msgs = []
+    gs = GraphedStep(step, warmup=1, optimizer=opt, log=msgs.append)
+    for _ in range(3):
+        gs(x)
+    assert gs.graph is None and gs.replays == 0 and len(msgs) == 1 and 'AccumulateGrad' in msgs[0]
+    del kept
+    assert live_grad_nodes(net.parameters()) == 0
+    gs = GraphedStep(step, warmup=1, optimizer=opt)
+    for _ in range(3):
+        gs(x)
+    torch.cuda.synchronize()
+    assert gs.failed is None and gs.replays == 2

@@ -433,6 +433,49 @@ def test_adamp_capture_handles_count_replays_and_go_stale_on_the_host():
     assert not kd.valid()
 
 
+def test_adamp_failed_capture_rolls_back_on_the_host():
+    """capture_end(handle, ok=False): the steps recorded inside a capture that failed are taken back from state[p]['step'] and from the
+    host's running count (no kernel runs here: what step() records while capturing is written by hand)."""
+    from creamfl_amd.algorithms.optimizers import AdamP
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(2)]
+    opt = AdamP(ps, lr=1e-3)
+    opt.prepare_capture()
+    for p in ps:
+        opt.state[p]['step'] = 4
+    opt._gstep_host = 4
+    h = opt.capture_begin()
+    for p in ps:                                 # step() inside the capture: counts, remembers the parameters
+        opt.state[p]['step'] += 1
+    opt._gstep_host += 1
+    h.nsteps += 1
+    h.params.extend(ps)
+    opt.capture_end(h, ok=False)
+    assert [opt.state[p]['step'] for p in ps] == [4, 4] and opt._gstep_host == 4
+    assert not h.valid() and h not in opt._live and opt._capture is None
+    h2 = opt.capture_end(opt.capture_begin())   # a later capture is unaffected
+    assert h2.valid()
+
+
+def test_live_grad_node_probe_on_the_cpu():
+    """graphs.live_grad_nodes: a referenced loss (with or without its buffers) keeps the parameters' AccumulateGrad nodes alive, a
+    detached one does not -- the precondition GraphedStep checks before a capture."""
+    from creamfl_amd.graphs import GraphedStep, live_grad_nodes
+    lin = torch.nn.Linear(4, 4)
+    assert live_grad_nodes(lin.parameters()) == 0
+    loss = lin(torch.randn(2, 4)).sum()
+    assert live_grad_nodes(lin.parameters()) == 2
+    loss.backward()
+    assert live_grad_nodes(lin.parameters()) == 2          # the buffers are gone, the graph's nodes are not
+    del loss
+    assert live_grad_nodes(lin.parameters()) == 0
+    kept = lin(torch.randn(2, 4)).sum().detach()
+    assert live_grad_nodes(lin.parameters()) == 0 and kept.grad_fn is None
+    frozen = torch.nn.Linear(2, 2).requires_grad_(False)
+    assert live_grad_nodes(frozen.parameters()) == 0
+    gs = GraphedStep(lambda t: t, optimizer=torch.optim.SGD(lin.parameters(), lr=0.1), enabled=False)
+    assert len(gs.guard_params) == 2
+
+
 def test_server_graph_host_logic_on_the_cpu():
     """--server_graph host logic without a GPU: the engine refuses graphs on the CPU / with data parallel on / with a tokenizer that
     wants the caption strings; captions are padded to the graph's width (multiple of 8, fixed by the first batch) and lengths

@@ -8,6 +8,12 @@ knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming 
         join   the gradient join of the residual blocks in the data-gradient GEMM's epilogue (default) vs in the BatchNorm backward
         wgfuse   conv3's weight gradient inside the BatchNorm backward-apply pass (default) vs the library's kernel on the side stream
         bnslice  the BatchNorm passes on the channel-sliced block map (no `final` launches, default) vs the whole-row map
+        wgrad3   the 3 x 3 weight gradients of layers 3 / 4 on csrc/wgrad3x3.hip (default) vs MIOpen's igemm_wrw
+        w3splitN that kernel on N image ranges (N / 32 of the chip for the layer3 shape) vs its default of 256 workgroups
+        wgrad    BOUND, not a product switch: every trunk weight gradient computed (default) vs replaced by a zero fill -- what the
+                 side stream's 15 ms of library kernels cost the step (their own time is hidden; the contention is not)
+        text     BOUND: the text tower run (default) vs its output replaced by a constant -- the image tower + head alone
+        sides    BOUND: both of the above together -- the main stream with nothing beside it
 """
 import argparse
 import json
@@ -61,6 +67,25 @@ def main():
             ops.WGRAD_FUSE[0] = bool(on)
         elif args.knob == 'bnslice':
             lib.cfl_bn_sliced(1 if on else 0)
+        elif args.knob in ('wgrad', 'text', 'sides'):
+            from creamfl_amd import ops
+            if args.knob in ('wgrad', 'sides'):
+                if not hasattr(ops, '_real_conv_wgrad'):
+                    ops._real_conv_wgrad = ops._conv_wgrad
+                ops._conv_wgrad = ops._real_conv_wgrad if on else (lambda a: torch.zeros_like(a[2]))
+            if args.knob in ('text', 'sides'):
+                m = eng.model
+                if not hasattr(m, '_real_text_tower'):
+                    m._real_text_tower = m._text_tower
+                    with torch.no_grad(), torch.autocast('cuda', dtype=eng.autocast_dtype, enabled=eng.autocast_dtype is not None):
+                        m._const_text = {k: (v.detach().clone() if torch.is_tensor(v) else v)
+                                         for k, v in m._real_text_tower(b[1], b[2], b[3]).items()}
+                m._text_tower = m._real_text_tower if on else (lambda *a, **k: dict(m._const_text))
+        elif args.knob == 'wgrad3':
+            from creamfl_amd import ops
+            ops.WGRAD3[0] = bool(on)
+        elif args.knob.startswith('w3split'):
+            lib.cfl_conv3x3_wgrad_splits(int(args.knob[7:] or 16) if on else 0)
         elif args.knob == 'join':
             from creamfl_amd import ops
             ops._NO_JOIN_FUSE = not on

@@ -237,6 +237,43 @@ def case_gemm16(H, Ci, Co, variants=(0,), N=256, join=False):
     return out
 
 
+def case_wgrad3(H, C, N=256, splits=(0,)):
+    """3 x 3 / stride 1 weight gradient (csrc/wgrad3x3.hip) vs MIOpen's kernel at one ResNet-101 shape, bf16 channels_last."""
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    cl = torch.channels_last
+    x = torch.randn(N, C, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=cl)
+    dy = torch.randn(N, C, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=cl)
+    w = torch.zeros(C, C, 3, 3, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=cl)
+    flop = 2.0 * N * H * H * 9 * C * C
+    algo = 2.0 * N * H * H * 2 * C + 2.0 * 9 * C * C
+    out = {'case': f'wgrad3 {H}x{H} {C}->{C} N={N}', 'gflop': round(flop / 1e9, 1), 'algorithmic_mb': round(algo / 1e6, 1),
+           'mfma_floor_us': round(flop / 2.5e9, 1), 'hbm_floor_us': round(algo / 6.3e6, 1)}
+    args = (dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    torch.backends.cudnn.benchmark = True
+    ref = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+    us_lib, _ = timed(lambda: torch.ops.aten.convolution_backward(*args, [False, True, False]), iters=20)
+    out['library_us_wall'] = round(us_lib, 1)
+    for sp in splits:
+        lib.cfl_conv3x3_wgrad_splits(sp)
+        dw = ops.conv3x3_wgrad(dy, x, w)
+        if dw is None:
+            out['own'] = 'shape not taken'
+            break
+        err = float((dw.float() - ref.float()).abs().max()) / max(float(ref.float().abs().max()), 1e-9)
+        us, prof = timed(lambda: ops.conv3x3_wgrad(dy, x, w), iters=20)
+        k = prof.get('cfl_conv3x3_wgrad_kernel', us)
+        tag = f's{sp}' if sp else 'default'
+        out[f'{tag}_kernel_us'] = k
+        out[f'{tag}_reduce_us'] = prof.get('cfl_conv3x3_wgrad_reduce_kernel')
+        out[f'{tag}_wall_us'] = round(us, 1)
+        out[f'{tag}_TFLOPs'] = round(flop / k / 1e6)
+        out[f'{tag}_frac_mfma_peak'] = round(flop / k / 1e6 / 2500.0, 3)
+        out[f'{tag}_relerr_vs_library'] = round(err, 5)
+    lib.cfl_conv3x3_wgrad_splits(0)
+    return out
+
+
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -328,6 +365,9 @@ def main():
             out.append(case_gemm16(H, Ci, Co, (0,), join=True))
         for (H, Ci, Co) in [(56, 256, 64), (28, 512, 128), (14, 1024, 256), (7, 2048, 512)]:
             out.append(case_gemm16(H, Ci, Co, (0,)))
+    if 'wgrad3' in cases:
+        out.append(case_wgrad3(14, 256, splits=(0, 16, 8)))
+        out.append(case_wgrad3(7, 512, splits=(0,)))
     if 'opt' in cases:
         out += [case_opt()]
     for r in out:

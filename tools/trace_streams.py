@@ -36,10 +36,12 @@ out = {'steps': steps, 'wall_ms_per_step': round(wall, 3), 'queue_key': qkey, 'q
 for q, iv in sorted(per.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
     iv.sort()
     busy, cur_s, cur_e = 0, None, None
+    gaps = []
     for s, e, _ in iv:
         if cur_e is None or s > cur_e:
             if cur_e is not None:
                 busy += cur_e - cur_s
+                gaps.append(s - cur_e)
             cur_s, cur_e = s, e
         else:
             cur_e = max(cur_e, e)
@@ -51,6 +53,12 @@ for q, iv in sorted(per.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])
         cnt[n] += 1
     out['queues'][str(q)] = {'launches_per_step': round(len(iv) / steps, 1), 'busy_ms_per_step': round(busy / steps / 1e6, 3),
                              'kernel_ms_per_step': round(sum(agg.values()) / steps / 1e6, 3),
+                             # idle intervals between consecutive busy intervals of this queue: how much of the step the queue waits
+                             # (for the host, for another queue's event, for the dispatch of a dependent kernel)
+                             'gaps': {'per_step': round(len(gaps) / steps, 1), 'idle_ms_per_step': round(sum(gaps) / steps / 1e6, 3),
+                                      'median_us': round(sorted(gaps)[len(gaps) // 2] / 1e3, 2) if gaps else 0,
+                                      'idle_ms_in_gaps_over_20us': round(sum(g for g in gaps if g > 20000) / steps / 1e6, 3),
+                                      'n_over_20us_per_step': round(sum(1 for g in gaps if g > 20000) / steps, 1)},
                              'top': [{'kernel': n, 'ms_per_step': round(t / steps / 1e6, 3), 'launches_per_step': round(cnt[n] / steps, 1),
                                       'avg_us': round(t / cnt[n] / 1e3, 1)} for n, t in agg.most_common(a.top)]}
 print(json.dumps(out, indent=1))
