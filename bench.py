@@ -244,6 +244,10 @@ def parse_args(argv=None):
     import bench_clients
     bench_clients.add_arguments(ap)
     ap.add_argument('--no-recall', action='store_true')
+    ap.add_argument('--no-client-steps', action='store_true',
+                    help='config 1, one rank: skip the `extra.client_steps` record (the clients\' contrast steps of configs[2], measured by a '
+                         'child process AFTER the timed region)')
+    ap.add_argument('--client-steps-timeout', type=int, default=600)
     ap.add_argument('--no-mfu', action='store_true', help='skip the FLOP-counting forward pass (profiling runs: every launch then belongs to a step)')
     ap.add_argument('--prewarm', action='store_true',
                     help='let a CHILD process run 3 untimed steps first (MIOpen compiles / selects its kernels there).  Off by '
@@ -549,6 +553,9 @@ def main():
         recall = None
         if not args.no_recall:
             recall = coco_1k_recall(args.dim, dev)
+        extra = None
+        if world == 1 and args.config == 1 and not args.no_client_steps:
+            extra = {'client_steps': client_steps(args)}
         # model-FLOPs utilisation of the step: forward + backward = 3 x forward model FLOPs per step and GPU
         mfma_peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else F32_MFMA_PEAK_TFLOPS
         mfu = None
@@ -585,7 +592,7 @@ def main():
                       'backend': ('rccl' if args.backend == 'nccl' else 'gloo (SMOKE MODE: not a scaling measurement)') if use_dp
                       else None, 'rccl_ranks': torch.distributed.get_world_size() if (use_dp and args.backend == 'nccl') else 0,
                       'gpus_visible': n_visible},
-            'comm': comm, 'roofline': roof, 'cpu_baseline': cpu, 'mfu': mfu, 'recall_1': recall,
+            'comm': comm, 'roofline': roof, 'cpu_baseline': cpu, 'mfu': mfu, 'recall_1': recall, 'extra': extra,
             'parity_unpinned': ['AdamP (adamp==0.3.0 is not vendored: checked against the paper restatement oracle/adamp.py)'],
             'hip_kernels_us_warmup_step': hip_us,
         }
@@ -636,6 +643,48 @@ def _host_memory_limit_gb():
     except (OSError, ValueError):
         pass
     return None
+
+
+def client_steps(args):
+    """`extra.client_steps` of the default line: the CLIENT side of configs[2] where the driver can see
+    it -- the contrast step of one image / text / multi-modal client at the config-2 defaults (public batch 128 of 224 x 224 images /
+    COCO-shaped captions, banks M = 50 000, D = 256, inter + intra; the product path = replayed from a HIP graph, eager beside it), and
+    the bank pass (rows A3 + A4, the kernel north_star names) HIP-event timed inside the eager region with its fraction of HBM.
+    Measured by a CHILD process (`bench.py --config 2 --round none`) after this process's timed region and after its GPU memory was
+    released: nothing of it can touch `value`.  The configs[1] fields of the line are untouched."""
+    import subprocess
+    torch.cuda.empty_cache()
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', '2', '--round', 'none', '--steps', '30', '--warmup', '5',
+           '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.perf_counter()
+    try:
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.client_steps_timeout)
+    except subprocess.TimeoutExpired:
+        return {'error': 'client-steps child exceeded %d s' % args.client_steps_timeout}
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
+    if res.returncode != 0 or not lines:
+        return {'error': 'client-steps child rc=%d: %s' % (res.returncode, res.stderr.decode()[-300:])}
+    line = json.loads(lines[-1])
+    out = {'how': 'child process `bench.py --config 2 --round none --steps 30 --warmup 5` after the timed region; fp32 clients (the '
+                  'reference\'s client precision), product path = HIP-graph replay',
+           'workload': line['config']['workload'], 'child_seconds': round(time.perf_counter() - t0, 1)}
+    for kind, name in (('img', 'image'), ('txt', 'text'), ('mm', 'multi_modal')):
+        c = (line.get('clients') or {}).get(kind)
+        if not c:
+            continue
+        best = c.get('graph') or c['eager']
+        out[name] = {'ms_per_step': best['ms_per_step'], 'pairs_per_s': best['pairs_per_s'], 'path': 'hip graph' if c.get('graph') else 'eager',
+                     'eager_ms_per_step': c['eager']['ms_per_step'], 'batch': c['batch'],
+                     'capture_failed': (c.get('graph') or {}).get('capture_failed'),
+                     'a3a4_kernels_us_per_step': c.get('a3a4_kernels_us_per_step'),
+                     'hand_written_kernels_us_per_step': c.get('hand_written_kernels_us_per_step'),
+                     'bank_pass_avg_launch_us': (c.get('bank_pass') or {}).get('avg_launch_us')}
+    roof = line.get('roofline')
+    if roof:
+        out['bank_pass_roofline'] = {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us',
+                                                              'launches', 'algorithmic_bytes', 'how')}
+    return out
 
 
 def cpu_baseline(cfg, args):
@@ -706,6 +755,7 @@ def cpu_baseline_child(args):
     if mem is not None:
         _rss_watchdog(mem)
     note = ''
+    same_batch = None
     for batch in ([args.cpu_batch] if args.cpu_batch <= 64 else [args.cpu_batch, 64]):
         if batch > 64 and mem is not None and mem < 0.35 * batch:        # ~0.25 GB of saved fp32 activations per ResNet-101 sample
             note = '; batch %d needs ~%d GB of host memory, %.0f GB available -> batch 64' % (batch, int(0.25 * batch), mem)
@@ -725,6 +775,11 @@ def cpu_baseline_child(args):
         warm = [one(), one()]
         if batch > 64 and warm[1] > args.cpu_step_limit:
             note = '; one step at batch %d took %.1f s (> %.0f s) -> batch 64' % (batch, warm[1], args.cpu_step_limit)
+            # the GPU's own workload: the second step at the config's batch IS a measurement -- one warm-up, one
+            # timed step -- and is reported beside the full protocol at batch 64 instead of being thrown away
+            same_batch = {'batch': batch, 'value': round(batch / warm[1], 3), 'unit': 'pairs/s', 'step_s': round(warm[1], 3),
+                          'first_step_s': round(warm[0], 3), 'protocol': '1 warm-up + 1 timed step (a step takes > %.0f s: the '
+                          'median-of-%d protocol runs at batch 64)' % (args.cpu_step_limit, args.cpu_steps)}
             del model, opt, b
             continue
         warm += [one() for _ in range(max(0, args.cpu_warmup - 2))]
@@ -736,7 +791,11 @@ def cpu_baseline_child(args):
             'step_s_median': round(med, 3), 'step_s_min_max': [round(times[0], 3), round(times[-1], 3)],
             'protocol': 'BASELINE.md section 3: %d warm-ups + median of %d timed steps, threads = usable cores' % (len(warm), len(times)),
             'sample': 'same step (%s+BERT-base fp32, d=%d, oracle head+loss, clip, AdamP) on the same seeded batch, batch %d%s'
-                      % (args.cnn, args.dim, batch, note)}))
+                      % (args.cnn, args.dim, batch, note),
+            'same_batch_as_gpu': same_batch if same_batch is not None else ({'batch': batch, 'value': round(batch / med, 3),
+                                                                             'unit': 'pairs/s', 'step_s': round(med, 3),
+                                                                             'protocol': 'the full protocol above'}
+                                                                            if batch == args.batch else None)}))
         return
     raise SystemExit('cpu baseline: no batch size fits')
 

@@ -493,15 +493,16 @@ GRU_FUSED = [_os.environ.get('CFL_NO_GRU_FUSED', '0') != '1']
 
 class _GruLastFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, words, lens, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, words, lens, w_ih, w_hh, b_ih, b_hh, track=True):
         lib = _lib.load()
         B, T, E = words.shape
         H = w_hh.shape[1]
         x2 = words.reshape(B * T, E)
         xp = torch.addmm(b_ih, x2, w_ih.t())                               # [B * T, 3H]: the input side of every step at once
-        # (needs_input_grad is True under no_grad() too whenever a weight has requires_grad: the frozen old model's forward of the
-        # intra contrast must not write and keep the [T+1, B, H] states and [B, T, 4H] gates)
-        need = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        # (needs_input_grad is True under no_grad() too whenever a weight has requires_grad, and grad mode is always OFF inside a
+        # Function's forward: the caller passes its own grad mode as `track` -- the frozen old model's forward of the intra contrast
+        # must not write and keep the [T+1, B, H] states and [B, T, 4H] gates)
+        need = bool(track) and any(ctx.needs_input_grad)
         out = torch.empty(B, H, dtype=torch.float32, device=words.device)
         hs = torch.empty(T + 1, B, H, dtype=torch.float32, device=words.device) if need else None
         gates = torch.empty(B, T, 4 * H, dtype=torch.float32, device=words.device) if need else None
@@ -528,16 +529,16 @@ class _GruLastFn(torch.autograd.Function):
         dw_hh = dg.t() @ hs[:T].view(T * B, H) if need[3] else None
         db_ih = dxp.sum(0) if need[4] else None
         db_hh = dg.sum(0) if need[5] else None
-        return dwords, None, dw_ih, dw_hh, db_ih, db_hh
+        return dwords, None, dw_ih, dw_hh, db_ih, db_hh, None
 
 
 class _GruCell0Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_last, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x_last, w_ih, w_hh, b_ih, b_hh, track=True):
         lib = _lib.load()
         B, H = x_last.shape[0], w_hh.shape[1]
         gx = torch.addmm(b_ih, x_last, w_ih.t())
-        need = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        need = bool(track) and any(ctx.needs_input_grad)
         out = torch.empty(B, H, dtype=torch.float32, device=x_last.device)
         saved = torch.empty(B, 3 * H, dtype=torch.float32, device=x_last.device) if need else None
         _lib.check(lib.cfl_gru_cell0_fwd(_ptr(gx), _ptr(b_hh), _ptr(out), _ptr(saved), B, H, _stream(x_last)), 'cfl_gru_cell0_fwd')
@@ -562,7 +563,7 @@ class _GruCell0Fn(torch.autograd.Function):
         dw_hh = torch.zeros_like(w_hh) if need[2] else None
         db_ih = dgx.sum(0) if need[3] else None
         db_hh = dgh.sum(0) if need[4] else None
-        return dx, dw_ih, dw_hh, db_ih, db_hh
+        return dx, dw_ih, dw_hh, db_ih, db_hh, None
 
 
 class _EmbeddingFn(torch.autograd.Function):
@@ -636,11 +637,12 @@ def bigru_last_states(rnn, words, lengths):
             raise RuntimeError(f'length {ll[0]} exceeds the padded width {T}')
     lens = lengths.to(device=words.device, dtype=torch.int32, non_blocking=True).contiguous()
     words = words.contiguous()
-    fwd = _GruLastFn.apply(words, lens, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+    track = torch.is_grad_enabled()
+    fwd = _GruLastFn.apply(words, lens, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, track)
     last = (lens.to(torch.int64) - 1).clamp_(0, T - 1)
     x_last = words.gather(1, last.view(B, 1, 1).expand(B, 1, words.shape[2])).squeeze(1)
     bwd = _GruCell0Fn.apply(x_last, rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse,
-                            rnn.bias_hh_l0_reverse)
+                            rnn.bias_hh_l0_reverse, track)
     return torch.cat([fwd, bwd], 1)
 
 
