@@ -90,6 +90,10 @@ SIGNATURES = {
     'cfl_rank_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cfl_rank_count': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_bn_sliced': (c_int, [c_int]),
+    'cfl_conv1x1_wgrad_supported': (c_int, [c_longlong, c_int, c_int]),
+    'cfl_conv1x1_wgrad_ws_bytes': (c_size_t, [c_longlong, c_int, c_int]),
+    'cfl_conv1x1_wgrad': (c_int, [_P, _P, c_longlong, c_int, c_int, _P, _P, _P]),
+    'cfl_conv1x1_wgrad_workgroups': (c_int, [c_int]),
     'cfl_conv3x3_wgrad_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_wgrad_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -1405,8 +1405,8 @@ def _miopen(covered, fn, *args):
             torch._C._set_cudnn_benchmark(True)
 
 
-# Round 6: the 3 x 3 / stride 1 weight gradients of layers 3 and 4 (14 x 14 and 7 x 7 maps: 25 of the 33 bottlenecks of a ResNet-101)
-# on the hand-written kernel of csrc/wgrad3x3.hip instead of MIOpen's igemm_wrw -- it moves the operands once and runs at several times
+# Round 6: the 3 x 3 / stride 1 weight gradients of the bottlenecks (56 x 56 x 64, 28 x 28 x 128, 14 x 14 x 256, 7 x 7 x 512: 30 of the 33
+# conv2 layers of a ResNet-101; the three stride-2 ones stay on the library) on the hand-written kernel of csrc/wgrad3x3.hip instead of MIOpen's igemm_wrw -- it moves the operands once and runs at several times
 # the library kernel's MFMA rate, and what the side stream does not ask of HBM and of the matrix pipes the main stream gets
 # (profiles/r6_bound_wgrad.json: the weight gradients cost the step 6.5 ms).  CFL_NO_WGRAD3=1 / tools/ab_step.py --knob wgrad3 is the A/B.
 WGRAD3 = [_os.environ.get('CFL_NO_WGRAD3', '0') != '1']
@@ -1437,10 +1437,47 @@ def conv3x3_wgrad(dy, x, weight):
     return dw
 
 
+# ... and the 1 x 1 / stride 1 ones (66 per step: conv1 / conv3 of every bottleneck, the stride-1 downsample) on csrc/wgrad1x1.hip instead of
+# the library's batched GEMM with atomics + zero fill + cast.  CFL_NO_WGRAD1=1 / tools/ab_step.py --knob wgrad1 is the A/B.
+WGRAD1 = [_os.environ.get('CFL_NO_WGRAD1', '0') != '1']
+WGRAD1_TAKEN = [0]
+
+
+def conv1x1_wgrad(dy, x, weight):
+    """dW of y = conv2d(x, weight) for a 1 x 1 / stride 1 weight, all bf16 channels_last: the kernel of csrc/wgrad1x1.hip.  None when
+    the shape / layout is not taken (the caller goes to the library)."""
+    if not (weight.dim() == 4 and weight.shape[2] == 1 and weight.shape[3] == 1 and x.dim() == 4 and dy.dim() == 4):
+        return None
+    if not (dy.dtype == x.dtype == weight.dtype == torch.bfloat16 and x.is_cuda):
+        return None
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    if tuple(dy.shape) != (N, Co, H, W) or weight.shape[1] != Ci:
+        return None
+    M = N * H * W
+    lib = _lib.load()
+    if not lib.cfl_conv1x1_wgrad_supported(M, Ci, Co):
+        return None
+    cl = torch.channels_last
+    if not (x.is_contiguous(memory_format=cl) and dy.is_contiguous(memory_format=cl)):
+        return None
+    if not (weight.is_contiguous() or weight.is_contiguous(memory_format=cl)):
+        return None
+    dw = torch.empty_like(weight)                                        # [Co][Ci] in memory in either format
+    ws = _ws(lib.cfl_conv1x1_wgrad_ws_bytes(M, Ci, Co), x.device)
+    _lib.check(lib.cfl_conv1x1_wgrad(_ptr(dy), _ptr(x), M, Ci, Co, _ptr(dw), _ptr(ws), _stream(x)), 'cfl_conv1x1_wgrad')
+    WGRAD1_TAKEN[0] += 1
+    return dw
+
+
 def _conv_wgrad(args):
     dy, x, w = args[0], args[1], args[2]
     if WGRAD3[0] and w.shape[2] == 3 and args[4][0] == 1 and args[5][0] == 1:
         g = conv3x3_wgrad(dy, x, w)
+        if g is not None:
+            return g
+    if WGRAD1[0] and w.shape[2] == 1 and w.shape[3] == 1 and args[4][0] == 1 and args[5][0] == 0:
+        g = conv1x1_wgrad(dy, x, w)
         if g is not None:
             return g
     cov = _fdb_covered('W', x, w, dy.shape, args[4][0], args[5][0])

@@ -416,14 +416,27 @@ int cfl_bn_bwd_wgrad(const void* dy, const void* x, const void* a_in, int P, con
  *   dw[co][kh][kw][ci] (bf16, the channels_last weight's own memory order) = sum_{n,h,w} dy[n,h,w,co] x[n,h+kh-1,w+kw-1,ci]
  * dy [N,H,W,Co], x [N,H,W,Ci] bf16 rows.  One MFMA K step per zero-padded image row, both operands read transposed from LDS, the nine
  * taps share operands through a rolling window of rows and modular w-shifts; split-K over image ranges (one range per XCD at a time)
- * with fp32 partials and a fixed-order reduce: deterministic.  `supported`: (H, W) = (14, 14) or (7, 7), Ci % 64 == 0,
- * Co % 128 == 0 (layers 3 and 4 of ResNet-50 / -101).  ws: cfl_conv3x3_wgrad_ws_bytes (splits x Co x 9 x Ci floats).
+ * with fp32 partials and a fixed-order reduce: deterministic.  `supported`: square maps of 7, 14 or 28 with Ci % 64 == 0 and
+ * Co % 128 == 0, or 56 x 56 with Co == 64 (every stride-1 conv2 of a ResNet-50 / -101).  ws: cfl_conv3x3_wgrad_ws_bytes
+ * (splits x Co x 9 x Ci floats).
  * cfl_conv3x3_wgrad_splits(n): n > 0 forces the number of image ranges (rounded down to a multiple of 8; measurements: 16 runs the
  * layer3 shape on half of the chip), 0 restores the default (256 workgroups), negative only queries; returns the previous value. */
 int cfl_conv3x3_wgrad_supported(int N, int H, int W, int Ci, int Co);
 size_t cfl_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
 int cfl_conv3x3_wgrad(const void* dy, const void* x, int N, int H, int W, int Ci, int Co, void* dw, void* ws, void* stream);
 int cfl_conv3x3_wgrad_splits(int splits);
+/* Weight gradient of a 1 x 1 / stride 1 convolution on channels_last bf16 activations (torchvision Bottleneck.conv1 / conv3 /
+ * downsample[0] inside src/networks/models/image_encoder.py:27-36; the reference leaves it to cuDNN, this build's fallback is the
+ * library's batched GEMM with fp32 atomics):   dw[co][ci] (bf16) = sum_m dy[m, co] x[m, ci],   dy [M, Co], x [M, Ci] bf16 rows.
+ * Row-major LDS-DMA staging, transposing LDS reads, up to 256 x 256 of dw per workgroup, ~128 workgroups, split-K over row ranges with
+ * fp32 partials and a fixed-order reduce: deterministic.  `supported`: (Co, Ci) multiples of (256, 256), (128, 256), (256, 128), or
+ * Co == 64 with Ci % 256 == 0, Ci == 64 with Co % 256 == 0, 64 x 64 (every stride-1 1 x 1 convolution of a ResNet-50 / -101).
+ * ws: cfl_conv1x1_wgrad_ws_bytes (splits x Co x Ci floats).  cfl_conv1x1_wgrad_workgroups(n): n > 0 sets the number of workgroups
+ * the split count aims at (default 128: the kernel is bound by bytes and lives on a side stream); returns the previous value. */
+int cfl_conv1x1_wgrad_supported(long long M, int Ci, int Co);
+size_t cfl_conv1x1_wgrad_ws_bytes(long long M, int Ci, int Co);
+int cfl_conv1x1_wgrad(const void* dy, const void* x, long long M, int Ci, int Co, void* dw, void* ws, void* stream);
+int cfl_conv1x1_wgrad_workgroups(int wgs);
 /* cfl_bn_fwd / cfl_bn_apply / cfl_bn_bwd for FP32 activations (channels_last rows of C floats; every other argument as in the bf16
  * entries below, same kernels instantiated on 32-byte channel groups): BatchNorm2d (+ residual add) (+ ReLU) of the clients' fp32
  * encoders (src/networks/resnet_client.py:33-66,162-201 BasicBlock / stem; the reference runs them in fp32, ClientTrainer.py has no

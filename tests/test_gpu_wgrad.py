@@ -17,7 +17,8 @@ def _ref_dw(x, dy, ksize=3):
 
 
 @pytest.mark.parametrize('n,h,ci,co', [(8, 14, 64, 128), (37, 14, 128, 128), (3, 14, 256, 256), (40, 7, 128, 256), (9, 7, 512, 512),
-                                       (256, 14, 256, 256)])
+                                       (256, 14, 256, 256), (5, 28, 128, 128), (19, 28, 64, 256), (3, 56, 64, 64), (11, 56, 128, 64),
+                                       (64, 28, 128, 128), (32, 56, 64, 64)])
 def test_conv3x3_wgrad_matches_the_definition(n, h, ci, co):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
@@ -70,13 +71,15 @@ def test_conv3x3_wgrad_split_override_and_refusals():
     finally:
         lib.cfl_conv3x3_wgrad_splits(old)
     # shapes / layouts the kernel does not take go to the library (None here)
-    assert lib.cfl_conv3x3_wgrad_supported(8, 28, 28, 128, 128) == 0 and lib.cfl_conv3x3_wgrad_supported(8, 14, 14, 96, 128) == 0
+    assert lib.cfl_conv3x3_wgrad_supported(8, 28, 28, 128, 128) == 1 and lib.cfl_conv3x3_wgrad_supported(8, 14, 14, 96, 128) == 0
     assert lib.cfl_conv3x3_wgrad_supported(8, 14, 14, 64, 64) == 0 and lib.cfl_conv3x3_wgrad_supported(8, 14, 14, 64, 128) == 1
+    assert lib.cfl_conv3x3_wgrad_supported(8, 56, 56, 64, 64) == 1 and lib.cfl_conv3x3_wgrad_supported(8, 56, 56, 64, 128) == 0
+    assert lib.cfl_conv3x3_wgrad_supported(8, 112, 112, 64, 64) == 0 and lib.cfl_conv3x3_wgrad_supported(8, 14, 7, 64, 128) == 0
     assert ops.conv3x3_wgrad(dy.contiguous(), x, w) is None                              # NCHW gradient
     assert ops.conv3x3_wgrad(dy.float(), x.float(), w.float()) is None                  # fp32 (the clients' encoders)
-    x28 = torch.zeros(2, 128, 28, 28, dtype=torch.bfloat16, device=dev).contiguous(memory_format=cl)
-    w28 = torch.zeros(128, 128, 3, 3, dtype=torch.bfloat16, device=dev).contiguous(memory_format=cl)
-    assert ops.conv3x3_wgrad(x28, x28, w28) is None
+    x9 = torch.zeros(2, 128, 9, 9, dtype=torch.bfloat16, device=dev).contiguous(memory_format=cl)
+    w9 = torch.zeros(128, 128, 3, 3, dtype=torch.bfloat16, device=dev).contiguous(memory_format=cl)
+    assert ops.conv3x3_wgrad(x9, x9, w9) is None
 
 
 def test_conv_split_backward_uses_the_kernel_and_matches_the_library():
@@ -108,3 +111,75 @@ def test_conv_split_backward_uses_the_kernel_and_matches_the_library():
     sc = float(grads[False][0].abs().max())
     np.testing.assert_allclose(grads[True][0].numpy(), grads[False][0].numpy(), rtol=2.0 ** -6, atol=4e-3 * sc)
     assert torch.equal(grads[True][1], grads[False][1])                 # the data gradient is untouched
+
+
+@pytest.mark.parametrize('n,h,ci,co', [(8, 14, 1024, 256), (8, 14, 256, 1024), (5, 7, 2048, 512), (5, 7, 512, 2048), (3, 7, 1024, 512),
+                                       (4, 28, 512, 128), (4, 28, 128, 512), (2, 56, 256, 128), (2, 56, 256, 64), (2, 56, 64, 256),
+                                       (2, 56, 64, 64), (3, 7, 256, 256), (1, 5, 256, 64), (256, 14, 1024, 256), (64, 28, 128, 512)])
+def test_conv1x1_wgrad_matches_the_definition(n, h, ci, co):
+    """csrc/wgrad1x1.hip: dW[co, ci] = sum_m dY[m, co] X[m, ci] against fp64 (small) / fp32 (large) on the same bf16-valued inputs; row
+    counts that are no multiple of the 16-row stage or of the split count; deterministic."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7 * n + ci + co + h)
+    cl = torch.channels_last
+    x = (torch.randn(n, ci, h, h, generator=g) * 0.8 + 0.25).to(torch.bfloat16).to(dev).contiguous(memory_format=cl)
+    dy = (torch.randn(n, co, h, h, generator=g) * 0.5 - 0.1).to(torch.bfloat16).to(dev).contiguous(memory_format=cl)
+    w = torch.zeros(co, ci, 1, 1, dtype=torch.bfloat16, device=dev)
+    before = ops.WGRAD1_TAKEN[0]
+    dw = ops.conv1x1_wgrad(dy, x, w)
+    assert dw is not None and ops.WGRAD1_TAKEN[0] == before + 1 and dw.shape == w.shape and dw.dtype == torch.bfloat16
+    M = n * h * h
+    xm, dm = x.permute(0, 2, 3, 1).reshape(M, ci), dy.permute(0, 2, 3, 1).reshape(M, co)
+    if M * (ci + co) > (1 << 23):
+        ref = (dm.float().t() @ xm.float()).cpu()
+    else:
+        ref = (dm.double().cpu().t() @ xm.double().cpu()).float()
+    got = dw.float().cpu().view(co, ci)
+    scale = float(ref.abs().max())
+    err = (got - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -8).max()) <= 2e-3 * scale, (float(err.max()), scale)
+    assert torch.equal(dw, ops.conv1x1_wgrad(dy, x, w))
+    # the channels_last weight of the trunk (same memory for a 1 x 1 kernel) is taken as well; other layouts / dtypes / shapes are not
+    assert ops.conv1x1_wgrad(dy, x, w.contiguous(memory_format=cl)) is not None
+    assert ops.conv1x1_wgrad(dy.float(), x.float(), w.float()) is None and ops.conv1x1_wgrad(dy.contiguous(), x, w) is None
+
+
+def test_conv1x1_wgrad_through_conv_split_matches_the_library():
+    """The product's autograd node with a bottleneck's conv3 shape: weight gradient from csrc/wgrad1x1.hip, equal to the library's to
+    bf16 rounding; the data gradient (the hand-written GEMM either way) bit-identical."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import _lib, ops, streams
+    dev = torch.device('cuda:0')
+    cl = torch.channels_last
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(16, 256, 14, 14, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    w = (torch.randn(1024, 256, 1, 1, generator=g) * 0.05).to(torch.bfloat16).to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    gy = torch.randn(16, 1024, 14, 14, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=cl)
+    grads = {}
+    for on in (True, False):
+        ops.WGRAD1[0] = on
+        try:
+            x.grad = w.grad = None
+            before = ops.WGRAD1_TAKEN[0]
+            y = ops.conv_split(x, w, stride=1, padding=0)
+            y.backward(gy)
+            streams.join_into_current(dev)
+            torch.cuda.synchronize()
+            assert (ops.WGRAD1_TAKEN[0] - before) == (1 if on else 0)
+            grads[on] = (w.grad.float().cpu().clone(), x.grad.float().cpu().clone())
+        finally:
+            ops.WGRAD1[0] = True
+    sc = float(grads[False][0].abs().max())
+    np.testing.assert_allclose(grads[True][0].numpy(), grads[False][0].numpy(), rtol=2.0 ** -6, atol=4e-3 * sc)
+    assert torch.equal(grads[True][1], grads[False][1])
+    lib = _lib.load()
+    old = lib.cfl_conv1x1_wgrad_workgroups(256)
+    try:
+        a = ops.conv1x1_wgrad(gy, x.detach(), w.detach()).float().cpu()
+    finally:
+        lib.cfl_conv1x1_wgrad_workgroups(old)
+    np.testing.assert_allclose(a.numpy(), grads[False][0].numpy(), rtol=2.0 ** -6, atol=4e-3 * sc)

@@ -8,6 +8,8 @@ knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming 
         join   the gradient join of the residual blocks in the data-gradient GEMM's epilogue (default) vs in the BatchNorm backward
         wgfuse   conv3's weight gradient inside the BatchNorm backward-apply pass (default) vs the library's kernel on the side stream
         bnslice  the BatchNorm passes on the channel-sliced block map (no `final` launches, default) vs the whole-row map
+        wgrad1   the 1 x 1 weight gradients on csrc/wgrad1x1.hip (default) vs the library's batched GEMM
+        w1wgsN   that kernel aiming at N workgroups vs its default of 128
         wgrad3   the 3 x 3 weight gradients of layers 3 / 4 on csrc/wgrad3x3.hip (default) vs MIOpen's igemm_wrw
         w3splitN that kernel on N image ranges (N / 32 of the chip for the layer3 shape) vs its default of 256 workgroups
         wgrad    BOUND, not a product switch: every trunk weight gradient computed (default) vs replaced by a zero fill -- what the
@@ -81,6 +83,11 @@ def main():
                         m._const_text = {k: (v.detach().clone() if torch.is_tensor(v) else v)
                                          for k, v in m._real_text_tower(b[1], b[2], b[3]).items()}
                 m._text_tower = m._real_text_tower if on else (lambda *a, **k: dict(m._const_text))
+        elif args.knob == 'wgrad1':
+            from creamfl_amd import ops
+            ops.WGRAD1[0] = bool(on)
+        elif args.knob.startswith('w1wgs'):
+            lib.cfl_conv1x1_wgrad_workgroups(int(args.knob[5:] or 256) if on else 128)
         elif args.knob == 'wgrad3':
             from creamfl_amd import ops
             ops.WGRAD3[0] = bool(on)

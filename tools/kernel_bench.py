@@ -274,6 +274,43 @@ def case_wgrad3(H, C, N=256, splits=(0,)):
     return out
 
 
+def case_wgrad1(H, Ci, Co, N=256, wgs=(128,)):
+    """1 x 1 weight gradient (csrc/wgrad1x1.hip) vs the library's kernel at one ResNet-101 shape, bf16 channels_last."""
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(4)
+    cl = torch.channels_last
+    x = torch.randn(N, Ci, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=cl)
+    dy = torch.randn(N, Co, H, H, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=cl)
+    w = torch.zeros(Co, Ci, 1, 1, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=cl)
+    M = N * H * H
+    flop = 2.0 * M * Ci * Co
+    algo = 2.0 * M * (Ci + Co) + 2.0 * Ci * Co
+    out = {'case': f'wgrad1 {H}x{H} {Ci}->{Co} N={N}', 'gflop': round(flop / 1e9, 1), 'algorithmic_mb': round(algo / 1e6, 1),
+           'hbm_floor_us': round(algo / 6.3e6, 1)}
+    args = (dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+    torch.backends.cudnn.benchmark = True
+    ref = torch.ops.aten.convolution_backward(*args, [False, True, False])[1]
+    us_lib, _ = timed(lambda: torch.ops.aten.convolution_backward(*args, [False, True, False]), iters=20)
+    out['library_us_wall'] = round(us_lib, 1)
+    old = lib.cfl_conv1x1_wgrad_workgroups(0)
+    for n in wgs:
+        lib.cfl_conv1x1_wgrad_workgroups(n)
+        dw = ops.conv1x1_wgrad(dy, x, w)
+        if dw is None:
+            out['own'] = 'shape not taken'
+            break
+        err = float((dw.float() - ref.float()).abs().max()) / max(float(ref.float().abs().max()), 1e-9)
+        us, prof = timed(lambda: ops.conv1x1_wgrad(dy, x, w), iters=20)
+        k = prof.get('cfl_conv1x1_wgrad_kernel', us)
+        out[f'wg{n}_kernel_us'] = k
+        out[f'wg{n}_reduce_us'] = prof.get('cfl_conv1x1_wgrad_reduce_kernel')
+        out[f'wg{n}_wall_us'] = round(us, 1)
+        out[f'wg{n}_algorithmic_TBps'] = round(algo / k / 1e6, 2)
+        out[f'wg{n}_relerr_vs_library'] = round(err, 5)
+    lib.cfl_conv1x1_wgrad_workgroups(old)
+    return out
+
+
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -366,8 +403,14 @@ def main():
         for (H, Ci, Co) in [(56, 256, 64), (28, 512, 128), (14, 1024, 256), (7, 2048, 512)]:
             out.append(case_gemm16(H, Ci, Co, (0,)))
     if 'wgrad3' in cases:
-        out.append(case_wgrad3(14, 256, splits=(0, 16, 8)))
+        out.append(case_wgrad3(14, 256, splits=(0, 16)))
         out.append(case_wgrad3(7, 512, splits=(0,)))
+        out.append(case_wgrad3(28, 128, splits=(0, 64)))
+        out.append(case_wgrad3(56, 64, splits=(0, 128)))
+    if 'wgrad1' in cases:
+        for (H, Ci, Co) in [(14, 1024, 256), (14, 256, 1024), (28, 512, 128), (28, 128, 512), (56, 256, 64), (56, 64, 256), (56, 64, 64),
+                            (7, 2048, 512), (7, 512, 2048)]:
+            out.append(case_wgrad1(H, Ci, Co, wgs=(128, 256, 64)))
     if 'opt' in cases:
         out += [case_opt()]
     for r in out:

@@ -20,12 +20,12 @@ runtime.configure_env()
 import torch  # noqa: E402
 
 
-def train_and_eval(task, steps, batch, lr, fp32, state, dev, cnn='resnet18', dim=64, n_eval=200, log_every=50):
+def train_and_eval(task, steps, batch, lr, fp32, state, dev, cnn='resnet18', dim=64, n_eval=200, log_every=50, seed=3):
     from creamfl_amd.algorithms.eval_coco import COCOEvaluator
     from creamfl_amd.algorithms.retrieval_trainer import TrainerEngine
     from creamfl_amd.utils.config import default_config
     from learnable_task import EvalLoader
-    torch.manual_seed(3)
+    torch.manual_seed(seed)
     cfg = default_config(embed_dim=dim, cnn_type=cnn, not_bert=False)
     cfg.model.bert_name = 'bert-mini'
     cfg.optimizer.learning_rate = lr
@@ -68,16 +68,20 @@ def main():
     ap.add_argument('--noise', type=float, default=0.3)
     ap.add_argument('--img', type=int, default=64)
     ap.add_argument('--cnn', default='resnet18')
+    ap.add_argument('--seeds', type=int, default=1, help='model-initialisation seeds 3, 4, ...: one bf16 + one fp32 run per seed')
+    ap.add_argument('--n-eval', type=int, default=0, help='held-out identities evaluated (0 = all; a multiple of 5)')
     args = ap.parse_args()
     from learnable_task import LearnableTask
     dev = torch.device('cuda', 0)
     task = LearnableTask(n_id=args.n_id, img=args.img, seed=0, noise=args.noise, device=dev)
-    with torch.backends.cudnn.flags(enabled=True, benchmark=False):
-        a, state = train_and_eval(task, args.steps, args.batch, args.lr, False, None, dev, cnn=args.cnn, n_eval=args.n_id)
-        print(json.dumps(dict(a, **vars(args))), flush=True)
-    with torch.backends.cudnn.flags(enabled=True, benchmark=True):       # fp32 immediate mode = fallback kernels (~0.4 s per step)
-        b, _ = train_and_eval(task, args.steps, args.batch, args.lr, True, state, dev, cnn=args.cnn, n_eval=args.n_id)
-        print(json.dumps(dict(b, **vars(args))), flush=True)
+    n_eval = args.n_eval or args.n_id
+    for seed in range(3, 3 + args.seeds):
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            a, state = train_and_eval(task, args.steps, args.batch, args.lr, False, None, dev, cnn=args.cnn, n_eval=n_eval, seed=seed)
+            print(json.dumps(dict(a, seed=seed, **vars(args))), flush=True)
+        with torch.backends.cudnn.flags(enabled=True, benchmark=True):       # fp32 immediate mode = fallback kernels (~0.4 s per step)
+            b, _ = train_and_eval(task, args.steps, args.batch, args.lr, True, state, dev, cnn=args.cnn, n_eval=n_eval, seed=seed)
+            print(json.dumps(dict(b, seed=seed, **vars(args))), flush=True)
 
 
 if __name__ == '__main__':
