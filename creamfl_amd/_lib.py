@@ -98,6 +98,7 @@ SIGNATURES = {
     'cfl_conv3x3_wgrad_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_conv3x3_wgrad_splits': (c_int, [c_int]),
+    'cfl_conv3x3_wgrad_debug': (c_int, [c_int]),
     'cfl_bn_bwd_wgrad_supported': (c_int, [c_longlong, c_int, c_int]),
     'cfl_bn_bwd_wgrad_ws_bytes': (c_size_t, [c_longlong, c_int, c_int]),
     'cfl_bn_bwd_wgrad': (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_longlong, c_int, _P, _P, _P, _P, _P, _P]),

@@ -34,7 +34,7 @@ __host__ __device__ inline size_t img_bytes(int M, int D) { return (size_t)((M +
 
 // 16-byte piece s of row g lives at piece s ^ swz(g): bits [3:2] = g & 3 (the four rows of a transposing read fall into
 // four different 64-byte bank windows), bits [1:0] = L[g >> 2], L = {0, 2, 3, 1} (the 16 lanes of every ds_read_b128
-// service group -- 8 rows at piece s, 8 at piece s ^ 1 -- hit 16 different pieces).  tools/lds_swizzle_check.py enumerates
+// service group -- 8 rows at piece s, 8 at piece s ^ 1 -- hit 16 different pieces).  docs/history/tools/lds_swizzle_check.py enumerates
 // every access pattern of both kernels against the LDS service groups: 0 conflict cycles.
 __host__ __device__ inline int img_swz(int g) { return ((g & 3) << 2) | ((0x78 >> (2 * ((g >> 2) & 3))) & 3); }
 __host__ __device__ inline int img_off(int DP, int plane, int g, int piece) {
@@ -75,7 +75,7 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 // 8 bank rows (4 q .. 4 q + 3 for q = 0, 1 relative to r0) of one column per lane, by two transposing reads: lane p of a
 // 16-lane group addresses row (p >> 2), columns 4 (p & 3) .. + 3 of the group's [4 rows x 16 columns] block and receives
-// column p of it (probed on gfx950: out[j] = E[4 j + (i >> 2)][i & 3], tools/hip/tr_probe.hip).
+// column p of it (probed on gfx950: out[j] = E[4 j + (i >> 2)][i & 3], docs/history/tools/hip/tr_probe.hip).
 __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
 // accumulator layout (lane = feature row, 16 registers = 16 of the 32 bank rows, the other 16 in lane ^ 32) makes the row
 // maximum 15 in-lane v_max + ONE v_permlane32_swap instead of two swaps per 16 rows.  Same image (the A fragment of lane l is
 // piece 2 ks + (l >> 5) of bank row l & 15 of slot (l >> 4) & 1: conflict-free under the image's swizzle,
-// tools/lds_swizzle_check.py), same splits, same partial layout; two 32-row buffers, LDS-DMA one step ahead, the soft-max of a
+// docs/history/tools/lds_swizzle_check.py), same splits, same partial layout; two 32-row buffers, LDS-DMA one step ahead, the soft-max of a
 // step deferred into the next step's first fragment-read latency.
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 

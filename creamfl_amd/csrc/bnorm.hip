@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void cfl_bn_bwd_apply_kernel(const G* __restri
 // (768 * 64 / C of them: 48 at C = 1024, 192 at C = 256), sums them in its prologue in a fixed order (every workgroup of the
 // slice redundantly, bit-identically) and the `final` launch between the two passes disappears: 2 x 104 launches of
 // 5 - 10 us per server step sat serially between the BatchNorm passes (step 41.7 vs 42.9 ms with all of them skipped).
-// Streams as fast as whole rows (tools/hip/slice_stream_probe.hip: 1 - 10 % faster at the trunk shapes).  Narrow tensors
+// Streams as fast as whole rows (docs/history/tools/hip/slice_stream_probe.hip: 1 - 10 % faster at the trunk shapes).  Narrow tensors
 // (C < 256: 384 / 768 partial rows per slice) keep the whole-row map above with its `final` kernels.
 constexpr int SL_RL = 32;                                        // row lanes of a sliced workgroup (256 threads / 8)
 

@@ -2,7 +2,7 @@
 //
 // A 1x1 convolution on a channels_last activation is a GEMM on the [M = N*H*W, C] view (torchvision Bottleneck conv1 /
 // conv3 inside src/networks/models/image_encoder.py:27-36), and the trunk convolutions are ~45 % of the bench step.
-// tools/conv_probe.py / wgrad_probe.py show MIOpen at the HBM roofline only in layer1 and at 2-3 TB/s /
+// docs/history/tools/conv_probe.py / wgrad_probe.py show MIOpen at the HBM roofline only in layer1 and at 2-3 TB/s /
 // 550-700 TFLOP/s in layer3.  Measured (tools/kernel_bench.py --cases gemm16 / wgrad16, MI355X):
 //   NT  C[M,N] = A[M,K] B[N,K]^T : ties MIOpen's FORWARD (14x14 256->1024: 49 vs 46 us; 56x56 64->64: 35 vs 34 us) but
 //       beats its BACKWARD-DATA kernels on every ResNet-101 shape (14x14 1024->256: 78 -> 48 us; 56x56 256->64:

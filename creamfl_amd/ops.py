@@ -1500,7 +1500,7 @@ class _ConvSplitFn(torch.autograd.Function):
     """y = conv2d(x, w, stride, padding) (no bias, groups 1) with the backward split in two:
       * the DATA gradient stays on the critical path (main stream); for 1x1 / stride-1 kernels it runs on the
         hand-written bf16 MFMA GEMM (dX[M, Ci] = dY[M, Co] @ W[Co, Ci]), which beats MIOpen's backward-data kernels on
-        every ResNet-101 shape (tools/wgrad_probe.py vs tools/kernel_bench.py --cases gemm16);
+        every ResNet-101 shape (docs/history/tools/wgrad_probe.py vs tools/kernel_bench.py --cases gemm16);
       * the WEIGHT gradient, which nothing but the optimizer waits for, is issued on the auxiliary 'wgrad' stream and
         overlaps the HBM-bound BN / data-gradient kernels of the layers below (streams.py).  MIOpen computes it."""
 
@@ -1608,7 +1608,7 @@ class _ConvSplitFn(torch.autograd.Function):
                   and not _NO_FWD_DGRAD):
                 # k x k / stride 1 / same padding: dX = conv2d(dY, W') with the rotated, transposed weight -- MIOpen's FORWARD
                 # kernels run this 1.3-1.6x faster than its backward-data kernels on every ResNet-101 shape (3x3, batch 256:
-                # 56x56x64 169 -> 134 us, 28x28x128 126 -> 97, 14x14x256 120 -> 75, 7x7x512 138 -> 104; tools/dgrad3x3_probe.py)
+                # 56x56x64 169 -> 134 us, 28x28x128 126 -> 97, 14x14x256 120 -> 75, 7x7x512 138 -> 104; docs/history/tools/dgrad3x3_probe.py)
                 wr = _WT['views'].get(weight.data_ptr()) if _WT['valid'] else None
                 if wr is None and dy.numel() >= (1 << 22):
                     # not prepared (client trainers): two small kernels, repaid by the faster convolution on large maps only
@@ -1702,7 +1702,7 @@ def _stem_weight_s2d_inverse(g4, like):
 class _StemConvFn(torch.autograd.Function):
     """torchvision ResNet.conv1 (image_encoder.py:27-36).  MIOpen runs the problem as written at 376 us forward / 406 us weight
     gradient (batch 256: 3-channel, 6-byte pixels, K = 147); after space-to-depth (csrc/pool.hip: cfl_stem_s2d, one pass, 16
-    channels) the same convolution is a 4x4 / stride-1 one that its kernels run in 229 / 225 us (tools/stem_probe.py).  The input
+    channels) the same convolution is a 4x4 / stride-1 one that its kernels run in 229 / 225 us (docs/history/tools/stem_probe.py).  The input
     needs no gradient (images); the weight gradient is deferred to the auxiliary stream like every trunk convolution's."""
 
     @staticmethod

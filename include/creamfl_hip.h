@@ -425,6 +425,9 @@ int cfl_conv3x3_wgrad_supported(int N, int H, int W, int Ci, int Co);
 size_t cfl_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
 int cfl_conv3x3_wgrad(const void* dy, const void* x, int N, int H, int W, int Ci, int Co, void* dw, void* ws, void* stream);
 int cfl_conv3x3_wgrad_splits(int splits);
+/* measurement only (tools/kernel_bench.py --cases w3dbg): 1 = the layer3-shaped kernel without its staging, 2 = staging and barriers
+ * only -- the RESULTS ARE WRONG in these modes; 0 restores the kernel, negative only queries; returns the previous mode */
+int cfl_conv3x3_wgrad_debug(int mode);
 /* Weight gradient of a 1 x 1 / stride 1 convolution on channels_last bf16 activations (torchvision Bottleneck.conv1 / conv3 /
  * downsample[0] inside src/networks/models/image_encoder.py:27-36; the reference leaves it to cuDNN, this build's fallback is the
  * library's batched GEMM with fp32 atomics):   dw[co][ci] (bf16) = sum_m dy[m, co] x[m, ci],   dy [M, Co], x [M, Ci] bf16 rows.

@@ -407,6 +407,21 @@ def main():
         out.append(case_wgrad3(7, 512, splits=(0,)))
         out.append(case_wgrad3(28, 128, splits=(0, 64)))
         out.append(case_wgrad3(56, 64, splits=(0, 128)))
+    if 'w3dbg' in cases:
+        # switch-off decomposition of the 3 x 3 weight-gradient kernel at layer3's shape (results of modes 1 / 2 are wrong on purpose)
+        lib = _lib.load()
+        g = torch.Generator(device='cuda').manual_seed(3)
+        cl = torch.channels_last
+        x = torch.randn(256, 256, 14, 14, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=cl)
+        dy = torch.randn(256, 256, 14, 14, generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=cl)
+        w = torch.zeros(256, 256, 3, 3, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=cl)
+        rec = {'case': 'w3dbg 14x14 256->256 N=256'}
+        for mode, name in ((0, 'full'), (1, 'no_staging'), (2, 'staging_and_barriers_only')):
+            lib.cfl_conv3x3_wgrad_debug(mode)
+            us, prof = timed(lambda: ops.conv3x3_wgrad(dy, x, w), iters=20)
+            rec[name + '_us'] = prof.get('cfl_conv3x3_wgrad_kernel', us)
+        lib.cfl_conv3x3_wgrad_debug(0)
+        out.append(rec)
     if 'wgrad1' in cases:
         for (H, Ci, Co) in [(14, 1024, 256), (14, 256, 1024), (28, 512, 128), (28, 128, 512), (56, 256, 64), (56, 64, 256), (56, 64, 64),
                             (7, 2048, 512), (7, 512, 2048)]:
