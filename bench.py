@@ -426,7 +426,8 @@ def main():
     _ops.GEMM_COUNTERS['flops'] = _ops.GEMM_COUNTERS['bytes'] = 0
     _lib.prof_reset()
     _lib.prof_select(dominant)
-    _lib.prof_enable(True)
+    if not os.environ.get('BENCH_NO_PROF'):      # (diagnosis only: the timed region without the dominant kernel's event timing -> no roofline)
+        _lib.prof_enable(True)
     t0 = time.perf_counter()
     trace = []
     for _ in range(args.steps):

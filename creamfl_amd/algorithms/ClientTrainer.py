@@ -252,7 +252,7 @@ class ClientTrainer:
             loss, _, _ = client_contrast_loss(feature, g_same, g_other, d_idx, old_feature,
                                               interintra_weight=self.args.interintra_weight,
                                               loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
-                                              use_intra=use_intra)
+                                              use_intra=use_intra, root=True)        # the backward starts at this loss (:420)
             with runtime.backward_here():
                 loss.backward()
             self.optimizer.step()

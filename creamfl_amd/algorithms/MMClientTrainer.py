@@ -158,7 +158,7 @@ class MMClientTrainer(EngineBase):
             loss, _, _ = mm_client_contrast_loss(out_img, out_txt, g_img, g_txt, d_idx, old_img, old_txt,
                                                  interintra_weight=self.args.interintra_weight,
                                                  loss_scale=bool(self.args.loss_scale), use_inter=use_inter,
-                                                 use_intra=use_intra)
+                                                 use_intra=use_intra, root=True)     # _step backpropagates from this loss
             self._step(loss)
             return loss.detach()
         return step

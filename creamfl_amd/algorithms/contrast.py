@@ -11,8 +11,9 @@ TEMPERATURE = 0.5        # hard-coded in the reference (ClientTrainer.py:388,411
 
 def client_contrast_loss(feature, global_same, global_other, d_idx, old_feature=None,
                          interintra_weight=0.5, loss_scale=False, use_inter=True, use_intra=True,
-                         temperature=TEMPERATURE):
-    """Uni-modal client.  Returns (loss, loss_inter | None, loss_moon | None).
+                         temperature=TEMPERATURE, root=False):
+    """Uni-modal client.  Returns (loss, loss_inter | None, loss_moon | None).  root=True: the caller runs `loss.backward()` on
+    the returned loss itself, as the reference does (ClientTrainer.py:420) -- see ops.client_contrast_fused.
 
     both  : (loss_moon + loss_inter) * w                                   ClientTrainer.py:417
             (loss_moon + loss_inter / (loss_inter/loss_moon).detach()) * w   :419 (--loss_scale)
@@ -26,7 +27,7 @@ def client_contrast_loss(feature, global_same, global_other, d_idx, old_feature=
         # one pass over the bank + one epilogue launch: both terms, their combination and all gradients (csrc/bank_attn.hip)
         loss, loss_inter, loss_moon, _, _ = ops.client_contrast_fused(
             feature, global_same, global_other, d_idx, old_feature, temperature, weight=interintra_weight,
-            loss_scale=loss_scale, use_inter=use_inter, use_intra=use_intra)
+            loss_scale=loss_scale, use_inter=use_inter, use_intra=use_intra, root=root)
         return loss, loss_inter, loss_moon
     if use_inter:
         loss_inter = ops.inter_contrast(feature, global_other, d_idx, temperature)[0]
@@ -48,7 +49,7 @@ def client_contrast_loss(feature, global_same, global_other, d_idx, old_feature=
 
 def mm_client_contrast_loss(out_img, out_txt, global_img, global_txt, d_idx, old_img=None, old_txt=None,
                             interintra_weight=0.5, loss_scale=False, use_inter=True, use_intra=True,
-                            temperature=TEMPERATURE):
+                            temperature=TEMPERATURE, root=False):
     """Multi-modal client (MMClientTrainer.py:150-324): the intra CE runs over the stacked [2B, 2]
     logits (mean over 2B rows), the inter term is CE(img vs G_txt) + CE(txt vs G_img)."""
     loss_inter = loss_intra = None
@@ -59,7 +60,7 @@ def mm_client_contrast_loss(out_img, out_txt, global_img, global_txt, d_idx, old
         # per modality one pass over the bank + one finish launch (A4 inside); the second finish combines both modalities
         return ops.mm_client_contrast_fused(out_img, out_txt, global_img, global_txt, d_idx, old_img, old_txt, temperature,
                                             weight=interintra_weight, loss_scale=loss_scale, use_inter=use_inter,
-                                            use_intra=use_intra)
+                                            use_intra=use_intra, root=root)
     if use_intra:
         loss_intra = (ops.intra_contrast(out_img, global_img, d_idx, old_img, temperature, mean_divisor=2 * b)
                       + ops.intra_contrast(out_txt, global_txt, d_idx, old_txt, temperature, mean_divisor=2 * b))

@@ -63,6 +63,11 @@ __device__ __forceinline__ void store_wt_x4(float* p, const f32x4 v) {
 //     out5 = {loss, loss_inter, loss_moon, coef_inter, coef_moon}: the combined loss of ClientTrainer.py:416-419 and the
 //     factors the backward applies to the two unit gradients.   mode bit 1: intra term present, bit 2: --loss_scale,
 //     bit 3: add the li / lm out5 already holds (the other modality of a multi-modal client) before combining
+//     bit 4 (round 6, "direct"): without --loss_scale the two coefficients are known on the host (w, w | 1 | 1), so when the
+//     caller declares the loss the ROOT of the backward pass (upstream gradient = the 1 of loss.backward()) the FINAL gradient
+//       dF[f][d] = ci (inv_tau / B) (O / L - G_other[idx]) + cm sigmoid(z) (inv_tau / Bdiv) (F_old - G_same[idx])
+//     is written here, once, and the backward launch (2 reads + 1 write of [B, D] and ~5 us) does not exist.  Every column block
+//     of a row then forms the row's intra dots itself (3 KB of L2-resident rows, 4 x redundant) instead of waiting for block 0.
 template <int NJ>      // a thread merges the splits xg + 16 j, j < NJ (S <= 16 NJ)
 __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
                                                                const float* __restrict__ part_o, int S, int DP,
@@ -76,23 +81,50 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
     __shared__ float redm[4];
     __shared__ f32x4 red[16][16];
     __shared__ float redl[16];
-    __shared__ float row_lse, row_pos;
+    __shared__ float row_lse, row_pos, row_c;
     __shared__ int is_last;
     const int ncb = DP / 64;                        // blocks per row: 64 columns (16 lanes x 4) each
     const int fl = blockIdx.x / ncb, quarter = blockIdx.x % ncb, rg = blockIdx.y;
     const int f = rg * BR + fl;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool live = f < B;
-    // Row terms (column block 0 of a row; wave 0: the exact positive dot of the inter term, wave 1: the intra / MOON term): their
-    // operands -- the feature row, the bank row(s) of the row's public-set index, the old feature row -- are requested HERE, ahead
-    // of the split merge, so that the index -> bank-row dependency and the merge's own loads share one stretch of memory latency
-    // (they used to run after the merge's two barriers, as loops of one load per trip: ~half of this kernel's time at D = 256).
+    // Row terms (wave 0 of column block 0: the exact positive dot of the inter term; wave 1: the intra / MOON term): their operands
+    // -- the feature row, the bank row(s) of the row's public-set index, the old feature row -- and the merge's own loads share
+    // one stretch of memory latency: issue order = index, split partials (independent of the index), then everything the index
+    // addresses (the row operands; the 16 bytes of G_other[idx] / G_same[idx] / F_old a gradient-writing thread needs).  They used
+    // to run after the merge's two barriers as loops of one load per trip: ~half of this kernel's time at D = 256.
     constexpr int NKP = 12;                                  // D <= 768 = 12 x 64 lanes
     float pf[NKP], pg[NKP], po[NKP];
+    const bool direct = (mode & 16) != 0;
+    const bool merge = live && (mode & 1);
     const bool rowwork = live && quarter == 0;
-    const long long tgt = rowwork ? idx[f] : -1;
+    const bool w_inter = rowwork && (mode & 1) && wv == 0;
+    const bool w_intra = live && (mode & 2) && wv == 1 && (quarter == 0 || (direct && (mode & 1)));
+    const float coef = (mode & 3) == 3 ? weight : 1.f;       // direct: both coefficients, known on the host (no --loss_scale)
+    const int c4 = (t & 15) * 4, xg = t >> 4;
+    const int d4 = quarter * 64 + c4;
+    const bool want_o = dF != nullptr;
+    const bool gwriter = merge && want_o && xg == 0 && d4 < D;                // the 16 threads that store the row's gradient piece
+    const long long tgt = (w_inter || w_intra || gwriter) ? idx[f] : -1;
     const bool ok = tgt >= 0 && tgt < M;
-    const bool w_inter = rowwork && (mode & 1) && wv == 0, w_intra = rowwork && (mode & 2) && wv == 1;
+    // 16 float4 lanes (one quarter of the columns) x 16 split groups.  ONE memory round trip: a thread first issues every load it
+    // will ever need (<= 16 splits: max, sum and its 16 bytes of O), then the block agrees on the reference.  The partials of one
+    // feature row are contiguous ([row][split][DP]): the four blocks of a row sweep one region.
+    float pmv[NJ], plv[NJ];
+    f32x4 ov[NJ];
+    if (merge) {
+        const float* pm = part_m + (size_t)rg * S * BR + fl;
+        const float* pl = part_l + (size_t)rg * S * BR + fl;
+        const float* pob = part_o + (((size_t)rg * BR + fl) * S) * DP + d4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int x = xg + 16 * j;
+            const int xc = x < S ? x : S - 1;                      // unconditional loads (clamped), masked below
+            pmv[j] = pm[(size_t)xc * BR];
+            plv[j] = pl[(size_t)xc * BR];
+            ov[j] = want_o ? *reinterpret_cast<const f32x4*>(pob + (size_t)xc * DP) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     if (w_inter || w_intra) {
         const float* fr = F + (long long)f * D;
         const float* g = (w_inter ? Go : Gs) + (ok ? tgt : 0) * D;
@@ -106,26 +138,39 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
             po[j] = (k < D && w_intra) ? o[kc] : 0.f;
         }
     }
-    if (live && (mode & 1)) {
-        const float* pm = part_m + (size_t)rg * S * BR + fl;
-        const float* pl = part_l + (size_t)rg * S * BR + fl;
-        // 16 float4 lanes (one quarter of the columns) x 16 split groups.  ONE memory round trip: a thread first issues every
-        // load it will ever need (<= 16 splits: max, sum and its 16 bytes of O), then the block agrees on the reference.  The
-        // partials of one feature row are contiguous ([row][split][DP]): the four blocks of a row sweep one region.
-        const int c4 = (t & 15) * 4, xg = t >> 4;
-        const int d4 = quarter * 64 + c4;
-        const bool want_o = dF != nullptr;
-        const float* po = part_o + (((size_t)rg * BR + fl) * S) * DP + d4;
-        float pmv[NJ], plv[NJ];
-        f32x4 ov[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int x = xg + 16 * j;
-            const int xc = x < S ? x : S - 1;                      // unconditional loads (clamped), masked below
-            pmv[j] = pm[(size_t)xc * BR];
-            plv[j] = pl[(size_t)xc * BR];
-            ov[j] = want_o ? *reinterpret_cast<const f32x4*>(po + (size_t)xc * DP) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gpos = {0.f, 0.f, 0.f, 0.f}, gsame = gpos, fold = gpos;
+    if (gwriter) {
+        if (ok) gpos = *reinterpret_cast<const f32x4*>(Go + tgt * D + d4);
+        if (direct && (mode & 2)) {
+            if (ok) gsame = *reinterpret_cast<const f32x4*>(Gs + tgt * D + d4);
+            fold = *reinterpret_cast<const f32x4*>(Fo + (long long)f * D + d4);
         }
+    }
+    // the intra / MOON term of the row (A4): in a direct block ahead of the merge's barriers, its coefficient goes through LDS
+    if (w_intra) {
+        float pos = 0.f, neg = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKP; ++j) { pos = fmaf(pf[j], pg[j], pos); neg = fmaf(pf[j], po[j], neg); }
+        pos = wave_sum(pos); neg = wave_sum(neg);
+        const float z = (neg - pos) * inv_tau;
+        const float c = sigmoidf(z) * inv_tau / (float)Bdiv;
+        if (lane == 0) {
+            row_c = c;
+            if (quarter == 0) {
+                __hip_atomic_store(rowbuf + Bp + f, softplusf(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        if (dF_moon && quarter == 0) {                        // (absent in a direct call with an inter term: the merge below adds it)
+            const float cc = direct ? c * coef : c;
+#pragma unroll
+            for (int j = 0; j < NKP; ++j) {
+                const int k = lane + 64 * j;
+                if (k < D) dF_moon[(long long)f * D + k] = cc * (po[j] - pg[j]);
+            }
+        }
+    }
+    if (merge) {
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { if (xg + 16 * j >= S) pmv[j] = -INFINITY; mx = fmaxf(mx, pmv[j]); }
@@ -150,41 +195,24 @@ __global__ __launch_bounds__(256) void cfl_contrast_finish_kernel(const float* _
 #pragma unroll
             for (int g = 1; g < 16; ++g) { acc += red[g][t]; L += redl[g]; }
             if (quarter == 0 && t == 0) { row_lse = (mx + log2f(L)) * 0.6931471805599453f; lse2[f] = row_lse; }
-            if (want_o && d4 < D) {
-                const long long tgt = idx[f];
-                f32x4 gpos = {0.f, 0.f, 0.f, 0.f};
-                if (tgt >= 0 && tgt < M) gpos = *reinterpret_cast<const f32x4*>(Go + tgt * D + d4);
+            if (gwriter) {
                 const float inv = 1.f / L;
-                *reinterpret_cast<f32x4*>(dF + (long long)f * D + d4) = (acc * inv - gpos) * (inv_tau / (float)B);
+                f32x4 v = (acc * inv - gpos) * (inv_tau / (float)B);
+                if (direct) {
+                    v *= coef;
+                    if (mode & 2) v += (fold - gsame) * (row_c * coef);
+                }
+                *reinterpret_cast<f32x4*>(dF + (long long)f * D + d4) = v;
             }
         }
     }
-    if (live && quarter == 0) {
+    if (rowwork) {
         if (w_inter) {
             float dot = 0.f;
 #pragma unroll
             for (int j = 0; j < NKP; ++j) dot = fmaf(pf[j], pg[j], dot);
             dot = wave_sum(dot) * inv_tau;
             if (lane == 0) { row_pos = dot; if (pos_out) pos_out[f] = dot; }
-        }
-        if (w_intra) {
-            float pos = 0.f, neg = 0.f;
-#pragma unroll
-            for (int j = 0; j < NKP; ++j) { pos = fmaf(pf[j], pg[j], pos); neg = fmaf(pf[j], po[j], neg); }
-            pos = wave_sum(pos); neg = wave_sum(neg);
-            const float z = (neg - pos) * inv_tau;
-            if (lane == 0) {
-                __hip_atomic_store(rowbuf + Bp + f, softplusf(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            if (dF_moon) {
-                const float c = sigmoidf(z) * inv_tau / (float)Bdiv;
-#pragma unroll
-                for (int j = 0; j < NKP; ++j) {
-                    const int k = lane + 64 * j;
-                    if (k < D) dF_moon[(long long)f * D + k] = c * (po[j] - pg[j]);
-                }
-            }
         }
         __syncthreads();
         if ((mode & 1) && t == 0) {
@@ -317,6 +345,10 @@ static int launch_finish(const AttnWs& w, int S, int DP, int RGF, int Bp, const 
                          hipStream_t stream) {
     float* dfi = (want_grad && (mode & 1)) ? dF_inter : (float*)nullptr;
     float* dfm = (want_grad && (mode & 2)) ? dF_moon : (float*)nullptr;
+    if (want_grad == 2) {                  // direct: ONE final gradient, in dF_inter's place (the merge adds the intra part itself)
+        mode |= 16;
+        dfm = (mode & 1) ? (float*)nullptr : dF_inter;
+    }
     const int bd = (mode & 2) ? B_div : B;
 #define CFL_FINISH(NJ)                                                                                                              \
     CFL_LAUNCH(K_LSE_FINAL, cfl_contrast_finish_kernel<NJ>, dim3((DP / 64) * BR, RGF), dim3(256), 0, stream, w.part_m, w.part_l, w.part_o, S, DP, F, \
@@ -368,7 +400,9 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
     if (!F || !idx || !out5 || !ws || !sync || B <= 0 || M <= 0 || D <= 0 || !(inv_tau > 0.f) || !(mode & 3)) return CFL_EINVAL;
     if ((mode & 1) && (!G_other || !image_other || !lse)) return CFL_EINVAL;
     if ((mode & 2) && (!G_same || !F_old || B_div <= 0)) return CFL_EINVAL;
-    if (want_grad && (((mode & 1) && !dF_inter) || ((mode & 2) && !dF_moon))) return CFL_EINVAL;
+    if (want_grad < 0 || want_grad > 2) return CFL_EINVAL;
+    if (want_grad == 1 && (((mode & 1) && !dF_inter) || ((mode & 2) && !dF_moon))) return CFL_EINVAL;
+    if (want_grad == 2 && (!dF_inter || (mode & 4))) return CFL_EINVAL;      // direct: host-known coefficients only (no --loss_scale)
     if (!cfl_bank_gsplit_supported(B, M, D)) return CFL_ELIMIT;
     if ((((uintptr_t)F | (uintptr_t)G_other | (uintptr_t)image_other) & 15)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;

@@ -216,22 +216,27 @@ class _ClientContrastFn(torch.autograd.Function):
     allocations and one ctypes call (the workspace, its size and the election counter are cached per device / shape)."""
 
     @staticmethod
-    def forward(ctx, F, G_other, G_same, idx, F_old, inv_tau, weight, mode, b_div):
+    def forward(ctx, F, G_other, G_same, idx, F_old, inv_tau, weight, mode, b_div, root=False):
         lib = _lib.load()
         B, D = F.shape
         M = (G_other if (mode & 1) else G_same).shape[0]
         dev = F.device
         need = ctx.needs_input_grad[0]
+        # root (the caller backpropagates from THIS loss: upstream gradient 1) and no --loss_scale: the finish launch writes the final
+        # gradient and the backward pass launches nothing (include/creamfl_hip.h, want_grad = 2)
+        direct = bool(need and root and not (mode & 4))
         out = torch.empty(8, dtype=torch.float32, device=dev)          # out5 = out[0:5]; the differentiable loss = out[5]
         aux = torch.empty(2, B, dtype=torch.float32, device=dev) if (mode & 1) else None        # lse, pos
-        dFs = torch.empty(2, B, D, dtype=torch.float32, device=dev) if need else None            # inter, moon unit gradients
+        dFs = None
+        if need:                                                       # unit gradients (inter, moon) | the final gradient
+            dFs = torch.empty((B, D) if direct else (2, B, D), dtype=torch.float32, device=dev)
         st = _contrast_state(dev, _bank_plan(B, M, D, bool(need)))
         p_out = out.data_ptr()
         p_aux = aux.data_ptr() if aux is not None else 0
         p_dfs = dFs.data_ptr() if need else 0
-        tail = (B, M, D, b_div, inv_tau, weight, mode, int(need),
-                p_out, p_aux, p_aux + 4 * B if p_aux else 0, p_dfs if (need and (mode & 1)) else 0,
-                p_dfs + 4 * B * D if (need and (mode & 2)) else 0, st['ws'].data_ptr(), st['sync'].data_ptr(),
+        tail = (B, M, D, b_div, inv_tau, weight, mode, 2 if direct else int(need),
+                p_out, p_aux, p_aux + 4 * B if p_aux else 0, p_dfs if (need and ((mode & 1) or direct)) else 0,
+                p_dfs + 4 * B * D if (need and (mode & 2) and not direct) else 0, st['ws'].data_ptr(), st['sync'].data_ptr(),
                 _raw_stream(dev))
         p_same = G_same.data_ptr() if G_same is not None else 0
         p_old = F_old.data_ptr() if F_old is not None else 0
@@ -243,6 +248,7 @@ class _ClientContrastFn(torch.autograd.Function):
         ctx.mode = mode
         ctx.save_for_backward(out, dFs if need else out)
         ctx.has = need
+        ctx.direct = direct
         ctx.mark_non_differentiable(out)
         if aux is not None:
             ctx.mark_non_differentiable(aux)
@@ -254,6 +260,8 @@ class _ClientContrastFn(torch.autograd.Function):
         out, dFs = ctx.saved_tensors
         if not ctx.has:
             raise _lib.CreamflHipError('client_contrast backward without saved gradients')
+        if ctx.direct:                         # the caller declared the loss the root: gloss is the 1 of loss.backward()
+            return dFs, None, None, None, None, None, None, None, None, None
         _, B, D = dFs.shape
         g = gloss if (gloss.dtype == torch.float32 and gloss.is_contiguous()) else gloss.to(torch.float32).contiguous()
         dF = torch.empty(B, D, dtype=torch.float32, device=dFs.device)
@@ -261,13 +269,16 @@ class _ClientContrastFn(torch.autograd.Function):
         _lib.check(lib.cfl_client_contrast_bwd(p if (ctx.mode & 1) else 0, p + 4 * B * D if (ctx.mode & 2) else 0, out.data_ptr(),
                                                g.data_ptr(), B, D, dF.data_ptr(), _raw_stream(dF.device)),
                    'cfl_client_contrast_bwd')
-        return dF, None, None, None, None, None, None, None, None
+        return dF, None, None, None, None, None, None, None, None, None
 
 
 def client_contrast_fused(feature, global_same, global_other, d_idx, old_feature, temperature=0.5, weight=1.0, loss_scale=False,
-                          use_inter=True, use_intra=True, mean_divisor=None):
+                          use_inter=True, use_intra=True, mean_divisor=None, root=False):
     """Rows A3 + A4 and their combination (ClientTrainer.py:386-419) in two launches (bank pass, finish).
-    Returns (loss, loss_inter | None, loss_moon | None, lse | None, pos | None).  Needs bank_attn_supported(B, M, D)."""
+    Returns (loss, loss_inter | None, loss_moon | None, lse | None, pos | None).  Needs bank_attn_supported(B, M, D).
+    root=True is the caller's promise that it calls `loss.backward()` on the returned loss itself (ClientTrainer.py:420): the upstream
+    gradient is then the constant 1, the finish launch writes the final feature gradient and the backward launches nothing.  A loss
+    that is scaled or summed into something else before the backward pass must keep root=False (--loss_scale always does)."""
     F = _f32(feature, 'feature')
     mode = (1 if use_inter else 0) | (2 if use_intra else 0) | (4 if loss_scale else 0)
     if not (mode & 3):
@@ -283,7 +294,7 @@ def client_contrast_fused(feature, global_same, global_other, d_idx, old_feature
     if Fo is not None and Fo.shape != F.shape:
         raise RuntimeError(f'shape mismatch {tuple(F.shape)} vs {tuple(Fo.shape)}')
     loss, out, aux = _ClientContrastFn.apply(F, Go, Gs, _idx(d_idx, F.device), Fo, 1.0 / float(temperature), float(weight), mode,
-                                            int(mean_divisor) if mean_divisor else F.shape[0])
+                                            int(mean_divisor) if mean_divisor else F.shape[0], bool(root))
     return (loss, out[1] if use_inter else None, out[2] if use_intra else None,
             aux[0] if aux is not None else None, aux[1] if aux is not None else None)
 
@@ -295,22 +306,25 @@ class _MMClientContrastFn(torch.autograd.Function):
     launches forward, ONE launch backward for both modalities (they share the coefficient pair in `out`)."""
 
     @staticmethod
-    def forward(ctx, F_img, F_txt, G_img, G_txt, idx, Fo_img, Fo_txt, inv_tau, weight, mode):
+    def forward(ctx, F_img, F_txt, G_img, G_txt, idx, Fo_img, Fo_txt, inv_tau, weight, mode, root=False):
         lib = _lib.load()
         B, D = F_img.shape
         M = G_img.shape[0]
         dev = F_img.device
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        direct = bool(need and root and not (mode & 4))       # see _ClientContrastFn: the final gradients from the finish launches
         out = torch.empty(8, dtype=torch.float32, device=dev)
         aux = torch.empty(2, 2, B, dtype=torch.float32, device=dev) if (mode & 1) else None     # [modality][lse, pos][B]
-        dFs = torch.empty(2, 2, B, D, dtype=torch.float32, device=dev) if need else None          # [inter, moon][modality][B, D]
+        dFs = None
+        if need:                                              # [inter, moon][modality][B, D] | direct: [modality][B, D]
+            dFs = torch.empty((2, B, D) if direct else (2, 2, B, D), dtype=torch.float32, device=dev)
         st = _contrast_state(dev, _bank_plan(B, M, D, bool(need)))
         stream = _raw_stream(dev)
         for k, (F, G_other, G_same, F_old) in enumerate(((F_img, G_txt, G_img, Fo_img), (F_txt, G_img, G_txt, Fo_txt))):
             p_aux = aux.data_ptr() + 8 * B * k if aux is not None else 0
-            p_dfi = dFs.data_ptr() + 4 * B * D * k if (need and (mode & 1)) else 0
-            p_dfm = dFs.data_ptr() + 4 * B * D * (2 + k) if (need and (mode & 2)) else 0
-            tail = (B, M, D, 2 * B, inv_tau, weight, mode | (8 if k else 0), int(need), out.data_ptr(), p_aux,
+            p_dfi = dFs.data_ptr() + 4 * B * D * k if (need and ((mode & 1) or direct)) else 0
+            p_dfm = dFs.data_ptr() + 4 * B * D * (2 + k) if (need and (mode & 2) and not direct) else 0
+            tail = (B, M, D, 2 * B, inv_tau, weight, mode | (8 if k else 0), 2 if direct else int(need), out.data_ptr(), p_aux,
                     p_aux + 4 * B if p_aux else 0, p_dfi, p_dfm, st['ws'].data_ptr(), st['sync'].data_ptr(), stream)
             p_other = G_other.data_ptr() if (mode & 1) else 0
             p_same = G_same.data_ptr() if (mode & 2) else 0
@@ -321,6 +335,7 @@ class _MMClientContrastFn(torch.autograd.Function):
         ctx.mode = mode
         ctx.save_for_backward(out, dFs if need else out)
         ctx.has = need
+        ctx.direct = direct
         ctx.mark_non_differentiable(out)
         if aux is not None:
             ctx.mark_non_differentiable(aux)
@@ -332,6 +347,8 @@ class _MMClientContrastFn(torch.autograd.Function):
         out, dFs = ctx.saved_tensors
         if not ctx.has:
             raise _lib.CreamflHipError('mm_client_contrast backward without saved gradients')
+        if ctx.direct:
+            return dFs[0], dFs[1], None, None, None, None, None, None, None, None, None
         _, _, B, D = dFs.shape
         g = gloss if (gloss.dtype == torch.float32 and gloss.is_contiguous()) else gloss.to(torch.float32).contiguous()
         dF = torch.empty(2, B, D, dtype=torch.float32, device=dFs.device)
@@ -339,11 +356,11 @@ class _MMClientContrastFn(torch.autograd.Function):
         _lib.check(lib.cfl_client_contrast_bwd(p if (ctx.mode & 1) else 0, p + 8 * B * D if (ctx.mode & 2) else 0, out.data_ptr(),
                                                g.data_ptr(), 2 * B, D, dF.data_ptr(), _raw_stream(dF.device)),
                    'cfl_client_contrast_bwd')
-        return dF[0], dF[1], None, None, None, None, None, None, None, None
+        return dF[0], dF[1], None, None, None, None, None, None, None, None, None
 
 
 def mm_client_contrast_fused(out_img, out_txt, global_img, global_txt, d_idx, old_img=None, old_txt=None, temperature=0.5,
-                             weight=1.0, loss_scale=False, use_inter=True, use_intra=True):
+                             weight=1.0, loss_scale=False, use_inter=True, use_intra=True, root=False):
     """The multi-modal client's contrast terms and their combination (MMClientTrainer.py:164-206; intra only :246-264; inter only
     :301-308): 4 launches forward, 1 backward.  Returns (loss, loss_inter | None, loss_intra | None).  Needs
     bank_attn_supported(B, M, D)."""
@@ -360,7 +377,7 @@ def mm_client_contrast_fused(out_img, out_txt, global_img, global_txt, d_idx, ol
         if Oi.shape != Fi.shape or Ot.shape != Ft.shape:
             raise RuntimeError(f'shape mismatch {tuple(Fi.shape)} vs {tuple(Oi.shape)} / {tuple(Ot.shape)}')
     loss, out, _ = _MMClientContrastFn.apply(Fi, Ft, Gi, Gt, _idx(d_idx, Fi.device), Oi, Ot, 1.0 / float(temperature), float(weight),
-                                            mode)
+                                            mode, bool(root))
     return loss, out[1] if use_inter else None, out[2] if use_intra else None
 
 

@@ -128,6 +128,11 @@ int cfl_client_contrast_bwd(const float* dF_inter, const float* dF_moon, const f
  * launch runs.  D <= 768, D % 4 == 0 (cfl_bank_gsplit_supported); ws >= cfl_bank_gsplit_ws_bytes.
  * (Rounds 1-3 kept two earlier generations of the bank pass as A/B references; round 4 keeps ONE: the exact-fp32 two-pass
  * kernels cfl_bank_lse_fwd / _bwd, which also serve D % 4 != 0 and D > 768.)
+ * want_grad: 0 no gradient; 1 the two UNIT gradients (dF_inter, dF_moon; cfl_client_contrast_bwd combines them with the
+ * coefficients of out5 and the upstream gradient); 2 (round 6, "direct") the FINAL gradient for an upstream gradient of 1 --
+ * the loss is the root of loss.backward() as at ClientTrainer.py:420 / MMClientTrainer.py:207 -- written once into dF_inter
+ * ([B, D]; dF_moon unused), no backward launch.  Only without mode bit 2 (--loss_scale makes the coefficients data-dependent:
+ * CFL_EINVAL).
  */
 size_t cfl_bank_image_bytes(int M, int D);
 int cfl_bank_image_build(const float* G, int M, int D, void* image, void* stream);

@@ -8,19 +8,28 @@ its kernels do.  Here every identity i has
 A training batch holds B DISTINCT identities (no false negatives inside the all-pairs loss, src/criterions/probemb.py:171-183);
 the held-out evaluation set is n_eval identities x 5 captions with fresh noise and fresh fillers, in the batch-tuple contract of
 src/datasets/_dataloader.py:49-64 (every caption row repeats its image), with the `.dataset` attributes COCOEvaluator reads.
-Chance R@1 is 100 / n_eval."""
+Chance R@1 is 100 / n_eval.
+`caption_swap` = p > 0 makes the task AMBIGUOUS instead of merely longer to learn: every caption (training and held-out) carries,
+with probability p, the signature of a random other identity.  A converged model then ends near R@1 = 100 (1 - p) in both
+directions whatever its precision -- a ceiling that is set by the data, reached on a plateau (stable across seeds), and well below
+100 %, so that a path whose gradients are systematically off (it fits the clean pairs less sharply, or the false ones more) shows up
+as points of R@1 instead of disappearing into 99 %."""
 import torch
 
 
 class LearnableTask:
-    def __init__(self, n_id=1000, img=64, seed=0, noise=0.5, device='cpu'):
+    def __init__(self, n_id=1000, img=64, seed=0, noise=0.5, device='cpu', caption_swap=0.0):
         g = torch.Generator().manual_seed(seed)
         self.n_id, self.img, self.noise, self.device = n_id, img, noise, torch.device(device)
+        self.caption_swap = float(caption_swap)
         proto = torch.randn(n_id, 3, 8, 8, generator=g)
         self.proto = torch.nn.functional.interpolate(proto, size=(img, img), mode='nearest').to(self.device)
 
     def _captions(self, ids, gen):
         B = len(ids)
+        if self.caption_swap > 0:
+            swap = torch.rand(B, generator=gen) < self.caption_swap
+            ids = torch.where(swap, torch.randint(0, self.n_id, (B,), generator=gen), ids)
         nf = torch.randint(2, 7, (B,), generator=gen)
         lens = nf + 5                                              # <start> + 3 digits + fillers + <end>
         L = int(lens.max())

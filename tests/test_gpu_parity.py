@@ -153,22 +153,28 @@ def test_a1_linearity_in_upstream_gradient(dev):
 
 
 # ------------------------------------------------------------------------------------------ A3 / A4
-def _run_contrast(dev, f, g_same, g_other, d_idx, f_old, w, scale, use_inter=True, use_intra=True):
+def _run_contrast(dev, f, g_same, g_other, d_idx, f_old, w, scale, use_inter=True, use_intra=True, root=False):
     from creamfl_amd.algorithms.contrast import client_contrast_loss
     fg = f.to(dev).requires_grad_(True)
     loss, li, lm = client_contrast_loss(fg, g_same.to(dev), g_other.to(dev), d_idx, f_old.to(dev),
                                         interintra_weight=w, loss_scale=scale, use_inter=use_inter,
-                                        use_intra=use_intra)
+                                        use_intra=use_intra, root=root)
     loss.backward()
     return (loss.item(), None if li is None else li.item(), None if lm is None else lm.item(),
             fg.grad.cpu().numpy())
 
 
+@pytest.mark.parametrize('root', [False, True])
 @pytest.mark.parametrize('fname', golden_files('a34_'))
-def test_a34_client_contrast_golden(dev, fname):
+def test_a34_client_contrast_golden(dev, fname, root):
+    """root=True: the trainers' form -- the loss is the root of the backward pass, the finish launch writes the final gradient
+    (want_grad = 2) and the backward launches nothing; same goldens, same tolerances (--loss_scale goldens take the two-gradient
+    form either way)."""
+    from functools import partial
     z = _load(fname)
     args = (torch.from_numpy(z['f']), torch.from_numpy(z['g_same']), torch.from_numpy(z['g_other']),
             [int(v) for v in z['d_idx']], torch.from_numpy(z['f_old']))
+    _run_contrast = partial(globals()['_run_contrast'], root=root)
     loss, li, lm, df = _run_contrast(dev, *args, float(z['weight']), bool(z['loss_scale']))
     _close(loss, float(z['loss']), 1e-4, 0)
     _close(li, float(z['loss_inter']), 1e-4, 0)
@@ -187,26 +193,30 @@ def test_a34_client_contrast_golden(dev, fname):
     _close(df3, cf['d_moon'].numpy(), 1e-4, 2e-5 * np.abs(cf['d_moon'].numpy()).max())
 
 
-def _run_mm_contrast(dev, z_or_args, w, scale, use_inter=True, use_intra=True):
+def _run_mm_contrast(dev, z_or_args, w, scale, use_inter=True, use_intra=True, root=False):
     from creamfl_amd.algorithms.contrast import mm_client_contrast_loss
     out_img, out_txt, g_img, g_txt, d_idx, old_img, old_txt = z_or_args
     ig, tg = out_img.to(dev).requires_grad_(True), out_txt.to(dev).requires_grad_(True)
     loss, li, lm = mm_client_contrast_loss(ig, tg, g_img.to(dev), g_txt.to(dev), d_idx, old_img.to(dev), old_txt.to(dev),
-                                           interintra_weight=w, loss_scale=scale, use_inter=use_inter, use_intra=use_intra)
+                                           interintra_weight=w, loss_scale=scale, use_inter=use_inter, use_intra=use_intra,
+                                           root=root)
     loss.backward()
     return (loss.item(), None if li is None else li.item(), None if lm is None else lm.item(), ig.grad.cpu().numpy(),
             tg.grad.cpu().numpy())
 
 
+@pytest.mark.parametrize('root', [False, True])
 @pytest.mark.parametrize('fname', golden_files('a34mm_'))
-def test_a34_mm_client_contrast_golden(dev, fname):
+def test_a34_mm_client_contrast_golden(dev, fname, root):
     """The multi-modal client's contrast block (MMClientTrainer.py:164-206 both terms +- --loss_scale, :246-264 intra only,
     :301-308 inter only) through creamfl_amd.algorithms.contrast.mm_client_contrast_loss vs the reference statement sequence
     (a34mm_*.npz): loss terms 1e-4, both feature gradients 1e-3 of scale; duplicate indices, B not a multiple of 16."""
+    from functools import partial
     z = _load(fname)
     args = (torch.from_numpy(z['out_img']), torch.from_numpy(z['out_txt']), torch.from_numpy(z['g_img']),
             torch.from_numpy(z['g_txt']), [int(v) for v in z['d_idx']], torch.from_numpy(z['old_img']),
             torch.from_numpy(z['old_txt']))
+    _run_mm_contrast = partial(globals()['_run_mm_contrast'], root=root)
     loss, li, lm, di, dt = _run_mm_contrast(dev, args, float(z['weight']), bool(z['loss_scale']))
     _close(loss, float(z['loss']), 1e-4, 0)
     _close(li, float(z['loss_inter']), 1e-4, 0)
@@ -225,12 +235,16 @@ def test_a34_mm_client_contrast_golden(dev, fname):
     _close(dt, z['d_txt_inter_only'], 1e-3, 1e-4 * np.abs(z['d_txt_inter_only']).max())
 
 
+@pytest.mark.parametrize('root', [False, True])
 @pytest.mark.parametrize('b,m,d,scale', [(128, 50000, 256, False), (128, 50000, 256, True), (50, 7001, 768, True),
-                                         (33, 999, 100, False), (5, 40, 18, True)])
-def test_a34_mm_client_contrast_shapes(dev, b, m, d, scale):
+                                         (50, 7001, 512, False), (33, 999, 100, False), (5, 40, 18, True)])
+def test_a34_mm_client_contrast_shapes(dev, b, m, d, scale, root):
     """Same block at the public-set size (M = 50 000), at d = 768 (column-split wave pairs), at a width the fused kernels do not
     take (d % 4 != 0: the four-op fallback chain), vs the fp32 oracle restatement and the fp64 closed forms of the two
-    modalities; the fused path must be 4 forward launches + 1 backward launch."""
+    modalities; the fused path must be 4 forward launches + 1 backward launch -- and, with the loss declared the root of the
+    backward pass and no --loss_scale, 4 + 0."""
+    from functools import partial
+    _run_mm_contrast = partial(globals()['_run_mm_contrast'], root=root)
     from creamfl_amd import _lib, ops
     gen = torch.Generator().manual_seed(b + m + d)
     g_img = _unit(gen, m, d)
@@ -253,7 +267,7 @@ def test_a34_mm_client_contrast_shapes(dev, b, m, d, scale):
     launches = {k: v[0] for k, v in _lib.prof_query().items()}
     _lib.prof_enable(False)
     if fused:
-        assert sum(launches.values()) == 5, launches
+        assert sum(launches.values()) == (4 if (root and not scale) else 5), launches
     ci = oracle.client_contrast_grads_closed_form(out_img, g_img, g_txt, d_idx, old_img)
     ct = oracle.client_contrast_grads_closed_form(out_txt, g_txt, g_img, d_idx, old_txt)
     inter = (ci['loss_inter'] + ct['loss_inter']).item()
@@ -334,10 +348,13 @@ def test_a34_image_path_equals_fp32_bank_path(dev, b, m, d, monkeypatch):
     _close(got[3], ref[3], 1e-4, 3e-5 * np.abs(ref[3]).max())
 
 
+@pytest.mark.parametrize('root', [False, True])
 @pytest.mark.parametrize('m,d', [(9, 32), (4097, 256), (300, 768)])
-def test_a34_duplicate_and_boundary_indices(dev, m, d):
+def test_a34_duplicate_and_boundary_indices(dev, m, d, root):
     """collisions in the batch's public-set indices (the same representation is the positive of several rows), the first and the
     last bank row as positives, inter + intra terms with and without loss_scale: == the closed-form oracle."""
+    from functools import partial
+    _run_contrast = partial(globals()['_run_contrast'], root=root)
     gen = torch.Generator().manual_seed(m + d)
     g_same, g_other = _unit(gen, m, d), _unit(gen, m, d)
     d_idx = [0, m - 1, 0, 0, m - 1, m // 2, m // 2, 1, m - 2, 0, m - 1, 3 % m]
@@ -352,13 +369,55 @@ def test_a34_duplicate_and_boundary_indices(dev, m, d):
     _, _, _, dm = _run_contrast(dev, *args, 1.0, False, use_inter=False)
     _close(di, cf['d_inter'].numpy(), 1e-4, 3e-5 * np.abs(cf['d_inter'].numpy()).max())
     _close(dm, cf['d_moon'].numpy(), 1e-4, 3e-5 * np.abs(cf['d_moon'].numpy()).max())
-    # both terms with loss_scale: (loss_moon + loss_inter / (loss_inter / loss_moon).detach()) * w  (ClientTrainer.py:416-419)
+    # both terms, plain combination (the direct form when root): (loss_moon + loss_inter) * w
     w = 0.25
+    loss, _, _, df = _run_contrast(dev, *args, w, False)
+    _close(loss, (cf['loss_moon'].item() + cf['loss_inter'].item()) * w, 1e-4, 0)
+    want = (cf['d_moon'].numpy() + cf['d_inter'].numpy()) * w
+    _close(df, want, 2e-4, 5e-5 * np.abs(want).max())
+    # both terms with loss_scale: (loss_moon + loss_inter / (loss_inter / loss_moon).detach()) * w  (ClientTrainer.py:416-419)
     loss, li2, lm2, df = _run_contrast(dev, *args, w, True)
     ratio = cf['loss_inter'].item() / cf['loss_moon'].item()
     _close(loss, (cf['loss_moon'].item() + cf['loss_inter'].item() / ratio) * w, 1e-4, 0)
     want = (cf['d_moon'].numpy() + cf['d_inter'].numpy() / ratio) * w
     _close(df, want, 2e-4, 5e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize('b,m,d', [(128, 50000, 256), (256, 20000, 512), (37, 900, 768), (130, 3000, 128)])
+def test_a34_root_form_equals_the_two_launch_form(dev, b, m, d):
+    """The direct finish (final gradient for an upstream gradient of 1, no backward launch) against the unit gradients + backward
+    launch of the same step: same loss bit for bit (the forward is the same code), gradients to fp32 rounding of the last
+    combination; 2 launches instead of 3; a scaled loss (root=False) still gets its scale."""
+    from creamfl_amd import _lib, ops
+    gen = torch.Generator().manual_seed(b + m + d)
+    G, Gs = _unit(gen, m, d).to(dev), _unit(gen, m, d).to(dev)
+    idx = torch.randint(0, m, (b,), generator=gen).tolist()
+    f = torch.nn.functional.normalize(Gs.cpu()[idx] + 0.9 * _unit(gen, b, d), dim=-1)
+    fo = torch.nn.functional.normalize(f + 0.4 * _unit(gen, b, d), dim=-1).to(dev)
+
+    def run(root, scale_by=None, **kw):
+        fg = f.to(dev).requires_grad_(True)
+        loss = ops.client_contrast_fused(fg, Gs, G, idx, fo, 0.5, weight=0.3, root=root, **kw)[0]
+        (loss if scale_by is None else loss * scale_by).backward()
+        return loss.item(), fg.grad
+
+    for kw in ({}, {'use_intra': False}, {'use_inter': False}):
+        run(True, **kw)                                                 # bank image built, modules loaded
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        l1, g1 = run(True, **kw)
+        torch.cuda.synchronize()
+        n1 = sum(v[0] for v in _lib.prof_query().values())
+        _lib.prof_reset()
+        l0, g0 = run(False, **kw)
+        torch.cuda.synchronize()
+        n0 = sum(v[0] for v in _lib.prof_query().values())
+        _lib.prof_enable(False)
+        assert l1 == l0
+        assert n0 - n1 == 1 and n1 == (1 if kw.get('use_inter') is False else 2), (n0, n1)
+        torch.testing.assert_close(g1, g0, rtol=2e-6, atol=1e-7 * float(g0.abs().max()))
+        _, g3 = run(False, scale_by=3.0, **kw)
+        torch.testing.assert_close(g3, 3.0 * g0, rtol=2e-6, atol=1e-7 * float(g0.abs().max()))
 
 
 @pytest.mark.parametrize('b,m,d', [(1, 1, 4), (3, 200, 17), (64, 4097, 256), (65, 5000, 100), (128, 50000, 256),

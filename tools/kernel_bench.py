@@ -57,7 +57,8 @@ def case_a1(N, D):
             'algo_TFLOPs': round(flops / us / 1e6, 2), 'pairs_per_s': round(N / us * 1e6)}
 
 
-def case_a3(B, M, D):
+def case_a3(B, M, D, root=True):
+    """root: the trainers' form (the loss is the root of the backward pass: pass + finish, no backward launch)."""
     g = torch.Generator(device='cuda').manual_seed(1)
     G = unit(M, D, gen=g)
     Gs = unit(M, D, gen=g)
@@ -67,12 +68,14 @@ def case_a3(B, M, D):
     from creamfl_amd.algorithms.contrast import client_contrast_loss
 
     def step():
-        loss, _, _ = client_contrast_loss(f, Gs, G, idx, fo)
+        loss, _, _ = client_contrast_loss(f, Gs, G, idx, fo, root=root)
         loss.backward()
     us, prof = timed(step)
     flops = 4 * B * M * D
     byts = 2 * M * D * 4
-    return {'case': f'a3a4_client_contrast B={B} M={M} D={D}', 'us_per_step': round(us, 1), 'kernels_us': prof,
+    return {'case': f'a3a4_client_contrast B={B} M={M} D={D}' + ('' if root else ' two-gradient form'), 'us_per_step': round(us, 1),
+            'kernels_us': prof, 'kernels_sum_us': round(sum(v for v in prof.values() if v), 1),
+            'hbm_frac_of_8TBps': round(M * D * 4 / (sum(v for v in prof.values() if v) * 1e-6) / 8e12, 3),
             'algo_TFLOPs': round(flops / us / 1e6, 2), 'algo_GBps': round(byts / us / 1e3, 1),
             'pairs_per_s': round(B / us * 1e6)}
 
@@ -342,7 +345,8 @@ def main():
     if 'a1big' in cases:
         out += [case_a1(4096, 512)]
     if 'a3' in cases:
-        out += [case_a3(128, 50000, 256), case_a3(256, 50000, 512), case_a3(128, 50000, 768), case_a3(32, 50000, 256)]
+        out += [case_a3(128, 50000, 256), case_a3(128, 50000, 256, root=False), case_a3(256, 50000, 512), case_a3(128, 50000, 768),
+                case_a3(32, 50000, 256)]
     if 'pool' in cases:
         out += [case_pool()]
     if 'a3one' in cases:

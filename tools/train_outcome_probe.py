@@ -70,10 +70,11 @@ def main():
     ap.add_argument('--cnn', default='resnet18')
     ap.add_argument('--seeds', type=int, default=1, help='model-initialisation seeds 3, 4, ...: one bf16 + one fp32 run per seed')
     ap.add_argument('--n-eval', type=int, default=0, help='held-out identities evaluated (0 = all; a multiple of 5)')
+    ap.add_argument('--caption-swap', type=float, default=0.0, help='share of captions carrying another identity\'s signature')
     args = ap.parse_args()
     from learnable_task import LearnableTask
     dev = torch.device('cuda', 0)
-    task = LearnableTask(n_id=args.n_id, img=args.img, seed=0, noise=args.noise, device=dev)
+    task = LearnableTask(n_id=args.n_id, img=args.img, seed=0, noise=args.noise, device=dev, caption_swap=args.caption_swap)
     n_eval = args.n_eval or args.n_id
     for seed in range(3, 3 + args.seeds):
         with torch.backends.cudnn.flags(enabled=True, benchmark=False):
