@@ -43,6 +43,7 @@ HBM_PEAK_GBPS = 8000.0
 
 
 def add_arguments(ap):
+    ap.add_argument('--round-first', type=int, default=1, help='the federation round before the clients\' micro-benchmarks (a real run\'s order)')
     ap.add_argument('--pub', type=int, default=50000, help='config 2: public-set size M (banks, representations, con_w)')
     ap.add_argument('--client-batch', type=int, default=128, help='config 2: public-loader batch B of the contrast loops')
     ap.add_argument('--client-dim', type=int, default=256, help='config 2: feature_dim D (src/main.py:103 default)')
@@ -451,86 +452,102 @@ def run(a, world, rank, dev, use_dist, json_out):
     unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=g, device=dev), dim=-1)
     banks = (unit(M, D), unit(M, D))
     batch = coco_batch_on_device(B, dev, seed=1234 + rank, img=S)
-    kinds = ('img', 'txt', 'mm') if world == 1 else (KINDS8[rank % 8],)
-    clients = {}
-    for kind in kinds:
-        tr = first_of_kind(algo, kind, rank if world > 1 else None, world)
-        clients[kind] = measure_client(tr, kind, banks, batch, dev, a.steps, a.warmup, use_dist)
-    mine = clients[kinds[0]]
-    best = mine.get('graph') or mine['eager']
-    dt, pairs = best['seconds'], float(B * a.steps)
-    if use_dist:
-        t = torch.tensor([dt, pairs], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
-        tmax = t.clone()
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        dt, pairs = float(tmax[0]), float(t[1])
-    value = pairs / dt
-    # roofline of the bank pass, from this rank's eager timed region
-    roof = None
-    if mine.get('bank_pass'):
-        us = mine['bank_pass']['avg_launch_us']
-        work = M * D * 4 + 3 * B * D * 4                  # the bank (4 B per element: its bf16 hi / lo image) once + F, F_old, dF
-        if kinds[0] == 'mm':
-            work = M * D * 4 + 3 * B * D * 4              # (per launch: the multi-modal client launches it once per modality)
-        ach = work / (us * 1e-6) / 1e9
-        roof = {'kernel': 'cfl_bank_stream_kernel', 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None, 'avg_launch_us': us, 'launches': mine['bank_pass']['launches'],
-                'algorithmic_bytes': int(work),
-                'how': 'HIP start / stop events of the launch inside the eager timed region of the %s client (the graph replays the '
-                       'same kernel; events cannot ride in a captured graph)' % kinds[0]}
-    rnd = None
-    full = None
-    if a.round == 'full':
-        warm_s = None
-        if a.round_warm:
-            t0 = time.perf_counter()
-            mini, _ = build_federation(a, dev, 4 * B, mini=True)
-            random.seed(4321)
-            mini.train(0)
-            _fence(use_dist)
-            warm_s = round(time.perf_counter() - t0, 1)
-            del mini
-            torch.cuda.empty_cache()
-        # the federation's FIRST round starts on an empty allocator and a fresh server engine (its first steps allocate their
-        # gigabytes: 44 ms per public batch where the same loop runs 28-35 ms warm, tools/server_phase_probe.py); every later round
-        # of a real run is the steady state, so the SECOND round is the one reported phase by phase, the first one beside it
-        ph0, _, _, _ = timed_round(algo, use_dist, 0)
-        ph, counts, comm, sampled = timed_round(algo, use_dist, 1)
+    # ORDER (round 6): the federation round runs FIRST, as a real run has it -- a process that ran the three clients' micro-benchmarks
+    # before the round showed its server phases ~10 ms per public batch slower with a long tail (35 GB reserved instead of 19:
+    # tools/federation_step_trace.py, profiles/r5_federation_step_trace.jsonl); `--round-first 0` restores round 5's order.
+    def round_part():
+        rnd = None
+        full = None
+        if a.round == 'full':
+            warm_s = None
+            if a.round_warm:
+                t0 = time.perf_counter()
+                mini, _ = build_federation(a, dev, 4 * B, mini=True)
+                random.seed(4321)
+                mini.train(0)
+                _fence(use_dist)
+                warm_s = round(time.perf_counter() - t0, 1)
+                del mini
+                torch.cuda.empty_cache()
+            # the federation's FIRST round starts on an empty allocator and a fresh server engine (its first steps allocate their
+            # gigabytes: 44 ms per public batch where the same loop runs 28-35 ms warm, tools/server_phase_probe.py); every later round
+            # of a real run is the steady state, so the SECOND round is the one reported phase by phase, the first one beside it
+            ph0, _, _, _ = timed_round(algo, use_dist, 0)
+            ph, counts, comm, sampled = timed_round(algo, use_dist, 1)
+            if use_dist:
+                keys = sorted(ph)
+                t = torch.tensor([ph[k] for k in keys], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                ph_max = {k: float(v) for k, v in zip(keys, t)}
+            else:
+                ph_max = ph
+            n_pub_batches = -(-Mr // B)
+            full = full_size_exchange(a, dev, banks, world, rank, use_dist)
+            per_batch = {k: round(ph_max[k] / n_pub_batches * 1e3, 2) for k in ('global_train', 'global_reps', 'kd') if k in ph_max}
+            rnd = {'pub_data_num': Mr, 'public_batches': n_pub_batches, 'clients_sampled': sampled,
+                   'miniature_warm_up_round_s': warm_s, 'ms_per_public_batch': per_batch,
+                   'ran_before_the_client_micro_benchmarks': bool(a.round_first),
+                   'timed_round': 'the second round of the federation (steady state: warm allocator, warm server engine); the first '
+                                  'round is in first_round_phases_s_rank0',
+                   'first_round_phases_s_rank0': {k: round(v, 3) for k, v in sorted(ph0.items())},
+                   'scaling_note': 'every loop of the round is linear in the public batches (391 at the full M = 50 000); con_w '
+                                   '(quadratic in M) and the representation all-gather are in `full_M` at the full size',
+                   'clients_trained_by_this_rank': counts.get('clients_train', 0),
+                   'phases_s_rank0': {k: round(v, 3) for k, v in sorted(ph.items())},
+                   'phases_s_max_over_ranks': {k: round(v, 3) for k, v in sorted(ph_max.items())},
+                   'comm': {'gather_bytes': comm['gather_bytes'], 'rep_all_gather_ms': round(comm['rep_all_gather_s'] * 1e3, 3),
+                            'rep_collectives': comm['collectives'], 'agg_gather_bytes': comm['agg_gather_bytes'],
+                            'agg_all_gather_ms': round(comm['agg_all_gather_s'] * 1e3, 3),
+                            'con_w_ms': round(ph.get('con_w', 0.0) * 1e3, 3), 'rep_wire': a.rep_wire},
+                   'private_samples_per_client': fed['private_samples'],
+                   'graphs': {'server_graph': int(a.server_graph), 'mm_client_graph': int(a.mm_client_graph),
+                              'server': dict(getattr(algo.engine, 'graph_stats', {}) or {}),
+                              'mm_clients': [g for g in (getattr(t, 'graph_stats', None) for t in algo.mm_local_trainers) if g][:2]},
+                   'recall_1_after_round': None}
+            try:
+                sc = algo.best_scores['test']
+                rnd['recall_1_after_round'] = {'i2t': sc['i2t']['recall_1'], 't2i': sc['t2i']['recall_1']}
+            except (TypeError, KeyError):
+                pass
+        return rnd, full
+
+    def client_part():
+        kinds = ('img', 'txt', 'mm') if world == 1 else (KINDS8[rank % 8],)
+        clients = {}
+        for kind in kinds:
+            tr = first_of_kind(algo, kind, rank if world > 1 else None, world)
+            clients[kind] = measure_client(tr, kind, banks, batch, dev, a.steps, a.warmup, use_dist)
+        mine = clients[kinds[0]]
+        best = mine.get('graph') or mine['eager']
+        dt, pairs = best['seconds'], float(B * a.steps)
         if use_dist:
-            keys = sorted(ph)
-            t = torch.tensor([ph[k] for k in keys], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            ph_max = {k: float(v) for k, v in zip(keys, t)}
-        else:
-            ph_max = ph
-        n_pub_batches = -(-Mr // B)
-        full = full_size_exchange(a, dev, banks, world, rank, use_dist)
-        per_batch = {k: round(ph_max[k] / n_pub_batches * 1e3, 2) for k in ('global_train', 'global_reps', 'kd') if k in ph_max}
-        rnd = {'pub_data_num': Mr, 'public_batches': n_pub_batches, 'clients_sampled': sampled,
-               'miniature_warm_up_round_s': warm_s, 'ms_per_public_batch': per_batch,
-               'timed_round': 'the second round of the federation (steady state: warm allocator, warm server engine); the first '
-                              'round is in first_round_phases_s_rank0',
-               'first_round_phases_s_rank0': {k: round(v, 3) for k, v in sorted(ph0.items())},
-               'scaling_note': 'every loop of the round is linear in the public batches (391 at the full M = 50 000); con_w '
-                               '(quadratic in M) and the representation all-gather are in `full_M` at the full size',
-               'clients_trained_by_this_rank': counts.get('clients_train', 0),
-               'phases_s_rank0': {k: round(v, 3) for k, v in sorted(ph.items())},
-               'phases_s_max_over_ranks': {k: round(v, 3) for k, v in sorted(ph_max.items())},
-               'comm': {'gather_bytes': comm['gather_bytes'], 'rep_all_gather_ms': round(comm['rep_all_gather_s'] * 1e3, 3),
-                        'rep_collectives': comm['collectives'], 'agg_gather_bytes': comm['agg_gather_bytes'],
-                        'agg_all_gather_ms': round(comm['agg_all_gather_s'] * 1e3, 3),
-                        'con_w_ms': round(ph.get('con_w', 0.0) * 1e3, 3), 'rep_wire': a.rep_wire},
-               'private_samples_per_client': fed['private_samples'],
-               'graphs': {'server_graph': int(a.server_graph), 'mm_client_graph': int(a.mm_client_graph),
-                          'server': dict(getattr(algo.engine, 'graph_stats', {}) or {}),
-                          'mm_clients': [g for g in (getattr(t, 'graph_stats', None) for t in algo.mm_local_trainers) if g][:2]},
-               'recall_1_after_round': None}
-        try:
-            sc = algo.best_scores['test']
-            rnd['recall_1_after_round'] = {'i2t': sc['i2t']['recall_1'], 't2i': sc['t2i']['recall_1']}
-        except (TypeError, KeyError):
-            pass
+            t = torch.tensor([dt, pairs], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
+            tmax = t.clone()
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+            dt, pairs = float(tmax[0]), float(t[1])
+        value = pairs / dt
+        # roofline of the bank pass, from this rank's eager timed region
+        roof = None
+        if mine.get('bank_pass'):
+            us = mine['bank_pass']['avg_launch_us']
+            work = M * D * 4 + 3 * B * D * 4                  # the bank (4 B per element: its bf16 hi / lo image) once + F, F_old, dF
+            if kinds[0] == 'mm':
+                work = M * D * 4 + 3 * B * D * 4              # (per launch: the multi-modal client launches it once per modality)
+            ach = work / (us * 1e-6) / 1e9
+            roof = {'kernel': 'cfl_bank_stream_kernel', 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                    'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None, 'avg_launch_us': us, 'launches': mine['bank_pass']['launches'],
+                    'algorithmic_bytes': int(work),
+                    'how': 'HIP start / stop events of the launch inside the eager timed region of the %s client (the graph replays the '
+                           'same kernel; events cannot ride in a captured graph)' % kinds[0]}
+        return kinds, clients, dt, value, roof
+
+    if a.round_first:
+        rnd, full = round_part()
+        kinds, clients, dt, value, roof = client_part()
+    else:
+        kinds, clients, dt, value, roof = client_part()
+        rnd, full = round_part()
     if rank == 0:
         cpu = None
         if world == 1 and not a.no_cpu_baseline:

@@ -1458,6 +1458,8 @@ def conv3x3_wgrad(dy, x, weight):
 # the library's batched GEMM with atomics + zero fill + cast.  CFL_NO_WGRAD1=1 / tools/ab_step.py --knob wgrad1 is the A/B.
 WGRAD1 = [_os.environ.get('CFL_NO_WGRAD1', '0') != '1']
 WGRAD1_TAKEN = [0]
+WGRAD1_MAX_HW = [int(_os.environ.get('CFL_WGRAD1_MAX_HW', '0'))]      # > 0: only maps up to this height (measurement knob: stand-alone the
+#                                                                        kernel beats the library at 14 x 14 / 7 x 7 and loses at 56 x 56)
 
 
 def conv1x1_wgrad(dy, x, weight):
@@ -1472,6 +1474,8 @@ def conv1x1_wgrad(dy, x, weight):
     if tuple(dy.shape) != (N, Co, H, W) or weight.shape[1] != Ci:
         return None
     M = N * H * W
+    if WGRAD1_MAX_HW[0] and H > WGRAD1_MAX_HW[0]:
+        return None
     lib = _lib.load()
     if not lib.cfl_conv1x1_wgrad_supported(M, Ci, Co):
         return None

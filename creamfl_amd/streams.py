@@ -6,16 +6,47 @@ The step's main stream carries the image tower; independent work runs beside it:
   'wgrad' the weight gradients of the trunk convolutions, which nothing on the critical path waits for (ops.conv1x1)
 Kept at module level (not on nn.Modules, which must stay deepcopy-able).  Every consumer of gradients that may come from
 these streams -- the optimizer step, DDP's bucket all-reduce -- first calls `join_into_current`."""
+import ctypes
+import os
+
 import torch
 
 _STREAMS = {}
+_RAW = []                    # CU-masked HIP streams created here (kept for the life of the process)
+
+
+def _cu_masked_stream(device, spec):
+    """A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask), wrapped for torch.
+    spec = 'n' (n of every 256 CUs, spread evenly over the mask) or '0x...' (the mask itself, bit i = CU i).
+    Measurement knob of round 6 (CFL_WGRAD_CUS): do the side stream's weight-gradient kernels cost the main stream less when
+    they cannot take every CU?"""
+    if spec.lower().startswith('0x'):
+        mask = int(spec, 16)
+    else:
+        n = max(1, min(256, int(spec)))
+        mask, acc = 0, 0
+        for i in range(256):                  # Bresenham spread: n bits set among 256
+            acc += n
+            if acc >= 256:
+                acc -= 256
+                mask |= 1 << i
+    words = (ctypes.c_uint32 * 8)(*[(mask >> (32 * i)) & 0xffffffff for i in range(8)])
+    hip = ctypes.CDLL('libamdhip64.so')
+    raw = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), ctypes.c_uint32(8), words)
+    if rc != 0 or not raw.value:
+        raise RuntimeError('hipExtStreamCreateWithCUMask failed: %d' % rc)
+    _RAW.append(raw)
+    return torch.cuda.ExternalStream(raw.value, device=device)
 
 
 def get(device, name):
     key = (torch.device(device), name)
     s = _STREAMS.get(key)
     if s is None:
-        s = _STREAMS[key] = torch.cuda.Stream(device=device)
+        spec = os.environ.get('CFL_%s_CUS' % name.upper())
+        s = _STREAMS[key] = _cu_masked_stream(device, spec) if spec else torch.cuda.Stream(device=device)
         # Gradients of the text tower / the weight gradients are PRODUCED on these streams on purpose and joined before
         # anything consumes them (join_into_current): autograd's "AccumulateGrad stream mismatch" warning is expected here.
         warn_off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)

@@ -86,6 +86,9 @@ def main():
         elif args.knob == 'wgrad1':
             from creamfl_amd import ops
             ops.WGRAD1[0] = bool(on)
+        elif args.knob.startswith('w1hw'):       # 1 x 1 weight gradients on csrc/wgrad1x1.hip only up to this map height (off: every map)
+            from creamfl_amd import ops
+            ops.WGRAD1_MAX_HW[0] = int(args.knob[4:] or 14) if on else 0
         elif args.knob.startswith('w1wgs'):
             lib.cfl_conv1x1_wgrad_workgroups(int(args.knob[5:] or 256) if on else 128)
         elif args.knob == 'wgrad3':
