@@ -161,7 +161,7 @@ def offline_traffic(kernel, per_step, profiles_dir=None):
     launch-weighted."""
     profiles_dir = profiles_dir or os.path.join(ROOT, 'profiles')
     source = 'none: no offline PMC profile matches this run (traffic = null)'
-    for fn in ('r5_pmc_bench_traffic.json', 'r4_pmc_bench_traffic.json', 'r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
+    for fn in ('r6_pmc_bench_traffic.json', 'r5_pmc_bench_traffic.json', 'r4_pmc_bench_traffic.json', 'r3_pmc_bench_traffic.json', 'r2_pmc_bench_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(profiles_dir, fn)))
         except (OSError, ValueError):

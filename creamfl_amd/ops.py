@@ -1458,8 +1458,11 @@ def conv3x3_wgrad(dy, x, weight):
 # the library's batched GEMM with atomics + zero fill + cast.  CFL_NO_WGRAD1=1 / tools/ab_step.py --knob wgrad1 is the A/B.
 WGRAD1 = [_os.environ.get('CFL_NO_WGRAD1', '0') != '1']
 WGRAD1_TAKEN = [0]
-WGRAD1_MAX_HW = [int(_os.environ.get('CFL_WGRAD1_MAX_HW', '0'))]      # > 0: only maps up to this height (measurement knob: stand-alone the
-#                                                                        kernel beats the library at 14 x 14 / 7 x 7 and loses at 56 x 56)
+# maps up to this height only (0 = all).  Stand-alone the kernel beats the library at 7 x 7 / 14 x 14 (60 + 9 vs 64 us while moving a
+# third of its bytes), ties at 28 x 28 and loses at 56 x 56 (163 + 31 vs 114 us: 512 MB of operands against a 16 K-element output, where
+# its split-K partials and 128 workgroups are the wrong shape).  In the step (tools/ab_step.py --knob w1hwN, profiles/r6_ab_w1hw*.json):
+# all maps 42.81, up to 14: 42.56, up to 28: 42.43 ms -- layer1's nine 1 x 1 weight gradients stay on the library.
+WGRAD1_MAX_HW = [int(_os.environ.get('CFL_WGRAD1_MAX_HW', '28'))]
 
 
 def conv1x1_wgrad(dy, x, weight):

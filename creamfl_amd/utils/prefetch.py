@@ -9,10 +9,13 @@ issues their copies on a dedicated HIP stream and hands (device batch, event) to
 consumer's stream waits for the event (no host synchronisation anywhere).  Non-tensor items (caption strings, ids, index lists)
 pass through; batches that already live on the device pass through untouched.
 """
+import os
 import queue
 import threading
 
 import torch
+
+_INLINE = [os.environ.get('CFL_PREFETCH_INLINE', '0') == '1']      # measurement knob: no producer thread
 
 _H2D = {}        # device -> copy stream.  NOT one of streams.py's auxiliary streams: the end-of-backward join and the gradient
                  # reducer wait for those, and must not wait for the next batch's copy
@@ -77,6 +80,20 @@ class DevicePrefetcher:
     def __iter__(self):
         if self.device.type != 'cuda':
             yield from self.loader
+            return
+        if _INLINE[0]:
+            # measurement form: the loader iterated on the consumer's thread.  Measured SLOWER even for loaders whose batches are born in
+            # HBM (tools/federation_step_trace.py, profiles/r6_federation_step_trace.jsonl: 30.2 vs 28.2 ms per public batch): the
+            # producer thread's ~10 launches per batch overlap the host-bound step's GIL-free stretches (ctypes calls release the GIL)
+            for batch in self.loader:
+                staged, ev = self._stage(batch, h2d_stream := _copy_stream(self.device))
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for t in staged:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
+                yield staged
             return
         q = queue.Queue(maxsize=self.depth)
         stop = threading.Event()

@@ -10,6 +10,8 @@ knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming 
         bnslice  the BatchNorm passes on the channel-sliced block map (no `final` launches, default) vs the whole-row map
         wgrad1   the 1 x 1 weight gradients on csrc/wgrad1x1.hip (default) vs the library's batched GEMM
         w1wgsN   that kernel aiming at N workgroups vs its default of 128
+        w1hwN    that kernel for maps up to N x N only vs for every map (product default: 28)
+        flushN   streams.FLUSH_POLICY = N vs 0 (when the queued weight gradients go to their stream)
         wgrad3   the 3 x 3 weight gradients of layers 3 / 4 on csrc/wgrad3x3.hip (default) vs MIOpen's igemm_wrw
         w3splitN that kernel on N image ranges (N / 32 of the chip for the layer3 shape) vs its default of 256 workgroups
         wgrad    BOUND, not a product switch: every trunk weight gradient computed (default) vs replaced by a zero fill -- what the
@@ -88,7 +90,7 @@ def main():
             ops.WGRAD1[0] = bool(on)
         elif args.knob.startswith('w1hw'):       # 1 x 1 weight gradients on csrc/wgrad1x1.hip only up to this map height (off: every map)
             from creamfl_amd import ops
-            ops.WGRAD1_MAX_HW[0] = int(args.knob[4:] or 14) if on else 0
+            ops.WGRAD1_MAX_HW[0] = int(args.knob[4:] or 14) if on else 0        # (off = every map; the product default is 28)
         elif args.knob.startswith('w1wgs'):
             lib.cfl_conv1x1_wgrad_workgroups(int(args.knob[5:] or 256) if on else 128)
         elif args.knob == 'wgrad3':

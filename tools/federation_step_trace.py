@@ -22,6 +22,9 @@ def main():
     ap.add_argument('--sync-every', type=int, default=0, help='> 0: synchronise after every n-th step (GPU time per step, perturbs the loop)')
     ap.add_argument('--mini-first', type=int, default=0, help='the miniature warm-up federation of the bench first')
     ap.add_argument('--measure-first', type=int, default=0, help='the three client step measurements of the bench first')
+    ap.add_argument('--empty-cache', type=int, default=0, help='torch.cuda.empty_cache() before every server phase')
+    ap.add_argument('--gc-off', type=int, default=0, help='gc.disable() while a server phase runs')
+    ap.add_argument('--tag', default='')
     a = ap.parse_args()
     import bench_clients
     p2 = argparse.ArgumentParser()
@@ -58,12 +61,19 @@ def main():
         return out
 
     def train(*args, **kw):
+        import gc
         del stamps[:]
         torch.cuda.synchronize()
+        if a.empty_cache:
+            torch.cuda.empty_cache()
+        if a.gc_off:
+            gc.disable()
         t0 = time.perf_counter()
         stamps.append(t0)
         orig_train(*args, **kw)
         t_issue = time.perf_counter()
+        if a.gc_off:
+            gc.enable()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         d = [round((y - x) * 1e3, 2) for x, y in zip(stamps, stamps[1:])]
@@ -78,7 +88,7 @@ def main():
     for r in range(a.rounds):
         random.seed(1234)
         algo.train(r)
-    print(json.dumps({'mini_first': a.mini_first, 'measure_first': a.measure_first, 'threads': __import__('threading').active_count(), 'sync_every': a.sync_every, 'phases': phases}), flush=True)
+    print(json.dumps({'tag': a.tag, 'empty_cache': a.empty_cache, 'gc_off': a.gc_off, 'inline_loader': os.environ.get('CFL_PREFETCH_INLINE'), 'alloc_conf': os.environ.get('PYTORCH_HIP_ALLOC_CONF') or os.environ.get('PYTORCH_CUDA_ALLOC_CONF'), 'mini_first': a.mini_first, 'measure_first': a.measure_first, 'threads': __import__('threading').active_count(), 'sync_every': a.sync_every, 'phases': phases}), flush=True)
 
 
 if __name__ == '__main__':

@@ -34,3 +34,32 @@ print({k:(v.get('graph') or v.get('eager') or {}).get('ms_per_step') for k,v in 
 print(d['round']['ms_per_public_batch'], d['round']['phases_s_rank0'])
 print(d['roofline'])"
 tail -n 3 $OUT/config2.err
+# the server's global-training phase inside the federation process: producer thread vs inline loader, allocator knobs
+T="timeout 600 python tools/federation_step_trace.py --batches 50 --rounds 2"
+$T --tag base > $OUT/fed_base.json 2>> $OUT/fed.err
+CFL_PREFETCH_INLINE=1 $T --tag inline > $OUT/fed_inline.json 2>> $OUT/fed.err
+CFL_PREFETCH_INLINE=1 $T --tag inline_gcoff --gc-off 1 > $OUT/fed_inline_gcoff.json 2>> $OUT/fed.err
+CFL_PREFETCH_INLINE=1 PYTORCH_HIP_ALLOC_CONF=expandable_segments:True PYTORCH_CUDA_ALLOC_CONF=expandable_segments:True $T --tag inline_expandable > $OUT/fed_inline_expandable.json 2>> $OUT/fed.err
+cat $OUT/fed_*.json > $OUT/r6_federation_step_trace.jsonl
+python3 -c "
+import json
+for l in open('$OUT/r6_federation_step_trace.jsonl'):
+    d=json.loads(l)
+    print(d['tag'], [(p['wall_ms_per_batch'], p['issue_ms_per_batch'], p['median_rest_ms'], p['p90_rest_ms'], p['mem_gb']['reserved']) for p in d['phases']])"
+tail -n 3 $OUT/fed.err
+# kernel trace of the bench step at this code: per-kernel statistics, per-queue busy time, the main queue's largest idle gaps
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $OUT/trace_bench -o bench --output-format csv -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-recall --no-alone --no-client-steps --no-mfu > $OUT/trace_bench.log 2>&1
+TR=$(ls $OUT/trace_bench/*kernel_trace.csv $OUT/trace_bench/*/*kernel_trace.csv 2>/dev/null | head -1)
+python3 $ROOT/tools/trace_stats.py $TR > $OUT/r6_bench_kernel_stats.csv
+python3 $ROOT/tools/trace_streams.py $TR --gaps 14 > $OUT/r6_bench_streams.json
+rm -rf $OUT/trace_bench
+head -n 12 $OUT/r6_bench_kernel_stats.csv | cut -c1-160
+python3 -c "
+import json
+d=json.load(open('$OUT/r6_bench_streams.json'))
+print(d['wall_ms_per_step'])
+for q,v in d['queues'].items():
+    print(q, v['busy_ms_per_step'], v['gaps']['idle_ms_per_step'])
+    for g in v.get('largest_gaps', [])[:24]: print('   ', g)
+" | head -80

@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('trace')
 ap.add_argument('--after-nth', nargs=2, default=['cfl_adamp_pass3_kernel', '2'])
 ap.add_argument('--top', type=int, default=12)
+ap.add_argument('--gaps', type=int, default=0, help='list the n largest idle gaps per step of every queue with the kernels around them')
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -37,14 +38,19 @@ for q, iv in sorted(per.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])
     iv.sort()
     busy, cur_s, cur_e = 0, None, None
     gaps = []
-    for s, e, _ in iv:
+    gap_list = []
+    last_name = None
+    for s, e, nm in iv:
         if cur_e is None or s > cur_e:
             if cur_e is not None:
                 busy += cur_e - cur_s
                 gaps.append(s - cur_e)
+                gap_list.append((s - cur_e, last_name, nm, cur_e - t0))
             cur_s, cur_e = s, e
+            last_name = nm
         else:
-            cur_e = max(cur_e, e)
+            if e > cur_e:
+                cur_e, last_name = e, nm
     busy += (cur_e - cur_s) if cur_e is not None else 0
     agg = collections.Counter()
     cnt = collections.Counter()
@@ -61,4 +67,8 @@ for q, iv in sorted(per.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])
                                       'n_over_20us_per_step': round(sum(1 for g in gaps if g > 20000) / steps, 1)},
                              'top': [{'kernel': n, 'ms_per_step': round(t / steps / 1e6, 3), 'launches_per_step': round(cnt[n] / steps, 1),
                                       'avg_us': round(t / cnt[n] / 1e3, 1)} for n, t in agg.most_common(a.top)]}
+    if a.gaps:
+        gap_list.sort(reverse=True)
+        out['queues'][str(q)]['largest_gaps'] = [{'us': round(g / 1e3, 1), 'after': b[:60], 'before': n[:60],
+                                                  'at_ms_into_window': round(at / 1e6, 2)} for g, b, n, at in gap_list[:a.gaps * steps]]
 print(json.dumps(out, indent=1))
