@@ -115,7 +115,14 @@ def forward_flops(eng, images, captions, words, lens):
     bc = getattr(eng.model.txt_enc, 'config', None)
     if bc is not None:                                                               # BERT attention: QK^T and PV
         L = int(captions.shape[1])
-        total['text'] += bc.num_hidden_layers * 4 * N * L * L * bc.hidden_size
+        host = getattr(lens, '_cfl_host_lens', None)
+        from creamfl_amd.networks.models import pcme as _pcme
+        if host and not _pcme._NO_BERT_PACK[0] and max(host) <= 32 and images.is_cuda:
+            # packed tower: a sequence attends over its own tokens only (the last, [CLS]-only layer over the padded frame: L keys)
+            pairs = (bc.num_hidden_layers - 1) * sum(n * n for n in host) + N * L
+            total['text'] += 4 * pairs * bc.hidden_size
+        else:
+            total['text'] += bc.num_hidden_layers * 4 * N * L * L * bc.hidden_size
     torch.cuda.synchronize()
     total['total'] = total['image'] + total['text']
     return total
@@ -395,6 +402,14 @@ def main():
     def step():
         return eng.train_step(images, captions, words, lens)
 
+    # what the text tower runs on: the batch's real tokens (packed, when the lengths are known on the host) or the padded frame
+    from creamfl_amd.networks.models import pcme as _pcme
+    _host_lens = getattr(lens, '_cfl_host_lens', None)
+    text_tokens = {'padded_frame': int(captions.shape[0] * captions.shape[1]),
+                   'real': int(sum(_host_lens)) if _host_lens else None,
+                   'tower_runs_on': 'real tokens (packed, BertModel.pack_plan)' if (_host_lens and not _pcme._NO_BERT_PACK[0]
+                                                                                   and max(_host_lens) <= 32) else 'padded frame'}
+
     def fence():
         if use_dp:
             torch.distributed.barrier()
@@ -587,7 +602,7 @@ def main():
             'config': {'workload': 'server contrastive step: ResNet101+BERT-base PCME, d=%d, per-GPU batch %d, '
                                    'MCSoftContrastiveLoss + clip + AdamP (BASELINE.json configs[%d])' % (args.dim, args.batch, args.config),
                        'global_batch': args.batch * world, 'cnn': args.cnn, 'text': 'bert-base',
-                       'encoder_precision': args.dtype, 'head_loss_precision': 'f32',
+                       'encoder_precision': args.dtype, 'head_loss_precision': 'f32', 'text_tokens': text_tokens,
                        'parallelism': 'dp%d' % world, 'loss': round(loss_val, 4)},
             'ranks': {'world_size': torch.distributed.get_world_size() if use_dp else 1,
                       'backend': ('rccl' if args.backend == 'nccl' else 'gloo (SMOKE MODE: not a scaling measurement)') if use_dp

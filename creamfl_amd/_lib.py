@@ -59,6 +59,8 @@ SIGNATURES = {
     'cfl_attn_small_fwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong, _P]),
     'cfl_attn_small_bwd': (c_int, [_P, _P, _P, c_longlong, c_longlong, _P, c_int, c_int, c_int, c_int, _P, c_longlong, c_longlong,
                                    _P, _P, _P, c_longlong, c_longlong, _P]),
+    'cfl_attn_small_fwd_varlen': (c_int, [_P, _P, _P, c_longlong, _P, c_int, c_int, c_int, _P, c_longlong, _P]),
+    'cfl_attn_small_bwd_varlen': (c_int, [_P, _P, _P, c_longlong, _P, c_int, c_int, c_int, _P, c_longlong, _P, _P, _P, c_longlong, _P]),
     'cfl_stem_s2d': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     'cfl_maxpool3s2_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'cfl_maxpool3s2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),

@@ -112,7 +112,28 @@ struct AttnArgs {
     long long ldg, bsg;
     int B, L, heads;
     float scale;
+    const int* cu;                   // packed ("varlen") form: sequence b owns rows cu[b] .. cu[b + 1] - 1 of [T][...] tensors (bs unused,
+                                     // no mask: every row of a sequence is a token); NULL = the padded [B][L] form
 };
+
+// first row, row count and valid-key bits of one (batch) problem
+struct SeqRows { long long row0; int len; unsigned bits; };
+
+__device__ __forceinline__ u32 key_bits(const AttnArgs& a, int b);
+__device__ __forceinline__ SeqRows seq_rows(const AttnArgs& a, int b) {
+    SeqRows s;
+    if (a.cu) {
+        const int r0 = a.cu[b], r1 = a.cu[b + 1];
+        s.row0 = r0;
+        s.len = min(r1 - r0, 32);
+        s.bits = s.len >= 32 ? 0xffffffffu : ((1u << s.len) - 1u);
+    } else {
+        s.row0 = -1;
+        s.len = a.L;
+        s.bits = key_bits(a, b);
+    }
+    return s;
+}
 
 // valid-key bits of one batch row (bit j set = key j takes part)
 __device__ __forceinline__ u32 key_bits(const AttnArgs& a, int b) {
@@ -154,14 +175,15 @@ __global__ __launch_bounds__(256) void cfl_attn_small_fwd_kernel(AttnArgs a) {
     if (bh >= a.B * a.heads) return;
     const int b = bh / a.heads, h = bh % a.heads;
     u16 *Q = lds[wave], *K = Q + TILE, *V = K + TILE;
-    const long long off = (long long)b * a.bs + h * 64;
-    stage_tile(a.q + off, a.ld, a.L, Q, lane);
-    stage_tile(a.k + off, a.ld, a.L, K, lane);
-    stage_tile(a.v + off, a.ld, a.L, V, lane);
+    const SeqRows sr = seq_rows(a, b);
+    const long long off = (a.cu ? sr.row0 * a.ld : (long long)b * a.bs) + h * 64;
+    stage_tile(a.q + off, a.ld, sr.len, Q, lane);
+    stage_tile(a.k + off, a.ld, sr.len, K, lane);
+    stage_tile(a.v + off, a.ld, sr.len, V, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const u32 bits = key_bits(a, b);
+    const u32 bits = sr.bits;
     f32x16 acc;
     mma_rows(K, Q, acc, lane);                       // S^T[key][query]
     float p[16], m, inv_l;
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(256) void cfl_attn_small_fwd_kernel(AttnArgs a) {
     softmax_t(p, bits, a.scale, lane, m, inv_l);
     f32x16 out[2];
     mma_apply(p, V, out, lane);                      // O[query][d]
-    store_rows(out, a.o + (long long)b * a.bso + h * 64, a.ldo, a.L, lane);
+    store_rows(out, a.o + (a.cu ? sr.row0 * a.ldo : (long long)b * a.bso) + h * 64, a.ldo, sr.len, lane);
 }
 
 // two waves per workgroup: 4 staged tiles per wave (Q, K, V, dO) = 36 KB of LDS per workgroup
@@ -182,16 +204,18 @@ __global__ __launch_bounds__(128) void cfl_attn_small_bwd_kernel(AttnArgs a) {
     if (bh >= a.B * a.heads) return;
     const int b = bh / a.heads, h = bh % a.heads;
     u16 *Q = lds[wave], *K = Q + TILE, *V = K + TILE, *G = V + TILE;
-    const long long off = (long long)b * a.bs + h * 64;
-    stage_tile(a.q + off, a.ld, a.L, Q, lane);
-    stage_tile(a.k + off, a.ld, a.L, K, lane);
-    stage_tile(a.v + off, a.ld, a.L, V, lane);
-    stage_tile(a.dout + (long long)b * a.bso + h * 64, a.ldo, a.L, G, lane);
+    const SeqRows sr = seq_rows(a, b);
+    const int L = sr.len;
+    const long long off = (a.cu ? sr.row0 * a.ld : (long long)b * a.bs) + h * 64;
+    stage_tile(a.q + off, a.ld, L, Q, lane);
+    stage_tile(a.k + off, a.ld, L, K, lane);
+    stage_tile(a.v + off, a.ld, L, V, lane);
+    stage_tile(a.dout + (a.cu ? sr.row0 * a.ldo : (long long)b * a.bso) + h * 64, a.ldo, L, G, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const u32 bits = key_bits(a, b);
-    const long long goff = (long long)b * a.bsg + h * 64;
+    const u32 bits = sr.bits;
+    const long long goff = (a.cu ? sr.row0 * a.ldg : (long long)b * a.bsg) + h * 64;
     f32x16 acc, out[2];
     float p[16], w[16], m, inv_l;
     // ---- lanes = queries: P^T, dP^T -> delta, dS^T -> dQ
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(128) void cfl_attn_small_bwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) w[r] = p[r] * (acc[r] - delta) * a.scale;
     mma_apply(w, K, out, lane);                      // dQ[query][d] = sum_key dS[query][key] K[key][d]
-    store_rows(out, a.dq + goff, a.ldg, a.L, lane);
+    store_rows(out, a.dq + goff, a.ldg, L, lane);
     if (lane < 32) { stats[wave][0][lane] = m; stats[wave][1][lane] = inv_l; stats[wave][2][lane] = delta; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -226,9 +250,9 @@ __global__ __launch_bounds__(128) void cfl_attn_small_bwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) w[r] = p[r] * (acc[r] - stats[wave][2][acc_r(r, lane)]) * a.scale;
     // A operand rows must be keys: the accumulators hold [query regs][key lane], i.e. already "row = lane's key"
     mma_apply(p, G, out, lane);                      // dV[key][d] = sum_query P[query][key] dO[query][d]
-    store_rows(out, a.dv + goff, a.ldg, a.L, lane);
+    store_rows(out, a.dv + goff, a.ldg, L, lane);
     mma_apply(w, Q, out, lane);                      // dK[key][d] = sum_query dS[query][key] Q[query][d]
-    store_rows(out, a.dk + goff, a.ldg, a.L, lane);
+    store_rows(out, a.dk + goff, a.ldg, L, lane);
 }
 
 }  // namespace
@@ -259,6 +283,36 @@ int cfl_attn_small_bwd(const void* q, const void* k, const void* v, long long ld
     a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.ld = ld; a.bs = bs; a.mask = mask;
     a.dout = (const u16*)dout; a.ldo = ldo; a.bso = bso; a.dq = (u16*)dq; a.dk = (u16*)dk; a.dv = (u16*)dv; a.ldg = ldg; a.bsg = bsg;
     a.B = B; a.L = L; a.heads = heads; a.scale = 0.125f;
+    CFL_LAUNCH(K_ATTN_SMALL, cfl_attn_small_bwd_kernel, dim3(cfl_cdiv(B * heads, 2)), dim3(128), 0, stream, a);
+    return 0;
+}
+
+// ---- packed ("varlen") form, round 6: q / k / v / o / gradients are [T][...] with T = the batch's token count; sequence b owns rows
+// cu[b] .. cu[b + 1] - 1 (cu: B + 1 ints on the device, cu[0] = 0, every sequence <= 32 tokens).  Same kernels, same arithmetic per
+// sequence as the padded form with its key-padding mask -- the padded rows (a third of a COCO batch) are simply not there.
+int cfl_attn_small_fwd_varlen(const void* q, const void* k, const void* v, long long ld, const int* cu_seqlens, int B, int heads,
+                              int head_dim, void* o, long long ldo, void* stream_) {
+    if (!q || !k || !v || !o || !cu_seqlens || B <= 0 || heads <= 0) return CFL_EINVAL;
+    if (head_dim != 64 || ld % 8 != 0 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    AttnArgs a{};
+    a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.ld = ld; a.cu = cu_seqlens;
+    a.o = (u16*)o; a.ldo = ldo; a.B = B; a.L = 32; a.heads = heads; a.scale = 0.125f;
+    CFL_LAUNCH(K_ATTN_SMALL, cfl_attn_small_fwd_kernel, dim3(cfl_cdiv(B * heads, 4)), dim3(256), 0, stream, a);
+    return 0;
+}
+
+int cfl_attn_small_bwd_varlen(const void* q, const void* k, const void* v, long long ld, const int* cu_seqlens, int B, int heads,
+                              int head_dim, const void* dout, long long ldo, void* dq, void* dk, void* dv, long long ldg,
+                              void* stream_) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || !cu_seqlens || B <= 0 || heads <= 0) return CFL_EINVAL;
+    if (head_dim != 64 || ld % 8 != 0 || ldo % 8 != 0 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) & 15))
+        return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    AttnArgs a{};
+    a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.ld = ld; a.cu = cu_seqlens;
+    a.dout = (const u16*)dout; a.ldo = ldo; a.dq = (u16*)dq; a.dk = (u16*)dk; a.dv = (u16*)dv; a.ldg = ldg;
+    a.B = B; a.L = 32; a.heads = heads; a.scale = 0.125f;
     CFL_LAUNCH(K_ATTN_SMALL, cfl_attn_small_bwd_kernel, dim3(cfl_cdiv(B * heads, 2)), dim3(128), 0, stream, a);
     return 0;
 }

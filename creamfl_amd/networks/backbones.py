@@ -351,6 +351,20 @@ def _bert_fusable(x, weight, max_out=1 << 30):
     return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
 
 
+class PackPlan:
+    """Index tensors of a packed text-tower run (BertModel.pack_plan): tok_idx [T] flat positions b L + t of the real tokens in the
+    padded [B, L] frame, pos_ids [T] their positions t, cu [B + 1] int32 row offsets of the sequences, cls_rows [B] = cu[:-1]."""
+    __slots__ = ('B', 'L', 'T', 'tok_idx', 'pos_ids', 'cu', 'cls_rows')
+
+
+def _bert_fusable_model(m):
+    """every layer of this BertModel takes the fused bf16 kernels (bf16 weights, or bf16 autocast): the packed run's condition"""
+    w = m.encoder.layer[0].attention.self.query.weight
+    if not w.is_cuda or w.shape[0] % 8 or (w.shape[0] // m.config.num_attention_heads) != 64 or _NO_ATTN_SMALL:
+        return False
+    return w.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+
+
 class _BertEmbeddings(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -360,7 +374,10 @@ class _BertEmbeddings(nn.Module):
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
         self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
-    def forward(self, input_ids, token_type_ids=None):
+    def forward(self, input_ids, token_type_ids=None, pack=None):
+        if pack is not None:            # packed tokens [T]: the real tokens of the batch only, each with its own position
+            x = self.word_embeddings(input_ids.reshape(-1).index_select(0, pack.tok_idx)) + self.position_embeddings(pack.pos_ids)
+            return self.dropout(self.LayerNorm(x + self.token_type_embeddings.weight[0]))
         L = input_ids.shape[1]
         pos = torch.arange(L, device=input_ids.device)
         x = self.word_embeddings(input_ids) + self.position_embeddings(pos)[None]
@@ -376,7 +393,9 @@ class _SelfAttention(nn.Module):
         self.key = nn.Linear(c.hidden_size, c.hidden_size)
         self.value = nn.Linear(c.hidden_size, c.hidden_size)
 
-    def forward(self, x, mask, cls_only=False):
+    def forward(self, x, mask, cls_only=False, pack=None):
+        if pack is not None:
+            return self._forward_packed(x, mask, cls_only, pack)
         B, L, H = x.shape
         def split(t):
             return t.view(B, t.shape[1], self.h, H // self.h).transpose(1, 2)
@@ -398,6 +417,26 @@ class _SelfAttention(nn.Module):
             q, k, v = self.query(xq), self.key(x), self.value(x)
         o = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=mask)
         return o.transpose(1, 2).reshape(B, xq.shape[1], H)
+
+
+    def _forward_packed(self, x, mask, cls_only, pack):
+        """x: [T, H], the batch's real tokens (BertModel.pack_plan).  Full layers: the fused [3H, H] projection + the varlen form of
+        csrc/attn_small.hip.  The last layer of a `cls_only` call: the [CLS] rows query keys / values scattered back into the padded
+        [B, L, H] frame -- B queries, not worth a kernel of its own."""
+        from .. import ops
+        T, H = x.shape
+        if not cls_only:
+            w = torch.cat([self.query.weight, self.key.weight, self.value.weight], 0)
+            b = torch.cat([self.query.bias, self.key.bias, self.value.bias], 0)
+            return ops.bert_attention_varlen(F.linear(x, w, b), pack.cu, self.h)
+        B, L = pack.B, pack.L
+        q = self.query(x.index_select(0, pack.cls_rows))
+        k, v = self.key(x), self.value(x)
+
+        def padded(t):
+            return t.new_zeros(B * L, H).index_copy(0, pack.tok_idx, t).view(B, L, self.h, H // self.h).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q.view(B, 1, self.h, H // self.h).transpose(1, 2), padded(k), padded(v), attn_mask=mask)
+        return o.transpose(1, 2).reshape(B, H)
 
 
 class _SelfOutput(nn.Module):
@@ -425,7 +464,9 @@ class _Attention(nn.Module):
         self.self = _SelfAttention(c)
         self.output = _SelfOutput(c, c.hidden_size)
 
-    def forward(self, x, res, mask, cls_only=False):
+    def forward(self, x, res, mask, cls_only=False, pack=None):
+        if pack is not None:
+            return self.output(self.self(x, mask, cls_only, pack), res.index_select(0, pack.cls_rows) if cls_only else res)
         return self.output(self.self(x, mask, cls_only), res[:, :1] if cls_only else res)
 
 
@@ -448,8 +489,8 @@ class _BertLayer(nn.Module):
         self.intermediate = _Intermediate(c)
         self.output = _SelfOutput(c, c.intermediate_size)
 
-    def forward(self, x, res, mask, cls_only=False):
-        x, res = self.attention(x, res, mask, cls_only)
+    def forward(self, x, res, mask, cls_only=False, pack=None):
+        x, res = self.attention(x, res, mask, cls_only, pack)
         return self.output(self.intermediate(x), res)
 
 
@@ -458,11 +499,11 @@ class _BertEncoder(nn.Module):
         super().__init__()
         self.layer = nn.ModuleList([_BertLayer(c) for _ in range(c.num_hidden_layers)])
 
-    def forward(self, x, mask, cls_only=False):
+    def forward(self, x, mask, cls_only=False, pack=None):
         last = len(self.layer) - 1
         res = x
         for i, l in enumerate(self.layer):
-            x, res = l(x, res, mask, cls_only and i == last)
+            x, res = l(x, res, mask, cls_only and i == last, pack)
         return x
 
 
@@ -492,12 +533,46 @@ class BertModel(nn.Module):
     def from_pretrained(cls, name):
         return cls(name)
 
-    def forward(self, input_ids, attention_mask=None, token_type_ids=None, cls_only=False, **_):
+    @staticmethod
+    def pack_plan(host_lengths, L, device):
+        """The index tensors of a PACKED run from the captions' lengths as HOST integers (no device synchronisation: the loaders
+        know the lengths on the host, src/datasets/_dataloader.py:49-64 builds `cap_lengths` from python lists).  None when a
+        sequence does not fit the varlen attention kernel (> 32 tokens) or the lengths do not fit the padded frame."""
+        lens = [int(v) for v in host_lengths]
+        if not lens or min(lens) < 1 or max(lens) > min(L, 32):
+            return None
+        B = len(lens)
+        cu = [0]
+        for n in lens:
+            cu.append(cu[-1] + n)
+        tok = torch.tensor([b * L + t for b, n in enumerate(lens) for t in range(n)], dtype=torch.int64)
+        plan = PackPlan()
+        plan.B, plan.L, plan.T = B, L, cu[-1]
+        plan.tok_idx = tok.to(device)
+        plan.pos_ids = (tok % L).to(device)
+        plan.cu = torch.tensor(cu, dtype=torch.int32).to(device)
+        plan.cls_rows = torch.tensor(cu[:-1], dtype=torch.int64).to(device)
+        return plan
+
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, cls_only=False, pack=None, **_):
         """`cls_only=True`: the last layer is evaluated for the [CLS] position only and `last_hidden_state` is
         [B, 1, H] -- identical values and gradients for everything PCME consumes (it reads [:, 0, :] only,
-        src/networks/models/pcme.py:44), 1/12 less work in the tower."""
+        src/networks/models/pcme.py:44), 1/12 less work in the tower.
+        `pack` (a `pack_plan` of this batch; round 6): the tower runs on the batch's REAL tokens only, [T, H] -- the padded positions
+        of the reference's [B, L] frame (a third of a COCO-shaped batch) are masked out of every attention and never read by the
+        head, so nothing that is consumed changes (tests/test_gpu_bert.py) and a third of the tower's work goes away.  Taken on
+        the fused bf16 path only; without it, or with token types, the padded frame runs."""
         mask = None
         if attention_mask is not None:
             mask = attention_mask[:, None, None, :].to(torch.bool)
-        x = self.embeddings(input_ids, token_type_ids)
-        return {'last_hidden_state': self.encoder(x, mask, cls_only)}
+        if pack is not None and (token_type_ids is not None or attention_mask is None or not input_ids.is_cuda
+                                 or not _bert_fusable_model(self) or tuple(input_ids.shape) != (pack.B, pack.L)):
+            pack = None
+        x = self.embeddings(input_ids, token_type_ids, pack)
+        if pack is not None and not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled('cuda')):
+            raise RuntimeError('packed BERT run outside the bf16 path')
+        h = self.encoder(x, mask, cls_only, pack)
+        if pack is not None:
+            h = h[:, None, :] if cls_only else h.new_zeros(pack.B * pack.L, h.shape[-1]).index_copy(0, pack.tok_idx, h).view(
+                pack.B, pack.L, -1)
+        return {'last_hidden_state': h}

@@ -19,6 +19,7 @@ from .image_encoder import EncoderImage
 
 
 _NO_TWO_STREAM = bool(os.environ.get('CFL_NO_TWO_STREAM'))         # A/B switch for measurements
+_NO_BERT_PACK = [bool(os.environ.get('CFL_NO_BERT_PACK'))]     # A/B: the BERT tower on the padded [B, L] frame (round 5's form)
 
 
 class PCME(nn.Module):
@@ -53,7 +54,33 @@ class PCME(nn.Module):
                           torch.where(sentences == 1, torch.full_like(sentences, 101),
                                       torch.where(sentences == 2, torch.full_like(sentences, 102), sentences + 1000)))
         ids = ids.clamp_max(self.txt_enc.config.vocab_size - 1)
-        return {'input_ids': ids, 'attention_mask': mask}
+        out = {'input_ids': ids, 'attention_mask': mask}
+        plan = self._pack_plan(lengths, L, sentences.device)
+        if plan is not None:
+            out['pack'] = plan
+        return out
+
+    def _pack_plan(self, lengths, L, device):
+        """The packed-run plan of this batch (BertModel.pack_plan) when the lengths are known ON THE HOST -- a CPU tensor / list, or a
+        device tensor that carries its host copy (`_cfl_host_lens`: utils/synthetic.coco_batch and utils/prefetch.DevicePrefetcher
+        attach it); a bare device tensor gets the padded frame (reading it would stall the step's issue thread on the GPU).
+        The plan of the last batch is kept: a resident batch (bench.py) builds it once.  CFL_NO_BERT_PACK=1 switches packing off."""
+        if _NO_BERT_PACK[0] or not isinstance(self.txt_enc, BertModel) or torch.device(device).type != 'cuda':
+            return None
+        host = getattr(lengths, '_cfl_host_lens', None)
+        if host is None:
+            if torch.is_tensor(lengths):
+                if lengths.is_cuda:
+                    return None
+                host = tuple(lengths.tolist())
+            else:
+                host = tuple(int(v) for v in lengths)
+        c = getattr(self, '_pack_cache', None)
+        if c is not None and (c[0] is host or c[0] == host) and c[1] == L and c[2] == device:
+            return c[3]
+        plan = BertModel.pack_plan(host, L, device)
+        self._pack_cache = (host, L, device, plan)
+        return plan
 
     def _text_tower(self, sentences, captions_word, lengths):
         if self.config.not_bert:

@@ -1990,6 +1990,51 @@ class _AttnSmallFn(torch.autograd.Function):
         return dqkv, None, None
 
 
+class _AttnSmallVarlenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, cu, heads):
+        lib = _lib.load()
+        T, H3 = qkv.shape
+        H = H3 // 3
+        B = cu.numel() - 1
+        o = torch.empty(T, H, dtype=torch.bfloat16, device=qkv.device)
+        base = qkv.data_ptr()
+        _lib.check(lib.cfl_attn_small_fwd_varlen(ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * H), ctypes.c_void_p(base + 4 * H),
+                                                 H3, _ptr(cu), B, heads, H // heads, _ptr(o), H, _stream(qkv)),
+                   'cfl_attn_small_fwd_varlen')
+        ctx.save_for_backward(qkv, cu)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _lib.load()
+        qkv, cu = ctx.saved_tensors
+        T, H3 = qkv.shape
+        H = H3 // 3
+        do = _bf16c(do, 'do')
+        dqkv = torch.empty_like(qkv)              # every row belongs to a sequence: fully written
+        base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+        _lib.check(lib.cfl_attn_small_bwd_varlen(ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * H), ctypes.c_void_p(base + 4 * H),
+                                                 H3, _ptr(cu), cu.numel() - 1, ctx.heads, H // ctx.heads, _ptr(do), H,
+                                                 ctypes.c_void_p(gbase), ctypes.c_void_p(gbase + 2 * H),
+                                                 ctypes.c_void_p(gbase + 4 * H), H3, _stream(qkv)), 'cfl_attn_small_bwd_varlen')
+        return dqkv, None, None
+
+
+def bert_attention_varlen(qkv, cu_seqlens, heads):
+    """The same attention on PACKED tokens: qkv [T, 3H] (Q | K | V along the last axis), sequence b = rows cu_seqlens[b] ..
+    cu_seqlens[b + 1] - 1 (int32 [B + 1] on the device, every sequence <= 32 tokens, T = cu_seqlens[-1]: the caller's promise --
+    the plan is built on the host, BertModel.pack_plan).  -> [T, H]."""
+    qkv = _bf16c(qkv, 'qkv')
+    T, H3 = qkv.shape
+    if H3 % 3 or (H3 // 3) % heads or (H3 // 3) // heads != 64:
+        raise _lib.CreamflHipError(f'bert_attention_varlen: unsupported shape {tuple(qkv.shape)} with {heads} heads')
+    if cu_seqlens.dtype != torch.int32 or cu_seqlens.device != qkv.device or not cu_seqlens.is_contiguous():
+        raise _lib.CreamflHipError('bert_attention_varlen: cu_seqlens must be a contiguous int32 tensor on the device of qkv')
+    return _AttnSmallVarlenFn.apply(qkv, cu_seqlens, int(heads))
+
+
 def bert_attention_supported(L, head_dim):
     return L <= 32 and head_dim == 64
 

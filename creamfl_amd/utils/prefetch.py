@@ -57,7 +57,14 @@ class DevicePrefetcher:
     def _stage(self, batch, stream, slot=0):
         out, moved, used = [], False, []
         with torch.cuda.stream(stream):
-            for item in batch:
+            for pos, item in enumerate(batch):
+                host_lens = None
+                if pos == 3 and torch.is_tensor(item) and item.dim() == 1 and not item.is_floating_point():
+                    # caption_lens of the batch-tuple contract (src/datasets/_dataloader.py:49-64): keep the host's copy with the
+                    # device tensor -- the packed text tower plans on it without reading the device (PCME._pack_plan)
+                    host_lens = getattr(item, '_cfl_host_lens', None)
+                    if host_lens is None and not item.is_cuda:
+                        host_lens = tuple(item.tolist())
                 if torch.is_tensor(item) and not item.is_cuda:
                     if self.pin and not item.is_pinned() and item.numel() >= 4096:
                         ent = self._pinned_like(item, slot)
@@ -68,6 +75,8 @@ class DevicePrefetcher:
                         src = item
                     item = src.to(self.device, non_blocking=True)    # (a loader's own pinned tensors: the host allocator keeps them alive)
                     moved = True
+                if host_lens is not None:
+                    item._cfl_host_lens = host_lens
                 out.append(item)
         ev = None
         if moved:

@@ -25,7 +25,9 @@ def coco_batch(batch, device='cpu', seed=1234, bert=True, vocab=11755, min_len=8
     index = list(range(index0, index0 + batch))
     ann_ids = list(index)
     image_ids = [i // captions_per_image for i in index]
-    return (images.to(device), captions.to(device), None, lens.to(device), ann_ids, image_ids, index)
+    lens_dev = lens.to(device)
+    lens_dev._cfl_host_lens = tuple(lens.tolist())        # the lengths as the loader knows them, on the host (PCME._pack_plan)
+    return (images.to(device), captions.to(device), None, lens_dev, ann_ids, image_ids, index)
 
 
 class _Dataset:

@@ -196,6 +196,15 @@ int cfl_attn_small_fwd(const void* q, const void* k, const void* v, long long ld
 int cfl_attn_small_bwd(const void* q, const void* k, const void* v, long long ld, long long bs, const unsigned char* mask,
                        int B, int L, int heads, int head_dim, const void* dout, long long ldo, long long bso, void* dq, void* dk,
                        void* dv, long long ldg, long long bsg, void* stream);
+/* The same on PACKED tokens (round 6): the reference pads every caption of a batch to the longest one and masks the padding
+ * (pcme.py:43-57 builds the attention mask from the lengths); here the text tower may run on the T = sum(lengths) real tokens only,
+ * [T][...] tensors, sequence b = rows cu_seqlens[b] .. cu_seqlens[b + 1] - 1 (B + 1 device ints, cu_seqlens[0] = 0, <= 32 tokens
+ * each).  Per sequence the arithmetic is the padded kernel's with its key-padding mask. */
+int cfl_attn_small_fwd_varlen(const void* q, const void* k, const void* v, long long ld, const int* cu_seqlens, int B, int heads,
+                              int head_dim, void* o, long long ldo, void* stream);
+int cfl_attn_small_bwd_varlen(const void* q, const void* k, const void* v, long long ld, const int* cu_seqlens, int B, int heads,
+                              int head_dim, const void* dout, long long ldo, void* dq, void* dk, void* dv, long long ldg,
+                              void* stream);
 
 /* ---- ResNet stem max pooling, 3x3 / stride 2 / pad 1, NHWC bf16 ---------------------------------------------------
  * torchvision ResNet.maxpool of the trunk built at src/networks/models/image_encoder.py:27-36 (and the client trunk,

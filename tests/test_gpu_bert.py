@@ -152,3 +152,104 @@ def test_attn_small_matches_sdpa(dev, b, l, heads, masked):
     np.testing.assert_allclose(o.detach().float().cpu().numpy(), ro.detach().cpu().numpy(), rtol=2e-2, atol=2e-2)
     sc = float(ref_in.grad.abs().max()) + 1e-6
     np.testing.assert_allclose(qkv.grad.float().cpu().numpy(), ref_in.grad.cpu().numpy(), rtol=3e-2, atol=2e-2 * sc)
+
+
+@pytest.mark.parametrize('b,l,heads', [(2, 24, 12), (256, 24, 12), (3, 32, 4), (5, 7, 2), (1, 1, 1)])
+def test_attn_small_varlen_equals_the_padded_kernel(dev, b, l, heads):
+    """The packed form of csrc/attn_small.hip (sequence b = rows cu[b] .. cu[b + 1] - 1 of [T, 3H]) against the padded kernel with its
+    key-padding mask on the same tokens: per sequence the arithmetic is the same, so outputs and all three gradients agree BIT FOR
+    BIT on every real token (the padded frame's masked rows have no counterpart)."""
+    from creamfl_amd import ops
+    from creamfl_amd.networks.backbones import BertModel
+    H = heads * 64
+    gen = torch.Generator().manual_seed(b * 100 + l)
+    lens = torch.randint(1, l + 1, (b,), generator=gen)
+    lens[0] = l
+    plan = BertModel.pack_plan(lens.tolist(), l, dev)
+    qkv_pad = (torch.randn(b, l, 3 * H, generator=gen) * 1.5).to(torch.bfloat16).to(dev)
+    w_pad = torch.randn(b, l, H, generator=gen).to(torch.bfloat16).to(dev)
+    mask = (torch.arange(l)[None] < lens[:, None]).to(dev)
+    qp = qkv_pad.clone().requires_grad_(True)
+    o_pad = ops.bert_attention(qp, mask, heads)
+    # the gradient of a masked query row is multiplied by nothing downstream in the tower; here it must be zero to compare
+    o_pad.backward(w_pad * mask[:, :, None])
+    qv = qkv_pad.reshape(b * l, 3 * H).index_select(0, plan.tok_idx).clone().requires_grad_(True)
+    assert qv.shape[0] == int(lens.sum()) == plan.T
+    o_var = ops.bert_attention_varlen(qv, plan.cu, heads)
+    o_var.backward(w_pad.reshape(b * l, H).index_select(0, plan.tok_idx))
+    assert torch.equal(o_var, o_pad.reshape(b * l, H).index_select(0, plan.tok_idx))
+    assert torch.equal(qv.grad, qp.grad.reshape(b * l, 3 * H).index_select(0, plan.tok_idx))
+
+
+def test_bert_packed_tower_equals_the_padded_tower(dev):
+    """BertModel on the batch's real tokens only (`pack`, round 6) against the reference's padded [B, L] frame with its attention
+    mask (src/networks/models/pcme.py:43-57): the [CLS] states PCME reads and every parameter gradient agree to the bf16 rounding of
+    GEMMs of another row count (the library picks other tiles for T rows than for B L rows); dropout off.  Also the full
+    `last_hidden_state` of a call without `cls_only`, on the real tokens."""
+    from creamfl_amd.networks import backbones
+    torch.manual_seed(0)
+    m = backbones.BertModel('bert-mini').to(dev).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    B, L = 16, 24
+    gen = torch.Generator().manual_seed(5)
+    lens = torch.randint(3, L + 1, (B,), generator=gen).sort(descending=True).values
+    lens[0] = L
+    ids = torch.randint(1, 1000, (B, L), generator=gen).to(dev)
+    mask = (torch.arange(L)[None] < lens[:, None]).to(dev)
+    ids = ids * mask                                     # 0-padded, as the loaders deliver
+    plan = backbones.BertModel.pack_plan(lens.tolist(), L, dev)
+    assert plan.T == int(lens.sum())
+    wout = torch.randn(B, 256, device=dev)
+
+    def run(pack, cls_only=True):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            h = m(ids, attention_mask=mask, cls_only=cls_only, pack=pack)['last_hidden_state']
+        out = h[:, 0].float()
+        (out * wout).sum().backward()
+        return h.detach().float(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+    h1, g1 = run(plan)
+    h0, g0 = run(None)
+    assert h1.shape == h0.shape == (B, 1, 256)
+    np.testing.assert_allclose(h1.cpu().numpy(), h0.cpu().numpy(), rtol=3e-2, atol=3e-2)
+    assert set(g1) == set(g0)
+    for n in g0:
+        if n.endswith('key.bias'):
+            continue                                     # analytically zero: rounding noise
+        a, b_ = g1[n].flatten(), g0[n].flatten()
+        cos = float(torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30))
+        sc = float(b_.abs().max()) + 1e-6
+        assert cos >= 0.995 and float((a - b_).abs().max()) <= 0.06 * sc + 1e-4, (n, cos, float((a - b_).abs().max()), sc)
+    hf1, _ = run(plan, cls_only=False)
+    hf0, _ = run(None, cls_only=False)
+    mk = mask[:, :, None].float()
+    np.testing.assert_allclose((hf1 * mk).cpu().numpy(), (hf0 * mk).cpu().numpy(), rtol=3e-2, atol=3e-2)
+    assert float((hf1 * (1 - mk)).abs().max()) == 0.0   # the packed run leaves the padded positions zero
+
+
+def test_pcme_takes_the_packed_tower_only_with_host_lengths(dev):
+    """PCME packs when the caption lengths are known on the host (a CPU tensor, or a device tensor carrying `_cfl_host_lens` as
+    utils/synthetic.coco_batch and the prefetcher attach it) and keeps the padded frame for a bare device tensor (reading it would
+    synchronise the step's issue thread); the two give the same caption embedding; the plan of a resident batch is built once."""
+    from creamfl_amd.networks.models import pcme as pcme_mod
+    from creamfl_amd.utils.config import default_config
+    from creamfl_amd.utils.synthetic import coco_batch
+    torch.manual_seed(0)
+    cfg = default_config(embed_dim=64, cnn_type='resnet18', not_bert=False)
+    cfg.model.bert_name = 'bert-mini'
+    model = pcme_mod.PCME({'<pad>': 0}, cfg.model, False).to(dev).eval()
+    b = coco_batch(8, dev, seed=3, img=64)
+    lens = b[3]
+    assert lens.is_cuda and lens._cfl_host_lens == tuple(lens.tolist())
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        packed = model._bert_inputs(b[1], None, lens)
+        assert 'pack' in packed and packed['pack'].T == int(lens.sum())
+        assert model._bert_inputs(b[1], None, lens)['pack'] is packed['pack']            # cached for the resident batch
+        bare = lens.clone()                                                                # a device tensor without a host copy
+        assert 'pack' not in model._bert_inputs(b[1], None, bare)
+        e1 = model._text_tower(b[1], None, lens)['embedding'].float()
+        e0 = model._text_tower(b[1], None, bare)['embedding'].float()
+    assert float((e1 - e0).abs().max()) <= 3e-2
+    assert 'pack' in model._bert_inputs(b[1], None, lens.cpu())                            # host tensor: no copy needed

@@ -714,7 +714,9 @@ def test_first_server_step_answers_from_the_find_db(dev):
         saved.update(ops._FDB['known'])
         ops._FDB['known'] = saved
     assert torch.isfinite(loss)
-    assert len(new) >= 40 and all(new.values()), [k for k, v in new.items() if not v]
+    # (37 library problems since round 6: the 3 x 3 / stride 1 and the 1 x 1 weight gradients up to 28 x 28 run on csrc/wgrad3x3.hip /
+    # wgrad1x1.hip and never reach MIOpen; 46 before)
+    assert len(new) >= 30 and all(new.values()), [k for k, v in new.items() if not v]
     assert dt < 30.0, dt
     assert torch.backends.cudnn.benchmark is True                    # the per-call switch leaves the process setting alone
 
@@ -743,7 +745,10 @@ def test_bench_forward_flops_counts_both_towers(dev):
     c = BERT_CONFIGS['bert-mini']
     H, I, layers = c['hidden_size'], c['intermediate_size'], c['num_hidden_layers']
     L = int(b[1].shape[1])
-    full = layers * (2 * N * L * (4 * H * H + 2 * H * I) + 4 * N * L * L * H) + 2 * N * H * 64
+    # round 6: the tower runs on the batch's real tokens (coco_batch hands the lengths over on the host): T of the N L positions
+    T = sum(b[3]._cfl_host_lens)
+    assert 0.4 * N * L < T < N * L
+    full = layers * (2 * T * (4 * H * H + 2 * H * I) + 4 * sum(n * n for n in b[3]._cfl_host_lens) * H) + 2 * N * H * 64
     assert 0.70 * full <= f['text'] <= 1.001 * full, (f, full)          # the last layer runs for the [CLS] row only
     assert f['text'] >= (layers - 1) / layers * 0.98 * full - 4 * N * L * L * H
     # ResNet-18 at 64 x 64: 1.814 GMAC at 224 x 224 scales with the pixel count (fc + PIE on top)

@@ -12,6 +12,7 @@ knobs:  bres   the gradient-join data-gradient GEMM on the B-resident streaming 
         w1wgsN   that kernel aiming at N workgroups vs its default of 128
         w1hwN    that kernel for maps up to N x N only vs for every map (product default: 28)
         flushN   streams.FLUSH_POLICY = N vs 0 (when the queued weight gradients go to their stream)
+        bertpack the BERT tower on the batch's real tokens only (default) vs on the reference's padded [B, L] frame
         wgrad3   the 3 x 3 weight gradients of layers 3 / 4 on csrc/wgrad3x3.hip (default) vs MIOpen's igemm_wrw
         w3splitN that kernel on N image ranges (N / 32 of the chip for the layer3 shape) vs its default of 256 workgroups
         wgrad    BOUND, not a product switch: every trunk weight gradient computed (default) vs replaced by a zero fill -- what the
@@ -98,6 +99,9 @@ def main():
             ops.WGRAD3[0] = bool(on)
         elif args.knob.startswith('w3split'):
             lib.cfl_conv3x3_wgrad_splits(int(args.knob[7:] or 16) if on else 0)
+        elif args.knob == 'bertpack':     # the BERT tower on the batch's real tokens (default) vs on the padded [B, L] frame
+            from creamfl_amd.networks.models import pcme as _pc
+            _pc._NO_BERT_PACK[0] = not on
         elif args.knob == 'join':
             from creamfl_amd import ops
             ops._NO_JOIN_FUSE = not on
