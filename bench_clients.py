@@ -470,7 +470,7 @@ def run(a, world, rank, dev, use_dist, json_out):
                 del mini
                 torch.cuda.empty_cache()
             # the federation's FIRST round starts on an empty allocator and a fresh server engine (its first steps allocate their
-            # gigabytes: 44 ms per public batch where the same loop runs 28-35 ms warm, tools/server_phase_probe.py); every later round
+            # gigabytes: 44 ms per public batch where the same loop runs 28-35 ms warm, docs/history/tools/server_phase_probe.py); every later round
             # of a real run is the steady state, so the SECOND round is the one reported phase by phase, the first one beside it
             ph0, _, _, _ = timed_round(algo, use_dist, 0)
             ph, counts, comm, sampled = timed_round(algo, use_dist, 1)

@@ -81,7 +81,7 @@ class MMClientTrainer(EngineBase):
         `loss` / `output` must be dead before the contrast step is captured -- a live loss keeps its autograd graph's AccumulateGrad
         nodes alive, those are bound to the stream they were made on (here the default stream), the captured backward would make
         THAT stream wait for the capturing one, and the HIP runtime faults in hipStreamEndCapture when the legacy default stream
-        is pulled into a capture (tools/mm_graph_probe.py)."""
+        is pulled into a capture (docs/history/tools/mm_graph_probe.py)."""
         for idx, (images, captions, captions_word, caption_lens, _, _, index) in enumerate(self.train_loader or []):
             images, captions, caption_lens = images.to(self.device), captions.to(self.device), caption_lens.to(self.device)
             output = self._forward(self.model, images, captions, captions_word, caption_lens)

@@ -12,7 +12,7 @@ synchronisation and no data-dependent Python control flow inside, outputs = tens
 valid until the next call).  A call whose input shapes differ from the captured ones (the ragged last batch of an epoch) runs
 eagerly.
 
-One more condition, found the hard way (tools/mm_graph_probe.py): when the capture happens, NO loss of an earlier eager step on the
+One more condition, found the hard way (docs/history/tools/mm_graph_probe.py): when the capture happens, NO loss of an earlier eager step on the
 legacy default stream may still be alive.  A live loss keeps its autograd graph's AccumulateGrad nodes alive; a node belongs to the
 stream it was made on; the captured backward makes that stream wait for the capturing one -- and the HIP runtime does not turn the
 default stream's event record into a capture node, so the fork is never joined and hipStreamEndCapture faults (a segmentation

@@ -586,7 +586,7 @@ class _GruCell0Fn(torch.autograd.Function):
 class _EmbeddingFn(torch.autograd.Function):
     """nn.Embedding's lookup whose backward is, INSIDE a HIP-graph capture, ONE index_add_ (atomic adds into the zeroed table).
     torch's dense embedding backward switches, above 3072 indices, to a sort / unique-by-key path: ~10 launches and 70-180 us of
-    host time per call where this one takes 10 (tools/embed_sync_probe.py; neither waits for the device), and on this stack that
+    host time per call where this one takes 10 (docs/history/tools/embed_sync_probe.py; neither waits for the device), and on this stack that
     path does not survive a HIP-graph capture -- the replay of a text client's step padded to 128 x 32 = 4096 indices died with a
     memory fault (profiles/r5_embed_backward_probe.json), the same step with this backward replays.
     The atomic adds make the fp32 sum order-dependent, so the index_add_ form is used ONLY while a stream is capturing (or with

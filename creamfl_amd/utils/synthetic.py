@@ -66,8 +66,12 @@ def coco_batch_on_device(batch, device, seed=1234, vocab=11755, min_len=8, max_l
     device = torch.device(device)
     g = torch.Generator(device=device).manual_seed(seed)
     images = torch.randn(batch, 3, img, img, generator=g, device=device)
-    lens = torch.randint(min_len, max_len + 1, (batch,), generator=g, device=device).sort(descending=True).values
-    L = int(lens.max())
+    # the lengths are drawn on the HOST (a loader knows them there: src/datasets/_dataloader.py:49-64 builds cap_lengths from python
+    # lists) and travel with their device copy -- no device read for the frame width, and the packed text tower can plan on them
+    host_lens = torch.randint(min_len, max_len + 1, (batch,), generator=torch.Generator().manual_seed(seed)).sort(descending=True).values
+    L = int(host_lens.max())
+    lens = host_lens.to(device)
+    lens._cfl_host_lens = tuple(host_lens.tolist())
     captions = torch.randint(4, vocab, (batch, L), generator=g, device=device)
     pos = torch.arange(L, device=device)[None]
     captions[:, 0] = 1                                                     # <start>

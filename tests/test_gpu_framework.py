@@ -522,7 +522,7 @@ def test_bench_code_path_whole_model_fused_vs_unfused(dev):
       (a) ITSELF, run again from the same state: a race between the step's streams would show as run-to-run noise;
       (b) the same model with every CFL_NO_* knob off (library convolutions and data gradients, single stream);
       (c) fp32 trunks (one step).
-    What can be asked of such a comparison was MEASURED first (tools/guard_debug.py, profiles/r4_guard_calibration.txt): the
+    What can be asked of such a comparison was MEASURED first (docs/history/tools/guard_debug.py, profiles/r4_guard_calibration.txt): the
     library's bf16 weight-gradient / backward-data kernels are not run-to-run reproducible -- two identical UNFUSED runs agree
     per parameter only to cosine 0.68 in the low layers (two identical fused runs, whose data gradients are the deterministic
     hand-written GEMMs: 0.9965), and the trunk as a whole to ~0.8 -- so per-parameter cosine 0.999 is not a property even of the

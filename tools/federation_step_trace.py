@@ -1,5 +1,5 @@
 """Where do the 44 ms per public batch of the server's global-training phase go INSIDE a federation process (bench.py --config 2:
-35-45 ms) when a process holding only the server engine takes 27-28 ms (tools/server_graph_ab.py)?  Per-batch host timestamps of
+35-45 ms) when a process holding only the server engine takes 27-28 ms (docs/history/tools/server_graph_ab.py)?  Per-batch host timestamps of
 TrainerEngine.train_step inside MMFL.train (no synchronisation added; the phase's wall time by one synchronisation at its end),
 for two rounds of the bench's federation."""
 import argparse
