@@ -43,6 +43,7 @@ HBM_PEAK_GBPS = 8000.0
 
 
 def add_arguments(ap):
+    ap.add_argument('--client-conv-x3', type=int, default=0, help='the clients\' fp32 3x3 convolutions on csrc/conv3x3_x3.hip (flags.client_conv_x3)')
     ap.add_argument('--round-first', type=int, default=1, help='the federation round before the clients\' micro-benchmarks (a real run\'s order)')
     ap.add_argument('--pub', type=int, default=50000, help='config 2: public-set size M (banks, representations, con_w)')
     ap.add_argument('--client-batch', type=int, default=128, help='config 2: public-loader batch B of the contrast loops')
@@ -87,7 +88,7 @@ def reference_namespace(a, dev_index, M):
         cnn_type=a.server_cnn, bert_name=a.server_bert, image_size=a.image_size, test_pairs=5000 if M >= 5000 else max(100, M // 2),
         quiet=True, save_checkpoints=False, server_dp=0, rep_wire=a.rep_wire, client_graph=1,
         client_channels_last=int(a.client_layout == 'channels_last'), client_bf16=int(a.client_bf16),
-        server_graph=int(a.server_graph), mm_client_graph=int(a.mm_client_graph))
+        server_graph=int(a.server_graph), mm_client_graph=int(a.mm_client_graph), client_conv_x3=int(a.client_conv_x3))
 
 
 def build_federation(a, dev, M, mini=False):

@@ -96,6 +96,9 @@ SIGNATURES = {
     'cfl_conv1x1_wgrad_ws_bytes': (c_size_t, [c_longlong, c_int, c_int]),
     'cfl_conv1x1_wgrad': (c_int, [_P, _P, c_longlong, c_int, c_int, _P, _P, _P]),
     'cfl_conv1x1_wgrad_workgroups': (c_int, [c_int]),
+    'cfl_conv3x3_x3_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'cfl_conv3x3_x3_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'cfl_conv3x3_x3_rot_weight': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_conv3x3_wgrad_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_wgrad_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

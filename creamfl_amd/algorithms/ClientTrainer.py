@@ -123,6 +123,9 @@ class ClientTrainer:
         self._bf16 = bool(self.dset_name in IMAGE_SETS and is_cuda and int(flags.get(args, 'client_bf16')))
         if self._bf16:
             self._cl = True
+        if is_cuda and int(flags.get(args, 'client_conv_x3')):
+            from .. import ops
+            ops.X3CONV[0] = True                 # process-wide: every fp32 channels_last 3 x 3 / stride-1 convolution (flags.py)
 
     def _log(self, msg):
         if self.logger is not None:

@@ -57,6 +57,9 @@ class MMClientTrainer(EngineBase):
             elif int(flags.get(self.args, 'client_channels_last')) and MM_CHANNELS_LAST[0]:
                 self.model.to(memory_format=torch.channels_last)
                 self._cl = True
+            if int(flags.get(self.args, 'client_conv_x3')):
+                from .. import ops
+                ops.X3CONV[0] = True
 
     def _forward(self, model, images, captions, captions_word, caption_lens):
         if (getattr(self, '_cl', False) or self.autocast_dtype is not None) and images.is_cuda:

@@ -1,0 +1,199 @@
+// conv3x3_x3.hip -- 3 x 3 / stride 1 / padding 1 convolution of fp32 channels_last tensors at fp32-class accuracy on the bf16 matrix
+// pipe (the "3 x bf16 split" of tile_x3.h): forward, and -- the same kernel on the rotated, transposed weight -- data gradient.
+//
+//   y[n, h, w, co] = sum over (kh, kw, ci) of x[n, h + kh - 1, w + kw - 1, ci] * W[co, kh, kw, ci]                (zero padding)
+//
+// Where it sits: the BasicBlock convolutions of the CLIENTS' ResNet-18 (src/networks/resnet_client.py:33-66,102-201), which the
+// reference runs in fp32 (ClientTrainer.py has no mixed precision) on cuDNN.  On MI355X the library's fp32 implicit-GEMM / Winograd
+// kernels are 68 % of the three client kinds' kernel time and ~85 % of an image client's contrast step (profiles/
+// r5_client_step_kernel_stats.csv) at 45-100 TFLOP/s: the fp32 matrix rate of the chip is 157 TFLOP/s, the bf16 rate 2 500.  Every
+// fp32 operand element is split x = hi + lo (two bf16) while it is staged and each product runs as three bf16 MFMAs (hi.hi + lo.hi +
+// hi.lo; the dropped term is 2^-16 relative): products to ~1e-6 relative, i.e. MORE accurate than the library's Winograd path
+// (~1e-3 of scale), at a roof of 833 TFLOP/s of fp32-equivalent work.
+//
+// Implicit GEMM, M = N H W output positions, N = Co, K = 9 Ci walked as (tap, 32-channel chunk): a 128 x 128 (or 256 x 128) output
+// tile per workgroup, 4 waves as 2 x 2, the machinery of tile_x3.h (128-byte LDS rows [32 hi | 32 lo], XOR-swizzled, register
+// staging with the split on the VALU, double buffer, one barrier per K step).  The A operand of a K step is the input shifted by
+// the tap: row r of the tile reads position r + (kh - 1) W + (kw - 1) of the same image, or zeros where that leaves the image --
+// the nine validity bits of a thread's rows are computed once, the shift is one pointer offset per tap.  B is the weight as it lies
+// in memory ([Co][3][3][Ci] = a K-contiguous [Co, 9 Ci] matrix).
+// The data gradient dX = conv(dY, W') with W'[ci][kh][kw][co] = W[co][2 - kh][2 - kw][ci] is the same call on a weight prepared by
+// cfl_conv3x3_x3_rot_weight.  The weight gradient stays on the library (fp32): an fp32-accurate TN form is not built.
+#include "common.h"
+#include "tile_x3.h"
+
+namespace {
+
+template <int TM>
+struct ARegs { f32x4 r[2 * TM]; };
+
+// rows of this thread in a 64 TM-row stage: rl = p * 32 + (t >> 3), p < 2 TM; k quad kq = t & 7
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void cfl_conv3x3_x3_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                              int N, int H, int W, int Ci, int Co) {
+    using C = x3::Cfg<TM, TN>;
+    constexpr int BM = C::BM, BN = C::BN, NP = 2 * TM;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* lds = reinterpret_cast<char*>(lds_f);
+    const long long M = (long long)N * H * W;
+    const int ntc = Co / BN, ntr = (int)((M + BM - 1) / BM);
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const long long row0 = (long long)ti * BM;
+    const int col0 = tj * BN;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
+    const int kq = t & 7;
+
+    // this thread's A rows: source pointer of the centre tap and the nine validity bits
+    const float* abase[NP];
+    unsigned avalid[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const long long r = row0 + p * 32 + (t >> 3);
+        unsigned v = 0;
+        long long rc = r < M ? r : M - 1;
+        if (r < M) {
+            const int hw = (int)(r % ((long long)H * W));
+            const int h = hw / W, ww = hw % W;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if ((unsigned)(h + kh - 1) < (unsigned)H && (unsigned)(ww + kw - 1) < (unsigned)W) v |= 1u << (kh * 3 + kw);
+        }
+        avalid[p] = v;
+        abase[p] = x + rc * Ci + 4 * kq;
+    }
+    const Opnd Bo{w, (long long)9 * Ci, Co, 9 * Ci, 1};
+    const int nchunk = Ci / 32, nk = 9 * nchunk;
+
+    ARegs<TM> ra;
+    x3::StageRegs<true, BN> rb;
+    auto load_a = [&](int s) {
+        const int tap = s / nchunk, c0 = (s - tap * nchunk) * 32;
+        const long long off = ((long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * Ci + c0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bool ok = (avalid[p] >> tap) & 1u;
+            // (clamped address for the rows that read nothing: the centre tap of the row itself is always inside the tensor)
+            const f32x4 v = *reinterpret_cast<const f32x4*>(abase[p] + (ok ? off : (long long)c0));
+            ra.r[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_a = [&](char* st) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int rl = p * 32 + (t >> 3);
+            x3::bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 hh, ll;
+                x3::split1(ra.r[p][e], hh, ll);
+                hi[e] = hh; lo[e] = ll;
+            }
+            *reinterpret_cast<x3::bf16x4*>(st + x3::soff(rl, kq >> 1) + (kq & 1) * 8) = hi;
+            *reinterpret_cast<x3::bf16x4*>(st + x3::soff(rl, 4 + (kq >> 1)) + (kq & 1) * 8) = lo;
+        }
+    };
+    auto bk = [&](int s) { const int tap = s / nchunk; return tap * Ci + (s - tap * nchunk) * 32; };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    load_a(0);
+    x3::stage_kc<BN, 0>(Bo, col0, bk(0), rb.r, lds, XfIdentity());
+    store_a(lds);
+    x3::stage_kc<BN, 1>(Bo, col0, bk(0), rb.r, lds + BM * 128, XfIdentity());
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        const char* sa = lds + (s & 1) * C::STAGE_BYTES;
+        char* da = lds + ((s + 1) & 1) * C::STAGE_BYTES;
+        const bool more = s + 1 < nk;
+        if (more) {
+            load_a(s + 1);
+            x3::stage_kc<BN, 0>(Bo, col0, bk(s + 1), rb.r, da, XfIdentity());
+        }
+        x3::compute<TM, TN>(sa, sa + BM * 128, acc, lane, wr, wc);
+        if (more) {
+            store_a(da);
+            x3::stage_kc<BN, 1>(Bo, col0, bk(s + 1), rb.r, da + BM * 128, XfIdentity());
+        }
+        __syncthreads();
+    }
+    // C / D layout: a lane holds one column (co) of 16 rows per 32 x 32 tile: 32 lanes = 128 contiguous bytes of one output row
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int j = col0 + acc_col<TN>(wc, n, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long i = row0 + acc_row<TM>(wr, m, r, lane);
+                if (i < M) y[i * Co + j] = acc[m][n][r];
+            }
+        }
+}
+
+// wr[ci][kh][kw][co] = w[co][2 - kh][2 - kw][ci]   (both [out][3][3][in] in memory: the channels_last weight layout)
+__global__ __launch_bounds__(256) void cfl_conv3x3_rot_kernel(const float* __restrict__ w, int Ci, int Co, float* __restrict__ wr) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;                              // source tap
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Co && ci < Ci) ? w[((long long)co * 9 + tap) * Ci + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Ci && co < Co) wr[((long long)ci * 9 + (8 - tap)) * Co + co] = tile[tx][r];
+    }
+}
+
+inline bool x3conv_ok(int N, int H, int W, int Ci, int Co) {
+    return N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && Ci % 32 == 0 && Co % 64 == 0 && (long long)N * H * W < (1ll << 31);
+}
+
+}  // namespace
+
+extern "C" int cfl_conv3x3_x3_supported(int N, int H, int W, int Ci, int Co) { return x3conv_ok(N, H, W, Ci, Co) ? 1 : 0; }
+
+extern "C" int cfl_conv3x3_x3_fwd(const float* x, const float* w, int N, int H, int W, int Ci, int Co, float* y, int variant,
+                                  void* stream_) {
+    if (!x || !w || !y) return CFL_EINVAL;
+    if (!x3conv_ok(N, H, W, Ci, Co) || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long M = (long long)N * H * W;
+    // tile: 128 output channels where they divide, 256 positions when that still fills the chip twice
+    const bool bn128 = Co % 128 == 0;
+    if (variant == 0) variant = bn128 ? (M / 256 * (Co / 128) >= 512 ? 42 : 22) : (M / 256 * (Co / 64) >= 512 ? 41 : 21);
+#define CFL_X3CONV(TM_, TN_)                                                                                                   \
+    do {                                                                                                                       \
+        using C = x3::Cfg<TM_, TN_>;                                                                                           \
+        const int grid = (int)((M + C::BM - 1) / C::BM) * (Co / C::BN);                                                        \
+        CFL_SET_LDS((cfl_conv3x3_x3_kernel<TM_, TN_>), C::LDS_BYTES);                                                          \
+        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3_kernel<TM_, TN_>), dim3(grid), dim3(256), C::LDS_BYTES, stream, x, w, y, N, H, W, Ci, Co); \
+    } while (0)
+    switch (variant) {
+        case 42: if (!bn128) return CFL_ELIMIT; CFL_X3CONV(4, 2); break;
+        case 22: if (!bn128) return CFL_ELIMIT; CFL_X3CONV(2, 2); break;
+        case 41: CFL_X3CONV(4, 1); break;
+        case 21: CFL_X3CONV(2, 1); break;
+        default: return CFL_EINVAL;
+    }
+#undef CFL_X3CONV
+    return 0;
+}
+
+extern "C" int cfl_conv3x3_x3_rot_weight(const float* w, int Ci, int Co, float* w_rot, void* stream_) {
+    if (!w || !w_rot || Ci <= 0 || Co <= 0) return CFL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    CFL_LAUNCH(K_TRANSPOSE, cfl_conv3x3_rot_kernel, dim3(cfl_cdiv(Ci, 32), cfl_cdiv(Co, 32), 9), dim3(256), 0, stream, w, Ci, Co, w_rot);
+    return 0;
+}

@@ -101,6 +101,11 @@ class TrunkConv(nn.Conv2d):
         if (x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype and self.stride[0] == self.stride[1]
                 and self.padding[0] == self.padding[1] and isinstance(self.padding[0], int)):
             from .. import ops
+            if ops.X3CONV[0] and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)) \
+                    and ops.conv3x3_x3_supported(x, self.weight, self.stride[0], self.padding[0]):
+                # forward-only passes of an fp32 channels_last encoder (the clients' old model, representation extraction) on the
+                # 3 x bf16-split kernel as well (csrc/conv3x3_x3.hip)
+                return ops.conv3x3_x3_forward(x, self.weight)
             if ops.conv_gate_worthwhile(x, self.weight, self.stride[0], self.padding[0]):
                 # every other case (the fp32 NCHW client encoders; forward-only passes: representation extraction, evaluation):
                 # the library's kernels, but answered from the shipped find-db per call where it holds the problem instead of a

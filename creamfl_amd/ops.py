@@ -1508,13 +1508,59 @@ def _conv_wgrad(args):
     return _miopen(cov, torch.ops.aten.convolution_backward, *args, [False, True, False])[1]
 
 
+# Round 6: the 3 x 3 / stride 1 / padding 1 convolutions of fp32 channels_last tensors (the clients' ResNet-18 BasicBlocks: 16 of its
+# 20 convolutions) on csrc/conv3x3_x3.hip -- fp32-class accuracy on the bf16 matrix pipe (3 x bf16 split), forward and data gradient;
+# the weight gradient stays on the library.  `--client_conv_x3` (creamfl_amd/flags.py) / CFL_X3CONV=1 switch it on.
+X3CONV = [_os.environ.get('CFL_X3CONV', '0') == '1']
+X3CONV_TAKEN = [0]
+
+
+def conv3x3_x3_supported(x, w, stride, padding):
+    if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and w.dim() == 4):
+        return False
+    if not (w.shape[2] == 3 and w.shape[3] == 3 and stride == 1 and padding == 1 and w.shape[1] == x.shape[1]):
+        return False
+    cl = torch.channels_last
+    if not (x.is_contiguous(memory_format=cl) and w.is_contiguous(memory_format=cl)):
+        return False
+    N, Ci, H, W = x.shape
+    return bool(_lib.load().cfl_conv3x3_x3_supported(N, H, W, Ci, w.shape[0]))
+
+
+def conv3x3_x3_forward(x, w, variant=0):
+    """conv2d(x, w, stride 1, padding 1) for fp32 channels_last x [N, Ci, H, W] and w [Co, Ci, 3, 3] (csrc/conv3x3_x3.hip); no
+    autograd (the Functions that own the convolutions call it for their forward and, on the rotated weight, their data gradient)."""
+    N, Ci, H, W = x.shape
+    Co = w.shape[0]
+    y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().cfl_conv3x3_x3_fwd(_ptr(x), _ptr(w), N, H, W, Ci, Co, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd')
+    X3CONV_TAKEN[0] += 1
+    return y
+
+
+def conv3x3_x3_rotated(w):
+    """W'[ci][co][kh][kw] = W[co][ci][2 - kh][2 - kw] as a channels_last [Ci, Co, 3, 3] tensor: conv(dY, W') is the data gradient."""
+    Co, Ci = w.shape[0], w.shape[1]
+    wr = torch.empty((Ci, Co, 3, 3), dtype=torch.float32, device=w.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().cfl_conv3x3_x3_rot_weight(_ptr(w), Ci, Co, _ptr(wr), _stream(w)), 'cfl_conv3x3_x3_rot_weight')
+    return wr
+
+
 def _conv_dgrad(args):
     dy, x, w = args[0], args[1], args[2]
+    if X3CONV[0] and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and args[4][0] == 1 and args[5][0] == 1 \
+            and dy.is_cuda and dy.dtype == torch.float32 and w.dtype == torch.float32 and dy.dim() == 4 and dy.shape[1] == w.shape[0] \
+            and dy.is_contiguous(memory_format=torch.channels_last) and w.is_contiguous(memory_format=torch.channels_last) \
+            and _lib.load().cfl_conv3x3_x3_supported(dy.shape[0], dy.shape[2], dy.shape[3], w.shape[0], w.shape[1]):
+        # dX = conv(dY, W') on the rotated, transposed weight: the forward kernel with the roles of the channel counts swapped
+        return conv3x3_x3_forward(dy, conv3x3_x3_rotated(w))
     cov = _fdb_covered('B', x, w, dy.shape, args[4][0], args[5][0])
     return _miopen(cov, torch.ops.aten.convolution_backward, *args, [True, False, False])[0]
 
 
 def _conv_fwd(x, w, stride, padding):
+    if X3CONV[0] and conv3x3_x3_supported(x, w, stride, padding):
+        return conv3x3_x3_forward(x, w)
     kh = w.shape[2]
     out_shape = (x.shape[0], w.shape[0], (x.shape[2] + 2 * padding - kh) // stride + 1, (x.shape[3] + 2 * padding - w.shape[3]) // stride + 1)
     return _miopen(_fdb_covered('F', x, w, out_shape, stride, padding), torch.nn.functional.conv2d, x, w, None, stride, padding)

@@ -206,6 +206,18 @@ int cfl_attn_small_bwd_varlen(const void* q, const void* k, const void* v, long 
                               int head_dim, const void* dout, long long ldo, void* dq, void* dk, void* dv, long long ldg,
                               void* stream);
 
+/* ---- 3 x 3 / stride 1 / padding 1 convolution of fp32 channels_last tensors on the bf16 matrix pipe at fp32-class accuracy --------
+ * (round 6, csrc/conv3x3_x3.hip).  The BasicBlock convolutions of the clients' ResNet-18 (src/networks/resnet_client.py:33-66,
+ * 102-201), fp32 in the reference (cuDNN): y[n,h,w,co] = sum x[n,h+kh-1,w+kw-1,ci] w[co,kh,kw,ci]; x [N,H,W,Ci], w [Co,3,3,Ci],
+ * y [N,H,W,Co] dense fp32 (= torch channels_last memory).  Every operand element is split into two bf16 while it is staged and each
+ * product runs as three bf16 MFMAs (tile_x3.h): ~1e-6 relative per product.  Ci % 32 == 0, Co % 64 == 0.  variant 0 = the tile
+ * choice of the library (22 / 42: 128 / 256 positions x 128 channels, 21 / 41: x 64 channels).
+ * The data gradient is the same call on dY and the rotated, transposed weight: cfl_conv3x3_x3_rot_weight writes
+ * w_rot[ci][kh][kw][co] = w[co][2-kh][2-kw][ci]. */
+int cfl_conv3x3_x3_supported(int N, int H, int W, int Ci, int Co);
+int cfl_conv3x3_x3_fwd(const float* x, const float* w, int N, int H, int W, int Ci, int Co, float* y, int variant, void* stream);
+int cfl_conv3x3_x3_rot_weight(const float* w, int Ci, int Co, float* w_rot, void* stream);
+
 /* ---- ResNet stem max pooling, 3x3 / stride 2 / pad 1, NHWC bf16 ---------------------------------------------------
  * torchvision ResNet.maxpool of the trunk built at src/networks/models/image_encoder.py:27-36 (and the client trunk,
  * src/networks/resnet_client.py:19).  x [N,H,W,C] -> y [N,Ho,Wo,C], Ho = (H-1)/2+1; idx: one byte per output element

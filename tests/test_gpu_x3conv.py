@@ -1,0 +1,98 @@
+"""GPU: csrc/conv3x3_x3.hip -- the 3 x 3 / stride 1 / padding 1 convolution of fp32 channels_last tensors as 3 x bf16-split products
+on the bf16 matrix pipe (the clients' ResNet-18 BasicBlocks, src/networks/resnet_client.py:33-66,102-201; fp32 on cuDNN in the
+reference) -- against the definition in fp64 and against the library's fp32 kernels it replaces."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from creamfl_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def _case(n, h, w, ci, co, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)
+    return x, wt
+
+
+@pytest.mark.parametrize('n,h,w,ci,co,variant', [(2, 7, 7, 64, 64, 0), (3, 14, 14, 64, 128, 22), (1, 28, 28, 128, 128, 42), (5, 9, 13, 32, 64, 21),
+                                                 (4, 56, 56, 64, 64, 41), (1, 1, 1, 32, 64, 0), (2, 5, 3, 96, 192, 0), (16, 7, 7, 512, 512, 0)])
+def test_x3conv_forward_matches_the_definition(dev, n, h, w, ci, co, variant):
+    """y = conv2d(x, w, 1, 1) against fp64 on the same fp32 inputs: 1e-5 of the output's scale (a 3 x bf16-split product is ~1e-6
+    relative; the library's fp32 Winograd kernels are ~1e-3 of scale); ragged position counts, every tile variant, single pixels."""
+    from creamfl_amd import ops
+    x, wt = _case(n, h, w, ci, co, n + h + ci)
+    xd, wd = x.to(dev).contiguous(memory_format=CL), wt.to(dev).contiguous(memory_format=CL)
+    assert ops.conv3x3_x3_supported(xd, wd, 1, 1)
+    y = ops.conv3x3_x3_forward(xd, wd, variant)
+    assert y.shape == (n, co, h, w) and y.is_contiguous(memory_format=CL)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    sc = float(ref.abs().max())
+    assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 * sc
+    assert torch.equal(y, ops.conv3x3_x3_forward(xd, wd, variant))                 # deterministic
+    assert not ops.conv3x3_x3_supported(xd, wd, 2, 1)
+    if h * w > 1:                                                                  # (a 1 x 1 map is contiguous in both formats)
+        assert not ops.conv3x3_x3_supported(xd.contiguous(), wd, 1, 1)
+    assert not ops.conv3x3_x3_supported(xd.bfloat16(), wd.bfloat16(), 1, 1)
+
+
+def test_x3conv_rotated_weight_is_exact(dev):
+    from creamfl_amd import ops
+    _, wt = _case(1, 3, 3, 96, 160, 5)
+    wd = wt.to(dev).contiguous(memory_format=CL)
+    wr = ops.conv3x3_x3_rotated(wd)
+    assert wr.shape == (96, 160, 3, 3) and wr.is_contiguous(memory_format=CL)
+    assert torch.equal(wr.cpu(), wt.flip(2, 3).transpose(0, 1).contiguous())
+
+
+@pytest.mark.parametrize('n,hw,ci,co', [(4, 14, 64, 128), (2, 28, 128, 128), (8, 7, 256, 256)])
+def test_x3conv_through_the_trunk_convolution(dev, n, hw, ci, co, monkeypatch):
+    """TrunkConv (the module the client ResNets are built from) with the switch on: forward and data gradient from conv3x3_x3.hip,
+    weight gradient from the library; all three against fp64 autograd, and against the same module on the library alone."""
+    from creamfl_amd import ops
+    from creamfl_amd.networks.backbones import TrunkConv
+    x, wt = _case(n, hw, hw, ci, co, 11)
+    g = torch.Generator().manual_seed(3)
+    gy = torch.randn(n, co, hw, hw, generator=g)
+    conv = TrunkConv(ci, co, 3, 1, 1).to(dev).to(memory_format=CL)
+    with torch.no_grad():
+        conv.weight.copy_(wt.to(dev))
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, 'X3CONV', [on])
+        xd = x.to(dev).contiguous(memory_format=CL).requires_grad_(True)
+        conv.weight.grad = None
+        before = ops.X3CONV_TAKEN[0]
+        y = conv(xd)
+        y.backward(gy.to(dev).contiguous(memory_format=CL))
+        from creamfl_amd import streams
+        streams.join_into_current(dev)
+        torch.cuda.synchronize()
+        assert ops.X3CONV_TAKEN[0] - before == (2 if on else 0)                  # forward + data gradient
+        out[on] = (y.detach().cpu().double(), xd.grad.cpu().double(), conv.weight.grad.cpu().double())
+        with torch.no_grad():                                                   # the no-grad path (the clients' old model) too
+            before = ops.X3CONV_TAKEN[0]
+            y2 = conv(xd.detach())
+            assert ops.X3CONV_TAKEN[0] - before == (1 if on else 0)
+            assert float((y2 - y.detach()).abs().max()) <= 1e-6 * float(y.detach().abs().max()) if on else True
+    x64 = x.double().requires_grad_(True)
+    w64 = wt.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(gy.double())
+    for k, ref in enumerate((y64.detach(), x64.grad, w64.grad)):
+        sc = float(ref.abs().max())
+        err_x3 = float((out[True][k] - ref).abs().max()) / sc
+        err_lib = float((out[False][k] - ref).abs().max()) / sc
+        assert err_x3 <= (1e-5 if k < 2 else 2e-3), (k, err_x3, err_lib)         # (k = 2: the library's weight gradient in both runs)
+        assert err_lib <= 5e-3, (k, err_lib)

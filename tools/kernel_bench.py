@@ -314,6 +314,52 @@ def case_wgrad1(H, Ci, Co, N=256, wgs=(128,)):
     return out
 
 
+def case_x3conv(H, C, N=128):
+    """3 x 3 / stride 1 convolution of fp32 channels_last tensors: csrc/conv3x3_x3.hip (3 x bf16 split on the bf16 matrix pipe) vs the
+    library's fp32 kernels, forward and data gradient, at one BasicBlock shape of the clients' ResNet-18 (batch 128); errors of both
+    against fp64 on two images."""
+    import torch.nn.functional as F
+    cl = torch.channels_last
+    g = torch.Generator(device='cuda').manual_seed(H + C)
+    x = torch.randn(N, C, H, H, generator=g, device='cuda').contiguous(memory_format=cl)
+    w = (torch.randn(C, C, 3, 3, generator=g, device='cuda') / (3.0 * C ** 0.5)).contiguous(memory_format=cl)
+    dy = torch.randn(N, C, H, H, generator=g, device='cuda').contiguous(memory_format=cl)
+    flop = 2.0 * N * H * H * C * C * 9
+    out = {'case': f'x3conv {H}x{H} {C}->{C} N={N} fp32 channels_last', 'gflop': round(flop / 1e9, 1), 'gflop_on_the_bf16_pipe': round(3 * flop / 1e9, 1),
+           'mfma_floor_us': round(3 * flop / 2.5e15 * 1e6, 1)}
+    with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+        for _ in range(3):
+            F.conv2d(x, w, None, 1, 1)
+            torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])
+        us, _ = timed(lambda: F.conv2d(x, w, None, 1, 1), iters=20)
+        out['library_fwd_us'] = round(us, 1)
+        us, _ = timed(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]), iters=20)
+        out['library_dgrad_us'] = round(us, 1)
+        us, _ = timed(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]), iters=20)
+        out['library_wgrad_us'] = round(us, 1)
+        ylib = F.conv2d(x[:2], w, None, 1, 1)
+    ref = F.conv2d(x[:2].double(), w.double(), None, 1, 1)
+    sc = float(ref.abs().max())
+    out['library_fwd_relerr_vs_fp64'] = float((ylib.double() - ref).abs().max()) / sc
+    M = N * H * H
+    for v in (22, 42, 21, 41):
+        if v in (22, 42) and C % 128:
+            continue
+        y = ops.conv3x3_x3_forward(x, w, v)
+        out[f'x3_v{v}_relerr_vs_fp64'] = float((y[:2].double() - ref).abs().max()) / sc
+        us, prof = timed(lambda: ops.conv3x3_x3_forward(x, w, v), iters=20)
+        k = prof.get('cfl_conv3x3_x3_kernel', us)
+        out[f'x3_v{v}_fwd_us'] = k
+        out[f'x3_v{v}_TFLOPs_fp32_equivalent'] = round(flop / k / 1e6)
+    wr = ops.conv3x3_x3_rotated(w)
+    us, prof = timed(lambda: ops.conv3x3_x3_forward(dy, ops.conv3x3_x3_rotated(w)), iters=20)
+    out['x3_dgrad_us_incl_weight_rotation'] = round(sum(v for v in prof.values() if v), 1)
+    best = min(out[f'x3_v{v}_fwd_us'] for v in (22, 42, 21, 41) if f'x3_v{v}_fwd_us' in out)
+    out['speedup_fwd'] = round(out['library_fwd_us'] / best, 2)
+    out['speedup_dgrad'] = round(out['library_dgrad_us'] / out['x3_dgrad_us_incl_weight_rotation'], 2)
+    return out
+
+
 def case_opt(cnn='resnet101'):
     """fused clip + AdamP over the real parameter set of the bench model (ResNet-101 + BERT-base PCME)."""
     from creamfl_amd.algorithms.optimizers import AdamP
@@ -426,6 +472,9 @@ def main():
             rec[name + '_us'] = prof.get('cfl_conv3x3_wgrad_kernel', us)
         lib.cfl_conv3x3_wgrad_debug(0)
         out.append(rec)
+    if 'x3conv' in cases:
+        for H, C in ((28, 128), (56, 64), (14, 256), (7, 512)):
+            out.append(case_x3conv(H, C))
     if 'wgrad1' in cases:
         for (H, Ci, Co) in [(14, 1024, 256), (14, 256, 1024), (28, 512, 128), (28, 128, 512), (56, 256, 64), (56, 64, 256), (56, 64, 64),
                             (7, 2048, 512), (7, 512, 2048)]:
