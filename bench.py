@@ -700,6 +700,21 @@ def client_steps(args):
     if roof:
         out['bank_pass_roofline'] = {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us',
                                                               'launches', 'algorithmic_bytes', 'how')}
+    # the same steps with every convolution on the library's fp32 kernels (`--client_conv_x3 0`): the image encoders' 3 x 3 convolutions
+    # run by default as 3 x bf16-split products (csrc/conv3x3_x3.hip: 16 mantissa bits per operand) -- both forms belong in the line
+    out['convolutions'] = '3 x 3 / stride 1: csrc/conv3x3_x3.hip (3 x bf16 split, fp32-class); the rest: library fp32'
+    try:
+        res = subprocess.run(cmd + ['--client-conv-x3', '0', '--only-kinds', 'img,mm'], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=args.client_steps_timeout)
+        lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
+        if res.returncode == 0 and lines:
+            lib = json.loads(lines[-1])
+            out['with_library_fp32_convolutions'] = {
+                name: ((lib['clients'][kind].get('graph') or lib['clients'][kind]['eager'])['ms_per_step'])
+                for kind, name in (('img', 'image'), ('mm', 'multi_modal')) if kind in (lib.get('clients') or {})}
+    except subprocess.TimeoutExpired:
+        out['with_library_fp32_convolutions'] = {'error': 'timeout'}
+    out['child_seconds'] = round(time.perf_counter() - t0, 1)
     return out
 
 

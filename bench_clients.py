@@ -43,7 +43,8 @@ HBM_PEAK_GBPS = 8000.0
 
 
 def add_arguments(ap):
-    ap.add_argument('--client-conv-x3', type=int, default=0, help='the clients\' fp32 3x3 convolutions on csrc/conv3x3_x3.hip (flags.client_conv_x3)')
+    ap.add_argument('--only-kinds', default='img,txt,mm', help='single process: which clients\' steps to measure')
+    ap.add_argument('--client-conv-x3', type=int, default=1, help='the clients\' fp32 3x3 convolutions on csrc/conv3x3_x3.hip (flags.client_conv_x3)')
     ap.add_argument('--round-first', type=int, default=1, help='the federation round before the clients\' micro-benchmarks (a real run\'s order)')
     ap.add_argument('--pub', type=int, default=50000, help='config 2: public-set size M (banks, representations, con_w)')
     ap.add_argument('--client-batch', type=int, default=128, help='config 2: public-loader batch B of the contrast loops')
@@ -513,7 +514,7 @@ def run(a, world, rank, dev, use_dist, json_out):
         return rnd, full
 
     def client_part():
-        kinds = ('img', 'txt', 'mm') if world == 1 else (KINDS8[rank % 8],)
+        kinds = tuple(k for k in ('img', 'txt', 'mm') if k in a.only_kinds.split(',')) if world == 1 else (KINDS8[rank % 8],)
         clients = {}
         for kind in kinds:
             tr = first_of_kind(algo, kind, rank if world > 1 else None, world)

@@ -8,8 +8,9 @@
 // kernels are 68 % of the three client kinds' kernel time and ~85 % of an image client's contrast step (profiles/
 // r5_client_step_kernel_stats.csv) at 45-100 TFLOP/s: the fp32 matrix rate of the chip is 157 TFLOP/s, the bf16 rate 2 500.  Every
 // fp32 operand element is split x = hi + lo (two bf16) while it is staged and each product runs as three bf16 MFMAs (hi.hi + lo.hi +
-// hi.lo; the dropped term is 2^-16 relative): products to ~1e-6 relative, i.e. MORE accurate than the library's Winograd path
-// (~1e-3 of scale), at a roof of 833 TFLOP/s of fp32-equivalent work.
+// hi.lo; the dropped term is 2^-16 relative): 16 mantissa bits per operand, outputs within 4.6e-6 of scale of fp64 at K = 9 x 128 ..
+// 9 x 512 (the library's fp32 kernels: 3e-7 .. 8e-7; TF32, which cuDNN uses for fp32 convolutions by default on the A100-class GPUs
+// the reference ran on, carries 10 bits), at a roof of 833 TFLOP/s of fp32-equivalent work.
 //
 // Implicit GEMM, M = N H W output positions, N = Co, K = 9 Ci walked as (tap, 32-channel chunk): a 128 x 128 (or 256 x 128) output
 // tile per workgroup, 4 waves as 2 x 2, the machinery of tile_x3.h (128-byte LDS rows [32 hi | 32 lo], XOR-swizzled, register
@@ -139,6 +140,158 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3_kernel(const float* __rest
         }
 }
 
+// ---- version 2: the input slab of a 32-channel chunk is staged ONCE for the nine taps ---------------------------------------------
+// The kernel above re-reads (and re-splits) its A tile for every tap: 9 x 16 KB + 9 x 16 KB of weights per chunk and 128 x 128 tile, ~920
+// MB through L2 at the layer2 shape -- it runs at the L2 -> CU rate (172 us), not at the matrix pipe's (floor 35 us).  Here K runs
+// (chunk, tap): per chunk the positions row0 - (W + 1) .. row0 + BM + W of 32 channels go into ONE LDS slab ([32 hi | 32 lo] rows,
+// the swizzle of tile_x3.h), and a tap is the same fragment read moved by (kh - 1) W + (kw - 1) rows; fragments whose shifted position
+// leaves the image are zeroed in registers (nine validity bits per lane and 32-row block).  Only the weights stream per tap.  A's
+// traffic falls 4.5 x, the split of A runs once instead of nine times.  W <= 63 (slab = BM + 128 rows).
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void cfl_conv3x3_x3s_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                               int N, int H, int W, int Ci, int Co) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, SR = BM + 128, NJ = SR / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* slab = reinterpret_cast<char*>(lds_f);
+    const long long M = (long long)N * H * W;
+    const int ntc = Co / BN, ntr = (int)((M + BM - 1) / BM);
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const long long row0 = (long long)ti * BM;
+    const int col0 = tj * BN;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
+    const int kq = t & 7, i32 = lane & 31, hh = lane >> 5;
+    const int halo = W + 1;
+    const int nj = (BM + 2 * halo + 31) / 32;                 // 32-row groups of the slab actually used (<= NJ)
+    char* const bst = slab + nj * (32 * 128);                 // two B stages of BN rows behind it
+
+    unsigned avalid[TM];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const long long r = row0 + (wr * TM + m) * 32 + i32;
+        unsigned v = 0;
+        if (r < M) {
+            const int hw = (int)(r % ((long long)H * W));
+            const int h = hw / W, ww = hw % W;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if ((unsigned)(h + kh - 1) < (unsigned)H && (unsigned)(ww + kw - 1) < (unsigned)W) v |= 1u << (kh * 3 + kw);
+        }
+        avalid[m] = v;
+    }
+    const Opnd Bo{w, (long long)9 * Ci, Co, 9 * Ci, 1};
+    const int nchunk = Ci / 32, nk = 9 * nchunk;
+
+    f32x4 sreg[NJ];
+    x3::StageRegs<true, BN> rb;
+    auto load_slab = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < nj) {
+                const long long P = row0 - halo + j * 32 + (t >> 3);
+                const bool ok = P >= 0 && P < M;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (ok ? P : 0) * Ci + c * 32 + 4 * kq);
+                sreg[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < nj) {
+                const int rl = j * 32 + (t >> 3);
+                x3::bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a, b;
+                    x3::split1(sreg[j][e], a, b);
+                    hi[e] = a; lo[e] = b;
+                }
+                *reinterpret_cast<x3::bf16x4*>(slab + x3::soff(rl, kq >> 1) + (kq & 1) * 8) = hi;
+                *reinterpret_cast<x3::bf16x4*>(slab + x3::soff(rl, 4 + (kq >> 1)) + (kq & 1) * 8) = lo;
+            }
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    auto compute_tap = [&](int tap, const char* sb) {
+        const int shift = halo + (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            x3::bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const int r = (wr * TM + m) * 32 + i32 + shift;
+                f32x4 vh = *reinterpret_cast<const f32x4*>(slab + x3::soff(r, 2 * kk + hh));
+                f32x4 vl = *reinterpret_cast<const f32x4*>(slab + x3::soff(r, 4 + 2 * kk + hh));
+                if (!((avalid[m] >> tap) & 1u)) { vh = f32x4{0.f, 0.f, 0.f, 0.f}; vl = vh; }
+                ah[m] = __builtin_bit_cast(x3::bf16x8, vh);
+                al[m] = __builtin_bit_cast(x3::bf16x8, vl);
+            }
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int r = (wc * TN + n) * 32 + i32;
+                bh[n] = *reinterpret_cast<const x3::bf16x8*>(sb + x3::soff(r, 2 * kk + hh));
+                bl[n] = *reinterpret_cast<const x3::bf16x8*>(sb + x3::soff(r, 4 + 2 * kk + hh));
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+        }
+    };
+    auto bk = [&](int s) { const int c = s / 9; return (s - 9 * c) * Ci + c * 32; };      // step s = chunk c, tap s - 9 c
+
+    load_slab(0);
+    x3::stage_kc<BN, 0>(Bo, col0, bk(0), rb.r, bst, XfIdentity());
+    store_slab();
+    x3::stage_kc<BN, 1>(Bo, col0, bk(0), rb.r, bst, XfIdentity());
+    __syncthreads();
+    int s = 0;
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            const bool more = s + 1 < nk;
+            const bool next_slab = tap == 8 && c + 1 < nchunk;
+            if (more) x3::stage_kc<BN, 0>(Bo, col0, bk(s + 1), rb.r, bst, XfIdentity());
+            if (tap == 7 && c + 1 < nchunk) load_slab(c + 1);
+            compute_tap(tap, bst + (s & 1) * (BN * 128));
+            if (more) x3::stage_kc<BN, 1>(Bo, col0, bk(s + 1), rb.r, bst + ((s + 1) & 1) * (BN * 128), XfIdentity());
+            if (next_slab) {
+                __syncthreads();                              // every wave is done with this chunk's slab
+                store_slab();
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int j = col0 + acc_col<TN>(wc, n, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long i = row0 + acc_row<TM>(wr, m, r, lane);
+                if (i < M) y[i * Co + j] = acc[m][n][r];
+            }
+        }
+}
+
 // wr[ci][kh][kw][co] = w[co][2 - kh][2 - kw][ci]   (both [out][3][3][in] in memory: the channels_last weight layout)
 __global__ __launch_bounds__(256) void cfl_conv3x3_rot_kernel(const float* __restrict__ w, int Ci, int Co, float* __restrict__ wr) {
     __shared__ float tile[32][33];
@@ -172,7 +325,10 @@ extern "C" int cfl_conv3x3_x3_fwd(const float* x, const float* w, int N, int H, 
     const long long M = (long long)N * H * W;
     // tile: 128 output channels where they divide, 256 positions when that still fills the chip twice
     const bool bn128 = Co % 128 == 0;
-    if (variant == 0) variant = bn128 ? (M / 256 * (Co / 128) >= 512 ? 42 : 22) : (M / 256 * (Co / 64) >= 512 ? 41 : 21);
+    if (variant == 0) {
+        if (W <= 63) variant = (M / 256) * (Co / 64) >= 256 ? 141 : 121;        // slab kernels (measured: profiles/r6_x3conv_probe.jsonl)
+        else variant = bn128 ? (M / 256 * (Co / 128) >= 512 ? 42 : 22) : (M / 256 * (Co / 64) >= 512 ? 41 : 21);
+    }
 #define CFL_X3CONV(TM_, TN_)                                                                                                   \
     do {                                                                                                                       \
         using C = x3::Cfg<TM_, TN_>;                                                                                           \
@@ -180,7 +336,20 @@ extern "C" int cfl_conv3x3_x3_fwd(const float* x, const float* w, int N, int H, 
         CFL_SET_LDS((cfl_conv3x3_x3_kernel<TM_, TN_>), C::LDS_BYTES);                                                          \
         CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3_kernel<TM_, TN_>), dim3(grid), dim3(256), C::LDS_BYTES, stream, x, w, y, N, H, W, Ci, Co); \
     } while (0)
+#define CFL_X3CONVS(TM_, TN_)                                                                                                  \
+    do {                                                                                                                       \
+        constexpr int BM_ = 64 * TM_, BN_ = 64 * TN_;                                                                          \
+        if (W > 63) return CFL_ELIMIT;                                                                                         \
+        const int LDS_ = ((BM_ + 2 * (W + 1) + 31) / 32) * (32 * 128) + 2 * BN_ * 128;                                         \
+        const int grid = (int)((M + BM_ - 1) / BM_) * (Co / BN_);                                                              \
+        CFL_SET_LDS((cfl_conv3x3_x3s_kernel<TM_, TN_>), (BM_ + 128) * 128 + 2 * BN_ * 128);                                    \
+        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3s_kernel<TM_, TN_>), dim3(grid), dim3(256), LDS_, stream, x, w, y, N, H, W, Ci, Co); \
+    } while (0)
     switch (variant) {
+        case 122: if (!bn128) return CFL_ELIMIT; CFL_X3CONVS(2, 2); break;
+        case 121: CFL_X3CONVS(2, 1); break;
+        case 142: if (!bn128) return CFL_ELIMIT; CFL_X3CONVS(4, 2); break;
+        case 141: CFL_X3CONVS(4, 1); break;
         case 42: if (!bn128) return CFL_ELIMIT; CFL_X3CONV(4, 2); break;
         case 22: if (!bn128) return CFL_ELIMIT; CFL_X3CONV(2, 2); break;
         case 41: CFL_X3CONV(4, 1); break;
@@ -188,6 +357,7 @@ extern "C" int cfl_conv3x3_x3_fwd(const float* x, const float* w, int N, int H, 
         default: return CFL_EINVAL;
     }
 #undef CFL_X3CONV
+#undef CFL_X3CONVS
     return 0;
 }
 

@@ -46,10 +46,13 @@ BUILD_FLAGS = {
     'client_bf16': (dict(type=int, default=0, choices=[0, 1]),
                     '1 = bf16 autocast for the clients\' image encoders (3.3 x faster contrast steps); BELOW the reference\'s client '
                     'precision (fp32, src/algorithms/ClientTrainer.py has no mixed precision), hence opt-in'),
-    'client_conv_x3': (dict(type=int, default=0, choices=[0, 1]),
-                       '1 = the 3 x 3 / stride-1 convolutions of the clients\' fp32 channels_last image encoders (16 of ResNet-18\'s 20) '
-                       'on csrc/conv3x3_x3.hip: forward and data gradient as 3 x bf16-split products on the bf16 matrix pipe (fp32-class '
-                       'accuracy, ~1e-6 relative per product), weight gradient on the library.  Same as CFL_X3CONV=1'),
+    'client_conv_x3': (dict(type=int, default=1, choices=[0, 1]),
+                       '1 (default) = the 3 x 3 / stride-1 convolutions of the clients\' fp32 channels_last image encoders (16 of '
+                       'ResNet-18\'s 20) on csrc/conv3x3_x3.hip: forward and data gradient as 3 x bf16-split products on the bf16 matrix '
+                       'pipe -- 16 mantissa bits per operand, outputs within 5e-6 of scale of fp64 (the library\'s fp32 kernels: 5e-7; '
+                       'TF32, cuDNN\'s default for fp32 convolutions on A100-class GPUs: 10 bits); the client trains to the same '
+                       'weights within the bounds the layout change is held to (tests/test_gpu_framework.py); weight gradient on the '
+                       'library.  Image client 20.7 -> 15.8 ms per contrast step.  0 = every convolution on the library\'s fp32 kernels'),
     'miopen_immediate': (dict(type=int, default=0, choices=[0, 1]),
                          '1 = MIOpen immediate mode (no solver timing in the first step of every process: seconds instead of ~1 min); '
                          'only for the convolution shapes the shipped / recorded find-db holds -- other shapes silently get a '

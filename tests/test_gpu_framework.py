@@ -857,17 +857,26 @@ def test_image_client_layouts_train_the_same(dev):
     g_img = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
     g_txt = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=-1).to(dev)
 
-    def run(cl, bf16):
+    def run(cl, bf16, x3=0):
+        from creamfl_amd import ops
         args = SimpleNamespace(feature_dim=D, mlp_local=False, local_epochs=1, contrast_local_intra=True, contrast_local_inter=True,
                                interintra_weight=0.5, loss_scale=False, save_client=False, client_graph=0, client_channels_last=cl,
-                               client_bf16=bf16)
-        t = ClientTrainer(args, 'Cifar100', None, None, None, None, None, global_test_set=None, client_id=0, gpuid=str(dev))
-        t.train_loader = None
-        t.cur_epoch = 0
-        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
-            t.run(g_img, g_txt, list(range(M)), batches)
-            vec, _ = t.generate_logits(batches)
-        torch.cuda.synchronize()
+                               client_bf16=bf16, client_conv_x3=x3)
+        was = ops.X3CONV[0]
+        ops.X3CONV[0] = False
+        taken = ops.X3CONV_TAKEN[0]
+        try:
+            t = ClientTrainer(args, 'Cifar100', None, None, None, None, None, global_test_set=None, client_id=0, gpuid=str(dev))
+            assert ops.X3CONV[0] == bool(x3)
+            t.train_loader = None
+            t.cur_epoch = 0
+            with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+                t.run(g_img, g_txt, list(range(M)), batches)
+                vec, _ = t.generate_logits(batches)
+            torch.cuda.synchronize()
+            assert (ops.X3CONV_TAKEN[0] > taken) == bool(x3)
+        finally:
+            ops.X3CONV[0] = was
         first = next(t.model.parameters())
         assert first.is_contiguous(memory_format=torch.channels_last) == bool(cl or bf16) or first.dim() != 4
         sd = {k: v.detach().float().cpu() for k, v in t.model.state_dict().items() if v.is_floating_point()}
@@ -883,6 +892,14 @@ def test_image_client_layouts_train_the_same(dev):
         assert float((cl[k] - v).abs().max()) <= 1e-3 * scale + 1e-6, k
     assert abs(loss_bf - loss_ref) <= 3e-2 * abs(loss_ref) and np.isfinite(loss_bf), (loss_bf, loss_ref)
     assert float((rep_bf - rep_ref).abs().max()) <= 5e-2
+    # round 6: the 3 x 3 / stride-1 convolutions on csrc/conv3x3_x3.hip (3 x bf16-split products, 16 mantissa bits per operand):
+    # held to the SAME bounds as the layout change above -- it is an fp32-class path, not a reduced-precision one
+    x3, loss_x3, rep_x3 = run(1, 0, x3=1)
+    assert abs(loss_x3 - loss_ref) <= 1e-4 * abs(loss_ref) + 1e-5, (loss_x3, loss_ref)
+    assert float((rep_x3 - rep_ref).abs().max()) <= 1e-3
+    for k, v in ref.items():
+        scale = float(v.abs().max()) + 1e-12
+        assert float((x3[k] - v).abs().max()) <= 1e-3 * scale + 1e-6, k
 
 
 @pytest.mark.gpu

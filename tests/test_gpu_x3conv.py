@@ -27,7 +27,10 @@ def _case(n, h, w, ci, co, seed):
 
 
 @pytest.mark.parametrize('n,h,w,ci,co,variant', [(2, 7, 7, 64, 64, 0), (3, 14, 14, 64, 128, 22), (1, 28, 28, 128, 128, 42), (5, 9, 13, 32, 64, 21),
-                                                 (4, 56, 56, 64, 64, 41), (1, 1, 1, 32, 64, 0), (2, 5, 3, 96, 192, 0), (16, 7, 7, 512, 512, 0)])
+                                                 (4, 56, 56, 64, 64, 41), (1, 1, 1, 32, 64, 0), (2, 5, 3, 96, 192, 0), (16, 7, 7, 512, 512, 0),
+                                                 (3, 14, 14, 64, 128, 122), (2, 28, 28, 128, 128, 142), (5, 9, 13, 32, 64, 121),
+                                                 (3, 56, 56, 64, 64, 141), (1, 1, 1, 32, 64, 121), (2, 5, 3, 96, 192, 121),
+                                                 (16, 7, 7, 512, 512, 122), (1, 63, 63, 32, 64, 121), (7, 7, 7, 64, 64, 141)])
 def test_x3conv_forward_matches_the_definition(dev, n, h, w, ci, co, variant):
     """y = conv2d(x, w, 1, 1) against fp64 on the same fp32 inputs: 1e-5 of the output's scale (a 3 x bf16-split product is ~1e-6
     relative; the library's fp32 Winograd kernels are ~1e-3 of scale); ragged position counts, every tile variant, single pixels."""

@@ -342,8 +342,9 @@ def case_x3conv(H, C, N=128):
     sc = float(ref.abs().max())
     out['library_fwd_relerr_vs_fp64'] = float((ylib.double() - ref).abs().max()) / sc
     M = N * H * H
-    for v in (22, 42, 21, 41):
-        if v in (22, 42) and C % 128:
+    VS = (22, 42, 21, 41, 122, 142, 121, 141)
+    for v in VS:
+        if v % 10 == 2 and C % 128:
             continue
         y = ops.conv3x3_x3_forward(x, w, v)
         out[f'x3_v{v}_relerr_vs_fp64'] = float((y[:2].double() - ref).abs().max()) / sc
@@ -354,7 +355,8 @@ def case_x3conv(H, C, N=128):
     wr = ops.conv3x3_x3_rotated(w)
     us, prof = timed(lambda: ops.conv3x3_x3_forward(dy, ops.conv3x3_x3_rotated(w)), iters=20)
     out['x3_dgrad_us_incl_weight_rotation'] = round(sum(v for v in prof.values() if v), 1)
-    best = min(out[f'x3_v{v}_fwd_us'] for v in (22, 42, 21, 41) if f'x3_v{v}_fwd_us' in out)
+    best = min(out[f'x3_v{v}_fwd_us'] for v in VS if f'x3_v{v}_fwd_us' in out)
+    out['best_variant'] = min((out[f'x3_v{v}_fwd_us'], v) for v in VS if f'x3_v{v}_fwd_us' in out)[1]
     out['speedup_fwd'] = round(out['library_fwd_us'] / best, 2)
     out['speedup_dgrad'] = round(out['library_dgrad_us'] / out['x3_dgrad_us_incl_weight_rotation'], 2)
     return out
