@@ -225,9 +225,9 @@ def parse_args(argv=None):
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI, one GPU per rank (the measurement); gloo = smoke mode of the multi-rank path '
                          'on however many GPUs are visible (ranks share them, collectives through host memory)')
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--no-alone', action='store_true', help='skip the 4 extra steps that measure the dominant kernel with the auxiliary streams off')
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (pairs)')
     ap.add_argument('--dim', type=int, default=512)
     ap.add_argument('--cnn', default='resnet101')

@@ -292,6 +292,200 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3s_kernel(const float* __res
         }
 }
 
+// ---- version 3: nothing but reads and MFMAs inside a tap -------------------------------------------------------------------------
+// Version 2 runs at ~0.3 of the matrix pipe although its bytes are few: a tap's 24 MFMAs (768 pipe cycles) sit among ~350 other
+// instructions of the same wave -- 77 v_cndmask (zeroing the fragments whose shifted position leaves the image, and the weight
+// staging's bounds), 50 VALU for splitting the weight tile again in every workgroup and tap, shift / swizzle address arithmetic, 27
+// waits.  Here:
+//   * the WEIGHT is split ONCE per call by cfl_conv3x3_wimage_kernel into an image that is byte for byte the LDS stage
+//     ([tap][chunk][co] rows of [32 hi | 32 lo], 16-byte pieces XOR-swizzled): staging a tap's tile is 16-byte loads and 16-byte
+//     LDS stores, no VALU;
+//   * the slab rows are 144 bytes (128 + 16 padding: conflict-free ds_read_b128 without a swizzle), so a fragment address is
+//     row * 144 + constant, and a lane's NINE row addresses (one per tap) are computed once per workgroup -- a tap whose shifted
+//     position leaves the image points at a row of zeros instead (no select in the loop);
+//   * the nine taps of a chunk are unrolled: per tap 16 ds_read_b128, 2-4 global loads + LDS stores for the next tap's weights,
+//     one barrier.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __restrict__ x, const char* __restrict__ wimg, float* __restrict__ y,
+                                                               int N, int H, int W, int Ci, int Co) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, NJ = (BM + 128) / 32, NB = BN / 32, PITCH = 144;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* slab = reinterpret_cast<char*>(lds_f);
+    const long long M = (long long)N * H * W;
+    const int ntc = Co / BN, ntr = (int)((M + BM - 1) / BM);
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const long long row0 = (long long)ti * BM;
+    const int col0 = tj * BN;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
+    const int kq = t & 7, i32 = lane & 31, hh = lane >> 5;
+    const int halo = W + 1;
+    const int nj = (BM + 2 * halo + 31) / 32;                 // 32-row groups of the slab actually used (<= NJ)
+    const int zrow = nj * 32;                                 // a row of zeros behind the slab
+    char* const bst = slab + (nj * 32 + 1) * PITCH;           // two weight stages of BN rows behind it (16-byte aligned: 144 = 9 x 16)
+
+    // a lane's fragment row per tap (byte offset into the slab, lane half included)
+    int aoff[TM][9];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int rl = (wr * TM + m) * 32 + i32;
+        const long long r = row0 + rl;
+        int h = -4, ww = -4;                                  // (rows behind the tensor: every tap invalid)
+        if (r < M) {
+            const int hw = (int)(r % ((long long)H * W));
+            h = hw / W; ww = hw % W;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const bool ok = (unsigned)(h + kh - 1) < (unsigned)H && (unsigned)(ww + kw - 1) < (unsigned)W;
+            aoff[m][tap] = (ok ? rl + halo + (kh - 1) * W + (kw - 1) : zrow) * PITCH + hh * 16;
+        }
+    }
+    int boff[TN][4];                                          // weight fragments: hi kk = 0, 1, lo kk = 0, 1
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int rb = (wc * TN + n) * 32 + i32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) boff[n][j] = x3::soff(rb, (j >> 1) * 4 + 2 * (j & 1) + hh);
+    }
+    const int nchunk = Ci / 32;
+    const long long wstep = (long long)Co * 128;              // bytes between the tiles of consecutive (tap, chunk) steps
+    const char* wsrc = wimg + (long long)col0 * 128 + t * 16;
+
+    f32x4 sreg[NJ], breg[NB];
+    auto load_slab = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < nj) {
+                const long long P = row0 - halo + j * 32 + (t >> 3);
+                const bool ok = P >= 0 && P < M;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (ok ? P : 0) * Ci + c * 32 + 4 * kq);
+                sreg[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < nj) {
+                const int rl = j * 32 + (t >> 3);
+                x3::bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a, b;
+                    x3::split1(sreg[j][e], a, b);
+                    hi[e] = a; lo[e] = b;
+                }
+                *reinterpret_cast<x3::bf16x4*>(slab + rl * PITCH + kq * 8) = hi;
+                *reinterpret_cast<x3::bf16x4*>(slab + rl * PITCH + 64 + kq * 8) = lo;
+            }
+        }
+    };
+    auto load_b = [&](int c, int tap) {                       // step (c, tap): tile of BN x 128 bytes, contiguous in the image
+        const char* src = wsrc + ((long long)tap * nchunk + c) * wstep;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) breg[i] = *reinterpret_cast<const f32x4*>(src + i * 4096);
+    };
+    auto store_b = [&](char* dst) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(dst + t * 16 + i * 4096) = breg[i];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    if (t < 9) *reinterpret_cast<f32x4*>(slab + zrow * PITCH + t * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_slab(0);
+    load_b(0, 0);
+    store_slab();
+    store_b(bst);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const bool next_chunk = c + 1 < nchunk;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int par = (c + tap) & 1;                    // 9 taps per chunk: the stage parity alternates across chunks too
+            const char* sb = bst + par * (BN * 128);
+            if (tap < 8) load_b(c, tap + 1);
+            else if (next_chunk) load_b(c + 1, 0);
+            if (tap == 6 && next_chunk) load_slab(c + 1);
+            __builtin_amdgcn_sched_barrier(0);                // (the loads stay in front of the tap's MFMAs: their latency hides there)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                x3::bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    ah[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + kk * 32);
+                    al[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + 64 + kk * 32);
+                }
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    bh[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][kk]);
+                    bl[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][2 + kk]);
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap < 8 || next_chunk) store_b(bst + (par ^ 1) * (BN * 128));
+            if (tap == 8 && next_chunk) {
+                __syncthreads();                              // every wave is done with this chunk's slab
+                store_slab();
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int j = col0 + acc_col<TN>(wc, n, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long i = row0 + acc_row<TM>(wr, m, r, lane);
+                if (i < M) y[i * Co + j] = acc[m][n][r];
+            }
+        }
+}
+
+// The weight image of version 3: img[((tap * (Ci / 32) + c) * Co + co) * 128 bytes] = the 128-byte LDS row of output channel co for
+// the 32 input channels of chunk c at that tap: [32 hi | 32 lo] bf16 with the 16-byte pieces XOR-swizzled as x3::soff does for row
+// co (tiles start at multiples of 64, so the tile-local row and co agree in the bits the swizzle reads).  One thread per 4 channels.
+__global__ __launch_bounds__(256) void cfl_conv3x3_wimage_kernel(const float* __restrict__ w, int Ci, int Co, char* __restrict__ img) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // over [Co][9][Ci / 4]
+    const int q4 = Ci / 4;
+    if (i >= (long long)Co * 9 * q4) return;
+    const int co = (int)(i / (9 * q4)), rem = (int)(i % (9 * q4)), tap = rem / q4, ci = (rem % q4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w + ((long long)co * 9 + tap) * Ci + ci);
+    x3::bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 a, b;
+        x3::split1(v[e], a, b);
+        hi[e] = a; lo[e] = b;
+    }
+    const int c = ci >> 5, k = ci & 31;                       // chunk, channel inside it; piece k >> 3 (hi) / 4 + (k >> 3) (lo)
+    char* row = img + (((long long)tap * (Ci >> 5) + c) * Co + co) * 128;
+    const int sw = (co >> 1) & 7;
+    *reinterpret_cast<x3::bf16x4*>(row + (((k >> 3) ^ sw) << 4) + (k & 7) * 2) = hi;
+    *reinterpret_cast<x3::bf16x4*>(row + (((4 + (k >> 3)) ^ sw) << 4) + (k & 7) * 2) = lo;
+}
+
 // wr[ci][kh][kw][co] = w[co][2 - kh][2 - kw][ci]   (both [out][3][3][in] in memory: the channels_last weight layout)
 __global__ __launch_bounds__(256) void cfl_conv3x3_rot_kernel(const float* __restrict__ w, int Ci, int Co, float* __restrict__ wr) {
     __shared__ float tile[32][33];
@@ -358,6 +552,56 @@ extern "C" int cfl_conv3x3_x3_fwd(const float* x, const float* w, int N, int H, 
     }
 #undef CFL_X3CONV
 #undef CFL_X3CONVS
+    return 0;
+}
+
+extern "C" size_t cfl_conv3x3_x3_wimage_bytes(int Ci, int Co) {
+    return (Ci > 0 && Co > 0 && Ci % 32 == 0) ? cfl_align256((size_t)9 * Ci * Co * 4) : 0;
+}
+
+extern "C" int cfl_conv3x3_x3_wimage(const float* w, int Ci, int Co, void* img, void* stream_) {
+    if (!w || !img || Ci <= 0 || Co <= 0) return CFL_EINVAL;
+    if (Ci % 32 != 0 || Co % 64 != 0 || (((uintptr_t)w | (uintptr_t)img) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long n = (long long)Co * 9 * (Ci / 4);
+    CFL_LAUNCH(K_TRANSPOSE, cfl_conv3x3_wimage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Ci, Co, (char*)img);
+    return 0;
+}
+
+// variant: 0 = chosen here; 2MN = TM = M, TN = N (222, 242, 221, 241, 212, 211)
+extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, int H, int W, int Ci, int Co, float* y, int variant,
+                                      void* stream_) {
+    if (!x || !wimg || !y) return CFL_EINVAL;
+    if (!x3conv_ok(N, H, W, Ci, Co) || W > 63 || (((uintptr_t)x | (uintptr_t)wimg | (uintptr_t)y) & 15)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long M = (long long)N * H * W;
+    const bool bn128 = Co % 128 == 0;
+    if (variant == 0) {
+        // the largest tile that still leaves ~2 workgroups per CU (256 CUs)
+        const int tn = bn128 ? 2 : 1;
+        const long long per64 = (M + 63) / 64 * (Co / (64 * tn));
+        variant = 200 + 10 * (per64 / 4 >= 512 ? 4 : (per64 / 2 >= 512 ? 2 : 1)) + tn;
+        if (variant / 10 % 10 == 4 && tn == 2) variant = 222;                 // (4 x 2 holds 128 accumulators: one wave per SIMD)
+    }
+#define CFL_X3CONVP(TM_, TN_)                                                                                                  \
+    do {                                                                                                                       \
+        constexpr int BM_ = 64 * TM_, BN_ = 64 * TN_;                                                                          \
+        const int LDS_ = (((BM_ + 2 * (W + 1) + 31) / 32) * 32 + 1) * 144 + 2 * BN_ * 128;                                     \
+        const int grid = (int)((M + BM_ - 1) / BM_) * (Co / BN_);                                                              \
+        CFL_SET_LDS((cfl_conv3x3_x3p_kernel<TM_, TN_>), (BM_ + 128 + 1) * 144 + 2 * BN_ * 128);                                \
+        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3p_kernel<TM_, TN_>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, H, W, \
+                   Ci, Co);                                                                                                    \
+    } while (0)
+    switch (variant) {
+        case 222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2); break;
+        case 242: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(4, 2); break;
+        case 212: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(1, 2); break;
+        case 221: CFL_X3CONVP(2, 1); break;
+        case 241: CFL_X3CONVP(4, 1); break;
+        case 211: CFL_X3CONVP(1, 1); break;
+        default: return CFL_EINVAL;
+    }
+#undef CFL_X3CONVP
     return 0;
 }
 

@@ -1504,6 +1504,10 @@ def _conv_wgrad(args):
         g = conv1x1_wgrad(dy, x, w)
         if g is not None:
             return g
+    if X3CONV[0] and X3WGRAD[0] and w.dtype == torch.float32 and w.shape[2] == 3 and w.shape[3] == 3 and args[4][0] == 1 and args[5][0] == 1:
+        g = conv3x3_x3_wgrad(dy, x, w)
+        if g is not None:
+            return g
     cov = _fdb_covered('W', x, w, dy.shape, args[4][0], args[5][0])
     return _miopen(cov, torch.ops.aten.convolution_backward, *args, [False, True, False])[1]
 
@@ -1529,11 +1533,19 @@ def conv3x3_x3_supported(x, w, stride, padding):
 
 def conv3x3_x3_forward(x, w, variant=0):
     """conv2d(x, w, stride 1, padding 1) for fp32 channels_last x [N, Ci, H, W] and w [Co, Ci, 3, 3] (csrc/conv3x3_x3.hip); no
-    autograd (the Functions that own the convolutions call it for their forward and, on the rotated weight, their data gradient)."""
+    autograd (the Functions that own the convolutions call it for their forward and, on the rotated weight, their data gradient).
+    variant 0 / 2xx: version 3 (the weight split once into an image of the kernel's LDS stage; maps up to 63 wide); 21 .. 142: the
+    earlier kernels (any width)."""
     N, Ci, H, W = x.shape
     Co = w.shape[0]
+    lib = _lib.load()
     y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _lib.check(_lib.load().cfl_conv3x3_x3_fwd(_ptr(x), _ptr(w), N, H, W, Ci, Co, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd')
+    if (variant == 0 or variant >= 200) and W <= 63:
+        img = _ws(lib.cfl_conv3x3_x3_wimage_bytes(Ci, Co), x.device)
+        _lib.check(lib.cfl_conv3x3_x3_wimage(_ptr(w), Ci, Co, _ptr(img), _stream(x)), 'cfl_conv3x3_x3_wimage')
+        _lib.check(lib.cfl_conv3x3_x3_fwd_img(_ptr(x), _ptr(img), N, H, W, Ci, Co, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd_img')
+    else:
+        _lib.check(lib.cfl_conv3x3_x3_fwd(_ptr(x), _ptr(w), N, H, W, Ci, Co, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd')
     X3CONV_TAKEN[0] += 1
     return y
 
@@ -1544,6 +1556,36 @@ def conv3x3_x3_rotated(w):
     wr = torch.empty((Ci, Co, 3, 3), dtype=torch.float32, device=w.device, memory_format=torch.channels_last)
     _lib.check(_lib.load().cfl_conv3x3_x3_rot_weight(_ptr(w), Ci, Co, _ptr(wr), _stream(w)), 'cfl_conv3x3_x3_rot_weight')
     return wr
+
+
+# ... and their WEIGHT gradient on csrc/wgrad3x3_x3.hip (H = W in {7, 14, 28, 56}, channel counts multiples of 64: the thirteen stride-1
+# BasicBlock convolutions of ResNet-18).  CFL_NO_X3WGRAD=1 leaves it on the library while the forward / data gradient stay here.
+X3WGRAD = [_os.environ.get('CFL_NO_X3WGRAD', '0') != '1']
+X3WGRAD_TAKEN = [0]
+
+
+def conv3x3_x3_wgrad(dy, x, weight):
+    """dW of y = conv2d(x, weight, stride 1, padding 1) for a 3 x 3 weight, all fp32 channels_last, products as 3 x bf16-split MFMAs
+    (csrc/wgrad3x3_x3.hip).  None when the shape / layout is not taken (the caller goes to the library)."""
+    if not (weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3 and x.dim() == 4 and dy.dim() == 4):
+        return None
+    if not (dy.dtype == x.dtype == weight.dtype == torch.float32 and x.is_cuda):
+        return None
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    if tuple(dy.shape) != (N, Co, H, W) or weight.shape[1] != Ci:
+        return None
+    lib = _lib.load()
+    if not lib.cfl_conv3x3_x3_wgrad_supported(N, H, W, Ci, Co):
+        return None
+    cl = torch.channels_last
+    if not (x.is_contiguous(memory_format=cl) and dy.is_contiguous(memory_format=cl) and weight.is_contiguous(memory_format=cl)):
+        return None
+    dw = torch.empty_like(weight)                                        # [Co][3][3][Ci] in memory, as the weight
+    ws = _ws(lib.cfl_conv3x3_x3_wgrad_ws_bytes(N, H, W, Ci, Co), x.device)
+    _lib.check(lib.cfl_conv3x3_x3_wgrad(_ptr(dy), _ptr(x), N, H, W, Ci, Co, _ptr(dw), _ptr(ws), _stream(x)), 'cfl_conv3x3_x3_wgrad')
+    X3WGRAD_TAKEN[0] += 1
+    return dw
 
 
 def _conv_dgrad(args):

@@ -217,6 +217,22 @@ int cfl_attn_small_bwd_varlen(const void* q, const void* k, const void* v, long 
 int cfl_conv3x3_x3_supported(int N, int H, int W, int Ci, int Co);
 int cfl_conv3x3_x3_fwd(const float* x, const float* w, int N, int H, int W, int Ci, int Co, float* y, int variant, void* stream);
 int cfl_conv3x3_x3_rot_weight(const float* w, int Ci, int Co, float* w_rot, void* stream);
+/* Version 3 of the forward kernel (W <= 63) takes the weight as an IMAGE of its own LDS stage, written once per call by
+ * cfl_conv3x3_x3_wimage: img[((tap * Ci/32 + c) * Co + co) * 128 B] = [32 hi | 32 lo] bf16 of w[co][tap][32 c .. 32 c + 31], 16-byte
+ * pieces XOR-swizzled by (co >> 1) & 7; cfl_conv3x3_x3_wimage_bytes(Ci, Co) bytes (= the fp32 weight's size).  variant 0 = chosen by
+ * the library, 2MN = a tile of 64 M positions x 64 N channels (222, 242, 221, 241, 212, 211).  Data gradient: image of the rotated weight. */
+size_t cfl_conv3x3_x3_wimage_bytes(int Ci, int Co);
+int cfl_conv3x3_x3_wimage(const float* w, int Ci, int Co, void* img, void* stream);
+int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, int H, int W, int Ci, int Co, float* y, int variant, void* stream);
+/* The weight gradient of the same convolutions (csrc/wgrad3x3_x3.hip; the reference: autograd through cuDNN's fp32 backward-filter,
+ * src/algorithms/ClientTrainer.py:420 loss.backward()): dw[co,kh,kw,ci] = sum over (n,h,w) dy[n,h,w,co] x[n,h+kh-1,w+kw-1,ci], fp32 in
+ * and out, products as three bf16 MFMAs on operands split while they are staged.  H = W in {7, 14, 28, 56}, Ci % 64 == 0,
+ * Co % 64 == 0; split-K over row ranges into fp32 partials in ws (cfl_conv3x3_x3_wgrad_ws_bytes) + a fixed-order reduce:
+ * deterministic.  cfl_conv3x3_x3_wgrad_splits(n > 0) overrides the number of row ranges (0 = default; returns the old value). */
+int cfl_conv3x3_x3_wgrad_supported(int N, int H, int W, int Ci, int Co);
+size_t cfl_conv3x3_x3_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
+int cfl_conv3x3_x3_wgrad(const float* dy, const float* x, int N, int H, int W, int Ci, int Co, float* dw, void* ws, void* stream);
+int cfl_conv3x3_x3_wgrad_splits(int splits);
 
 /* ---- ResNet stem max pooling, 3x3 / stride 2 / pad 1, NHWC bf16 ---------------------------------------------------
  * torchvision ResNet.maxpool of the trunk built at src/networks/models/image_encoder.py:27-36 (and the client trunk,

@@ -342,19 +342,44 @@ def case_x3conv(H, C, N=128):
     sc = float(ref.abs().max())
     out['library_fwd_relerr_vs_fp64'] = float((ylib.double() - ref).abs().max()) / sc
     M = N * H * H
-    VS = (22, 42, 21, 41, 122, 142, 121, 141)
+    VS = (122, 142, 121, 141, 222, 242, 212, 221, 241, 211, 0)
     for v in VS:
         if v % 10 == 2 and C % 128:
             continue
         y = ops.conv3x3_x3_forward(x, w, v)
         out[f'x3_v{v}_relerr_vs_fp64'] = float((y[:2].double() - ref).abs().max()) / sc
         us, prof = timed(lambda: ops.conv3x3_x3_forward(x, w, v), iters=20)
-        k = prof.get('cfl_conv3x3_x3_kernel', us)
+        k = prof.get('cfl_conv3x3_x3_kernel', us)                   # (version 3: without the weight-image launch, ~3 us)
         out[f'x3_v{v}_fwd_us'] = k
         out[f'x3_v{v}_TFLOPs_fp32_equivalent'] = round(flop / k / 1e6)
     wr = ops.conv3x3_x3_rotated(w)
     us, prof = timed(lambda: ops.conv3x3_x3_forward(dy, ops.conv3x3_x3_rotated(w)), iters=20)
     out['x3_dgrad_us_incl_weight_rotation'] = round(sum(v for v in prof.values() if v), 1)
+    dwl = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    dw = ops.conv3x3_x3_wgrad(dy, x, w)
+    if dw is not None:
+        # errors against fp64 (CPU) on the first four images
+        xs, dys = x[:4].contiguous(memory_format=cl), dy[:4].contiguous(memory_format=cl)
+        ref64 = torch.ops.aten.convolution_backward(dys.double().cpu(), xs.double().cpu(), w.double().cpu(), None, [1, 1], [1, 1], [1, 1], False,
+                                                    [0, 0], 1, [False, True, False])[1]
+        sc64 = float(ref64.abs().max())
+        out['x3_wgrad_relerr_vs_fp64'] = float((ops.conv3x3_x3_wgrad(dys, xs, w).double().cpu() - ref64).abs().max()) / sc64
+        dwl4 = torch.ops.aten.convolution_backward(dys, xs, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        out['library_wgrad_relerr_vs_fp64'] = float((dwl4.double().cpu() - ref64).abs().max()) / sc64
+        out['x3_vs_library_wgrad_full_batch'] = float((dw - dwl).abs().max() / dwl.abs().max())
+        us, prof = timed(lambda: ops.conv3x3_x3_wgrad(dy, x, w), iters=20)
+        out['x3_wgrad_kernel_us'] = prof.get('cfl_conv3x3_x3_wgrad_kernel')
+        out['x3_wgrad_reduce_us'] = prof.get('cfl_conv3x3_x3_wgrad_reduce_kernel')
+        out['x3_wgrad_us'] = round(sum(v for v in prof.values() if v), 1)
+        out['speedup_wgrad'] = round(out['library_wgrad_us'] / out['x3_wgrad_us'], 2)
+        lib = ops._lib.load()
+        for sp in (64, 128, 256, 512):
+            old = lib.cfl_conv3x3_x3_wgrad_splits(sp)
+            try:
+                us, prof = timed(lambda: ops.conv3x3_x3_wgrad(dy, x, w), iters=10)
+            finally:
+                lib.cfl_conv3x3_x3_wgrad_splits(old)
+            out[f'x3_wgrad_splits{sp}_us'] = [prof.get('cfl_conv3x3_x3_wgrad_kernel'), prof.get('cfl_conv3x3_x3_wgrad_reduce_kernel')]
     best = min(out[f'x3_v{v}_fwd_us'] for v in VS if f'x3_v{v}_fwd_us' in out)
     out['best_variant'] = min((out[f'x3_v{v}_fwd_us'], v) for v in VS if f'x3_v{v}_fwd_us' in out)[1]
     out['speedup_fwd'] = round(out['library_fwd_us'] / best, 2)
