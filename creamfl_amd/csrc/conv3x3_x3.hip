@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
             const char* sb = bst + par * (BN * 128);
             if (tap < 8) load_b(c, tap + 1);
             else if (next_chunk) load_b(c + 1, 0);
-            if (tap == 6 && next_chunk) load_slab(c + 1);
+            if (tap == 1 && next_chunk) load_slab(c + 1);      // (first touch of these bytes: an HBM round trip, ~7 taps away)
             __builtin_amdgcn_sched_barrier(0);                // (the loads stay in front of the tap's MFMAs: their latency hides there)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -577,11 +577,9 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
     const long long M = (long long)N * H * W;
     const bool bn128 = Co % 128 == 0;
     if (variant == 0) {
-        // the largest tile that still leaves ~2 workgroups per CU (256 CUs)
-        const int tn = bn128 ? 2 : 1;
-        const long long per64 = (M + 63) / 64 * (Co / (64 * tn));
-        variant = 200 + 10 * (per64 / 4 >= 512 ? 4 : (per64 / 2 >= 512 ? 2 : 1)) + tn;
-        if (variant / 10 % 10 == 4 && tn == 2) variant = 222;                 // (4 x 2 holds 128 accumulators: one wave per SIMD)
+        // measured at the four BasicBlock shapes of ResNet-18, batch 128 (profiles/r6_x3conv_probe_v3.jsonl): 128 positions x 128
+        // channels where the channel count allows, x 64 otherwise; 64- and 256-position tiles lose 5-30 %
+        variant = bn128 ? 222 : 221;
     }
 #define CFL_X3CONVP(TM_, TN_)                                                                                                  \
     do {                                                                                                                       \

@@ -12,8 +12,8 @@
 // ds_read_b64_tr_b16, the zero padding of a row supplied by zero columns of the padded row, split-K with the tiles of one range on
 // one XCD, fp32 partials + a fixed-order reduce: deterministic) with two differences that the fp32 operands force:
 //   * an fp32 element cannot go to LDS by DMA and be split on the way, so rows are staged through registers: a thread loads 16-byte
-//     pieces of the row two rows ahead at the top of a row, and at the top of the NEXT row splits them (x = hi + lo, two bf16) and
-//     writes the hi and lo planes of that row's LDS slot -- plain HIP, the compiler's counted vmcnt waits are the pipeline;
+//     pieces of rows ahead at the top of a row (two register sets: two rows in flight), and two rows later splits them (x = hi + lo,
+//     two bf16) and writes the hi and lo planes of that row's LDS slot -- plain HIP, the compiler's counted vmcnt waits are the pipeline;
 //   * each (dY row, X shift) pair is three MFMAs into one accumulator: hi.hi + lo.hi + hi.lo (dropped term: 2^-16 relative).
 // A workgroup is 4 waves = 64 dY channels x 64 X channels x 9 taps (144 accumulator registers per lane), 27 MFMAs per fragment set
 // of 12 (the bf16 kernel: 9 per 6), so the matrix pipe sees three times the work per staged byte.
@@ -102,21 +102,24 @@ __global__ __launch_bounds__(256, OCC) void cfl_conv3x3_x3_wgrad_kernel(const fl
         py[i] = dy + p * Co + co0 + 4 * c4;
     }
     const long long stepX = (long long)W * Ci, stepY = (long long)W * Co;
-    f32x4 rx[NL], ry[NL];
+    // TWO register sets alternate: the loads of rows g + 2 and g + 3 are both in flight while row g is computed (a row's compute is
+    // 0.4-1.4 us, an HBM round trip under load ~2 us: with one set the kernel ran at one row per round trip, 100-110 us at every shape)
+    struct Regs { f32x4 x[NL], y[NL]; };
+    Regs RA, RB;
     int gl = g0 - 1;                                          // the row the pointers stand on
-    auto load_row = [&]() {                                   // rows are loaded in order: g0 - 1, g0, ...
+    auto load_row = [&](Regs& R) {                            // rows are loaded in order: g0 - 1, g0, ...
         const bool in = gl >= 0 && gl < TR;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const bool ok = in && st_ok[i];
-            rx[i] = ok ? *reinterpret_cast<const f32x4*>(px[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
-            ry[i] = ok ? *reinterpret_cast<const f32x4*>(py[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.x[i] = ok ? *reinterpret_cast<const f32x4*>(px[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.y[i] = ok ? *reinterpret_cast<const f32x4*>(py[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
             px[i] += stepX;
             py[i] += stepY;
         }
         ++gl;
     };
-    auto store_row = [&](int g) {                             // the registers hold row g
+    auto store_row = [&](const Regs& R, int g) {              // the registers hold row g
         char* s = xwlds + (g & 3) * C::SLOT;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(256, OCC) void cfl_conv3x3_x3_wgrad_kernel(const fl
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 __bf16 a, bb;
-                x3::split1(rx[i][e], a, bb);
+                x3::split1(R.x[i][e], a, bb);
                 xh[e] = a; xl[e] = bb;
-                x3::split1(ry[i][e], a, bb);
+                x3::split1(R.y[i][e], a, bb);
                 yh[e] = a; yl[e] = bb;
             }
             *reinterpret_cast<x3::bf16x4*>(s + st_off[i]) = xh;
@@ -193,18 +196,28 @@ __global__ __launch_bounds__(256, OCC) void cfl_conv3x3_x3_wgrad_kernel(const fl
     };
 
     if (g0 < g1) {
-        load_row(); store_row(g0 - 1);
-        load_row(); store_row(g0);
-        load_row(); store_row(g0 + 1);
-        load_row();                                           // row g0 + 2 waits in registers
+        load_row(RA); store_row(RA, g0 - 1);
+        load_row(RA); store_row(RA, g0);
+        load_row(RA); store_row(RA, g0 + 1);
+        load_row(RA);                                         // rows g0 + 2, g0 + 3 wait in registers
+        load_row(RB);
         __syncthreads();
         int h = g0 % H;
-        for (int g = g0; g < g1; ++g) {
-            store_row(g + 2);                                 // slot of row g - 2: last read during row g - 1
-            load_row();                                       // row g + 3: consumed at the top of the next row
+        for (int g = g0; g < g1; g += 2) {
+            store_row(RA, g + 2);                             // slot of row g - 2: last read during row g - 1
+            load_row(RA);                                     // row g + 4
+            __builtin_amdgcn_sched_barrier(0);
             row(g, h == 0, h == H - 1);
             h = h + 1 == H ? 0 : h + 1;
             __syncthreads();
+            if (g + 1 < g1) {
+                store_row(RB, g + 3);
+                load_row(RB);                                 // row g + 5
+                __builtin_amdgcn_sched_barrier(0);
+                row(g + 1, h == 0, h == H - 1);
+                h = h + 1 == H ? 0 : h + 1;
+                __syncthreads();
+            }
         }
     }
 
@@ -311,9 +324,9 @@ extern "C" int cfl_conv3x3_x3_wgrad(const float* dy, const float* x, int N, int 
     const int ns = xw_nsplit(N, H, Ci, Co);
     float* part = (float*)ws;
     int rc;
-    if (H == 7) rc = xw_launch<XWCfg<7, 7>, 1>(dy, x, N, Ci, Co, ns, part, stream);
-    else if (H == 14) rc = xw_launch<XWCfg<14, 14>, 1>(dy, x, N, Ci, Co, ns, part, stream);
-    else if (H == 28) rc = xw_launch<XWCfg<28, 28>, 1>(dy, x, N, Ci, Co, ns, part, stream);
+    if (H == 7) rc = xw_launch<XWCfg<7, 7>, 2>(dy, x, N, Ci, Co, ns, part, stream);
+    else if (H == 14) rc = xw_launch<XWCfg<14, 14>, 2>(dy, x, N, Ci, Co, ns, part, stream);
+    else if (H == 28) rc = xw_launch<XWCfg<28, 28>, 2>(dy, x, N, Ci, Co, ns, part, stream);
     else rc = xw_launch<XWCfg<56, 56>, 1>(dy, x, N, Ci, Co, ns, part, stream);
     if (rc) return rc;
     const long long n = (long long)Co * 9 * Ci;

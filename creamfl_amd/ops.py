@@ -1514,7 +1514,7 @@ def _conv_wgrad(args):
 
 # Round 6: the 3 x 3 / stride 1 / padding 1 convolutions of fp32 channels_last tensors (the clients' ResNet-18 BasicBlocks: 16 of its
 # 20 convolutions) on csrc/conv3x3_x3.hip -- fp32-class accuracy on the bf16 matrix pipe (3 x bf16 split), forward and data gradient;
-# the weight gradient stays on the library.  `--client_conv_x3` (creamfl_amd/flags.py) / CFL_X3CONV=1 switch it on.
+# the weight gradient: conv3x3_x3_wgrad below.  `--client_conv_x3` (creamfl_amd/flags.py) / CFL_X3CONV=1 switch it on.
 X3CONV = [_os.environ.get('CFL_X3CONV', '0') == '1']
 X3CONV_TAKEN = [0]
 
