@@ -305,7 +305,9 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3s_kernel(const float* __res
 //     position leaves the image points at a row of zeros instead (no select in the loop);
 //   * the nine taps of a chunk are unrolled: per tap 16 ds_read_b128, 2-4 global loads + LDS stores for the next tap's weights,
 //     one barrier.
-template <int TM, int TN>
+// DBG (measurements only, results are wrong): 1 no weight staging in the loop, 2 no per-tap barrier, 3 no MFMAs, 4 no fragment reads,
+// 6 no slab staging in the loop
+template <int TM, int TN, int DBG = 0>
 __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __restrict__ x, const char* __restrict__ wimg, float* __restrict__ y,
                                                                int N, int H, int W, int Ci, int Co) {
     constexpr int BM = 64 * TM, BN = 64 * TN, NJ = (BM + 128) / 32, NB = BN / 32, PITCH = 144;
@@ -391,6 +393,15 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(dst + t * 16 + i * 4096) = breg[i];
     };
+    // DBG = 5 (a real form: results are right): the weight tile of the next step goes to LDS by DMA (global_load_lds_dwordx4: the image
+    // is the stage byte for byte, wave w moves kilobytes w, w + 4, ...) -- no staging registers, no ds_write; issued behind the step's
+    // fragment reads (the compiler orders every LDS read behind every LDS-DMA it knows of), landed at the step's closing barrier
+    auto dma_b = [&](int c, int tap, char* dst) {
+        const char* src = wimg + (long long)col0 * 128 + ((long long)tap * nchunk + c) * wstep + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vptr)(src + (wid + 4 * i) * 1024), (lds_vptr)(dst + (wid + 4 * i) * 1024), 16, 0, 0);
+    };
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -411,43 +422,94 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
         for (int tap = 0; tap < 9; ++tap) {
             const int par = (c + tap) & 1;                    // 9 taps per chunk: the stage parity alternates across chunks too
             const char* sb = bst + par * (BN * 128);
-            if (tap < 8) load_b(c, tap + 1);
-            else if (next_chunk) load_b(c + 1, 0);
-            if (tap == 1 && next_chunk) load_slab(c + 1);      // (first touch of these bytes: an HBM round trip, ~7 taps away)
+            if (DBG != 1 && DBG != 5) {
+                if (tap < 8) load_b(c, tap + 1);
+                else if (next_chunk) load_b(c + 1, 0);
+            }
+            if (DBG != 6 && tap == 1 && next_chunk) load_slab(c + 1);      // (first touch of these bytes: an HBM round trip, ~7 taps away)
             __builtin_amdgcn_sched_barrier(0);                // (the loads stay in front of the tap's MFMAs: their latency hides there)
+            if (DBG == 5) {
+                x3::bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) {
+                        ah[kk][m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + kk * 32);
+                        al[kk][m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + 64 + kk * 32);
+                    }
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        bh[kk][n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][kk]);
+                        bl[kk][n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][2 + kk]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < 8) dma_b(c, tap + 1, bst + (par ^ 1) * (BN * 128));
+                else if (next_chunk) dma_b(c + 1, 0, bst + (par ^ 1) * (BN * 128));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][m], bh[kk][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk][m], bh[kk][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][m], bl[kk][n], acc[m][n], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 x3::bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+                if (DBG == 4) {
 #pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    ah[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + kk * 32);
-                    al[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + 64 + kk * 32);
+                    for (int m = 0; m < TM; ++m) { ah[m] = __builtin_bit_cast(x3::bf16x8, sreg[0]); al[m] = ah[m]; }
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) { bh[n] = __builtin_bit_cast(x3::bf16x8, breg[0]); bl[n] = bh[n]; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) {
+                        ah[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + kk * 32);
+                        al[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + 64 + kk * 32);
+                    }
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        bh[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][kk]);
+                        bl[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][2 + kk]);
+                    }
                 }
+                if (DBG == 3) {
 #pragma unroll
-                for (int n = 0; n < TN; ++n) {
-                    bh[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][kk]);
-                    bl[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][2 + kk]);
+                    for (int m = 0; m < TM; ++m) asm volatile("" :: "v"(ah[m]), "v"(al[m]));
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) asm volatile("" :: "v"(bh[n]), "v"(bl[n]));
+                } else {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
                 }
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (tap < 8 || next_chunk) store_b(bst + (par ^ 1) * (BN * 128));
+            if (DBG != 1 && DBG != 5 && (tap < 8 || next_chunk)) store_b(bst + (par ^ 1) * (BN * 128));
             if (tap == 8 && next_chunk) {
                 __syncthreads();                              // every wave is done with this chunk's slab
-                store_slab();
+                if (DBG != 6) store_slab();
             }
-            __syncthreads();
+            if (DBG != 2 || tap == 8) __syncthreads();
         }
     }
 #pragma unroll
@@ -579,24 +641,33 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
     if (variant == 0) {
         // measured at the four BasicBlock shapes of ResNet-18, batch 128 (profiles/r6_x3conv_probe_v3.jsonl): 128 positions x 128
         // channels where the channel count allows, x 64 otherwise; 64- and 256-position tiles lose 5-30 %
-        variant = bn128 ? 222 : 221;
+        // ... and the weight tiles by LDS-DMA (5xx): 3-5 % at three of the four shapes (profiles/r6_x3conv_decomposition.jsonl)
+        variant = bn128 ? 522 : 521;
     }
-#define CFL_X3CONVP(TM_, TN_)                                                                                                  \
+#define CFL_X3CONVP(TM_, TN_, DBG_)                                                                                              \
     do {                                                                                                                       \
         constexpr int BM_ = 64 * TM_, BN_ = 64 * TN_;                                                                          \
         const int LDS_ = (((BM_ + 2 * (W + 1) + 31) / 32) * 32 + 1) * 144 + 2 * BN_ * 128;                                     \
         const int grid = (int)((M + BM_ - 1) / BM_) * (Co / BN_);                                                              \
-        CFL_SET_LDS((cfl_conv3x3_x3p_kernel<TM_, TN_>), (BM_ + 128 + 1) * 144 + 2 * BN_ * 128);                                \
-        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3p_kernel<TM_, TN_>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, H, W, \
-                   Ci, Co);                                                                                                    \
+        CFL_SET_LDS((cfl_conv3x3_x3p_kernel<TM_, TN_, DBG_>), (BM_ + 128 + 1) * 144 + 2 * BN_ * 128);                          \
+        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3p_kernel<TM_, TN_, DBG_>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, \
+                   H, W, Ci, Co);                                                                                              \
     } while (0)
     switch (variant) {
-        case 222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2); break;
-        case 242: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(4, 2); break;
-        case 212: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(1, 2); break;
-        case 221: CFL_X3CONVP(2, 1); break;
-        case 241: CFL_X3CONVP(4, 1); break;
-        case 211: CFL_X3CONVP(1, 1); break;
+        case 222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 0); break;
+        case 242: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(4, 2, 0); break;
+        case 212: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(1, 2, 0); break;
+        case 221: CFL_X3CONVP(2, 1, 0); break;
+        case 241: CFL_X3CONVP(4, 1, 0); break;
+        case 211: CFL_X3CONVP(1, 1, 0); break;
+        case 1222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 1); break;      // measurement forms of 222 (wrong results)
+        case 2222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 2); break;
+        case 3222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 3); break;
+        case 4222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 4); break;
+        case 6222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 6); break;
+        case 522: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 5); break;       // weight tiles by LDS-DMA
+        case 542: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(4, 2, 5); break;
+        case 521: CFL_X3CONVP(2, 1, 5); break;
         default: return CFL_EINVAL;
     }
 #undef CFL_X3CONVP

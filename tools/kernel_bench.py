@@ -314,7 +314,7 @@ def case_wgrad1(H, Ci, Co, N=256, wgs=(128,)):
     return out
 
 
-def case_x3conv(H, C, N=128):
+def case_x3conv(H, C, N=128, dbg=False):
     """3 x 3 / stride 1 convolution of fp32 channels_last tensors: csrc/conv3x3_x3.hip (3 x bf16 split on the bf16 matrix pipe) vs the
     library's fp32 kernels, forward and data gradient, at one BasicBlock shape of the clients' ResNet-18 (batch 128); errors of both
     against fp64 on two images."""
@@ -342,12 +342,13 @@ def case_x3conv(H, C, N=128):
     sc = float(ref.abs().max())
     out['library_fwd_relerr_vs_fp64'] = float((ylib.double() - ref).abs().max()) / sc
     M = N * H * H
-    VS = (122, 142, 121, 141, 222, 242, 212, 221, 241, 211, 0)
+    VS = (222, 242, 221, 241, 522, 542, 521, 0) + ((1222, 2222, 3222, 4222, 6222) if dbg else ())
     for v in VS:
         if v % 10 == 2 and C % 128:
             continue
         y = ops.conv3x3_x3_forward(x, w, v)
-        out[f'x3_v{v}_relerr_vs_fp64'] = float((y[:2].double() - ref).abs().max()) / sc
+        if v < 1000:
+            out[f'x3_v{v}_relerr_vs_fp64'] = float((y[:2].double() - ref).abs().max()) / sc
         us, prof = timed(lambda: ops.conv3x3_x3_forward(x, w, v), iters=20)
         k = prof.get('cfl_conv3x3_x3_kernel', us)                   # (version 3: without the weight-image launch, ~3 us)
         out[f'x3_v{v}_fwd_us'] = k
@@ -380,8 +381,8 @@ def case_x3conv(H, C, N=128):
             finally:
                 lib.cfl_conv3x3_x3_wgrad_splits(old)
             out[f'x3_wgrad_splits{sp}_us'] = [prof.get('cfl_conv3x3_x3_wgrad_kernel'), prof.get('cfl_conv3x3_x3_wgrad_reduce_kernel')]
-    best = min(out[f'x3_v{v}_fwd_us'] for v in VS if f'x3_v{v}_fwd_us' in out)
-    out['best_variant'] = min((out[f'x3_v{v}_fwd_us'], v) for v in VS if f'x3_v{v}_fwd_us' in out)[1]
+    best = min(out[f'x3_v{v}_fwd_us'] for v in VS if v < 1000 and f'x3_v{v}_fwd_us' in out)
+    out['best_variant'] = min((out[f'x3_v{v}_fwd_us'], v) for v in VS if v < 1000 and f'x3_v{v}_fwd_us' in out)[1]
     out['speedup_fwd'] = round(out['library_fwd_us'] / best, 2)
     out['speedup_dgrad'] = round(out['library_dgrad_us'] / out['x3_dgrad_us_incl_weight_rotation'], 2)
     return out
@@ -501,7 +502,7 @@ def main():
         out.append(rec)
     if 'x3conv' in cases:
         for H, C in ((28, 128), (56, 64), (14, 256), (7, 512)):
-            out.append(case_x3conv(H, C))
+            out.append(case_x3conv(H, C, dbg='x3dbg' in cases))
     if 'wgrad1' in cases:
         for (H, Ci, Co) in [(14, 1024, 256), (14, 256, 1024), (28, 512, 128), (28, 128, 512), (56, 256, 64), (56, 64, 256), (56, 64, 64),
                             (7, 2048, 512), (7, 512, 2048)]:
