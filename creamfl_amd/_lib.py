@@ -124,6 +124,8 @@ SIGNATURES = {
     'cfl_bn_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_pool_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'cfl_bn_pool_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    'cfl_bn_pool_fwd_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    'cfl_bn_pool_bwd_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'cfl_grad_clip_coef': (c_int, [_P, _P, c_int, c_float, _P, _P, _P]),
     'cfl_adamp_step': (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P, c_float, c_float, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int, _P, _P]),

@@ -130,10 +130,11 @@ __global__ __launch_bounds__(256) void cfl_bn_apply_kernel(const G* __restrict__
 //             the pixel, rounded to bf16 like the tensor the pool backward would have written) instead of loading it.
 struct __attribute__((aligned(8))) B8 { unsigned int lo, hi; };          // 8 tap indices (same record as pool.hip)
 
-__global__ __launch_bounds__(256) void cfl_bn_pool_fwd_kernel(const U4* __restrict__ x, const float* __restrict__ mean,
+template <class G>
+__global__ __launch_bounds__(256) void cfl_bn_pool_fwd_kernel(const G* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int N, int H, int W, int C8, int Ho,
-                                                              int Wo, U4* __restrict__ y, B8* __restrict__ idx) {
+                                                              int Wo, G* __restrict__ y, B8* __restrict__ idx) {
     const long long total = (long long)N * Ho * Wo * C8;
     const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (i >= total) return;
@@ -165,13 +166,13 @@ __global__ __launch_bounds__(256) void cfl_bn_pool_fwd_kernel(const U4* __restri
             unpack8(x[(((long long)n * H + ih) * W + iw) * C8 + c], v);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
-            unpack8(pack8(v), v);                                        // the bf16 the unfused path stores and re-reads
+            unpack8(pack8g<G>(v), v);                                    // the value the unfused path stores and re-reads (bf16 rounding)
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; tap[k] = dh * 3 + dw; }
         }
     }
-    y[i] = pack8(best);
+    y[i] = pack8g<G>(best);
     B8 t;
     t.lo = tap[0] | (tap[1] << 8) | (tap[2] << 16) | (tap[3] << 24);
     t.hi = tap[4] | (tap[5] << 8) | (tap[6] << 16) | (tap[7] << 24);
@@ -179,12 +180,13 @@ __global__ __launch_bounds__(256) void cfl_bn_pool_fwd_kernel(const U4* __restri
 }
 
 // gradient of the pooling w.r.t. input pixel (n, h, w), channels 8 c .. 8 c + 7 (what cfl_maxpool_bwd_kernel writes there)
-__device__ __forceinline__ void pool_grad8(const U4* __restrict__ g, const B8* __restrict__ idx, int n, int h, int w, int c, int C8,
+template <class G>
+__device__ __forceinline__ void pool_grad8(const G* __restrict__ g, const B8* __restrict__ idx, int n, int h, int w, int c, int C8,
                                            int Ho, int Wo, float (&d)[8]) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;
     B8 tp[4];
-    U4 gv[4];
+    G gv[4];
     unsigned int want[4];
     bool ok[4];
 #pragma unroll
@@ -210,7 +212,7 @@ __device__ __forceinline__ void pool_grad8(const U4* __restrict__ g, const B8* _
             if (tk == want[q]) acc[k] += gg[k];
         }
     }
-    unpack8(pack8(acc), d);
+    unpack8(pack8g<G>(acc), d);
 }
 
 // XMASK: the ReLU mask is recomputed from x (y is not read) -- only without a residual, where y = relu(x*sc + sh) with
@@ -964,6 +966,51 @@ static int bn_bwd_t(const void* dy, const void* dy2, const void* x, const void* 
 #undef BN_APPLY
     return 0;
 }
+template <class G>
+static int bn_pool_fwd_t(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int N, int H,
+                         int W, int C, float eps, float momentum, void* y_pool, void* idx, float* save_mean, float* save_invstd, void* ws,
+                         void* stream_) {
+    if (!x || !gamma || !beta || !y_pool || !idx || !save_mean || !save_invstd || !ws || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long R = (long long)N * H * W;
+    const Plan p = bn_plan(R, C);
+    float* psum = (float*)ws;
+    float* psq = psum + (size_t)p.nblk * C;
+    CFL_LAUNCH(K_BN_STATS, (cfl_bn_stats_kernel<G>), dim3(p.nblk, p.gy), dim3(256), 0, stream, (const G*)x, R, C, p.rows_per_block, psum, psq);
+    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, p.nblk, C, R, eps,
+               momentum, save_mean, save_invstd, running_mean, running_var);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    CFL_LAUNCH(K_BN_POOL_FWD, (cfl_bn_pool_fwd_kernel<G>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const G*)x,
+               save_mean, save_invstd, gamma, beta, N, H, W, C / 8, Ho, Wo, (G*)y_pool, (B8*)idx);
+    return 0;
+}
+
+template <class G>
+static int bn_pool_bwd_t(const void* g_pool, const void* idx, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, int N, int H, int W, int C, void* dx, float* dgamma, float* dbeta, void* ws,
+                         void* stream_) {
+    if (!g_pool || !idx || !x || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || N <= 0 || H <= 0 ||
+        W <= 0 || C <= 0)
+        return CFL_EINVAL;
+    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long R = (long long)N * H * W;
+    const Plan p = bn_plan(R, C);
+    float* pdb = (float*)ws;
+    float* pdg = pdb + (size_t)p.nblk * C;
+    const dim3 grid(p.nblk, p.gy);
+    const G* none = nullptr;
+    CFL_LAUNCH(K_BN_POOL_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<G, true, true, true>), grid, dim3(256), 0, stream, (const G*)g_pool, none,
+               (const G*)x, none, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, (const unsigned char*)nullptr,
+               (const B8*)idx, H, W);
+    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
+    CFL_LAUNCH(K_BN_POOL_BWD_APPLY, (cfl_bn_bwd_apply_kernel<G, false, true, true, true>), grid, dim3(256), 0, stream, (const G*)g_pool, none,
+               (const G*)x, none, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, (G*)dx, (G*)nullptr,
+               (const unsigned char*)nullptr, (const B8*)idx, H, W);
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -1084,49 +1131,28 @@ int cfl_bn_bwd_wgrad(const void* dy, const void* x, const void* a_in, int P, con
 }
 
 // Stem tail in one pass per direction (see cfl_bn_pool_fwd_kernel).  x [N,H,W,C] bf16 (C % 8 == 0, C <= 2048);
-// y_pool [N,Ho,Wo,C] bf16, idx [N*Ho*Wo*C] bytes (Ho = (H-1)/2+1); ws: cfl_bn_ws_bytes(N*H*W, C).
+// y_pool [N,Ho,Wo,C] bf16, idx [N*Ho*Wo*C] bytes (Ho = (H-1)/2+1); ws: cfl_bn_ws_bytes(N*H*W, C).  The _f32 forms take fp32
+// activations (the clients' encoders, src/networks/resnet_client.py:25-29,64).
 int cfl_bn_pool_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int N, int H,
                     int W, int C, float eps, float momentum, void* y_pool, void* idx, float* save_mean, float* save_invstd, void* ws,
                     void* stream_) {
-    if (!x || !gamma || !beta || !y_pool || !idx || !save_mean || !save_invstd || !ws || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CFL_EINVAL;
-    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long R = (long long)N * H * W;
-    const Plan p = bn_plan(R, C);
-    float* psum = (float*)ws;
-    float* psq = psum + (size_t)p.nblk * C;
-    CFL_LAUNCH(K_BN_STATS, (cfl_bn_stats_kernel<U4>), dim3(p.nblk, p.gy), dim3(256), 0, stream, (const U4*)x, R, C, p.rows_per_block, psum, psq);
-    CFL_LAUNCH(K_BN_FINAL, cfl_bn_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, psum, psq, p.nblk, C, R, eps,
-               momentum, save_mean, save_invstd, running_mean, running_var);
-    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)N * Ho * Wo * (C / 8);
-    CFL_LAUNCH(K_BN_POOL_FWD, cfl_bn_pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const U4*)x,
-               save_mean, save_invstd, gamma, beta, N, H, W, C / 8, Ho, Wo, (U4*)y_pool, (B8*)idx);
-    return 0;
+    return bn_pool_fwd_t<U4>(x, gamma, beta, running_mean, running_var, N, H, W, C, eps, momentum, y_pool, idx, save_mean, save_invstd, ws, stream_);
+}
+int cfl_bn_pool_fwd_f32(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int N, int H,
+                        int W, int C, float eps, float momentum, void* y_pool, void* idx, float* save_mean, float* save_invstd, void* ws,
+                        void* stream_) {
+    return bn_pool_fwd_t<F8>(x, gamma, beta, running_mean, running_var, N, H, W, C, eps, momentum, y_pool, idx, save_mean, save_invstd, ws, stream_);
 }
 
-// g_pool: gradient w.r.t. y_pool [N,Ho,Wo,C] bf16; dx [N,H,W,C] bf16 = gradient w.r.t. x; ws as above.
+// g_pool: gradient w.r.t. y_pool [N,Ho,Wo,C]; dx [N,H,W,C] = gradient w.r.t. x (both in the activation's type); ws as above.
 int cfl_bn_pool_bwd(const void* g_pool, const void* idx, const void* x, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, int N, int H, int W, int C, void* dx, float* dgamma, float* dbeta, void* ws, void* stream_) {
-    if (!g_pool || !idx || !x || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !ws || N <= 0 || H <= 0 ||
-        W <= 0 || C <= 0)
-        return CFL_EINVAL;
-    if (C % 8 != 0 || ((C >> 3) < 256 && 256 % (C >> 3) != 0)) return CFL_ELIMIT;
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long R = (long long)N * H * W;
-    const Plan p = bn_plan(R, C);
-    float* pdb = (float*)ws;
-    float* pdg = pdb + (size_t)p.nblk * C;
-    const dim3 grid(p.nblk, p.gy);
-    const U4* none = nullptr;
-    CFL_LAUNCH(K_BN_POOL_BWD_REDUCE, (cfl_bn_bwd_reduce_kernel<U4, true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
-               (const U4*)x, none, save_mean, save_invstd, gamma, beta, R, C, p.rows_per_block, pdb, pdg, (const unsigned char*)nullptr,
-               (const B8*)idx, H, W);
-    CFL_LAUNCH(K_BN_BWD_FINAL, cfl_bn_bwd_final_kernel, dim3(cfl_cdiv(C, 16)), dim3(16 * BN_FG), 0, stream, pdb, pdg, p.nblk, C, dbeta, dgamma);
-    CFL_LAUNCH(K_BN_POOL_BWD_APPLY, (cfl_bn_bwd_apply_kernel<U4, false, true, true, true>), grid, dim3(256), 0, stream, (const U4*)g_pool, none,
-               (const U4*)x, none, save_mean, save_invstd, gamma, beta, dbeta, dgamma, R, C, p.rows_per_block, (U4*)dx, (U4*)nullptr,
-               (const unsigned char*)nullptr, (const B8*)idx, H, W);
-    return 0;
+    return bn_pool_bwd_t<U4>(g_pool, idx, x, gamma, beta, save_mean, save_invstd, N, H, W, C, dx, dgamma, dbeta, ws, stream_);
+}
+int cfl_bn_pool_bwd_f32(const void* g_pool, const void* idx, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                        const float* save_invstd, int N, int H, int W, int C, void* dx, float* dgamma, float* dbeta, void* ws,
+                        void* stream_) {
+    return bn_pool_bwd_t<F8>(g_pool, idx, x, gamma, beta, save_mean, save_invstd, N, H, W, C, dx, dgamma, dbeta, ws, stream_);
 }
 
 }  // extern "C"

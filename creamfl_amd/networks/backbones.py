@@ -135,6 +135,21 @@ class MaxPool3s2(nn.MaxPool2d):
         return super().forward(x)
 
 
+def stem_tail(bn, pool, x):
+    """maxpool(relu(bn(x))) of a ResNet stem: BatchNorm + ReLU + max pooling in one pass per direction where the fused kernels apply
+    (training mode, channels_last bf16 / fp32 on the GPU), the two modules otherwise."""
+    from .. import ops
+    if (bn.training and bn.track_running_stats and bn.momentum is not None and bn.affine
+            and isinstance(pool, MaxPool3s2) and ops.bn_relu_maxpool_supported(x, bn.num_features)):
+        if torch.cuda.is_current_stream_capturing():          # (as BNAct.forward: inside a HIP-graph capture the count lives on the device)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        else:
+            bn._nbt_pending += 1
+        return ops.bn_relu_maxpool(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+    return pool(bn(x, relu=True))
+
+
 def first_of(x):
     """Residual blocks hand (conv input, residual input) pairs to each other; consumers outside take the first."""
     return x[0] if isinstance(x, tuple) else x
@@ -221,15 +236,7 @@ class ResNetTrunk(nn.Module):
         return nn.Sequential(*layers)
 
     def features(self, x):
-        x = self.conv1(x)
-        from .. import ops
-        bn = self.bn1
-        if (bn.training and bn.track_running_stats and bn.momentum is not None and bn.affine
-                and isinstance(self.maxpool, MaxPool3s2) and ops.bn_relu_maxpool_supported(x, bn.num_features)):
-            bn._nbt_pending += 1                      # BatchNorm + ReLU + max pooling in one pass per direction (stem tail)
-            x = ops.bn_relu_maxpool(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
-        else:
-            x = self.maxpool(bn(x, relu=True))
+        x = stem_tail(self.bn1, self.maxpool, self.conv1(x))
         return first_of(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
 
     def forward(self, x):

@@ -8,7 +8,7 @@ import math
 import torch.nn as nn
 
 from .. import ops
-from .backbones import BasicBlock, BNAct, Bottleneck, MaxPool3s2, TrunkConv, first_of
+from .backbones import BasicBlock, BNAct, Bottleneck, MaxPool3s2, TrunkConv, first_of, stem_tail
 from .language_model import clamped_head, local_projection_head
 
 STAGE_WIDTHS = (64, 128, 256, 512)
@@ -61,7 +61,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*stage)
 
     def extract_conv_feature(self, x):
-        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        x = stem_tail(self.bn1, self.maxpool, self.conv1(x))
         for i in range(1, 5):
             x = getattr(self, f'layer{i}')(x)
         return first_of(x)

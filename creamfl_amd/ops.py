@@ -1165,8 +1165,9 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _ws(lib.cfl_bn_ws_bytes(N * H * W, C), x.device)
-        _lib.check(lib.cfl_bn_pool_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), N, H, W, C, eps,
-                                       momentum, _ptr(y), _ptr(idx), _ptr(mean), _ptr(invstd), _ptr(ws), _stream(x)), 'cfl_bn_pool_fwd')
+        fn = lib.cfl_bn_pool_fwd_f32 if x.dtype == torch.float32 else lib.cfl_bn_pool_fwd
+        _lib.check(fn(_ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), N, H, W, C, eps,
+                      momentum, _ptr(y), _ptr(idx), _ptr(mean), _ptr(invstd), _ptr(ws), _stream(x)), 'cfl_bn_pool_fwd')
         ctx.save_for_backward(x, idx, weight, bias, mean, invstd)
         return y
 
@@ -1175,8 +1176,8 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         lib = _lib.load()
         x, idx, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
-        if gy.dtype != torch.bfloat16:
-            gy = gy.to(torch.bfloat16)
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
         gy = gy.contiguous(memory_format=torch.channels_last)
         from . import streams
         streams.flush(x.device)                # a long HBM-bound phase: let the queued weight gradients run beside it
@@ -1184,8 +1185,9 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         dgamma = torch.empty_like(weight)
         dbeta = torch.empty_like(weight)
         ws = _ws(lib.cfl_bn_ws_bytes(N * H * W, C), x.device)
-        _lib.check(lib.cfl_bn_pool_bwd(_ptr(gy), _ptr(idx), _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), N, H, W, C,
-                                       _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_pool_bwd')
+        fn = lib.cfl_bn_pool_bwd_f32 if x.dtype == torch.float32 else lib.cfl_bn_pool_bwd
+        _lib.check(fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), N, H, W, C,
+                      _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream(x)), 'cfl_bn_pool_bwd')
         return dx, dgamma, dbeta, None, None, None, None
 
 
@@ -1193,8 +1195,9 @@ _NO_STEM_TAIL = _os.environ.get('CFL_NO_STEM_TAIL', '0') == '1'     # measuremen
 
 
 def bn_relu_maxpool_supported(x, num_features):
-    return (not _NO_STEM_TAIL and x.dtype == torch.bfloat16 and bn_act_supported(x, num_features) and num_features <= 2048 and x.shape[2] >= 2 and x.shape[3] >= 2
-            and torch.is_grad_enabled())
+    # (fp32: the clients' encoders, round 6 -- the same kernels on 32-byte channel groups)
+    return (not _NO_STEM_TAIL and x.dtype in (torch.bfloat16, torch.float32) and bn_act_supported(x, num_features) and num_features <= 2048
+            and x.shape[2] >= 2 and x.shape[3] >= 2 and torch.is_grad_enabled())
 
 
 def bn_relu_maxpool(x, weight, bias, running_mean, running_var, momentum, eps):

@@ -515,6 +515,14 @@ int cfl_bn_pool_fwd(const void* x, const float* gamma, const float* beta, float*
 int cfl_bn_pool_bwd(const void* g_pool, const void* idx, const void* x, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_invstd, int N, int H, int W, int C, void* dx, float* dgamma,
                     float* dbeta, void* ws, void* stream);
+/* The same two passes for fp32 activations (the clients' encoders, src/networks/resnet_client.py:25-29,64: bn1 -> relu -> maxpool;
+ * fp32 in the reference): x, y_pool, g_pool, dx are float tensors, nothing is rounded. */
+int cfl_bn_pool_fwd_f32(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int N, int H,
+                        int W, int C, float eps, float momentum, void* y_pool, void* idx, float* save_mean, float* save_invstd,
+                        void* ws, void* stream);
+int cfl_bn_pool_bwd_f32(const void* g_pool, const void* idx, const void* x, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, int N, int H, int W, int C, void* dx, float* dgamma,
+                        float* dbeta, void* ws, void* stream);
 
 /* ---- S1 tail: fused multi-tensor gradient clip + AdamP step ------
  * Replaces nn.utils.clip_grad_norm_(model.parameters(), 2) + AdamP.step()

@@ -297,6 +297,56 @@ def test_stem_tail_fused_is_bit_identical(n, c, h, w):
         assert ta.shape == tb.shape and torch.equal(ta, tb), name
 
 
+@pytest.mark.parametrize('n,c,h,w', [(4, 64, 112, 112), (3, 64, 7, 9), (2, 16, 2, 2), (5, 128, 13, 13)])
+def test_stem_tail_fp32_matches_the_unfused_form_and_torch(n, c, h, w):
+    """The fp32 instantiation (the clients' encoders, src/networks/resnet_client.py:25-29,64): pooled values, running statistics and
+    all three gradients BIT-identical to the fused fp32 BatchNorm followed by the library's max pooling on the same block map, and
+    within fp32 rounding of torch's own batch_norm -> relu -> max_pool2d under autograd."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.nn.functional as F
+    from creamfl_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(n * 100 + c + h)
+    x0 = torch.randn(n, c, h, w, generator=gen)
+    x0[:, :, ::3, ::2] = x0[:, :, :1, :1]                       # repeated values: ties inside windows
+    x0 = x0.to(dev).contiguous(memory_format=torch.channels_last)
+    gamma = (1 + 0.2 * torch.randn(c, generator=gen)).to(dev)
+    beta = (0.3 * torch.randn(c, generator=gen)).to(dev)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    g = torch.randn(n, c, ho, wo, generator=gen).to(dev).contiguous(memory_format=torch.channels_last)
+    assert ops.bn_relu_maxpool_supported(x0, c)
+
+    def run(kind):
+        x = x0.clone().requires_grad_(True)
+        wg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        if kind == 'fused':
+            y = ops.bn_relu_maxpool(x, wg, bg, rm, rv, 0.1, 1e-5)
+        elif kind == 'two':
+            y = F.max_pool2d(ops.bn_act_train(x, wg, bg, rm, rv, 0.1, 1e-5, relu=True), 3, 2, 1)
+        else:
+            y = F.max_pool2d(F.relu(F.batch_norm(x, rm, rv, wg, bg, True, 0.1, 1e-5)), 3, 2, 1)
+        assert y.dtype == torch.float32 and y.shape == (n, c, ho, wo)
+        y.backward(g)
+        torch.cuda.synchronize()
+        return y.detach(), x.grad, wg.grad, bg.grad, rm, rv
+
+    was = _lib.load().cfl_bn_sliced(0)
+    try:
+        a, b, t = run('fused'), run('two'), run('torch')
+    finally:
+        _lib.load().cfl_bn_sliced(was)
+    for name, ta, tb, tt in zip(['y', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var'], a, b, t):
+        if name in ('y', 'running_mean', 'running_var'):
+            assert torch.equal(ta, tb), name
+        else:                                                   # (ties: the library's pooling backward may route a tie to another tap)
+            sc = float(tb.abs().max()) + 1e-12
+            assert float((ta - tb).abs().max()) <= 2e-5 * sc, name
+        sc = float(tt.abs().max()) + 1e-12
+        assert float((ta - tt).abs().max()) <= (1e-4 if name in ('dx', 'dgamma', 'dbeta') else 2e-5) * sc, (name, float((ta - tt).abs().max()), sc)
+
+
 def test_prepared_weight_transposes_match_individual_ones():
     """ops.prepare_weight_transposes: every 1x1-convolution weight transposed by ONE launch; the data gradient computed
     with the prepared W^T must equal the one computed with the per-layer transpose (bit-exact), ragged shapes included."""
