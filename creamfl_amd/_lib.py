@@ -101,6 +101,7 @@ SIGNATURES = {
     'cfl_conv3x3_x3_rot_weight': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_conv3x3_x3_wimage_bytes': (c_size_t, [c_int, c_int]),
     'cfl_conv3x3_x3_wimage': (c_int, [_P, c_int, c_int, _P, _P]),
+    'cfl_conv3x3_x3_wimage_rot': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_conv3x3_x3_fwd_img': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     'cfl_conv3x3_x3_wgrad_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_x3_wgrad_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

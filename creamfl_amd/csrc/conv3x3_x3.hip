@@ -548,6 +548,31 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_wimage_kernel(const float* __
     *reinterpret_cast<x3::bf16x4*>(row + (((4 + (k >> 3)) ^ sw) << 4) + (k & 7) * 2) = lo;
 }
 
+// The image of the ROTATED, TRANSPOSED weight (the data gradient's operand) straight from the weight: rows = input channels ci, K =
+// (tap', co): img[((tap' * (Co / 32) + c) * Ci + ci) * 128 bytes] = [32 hi | 32 lo] of w[32 c .. 32 c + 31][8 - tap'][ci], swizzled by ci.
+// A block transposes one (32 co x 32 ci) tile of one tap through LDS: coalesced reads along ci, 128-byte rows written whole.
+__global__ __launch_bounds__(256) void cfl_conv3x3_wimage_rot_kernel(const float* __restrict__ w, int Ci, int Co, char* __restrict__ img) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;                              // source tap; the image's tap is 8 - tap
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((long long)(co0 + r) * 9 + tap) * Ci + ci0 + tx];
+    __syncthreads();
+    const int cil = threadIdx.x >> 3, q = threadIdx.x & 7;   // row (input channel) of the tile, quad of output channels
+    x3::bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 a, b;
+        x3::split1(tile[4 * q + e][cil], a, b);
+        hi[e] = a; lo[e] = b;
+    }
+    const int ci = ci0 + cil;
+    char* row = img + (((long long)(8 - tap) * (Co >> 5) + (co0 >> 5)) * Ci + ci) * 128;
+    const int sw = (ci >> 1) & 7;
+    *reinterpret_cast<x3::bf16x4*>(row + ((((q >> 1)) ^ sw) << 4) + (q & 1) * 8) = hi;
+    *reinterpret_cast<x3::bf16x4*>(row + (((4 + (q >> 1)) ^ sw) << 4) + (q & 1) * 8) = lo;
+}
+
 // wr[ci][kh][kw][co] = w[co][2 - kh][2 - kw][ci]   (both [out][3][3][in] in memory: the channels_last weight layout)
 __global__ __launch_bounds__(256) void cfl_conv3x3_rot_kernel(const float* __restrict__ w, int Ci, int Co, float* __restrict__ wr) {
     __shared__ float tile[32][33];
@@ -627,6 +652,14 @@ extern "C" int cfl_conv3x3_x3_wimage(const float* w, int Ci, int Co, void* img, 
     hipStream_t stream = (hipStream_t)stream_;
     const long long n = (long long)Co * 9 * (Ci / 4);
     CFL_LAUNCH(K_TRANSPOSE, cfl_conv3x3_wimage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Ci, Co, (char*)img);
+    return 0;
+}
+
+extern "C" int cfl_conv3x3_x3_wimage_rot(const float* w, int Ci, int Co, void* img, void* stream_) {
+    if (!w || !img || Ci <= 0 || Co <= 0) return CFL_EINVAL;
+    if (Co % 32 != 0 || Ci % 64 != 0 || (((uintptr_t)w | (uintptr_t)img) & 15)) return CFL_ELIMIT;     // (roles swapped: K = 9 Co)
+    hipStream_t stream = (hipStream_t)stream_;
+    CFL_LAUNCH(K_TRANSPOSE, cfl_conv3x3_wimage_rot_kernel, dim3(Ci / 32, Co / 32, 9), dim3(256), 0, stream, w, Ci, Co, (char*)img);
     return 0;
 }
 

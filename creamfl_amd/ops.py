@@ -1534,21 +1534,53 @@ def conv3x3_x3_supported(x, w, stride, padding):
     return bool(_lib.load().cfl_conv3x3_x3_supported(N, H, W, Ci, w.shape[0]))
 
 
-def conv3x3_x3_forward(x, w, variant=0):
+# weight images of FROZEN weights (requires_grad False: the clients' old model, evaluation) are kept across calls.  An entry belongs
+# to the tensor OBJECT (a weak reference whose death removes it: a recycled address or id cannot revive it) and holds the storage
+# address and version counter it was built from.  Trainable weights are never cached: inside a HIP-graph capture a cache hit would
+# leave the image's build out of the graph while the replays train the weight.
+_X3_IMAGES = {}
+
+
+def _x3_weight_image(w, rot=False):
+    import weakref
+    lib = _lib.load()
+    Co, Ci = w.shape[0], w.shape[1]
+    frozen = not w.requires_grad and w.grad_fn is None
+    key = (id(w), bool(rot))
+    if frozen:
+        hit = _X3_IMAGES.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == (w.data_ptr(), w._version, Co, Ci):
+            return hit[2]
+    img = _ws(lib.cfl_conv3x3_x3_wimage_bytes(Ci, Co), w.device)
+    if rot:
+        _lib.check(lib.cfl_conv3x3_x3_wimage_rot(_ptr(w), Ci, Co, _ptr(img), _stream(w)), 'cfl_conv3x3_x3_wimage_rot')
+    else:
+        _lib.check(lib.cfl_conv3x3_x3_wimage(_ptr(w), Ci, Co, _ptr(img), _stream(w)), 'cfl_conv3x3_x3_wimage')
+    if frozen and not torch.cuda.is_current_stream_capturing():      # (a buffer of a graph's private pool must not outlive the graph)
+        _X3_IMAGES[key] = (weakref.ref(w, lambda _r, k=key: _X3_IMAGES.pop(k, None)), (w.data_ptr(), w._version, Co, Ci), img)
+    return img
+
+
+def conv3x3_x3_forward(x, w, variant=0, rotated=False):
     """conv2d(x, w, stride 1, padding 1) for fp32 channels_last x [N, Ci, H, W] and w [Co, Ci, 3, 3] (csrc/conv3x3_x3.hip); no
     autograd (the Functions that own the convolutions call it for their forward and, on the rotated weight, their data gradient).
-    variant 0 / 2xx: version 3 (the weight split once into an image of the kernel's LDS stage; maps up to 63 wide); 21 .. 142: the
-    earlier kernels (any width)."""
-    N, Ci, H, W = x.shape
-    Co = w.shape[0]
+    variant 0 / >= 200: version 3 (the weight split once into an image of the kernel's LDS stage; maps up to 63 wide); 21 .. 142: the
+    earlier kernels (any width).  rotated=True: w is the FORWARD weight [Ci_out_of_this_call ... ] of the convolution whose data
+    gradient this is -- x is dY [N, Co_w, H, W], the result dX [N, Ci_w, H, W] (the image of the rotated weight is built directly)."""
     lib = _lib.load()
-    y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    if (variant == 0 or variant >= 200) and W <= 63:
-        img = _ws(lib.cfl_conv3x3_x3_wimage_bytes(Ci, Co), x.device)
-        _lib.check(lib.cfl_conv3x3_x3_wimage(_ptr(w), Ci, Co, _ptr(img), _stream(x)), 'cfl_conv3x3_x3_wimage')
-        _lib.check(lib.cfl_conv3x3_x3_fwd_img(_ptr(x), _ptr(img), N, H, W, Ci, Co, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd_img')
+    N, Cin, H, W = x.shape
+    if rotated:
+        assert w.shape[0] == Cin
+        Cout = w.shape[1]
     else:
-        _lib.check(lib.cfl_conv3x3_x3_fwd(_ptr(x), _ptr(w), N, H, W, Ci, Co, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd')
+        Cout = w.shape[0]
+    y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if (variant == 0 or variant >= 200) and W <= 63:
+        img = _x3_weight_image(w, rot=rotated)
+        _lib.check(lib.cfl_conv3x3_x3_fwd_img(_ptr(x), _ptr(img), N, H, W, Cin, Cout, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd_img')
+    else:
+        wk = conv3x3_x3_rotated(w) if rotated else w
+        _lib.check(lib.cfl_conv3x3_x3_fwd(_ptr(x), _ptr(wk), N, H, W, Cin, Cout, _ptr(y), int(variant), _stream(x)), 'cfl_conv3x3_x3_fwd')
     X3CONV_TAKEN[0] += 1
     return y
 
@@ -1598,7 +1630,7 @@ def _conv_dgrad(args):
             and dy.is_contiguous(memory_format=torch.channels_last) and w.is_contiguous(memory_format=torch.channels_last) \
             and _lib.load().cfl_conv3x3_x3_supported(dy.shape[0], dy.shape[2], dy.shape[3], w.shape[0], w.shape[1]):
         # dX = conv(dY, W') on the rotated, transposed weight: the forward kernel with the roles of the channel counts swapped
-        return conv3x3_x3_forward(dy, conv3x3_x3_rotated(w))
+        return conv3x3_x3_forward(dy, w, rotated=True)
     cov = _fdb_covered('B', x, w, dy.shape, args[4][0], args[5][0])
     return _miopen(cov, torch.ops.aten.convolution_backward, *args, [True, False, False])[0]
 

@@ -223,6 +223,7 @@ int cfl_conv3x3_x3_rot_weight(const float* w, int Ci, int Co, float* w_rot, void
  * the library, 2MN = a tile of 64 M positions x 64 N channels (222, 242, 221, 241, 212, 211).  Data gradient: image of the rotated weight. */
 size_t cfl_conv3x3_x3_wimage_bytes(int Ci, int Co);
 int cfl_conv3x3_x3_wimage(const float* w, int Ci, int Co, void* img, void* stream);
+int cfl_conv3x3_x3_wimage_rot(const float* w, int Ci, int Co, void* img, void* stream);   /* image of w_rot (Co x 9 Ci -> Ci x 9 Co) in one pass */
 int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, int H, int W, int Ci, int Co, float* y, int variant, void* stream);
 /* The weight gradient of the same convolutions (csrc/wgrad3x3_x3.hip; the reference: autograd through cuDNN's fp32 backward-filter,
  * src/algorithms/ClientTrainer.py:420 loss.backward()): dw[co,kh,kw,ci] = sum over (n,h,w) dy[n,h,w,co] x[n,h+kh-1,w+kw-1,ci], fp32 in

@@ -105,6 +105,35 @@ def test_x3_wgrad_refusals(dev):
     assert ops.conv3x3_x3_wgrad(dy, x32, torch.zeros(64, 32, 3, 3, device=dev).contiguous(memory_format=CL)) is None
 
 
+@pytest.mark.parametrize('n,hw,ci,co', [(2, 14, 64, 128), (1, 7, 256, 64), (3, 28, 128, 128)])
+def test_x3conv_data_gradient_from_the_rotated_image(dev, n, hw, ci, co):
+    """dX of y = conv2d(x, w, 1, 1): the forward kernel on the image of the rotated, transposed weight, built in one pass from w
+    (cfl_conv3x3_x3_wimage_rot) -- against fp64 autograd, and equal to the two-step form (rotate, then image); the image of a frozen
+    weight is kept across calls and rebuilt when the weight changes in place."""
+    from creamfl_amd import ops
+    _, wt = _case(n, hw, hw, ci, co, 7)
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(n, co, hw, hw, generator=g)
+    wd = wt.to(dev).contiguous(memory_format=CL)
+    dyd = dy.to(dev).contiguous(memory_format=CL)
+    dx = ops.conv3x3_x3_forward(dyd, wd, rotated=True)
+    assert dx.shape == (n, ci, hw, hw)
+    x64 = torch.zeros(n, ci, hw, hw, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x64, wt.double(), None, 1, 1).backward(dy.double())
+    sc = float(x64.grad.abs().max())
+    assert float((dx.cpu().double() - x64.grad).abs().max()) <= 1e-5 * sc
+    assert torch.equal(dx, ops.conv3x3_x3_forward(dyd, ops.conv3x3_x3_rotated(wd)))
+    # frozen weight: cached image; an in-place change of the weight must not be served from it
+    n_img = len(ops._X3_IMAGES)
+    assert torch.equal(dx, ops.conv3x3_x3_forward(dyd, wd, rotated=True)) and len(ops._X3_IMAGES) == n_img
+    wd.mul_(2.0)
+    assert float((ops.conv3x3_x3_forward(dyd, wd, rotated=True) - 2.0 * dx).abs().max()) <= 1e-6 * float(dx.abs().max())
+    del wd
+    import gc
+    gc.collect()
+    assert len(ops._X3_IMAGES) <= n_img - 1                                       # the entry died with its tensor
+
+
 def test_x3conv_rotated_weight_is_exact(dev):
     from creamfl_amd import ops
     _, wt = _case(1, 3, 3, 96, 160, 5)

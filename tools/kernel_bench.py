@@ -353,8 +353,8 @@ def case_x3conv(H, C, N=128, dbg=False):
         k = prof.get('cfl_conv3x3_x3_kernel', us)                   # (version 3: without the weight-image launch, ~3 us)
         out[f'x3_v{v}_fwd_us'] = k
         out[f'x3_v{v}_TFLOPs_fp32_equivalent'] = round(flop / k / 1e6)
-    wr = ops.conv3x3_x3_rotated(w)
-    us, prof = timed(lambda: ops.conv3x3_x3_forward(dy, ops.conv3x3_x3_rotated(w)), iters=20)
+    wg = w.clone().requires_grad_(True)                                      # (a trainable weight: its image is rebuilt per call)
+    us, prof = timed(lambda: ops.conv3x3_x3_forward(dy, wg, rotated=True), iters=20)
     out['x3_dgrad_us_incl_weight_rotation'] = round(sum(v for v in prof.values() if v), 1)
     dwl = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
     dw = ops.conv3x3_x3_wgrad(dy, x, w)
