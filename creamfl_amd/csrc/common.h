@@ -34,7 +34,7 @@ enum CflKernel {
     K_BN_BWD_APPLY_WG, K_BN_WGRAD_REDUCE,
     K_GRU_FWD, K_GRU_BWD, K_GRU_CELL0,
     K_CONV3_WGRAD, K_CONV3_WGRAD_REDUCE, K_CONV1_WGRAD, K_CONV1_WGRAD_REDUCE,
-    K_CONV3_X3, K_CONV3_X3_WGRAD, K_CONV3_X3_WGRAD_REDUCE,
+    K_CONV3_X3, K_CONV3_X3_WGRAD, K_CONV3_X3_WGRAD_REDUCE, K_CONV3_X3_WIMAGE,
     K_NUM
 };
 

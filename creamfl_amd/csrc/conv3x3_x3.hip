@@ -525,6 +525,196 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
         }
 }
 
+// ---- version 4 ("q"): the two memory streams on separate waves, weight tiles two taps ahead -------------------------------------------
+// What version 3's switch-off forms say (profiles/r6_x3conv_decomposition.jsonl): its memory work and its MFMAs overlap poorly.  A wave's
+// vector-memory operations complete IN ORDER: a wave that has the next chunk's slab loads (first touch of those bytes: an HBM round trip)
+// in its queue cannot see its next weight tile (an L2 hit) land before them, and a weight tile issued one tap ahead has one tap (~770 matrix
+// cycles) for an L2 round trip under a 4-5 TB/s L2 -> LDS load.  Here the streams belong to different waves and are deeper:
+//   * waves 0, 1 issue ALL weight-tile DMA (8 / 4 kilobyte pieces each per tap), TWO taps ahead, into a ring of three stages (nine taps per
+//     chunk: the stage of a tap is tap mod 3, static); their only wait is a counted vmcnt that leaves the youngest tile in flight.  The DMA
+//     is issued from inline assembly (the compiler would put s_waitcnt vmcnt(0) in front of every LDS read that follows a DMA it knows of);
+//   * waves 2, 3 load the next chunk's slab (registers) at the chunk's first tap and split / store it behind its last one: eight taps for
+//     the HBM round trip, and nobody waits for a weight tile behind them.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void cfl_conv3x3_x3q_kernel(const float* __restrict__ x, const char* __restrict__ wimg, float* __restrict__ y,
+                                                               int N, int H, int W, int Ci, int Co) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, NJ2 = (BM + 128) / 16, NKB = BN / 16, PITCH = 144;   // NKB: kilobyte pieces of a tile per loader wave
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* slab = reinterpret_cast<char*>(lds_f);
+    const long long M = (long long)N * H * W;
+    const int ntc = Co / BN, ntr = (int)((M + BM - 1) / BM);
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const long long row0 = (long long)ti * BM;
+    const int col0 = tj * BN;
+    const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), wr = wid >> 1, wc = wid & 1;
+    const int kq = t & 7, i32 = lane & 31, hh = lane >> 5;
+    const int halo = W + 1;
+    const int nj2 = (BM + 2 * halo + 15) / 16;                // 16-row groups of the slab actually used (<= NJ2)
+    const int zrow = nj2 * 16;                                // a row of zeros behind the slab
+    char* const bst = slab + (zrow + 1) * PITCH;              // three weight stages of BN rows behind it
+    const bool dma_wave = wid < 2;                            // wave-uniform roles
+
+    int aoff[TM][9];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int rl = (wr * TM + m) * 32 + i32;
+        const long long r = row0 + rl;
+        int h = -4, ww = -4;
+        if (r < M) {
+            const int hw = (int)(r % ((long long)H * W));
+            h = hw / W; ww = hw % W;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const bool ok = (unsigned)(h + kh - 1) < (unsigned)H && (unsigned)(ww + kw - 1) < (unsigned)W;
+            aoff[m][tap] = (ok ? rl + halo + (kh - 1) * W + (kw - 1) : zrow) * PITCH + hh * 16;
+        }
+    }
+    int boff[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int rb = (wc * TN + n) * 32 + i32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) boff[n][j] = x3::soff(rb, (j >> 1) * 4 + 2 * (j & 1) + hh);
+    }
+    const int nchunk = Ci / 32, nk = 9 * nchunk;
+    const long long wstep = (long long)Co * 128;
+    const char* wsrc = wimg + (long long)col0 * 128 + lane * 16;
+    const unsigned bst_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)bst;
+
+    // slab staging by the 128 threads of waves 2, 3: rows j * 16 + (t2 >> 3), channels 4 kq .. + 3
+    const int t2 = t & 127;
+    f32x4 sreg[NJ2];
+    auto load_slab = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j) {
+            if (j < nj2) {
+                const long long P = row0 - halo + j * 16 + (t2 >> 3);
+                const bool ok = P >= 0 && P < M;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (ok ? P : 0) * Ci + c * 32 + 4 * kq);
+                sreg[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j) {
+            if (j < nj2) {
+                const int rl = j * 16 + (t2 >> 3);
+                x3::bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a, b;
+                    x3::split1(sreg[j][e], a, b);
+                    hi[e] = a; lo[e] = b;
+                }
+                *reinterpret_cast<x3::bf16x4*>(slab + rl * PITCH + kq * 8) = hi;
+                *reinterpret_cast<x3::bf16x4*>(slab + rl * PITCH + 64 + kq * 8) = lo;
+            }
+        }
+    };
+    // weight tile of step s (chunk s / 9, tap s % 9) into stage s % 3: loader wave w moves kilobytes w, w + 2, ...
+    auto dma_b = [&](int s) {
+        const int c = s / 9, tap = s - 9 * c;
+        const char* src = wsrc + ((long long)tap * nchunk + c) * wstep + wid * 1024;
+        const unsigned dst = bst_a + (unsigned)((s % 3) * (BN * 128) + wid * 1024);
+#pragma unroll
+        for (int i = 0; i < NKB; ++i) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src + i * 2048), "s"(dst + i * 2048) : "memory");
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    if (t < 9) *reinterpret_cast<f32x4*>(slab + zrow * PITCH + t * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dma_wave) {
+        dma_b(0);
+        if (nk > 1) dma_b(1);
+    } else {
+        load_slab(0);
+        store_slab();
+    }
+    if (dma_wave) {
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NKB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int s = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const bool next_chunk = c + 1 < nchunk;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            const char* sb = bst + (tap % 3) * (BN * 128);
+            const bool more = s + 2 < nk;                     // (uniform)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                x3::bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    ah[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + kk * 32);
+                    al[m] = *reinterpret_cast<const x3::bf16x8*>(slab + aoff[m][tap] + 64 + kk * 32);
+                }
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    bh[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][kk]);
+                    bl[n] = *reinterpret_cast<const x3::bf16x8*>(sb + boff[n][2 + kk]);
+                }
+                if (kk == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma_wave) {
+                        if (more) dma_b(s + 2);               // stage (tap + 2) % 3 = (tap - 1) % 3: last read during the tap before
+                    } else if (tap == 0 && next_chunk) {
+                        load_slab(c + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap == 8 && next_chunk) {
+                __syncthreads();                              // every wave is done with this chunk's slab
+                if (!dma_wave) store_slab();
+            }
+            if (dma_wave) {                                   // the tile of step s + 1 has landed; the one of step s + 2 may still fly
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NKB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int j = col0 + acc_col<TN>(wc, n, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long i = row0 + acc_row<TM>(wr, m, r, lane);
+                if (i < M) y[i * Co + j] = acc[m][n][r];
+            }
+        }
+}
+
 // The weight image of version 3: img[((tap * (Ci / 32) + c) * Co + co) * 128 bytes] = the 128-byte LDS row of output channel co for
 // the 32 input channels of chunk c at that tap: [32 hi | 32 lo] bf16 with the 16-byte pieces XOR-swizzled as x3::soff does for row
 // co (tiles start at multiples of 64, so the tile-local row and co agree in the bits the swizzle reads).  One thread per 4 channels.
@@ -651,7 +841,7 @@ extern "C" int cfl_conv3x3_x3_wimage(const float* w, int Ci, int Co, void* img, 
     if (Ci % 32 != 0 || Co % 64 != 0 || (((uintptr_t)w | (uintptr_t)img) & 15)) return CFL_ELIMIT;
     hipStream_t stream = (hipStream_t)stream_;
     const long long n = (long long)Co * 9 * (Ci / 4);
-    CFL_LAUNCH(K_TRANSPOSE, cfl_conv3x3_wimage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Ci, Co, (char*)img);
+    CFL_LAUNCH(K_CONV3_X3_WIMAGE, cfl_conv3x3_wimage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Ci, Co, (char*)img);
     return 0;
 }
 
@@ -659,7 +849,7 @@ extern "C" int cfl_conv3x3_x3_wimage_rot(const float* w, int Ci, int Co, void* i
     if (!w || !img || Ci <= 0 || Co <= 0) return CFL_EINVAL;
     if (Co % 32 != 0 || Ci % 64 != 0 || (((uintptr_t)w | (uintptr_t)img) & 15)) return CFL_ELIMIT;     // (roles swapped: K = 9 Co)
     hipStream_t stream = (hipStream_t)stream_;
-    CFL_LAUNCH(K_TRANSPOSE, cfl_conv3x3_wimage_rot_kernel, dim3(Ci / 32, Co / 32, 9), dim3(256), 0, stream, w, Ci, Co, (char*)img);
+    CFL_LAUNCH(K_CONV3_X3_WIMAGE, cfl_conv3x3_wimage_rot_kernel, dim3(Ci / 32, Co / 32, 9), dim3(256), 0, stream, w, Ci, Co, (char*)img);
     return 0;
 }
 
@@ -686,6 +876,15 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
         CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3p_kernel<TM_, TN_, DBG_>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, \
                    H, W, Ci, Co);                                                                                              \
     } while (0)
+#define CFL_X3CONVQ(TM_, TN_)                                                                                                  \
+    do {                                                                                                                       \
+        constexpr int BM_ = 64 * TM_, BN_ = 64 * TN_;                                                                          \
+        const int LDS_ = (((BM_ + 2 * (W + 1) + 15) / 16) * 16 + 1) * 144 + 3 * BN_ * 128;                                     \
+        const int grid = (int)((M + BM_ - 1) / BM_) * (Co / BN_);                                                              \
+        CFL_SET_LDS((cfl_conv3x3_x3q_kernel<TM_, TN_>), (BM_ + 128 + 1) * 144 + 3 * BN_ * 128);                                \
+        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3q_kernel<TM_, TN_>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, H, W, \
+                   Ci, Co);                                                                                                    \
+    } while (0)
     switch (variant) {
         case 222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 0); break;
         case 242: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(4, 2, 0); break;
@@ -693,6 +892,9 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
         case 221: CFL_X3CONVP(2, 1, 0); break;
         case 241: CFL_X3CONVP(4, 1, 0); break;
         case 211: CFL_X3CONVP(1, 1, 0); break;
+        case 722: if (!bn128) return CFL_ELIMIT; CFL_X3CONVQ(2, 2); break;          // version 4: loader roles per wave, tiles two taps ahead
+        case 721: CFL_X3CONVQ(2, 1); break;
+        case 742: if (!bn128) return CFL_ELIMIT; CFL_X3CONVQ(4, 2); break;
         case 1222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 1); break;      // measurement forms of 222 (wrong results)
         case 2222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 2); break;
         case 3222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 3); break;
@@ -704,6 +906,7 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
         default: return CFL_EINVAL;
     }
 #undef CFL_X3CONVP
+#undef CFL_X3CONVQ
     return 0;
 }
 

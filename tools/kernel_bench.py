@@ -342,7 +342,7 @@ def case_x3conv(H, C, N=128, dbg=False):
     sc = float(ref.abs().max())
     out['library_fwd_relerr_vs_fp64'] = float((ylib.double() - ref).abs().max()) / sc
     M = N * H * H
-    VS = (222, 242, 221, 241, 522, 542, 521, 0) + ((1222, 2222, 3222, 4222, 6222) if dbg else ())
+    VS = (522, 542, 521, 722, 742, 721, 0) + ((222, 1222, 2222, 3222, 4222, 6222) if dbg else ())
     for v in VS:
         if v % 10 == 2 and C % 128:
             continue
