@@ -428,7 +428,7 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
 
 // ---- round 4: con_w log-probabilities on the bank pass (wide-batch forward of bank_gsplit.h) -------------------------------
 int cfl_conw_img_supported(int rows, int M, int D) {
-    return (rows >= 512 && M > 0 && D >= 4 && D <= 256 && D % 4 == 0) ? 1 : 0;
+    return (rows >= 512 && M > 0 && D >= 4 && D <= 512 && D % 4 == 0) ? 1 : 0;
 }
 
 size_t cfl_conw_img_ws_bytes(int rows, int M, int D) {
@@ -451,14 +451,25 @@ int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int 
     w.rowbuf = nullptr; w.part_o = nullptr;
     const float* F = V + (size_t)row0 * D;
     const float sc2 = 1.4426950408889634f;
-    CFL_SET_LDS((gs::cfl_bank_wide32_kernel<8>), 4 * 64 * 32 * 8);
-    CFL_SET_LDS((gs::cfl_bank_wide32_kernel<4>), 4 * 64 * 32 * 4);
-    if (p.DT == 8)
-        CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_wide32_kernel<8>), dim3(p.S * p.RG), dim3(512), 4 * 64 * 32 * 8, stream, F, (const char*)image,
-                   rows, M, D, sc2, p.S, p.RG, w.part_m, w.part_l);
-    else
-        CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_wide32_kernel<4>), dim3(p.S * p.RG), dim3(512), 4 * 64 * 32 * 4, stream, F, (const char*)image,
-                   rows, M, D, sc2, p.S, p.RG, w.part_m, w.part_l);
+    // two step buffers of two 16-row slots each; D <= 256: 8 waves x 32 rows, two workgroups per CU; D <= 512: 4 waves, one per CU
+#define CFL_WIDE32(DT_, NW_, ...)                                                                                                  \
+    do {                                                                                                                         \
+        CFL_SET_LDS((gs::cfl_bank_wide32_kernel<DT_, NW_, __VA_ARGS__>), 4 * 64 * 32 * DT_);                                      \
+        CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_wide32_kernel<DT_, NW_, __VA_ARGS__>), dim3(p.S * p.RG), dim3(64 * NW_), 4 * 64 * 32 * DT_, stream, F, \
+                   (const char*)image, rows, M, D, sc2, p.S, p.RG, w.part_m, w.part_l);                                          \
+    } while (0)
+    static const char* rbv = getenv("CFL_CONW_WIDE_RB");                // measurement knob: fragment-burst length of the 4-wave form
+    if (p.DT == 16) {
+        // measured at M = 50 000 (profiles/r6_a5_conw_lines.jsonl): bursts of 2 / 4 / 8 contraction steps 7.26 / 6.59 / 7.00 ms; with
+        // the issue order pinned (sched_group_barrier) 's' -1.3 %, 't' -2.6 % against the plain burst of 4 on the same lease
+        if (rbv && rbv[0] == '8') CFL_WIDE32(16, 4, 8);
+        else if (rbv && rbv[0] == '2') CFL_WIDE32(16, 4, 2);
+        else if (rbv && rbv[0] == 's') CFL_WIDE32(16, 4, 4, 1);
+        else if (rbv && rbv[0] == '4') CFL_WIDE32(16, 4, 4);
+        else CFL_WIDE32(16, 4, 4, 2);
+    } else if (p.DT == 8) CFL_WIDE32(8, 8, 4);
+    else CFL_WIDE32(4, 8, 4);
+#undef CFL_WIDE32
     CFL_LAUNCH(K_LSE_FINAL, cfl_conw_finish_kernel, dim3(cfl_cdiv(rows, 64)), dim3(256), 0, stream, w.part_m, w.part_l, p.S, F,
                G + (size_t)row0 * D, rows, D, out);
     return 0;

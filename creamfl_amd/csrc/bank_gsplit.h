@@ -431,13 +431,22 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
 // step deferred into the next step's first fragment-read latency.
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-template <int DT>
-__global__ __launch_bounds__(512, 2) void cfl_bank_wide32_kernel(const float* __restrict__ F, const char* __restrict__ img, int B, int M,
-                                                               int D, float sc2, int S, int RG, float* __restrict__ part_m,
-                                                               float* __restrict__ part_l) {
-    constexpr int DP = 32 * DT, SLOT = 64 * DP, STEP = 2 * SLOT, KS = DP / 16, RB = 4, FR = 256;
-    constexpr int NPT = STEP / 8192;                                      // 16-byte DMA pieces per thread and step
-    static_assert(KS % RB == 0, "bursts tile the contraction");
+//
+// D = 512 (round 6): the pre-split rows of V are D/2 = 256 registers per wave -- the whole budget of a wave at two waves per SIMD.
+// The same kernel runs there with NW = 4 waves (ONE per SIMD, up to 512 registers: V 256 + accumulators 48 + two fragment bursts),
+// 128 rows of V per workgroup, two 64 KB step buffers = one workgroup per CU: the LDS-read : MFMA ratio of a step is the one of the
+// 8-wave D = 256 form (every wave reads the whole step, 32 x 3 MFMAs of 32 cycles per 64 KB), the image passes a CU once per 128
+// rows (391 x 102 MB = 40 GB L2 -> LDS per client where the tile GEMM moves 78 GB), and what hides the fragment-read latency is
+// the next burst's reads issued ahead of this burst's MFMAs inside the one wave (the registers are there) instead of a second
+// wave.  D = 768 does not fit either way (384 registers of V, 2 x 96 KB of step buffers): it stays on the tile GEMM of bank.hip.
+template <int DT, int NW, int RB = 4, int SCHED = 0>
+__global__ __launch_bounds__(64 * NW, NW / 4) void cfl_bank_wide32_kernel(const float* __restrict__ F, const char* __restrict__ img, int B,
+                                                                        int M, int D, float sc2, int S, int RG,
+                                                                        float* __restrict__ part_m, float* __restrict__ part_l) {
+    constexpr int DP = 32 * DT, SLOT = 64 * DP, STEP = 2 * SLOT, KS = DP / 16, FR = 32 * NW;
+    constexpr int STRIPE = NW * 1024;                                     // bytes one DMA instruction of every wave covers
+    constexpr int NPT = STEP / STRIPE;                                    // 16-byte DMA pieces per thread and step
+    static_assert(KS % RB == 0 && STEP % STRIPE == 0 && SLOT % STRIPE == 0, "bursts tile the contraction, stripes tile a slot");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, kh = lane >> 5;
@@ -457,8 +466,8 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_wide32_kernel(const float* __
         const int valid = (2 * it + 1 < nmine) ? STEP : SLOT;
 #pragma unroll
         for (int j = 0; j < NPT; ++j)
-            if (j * 8192 < valid)
-                __builtin_amdgcn_global_load_lds((glb_vptr)(src + j * 8192), (lds_vptr)(dst + j * 8192), 16, 0, 0);
+            if (j * STRIPE < valid)
+                __builtin_amdgcn_global_load_lds((glb_vptr)(src + j * STRIPE), (lds_vptr)(dst + j * STRIPE), 16, 0, 0);
     };
     if (nstep > 0) dma_step(0);
     bf16x8 fh[KS], fl[KS];                                       // B operand: feature row r32, k = 16 ks + 8 kh .. + 7, pre-scaled
@@ -523,22 +532,61 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_wide32_kernel(const float* __
         f32x16 sa, sbb, sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sbb[r] = 0.f; sc[r] = 0.f; }
+        if (NW == 8) {
 #pragma unroll
-        for (int k0 = 0; k0 < KS; k0 += RB) {
-            bf16x8 ah[RB], al[RB];
-#pragma unroll
-            for (int e = 0; e < RB; ++e) {
-                const int off = la[(k0 + e) & 7] + ((k0 + e) >> 3) * 256;
-                ah[e] = *reinterpret_cast<const bf16x8*>(sb + off);
-                al[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
-            }
-            if (k0 == 0 && pend_ok) soft(pend, pend_row0);       // the previous step's soft-max, inside this burst's LDS latency
-            if (wave_live) {
+            for (int k0 = 0; k0 < KS; k0 += RB) {
+                bf16x8 ah[RB], al[RB];
 #pragma unroll
                 for (int e = 0; e < RB; ++e) {
-                    sa = MFMA32(ah[e], fh[k0 + e], sa);
-                    sbb = MFMA32(al[e], fh[k0 + e], sbb);
-                    sc = MFMA32(ah[e], fl[k0 + e], sc);
+                    const int off = la[(k0 + e) & 7] + ((k0 + e) >> 3) * 256;
+                    ah[e] = *reinterpret_cast<const bf16x8*>(sb + off);
+                    al[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
+                }
+                if (k0 == 0 && pend_ok) soft(pend, pend_row0);   // the previous step's soft-max, inside this burst's LDS latency
+                if (wave_live) {
+#pragma unroll
+                    for (int e = 0; e < RB; ++e) {
+                        sa = MFMA32(ah[e], fh[k0 + e], sa);
+                        sbb = MFMA32(al[e], fh[k0 + e], sbb);
+                        sc = MFMA32(ah[e], fl[k0 + e], sc);
+                    }
+                }
+            }
+        } else {
+            // one wave per SIMD: nobody else covers a burst's LDS latency, so burst k + 1 is read (second register set) before the
+            // MFMAs of burst k are issued; no branch on wave_live (a dead wave multiplies its clamped rows and stores nothing):
+            // a branch per burst makes the compiler wait for every read pair right behind its issue
+            bf16x8 ah[2][RB], al[2][RB];
+            auto rd = [&](int k0, bf16x8 (&h)[RB], bf16x8 (&l)[RB]) {
+#pragma unroll
+                for (int e = 0; e < RB; ++e) {
+                    const int off = la[(k0 + e) & 7] + ((k0 + e) >> 3) * 256;
+                    h[e] = *reinterpret_cast<const bf16x8*>(sb + off);
+                    l[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
+                }
+            };
+            rd(0, ah[0], al[0]);
+#pragma unroll
+            for (int k0 = 0; k0 < KS; k0 += RB) {
+                const int cur = (k0 / RB) & 1;
+                if (k0 + RB < KS) rd(k0 + RB, ah[cur ^ 1], al[cur ^ 1]);
+                if (k0 == 0 && pend_ok) soft(pend, pend_row0);
+#pragma unroll
+                for (int e = 0; e < RB; ++e) {
+                    sa = MFMA32(ah[cur][e], fh[k0 + e], sa);
+                    sbb = MFMA32(al[cur][e], fh[k0 + e], sbb);
+                    sc = MFMA32(ah[cur][e], fl[k0 + e], sc);
+                }
+                if (SCHED && k0 + RB < KS) {
+                    // issue order of the burst: the two fragment reads of contraction step e of the NEXT burst between the MFMA
+                    // triples of this one (left alone the compiler issues all eight reads behind the last MFMA and, two bursts
+                    // on, waits for lgkmcnt(0) with them fresh in flight)
+#pragma unroll
+                    for (int e = 0; e < RB; ++e) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, SCHED == 2 ? 1 : 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (SCHED == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    }
                 }
             }
         }
@@ -561,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void cfl_bank_wide32_kernel(const float* __
 
 struct GsPlan { int DT, DP, RG, S, RGF, Bp, wide, big; };
 // big: the wide-batch forward (no gradient state): 8 waves x NRG x 16 rows per workgroup on one slot stream
-static int gs_big_rows(int) { return 256; }
+static int gs_big_rows(int D) { return D > 256 ? 128 : 256; }       // cfl_bank_wide32_kernel: 8 waves x 32 rows, 4 waves beyond D = 256
 static GsPlan gs_plan(int B, int M, int D, int big = 0) {
     GsPlan p;
     p.wide = D > 256;

@@ -95,7 +95,8 @@ def case_pool(N=256, H=112, C=64):
             'algorithmic_MB_each_way': round(byts / 1e6, 1)}
 
 
-def case_a5(M, D, C=1):
+def case_a5(M, D, C=1, noimg=False):
+    """noimg: the 128 x 128 tile GEMM of bank.hip instead of the bank pass (the A/B of the wide kernel at 256 < D <= 512)"""
     g = torch.Generator(device='cuda').manual_seed(2)
     G = unit(M, D, gen=g)
     vecs = [torch.nn.functional.normalize(G + 0.5 * unit(M, D, gen=g), dim=-1) for _ in range(C)]
@@ -103,10 +104,15 @@ def case_a5(M, D, C=1):
     def step():
         lp = torch.stack([ops.conw_logprob(v, G) for v in vecs], 0)
         ops.conw_combine(vecs, lp)
-    us, prof = timed(step, iters=3, warm=1)
+    old = ops._CONW_NOIMG
+    ops._CONW_NOIMG = bool(noimg) or old
+    try:
+        us, prof = timed(step, iters=3, warm=1)
+    finally:
+        ops._CONW_NOIMG = old
     flops = 2 * M * M * D * C
-    return {'case': f'a5_conw M={M} D={D} C={C}', 'us_per_step': round(us, 1), 'kernels_us': prof,
-            'algo_TFLOPs': round(flops / us / 1e6, 2)}
+    return {'case': f'a5_conw M={M} D={D} C={C}' + (' tile GEMM' if noimg else ''), 'us_per_step': round(us, 1), 'kernels_us': prof,
+            'algo_TFLOPs': round(flops / us / 1e6, 2), 'of_3xbf16_roof': round(flops / us / 1e6 / 833.0, 3)}
 
 
 def case_a2(N, P, Cd, dh, D, dtype=torch.float32):
@@ -427,8 +433,8 @@ def main():
         out += [case_a3(128, 50000, 256)]
     if 'a5' in cases:
         out += [case_a5(args.conw_m, 256)]
-    if 'a5wide' in cases:            # D = 512 (configs[1]) / 768 (configs[4]): the 128 x 128 tile GEMM of bank.hip (no wide bank kernel)
-        out += [case_a5(args.conw_m, 512), case_a5(args.conw_m, 768)]
+    if 'a5wide' in cases:            # D = 512 (configs[1]): the 4-wave wide bank kernel vs the 128 x 128 tile GEMM of bank.hip; 768 (configs[4]): tile GEMM
+        out += [case_a5(args.conw_m, 512), case_a5(args.conw_m, 512, noimg=True), case_a5(args.conw_m, 384), case_a5(args.conw_m, 768)]
     if 'a2' in cases:
         out += [case_a2(256, 49, 2048, 1024, 512), case_a2(256, 49, 2048, 1024, 512, torch.bfloat16), case_a2(128, 49, 512, 256, 256)]
     if 'a6' in cases:
