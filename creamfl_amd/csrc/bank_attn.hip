@@ -428,7 +428,7 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
 
 // ---- round 4: con_w log-probabilities on the bank pass (wide-batch forward of bank_gsplit.h) -------------------------------
 int cfl_conw_img_supported(int rows, int M, int D) {
-    return (rows >= 512 && M > 0 && D >= 4 && D <= 512 && D % 4 == 0) ? 1 : 0;
+    return (rows >= 512 && M > 0 && D >= 4 && D <= 768 && D % 4 == 0) ? 1 : 0;
 }
 
 size_t cfl_conw_img_ws_bytes(int rows, int M, int D) {
@@ -459,7 +459,11 @@ int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int 
                    (const char*)image, rows, M, D, sc2, p.S, p.RG, w.part_m, w.part_l);                                          \
     } while (0)
     static const char* rbv = getenv("CFL_CONW_WIDE_RB");                // measurement knob: fragment-burst length of the 4-wave form
-    if (p.DT == 16) {
+    if (p.DT == 24) {                                                     // D = 768: 16-row steps, three 48 KB slot buffers
+        CFL_SET_LDS((gs::cfl_bank_wide16_kernel<24>), 3 * 64 * 32 * 24);
+        CFL_LAUNCH(K_BANK_STREAM, (gs::cfl_bank_wide16_kernel<24>), dim3(p.S * p.RG), dim3(256), 3 * 64 * 32 * 24, stream, F, (const char*)image,
+                   rows, M, D, sc2, p.S, p.RG, w.part_m, w.part_l);
+    } else if (p.DT == 16) {
         // measured at M = 50 000 (profiles/r6_a5_conw_lines.jsonl): bursts of 2 / 4 / 8 contraction steps 7.26 / 6.59 / 7.00 ms; with
         // the issue order pinned (sched_group_barrier) 's' -1.3 %, 't' -2.6 % against the plain burst of 4 on the same lease
         if (rbv && rbv[0] == '8') CFL_WIDE32(16, 4, 8);

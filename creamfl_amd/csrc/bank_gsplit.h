@@ -607,6 +607,158 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cfl_bank_wide32_kernel(const 
     }
 }
 
+// ---- D = 768 (round 6): 16-row steps on v_mfma_f32_16x16x32_bf16 ----------------------------------------------------------------
+// 384 registers of pre-split V per wave (32 rows) and 2 x 96 KB of step buffers rule out the 32 x 32 form above.  Here a step is ONE
+// 16-row slot (48 KB): three slot buffers (144 KB), the LDS-DMA two steps ahead with a counted vmcnt wait; a wave's 32 rows of V are
+// two 16-row B tiles of the 16 x 16 x 32 MFMA (the stream kernel's logits arrangement: A = the slot, a lane owns one row of V and
+// four of the slot's bank rows per tile), so every fragment read serves two MFMA triples and the LDS-read : MFMA ratio is the
+// 32 x 32 form's.  The running (max, sum) is kept PER LANE over the bank rows the lane sees (4 of every 16) -- partial log-sum-exps
+// over disjoint row sets merge associatively -- so the loop has no cross-lane operation at all; the four lanes of a row merge once,
+// at the end.  Four waves, one per SIMD, ~480 registers, one workgroup per CU, 128 rows of V per workgroup.
+#define MFMA16W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+template <int DT>
+__global__ __launch_bounds__(256, 1) void cfl_bank_wide16_kernel(const float* __restrict__ F, const char* __restrict__ img, int B, int M,
+                                                               int D, float sc2, int S, int RG, float* __restrict__ part_m,
+                                                               float* __restrict__ part_l) {
+    constexpr int DP = 32 * DT, SLOT = 64 * DP, KS = DT, RB = 2, NW = 4, FR = 32 * NW;
+    constexpr int STRIPE = NW * 1024, NPT = SLOT / STRIPE;                // 16-byte DMA pieces per thread and slot
+    static_assert(KS % (2 * RB) == 0 && SLOT % STRIPE == 0 && NPT <= 31, "bursts tile the contraction, stripes tile a slot");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f16 = lane & 15, kg = lane >> 4;
+    const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+    const int rg = j8 % RG, x = (j8 / RG) * 8 + xcd;
+    const int nslot = (M + SG - 1) / SG;
+    const int base = nslot / S, extra = nslot % S;
+    const int c0 = x * base + (x < extra ? x : extra);
+    const int nstep = base + (x < extra ? 1 : 0);                        // 16-row slots of this split = steps
+    const int limit = min(M, (c0 + nstep) * SG);
+    const bool wave_live = rg * FR + 32 * w < B;
+    const char* sbase = img + (size_t)c0 * SLOT + (w * 64 + lane) * 16;
+    auto dma_step = [&](int it, int buf) {
+        const char* src = sbase + (size_t)it * SLOT;
+        char* dst = lds + buf * SLOT + w * 1024;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            __builtin_amdgcn_global_load_lds((glb_vptr)(src + j * STRIPE), (lds_vptr)(dst + j * STRIPE), 16, 0, 0);
+    };
+    if (nstep > 0) dma_step(0, 0);
+    if (nstep > 1) dma_step(1, 1);
+    bf16x8 fh[2][KS], fl[2][KS];                                 // B operands: row 16 tt + f16 of the wave's 32, k = 32 ks + 8 kg .. + 7
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int fr = rg * FR + 32 * w + 16 * tt + f16;
+        const float* fp = F + (long long)(fr < B ? fr : B - 1) * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 32 * ks + 8 * kg;
+            const bool ok0 = fr < B && k0 < D, ok1 = fr < B && k0 + 4 < D;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(fp + (k0 < D ? k0 : 0));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(fp + (k0 + 4 < D ? k0 + 4 : 0));
+            v0 *= sc2; v1 *= sc2;
+            bf16x4 h0, l0, h1, l1;
+            split4(v0, ok0, h0, l0);
+            split4(v1, ok1, h1, l1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { fh[tt][ks][e] = h0[e]; fh[tt][ks][4 + e] = h1[e]; fl[tt][ks][e] = l0[e]; fl[tt][ks][4 + e] = l1[e]; }
+        }
+    }
+    int la[4];                                                   // A operand: bank row f16 of the slot, piece 4 ks + kg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) la[j] = f16 * (DP * 2) + (((4 * j + kg) ^ img_swz(f16)) << 4);
+    float run_m[2] = {-INFINITY, -INFINITY}, run_l[2] = {0.f, 0.f};
+    auto soft = [&](const f32x4 (&v)[2], int row0) {             // v[tt][r]: bank row row0 + 4 kg + r, row 16 tt + f16 of V
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = row0 + 4 * kg + r < limit ? v[tt][r] : -INFINITY;
+            const float mn = fmaxf(fmaxf(run_m[tt], fmaxf(y[0], y[1])), fmaxf(y[2], y[3]));
+            const float ref = mn == -INFINITY ? 0.f : mn;
+            float a = run_l[tt] * __builtin_amdgcn_exp2f(run_m[tt] - ref);
+            a += __builtin_amdgcn_exp2f(y[0] - ref) + __builtin_amdgcn_exp2f(y[1] - ref);
+            a += __builtin_amdgcn_exp2f(y[2] - ref) + __builtin_amdgcn_exp2f(y[3] - ref);
+            run_l[tt] = a;
+            run_m[tt] = mn;
+        }
+    };
+    if (nstep > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    f32x4 pend[2];
+    int pend_row0 = 0;
+    bool pend_ok = false;
+    int buf = 0;                                                 // step it lives in buffer it % 3
+    for (int it = 0; it < nstep; ++it) {
+        const int nb2 = buf == 0 ? 2 : buf - 1;                  // (it + 2) % 3: the buffer step it - 1 was read from
+        if (it + 2 < nstep) dma_step(it + 2, nb2);
+        const char* sb = lds + buf * SLOT;
+        f32x4 sa[2], sbb[2], sc[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { sa[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbb[tt] = sa[tt]; sc[tt] = sa[tt]; }
+        bf16x8 ah[2][RB], al[2][RB];
+        auto rd = [&](int k0, bf16x8 (&h)[RB], bf16x8 (&l)[RB]) {
+#pragma unroll
+            for (int e = 0; e < RB; ++e) {
+                const int off = la[(k0 + e) & 3] + ((k0 + e) >> 2) * 256;
+                h[e] = *reinterpret_cast<const bf16x8*>(sb + off);
+                l[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
+            }
+        };
+        rd(0, ah[0], al[0]);
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += RB) {
+            const int cur = (k0 / RB) & 1;
+            if (k0 + RB < KS) rd(k0 + RB, ah[cur ^ 1], al[cur ^ 1]);
+            if (k0 == 0 && pend_ok) soft(pend, pend_row0);       // the previous step's soft-max, inside the first bursts' LDS latency
+#pragma unroll
+            for (int e = 0; e < RB; ++e)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    sa[tt] = MFMA16W(ah[cur][e], fh[tt][k0 + e], sa[tt]);
+                    sbb[tt] = MFMA16W(al[cur][e], fh[tt][k0 + e], sbb[tt]);
+                    sc[tt] = MFMA16W(ah[cur][e], fl[tt][k0 + e], sc[tt]);
+                }
+            if (k0 + RB < KS) {
+#pragma unroll
+                for (int e = 0; e < RB; ++e) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) pend[tt] = sa[tt] + (sbb[tt] + sc[tt]);
+        pend_row0 = (c0 + it) * SG;
+        pend_ok = wave_live;
+        // step it + 1 must have landed (issued one iteration ago); step it + 2's pieces may stay in flight
+        // (a bare s_barrier: __syncthreads() is a fence the compiler drains vmcnt to 0 for, which would put step it + 2's round trip
+        // back on the critical path; every ds_read of this step was consumed by an MFMA above)
+        if (it + 2 < nstep) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (pend_ok) soft(pend, pend_row0);
+    if (!wave_live) return;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float om = __shfl_xor(run_m[tt], off, 64), ol = __shfl_xor(run_l[tt], off, 64);
+            const float mn = fmaxf(run_m[tt], om);
+            const float ref = mn == -INFINITY ? 0.f : mn;
+            run_l[tt] = run_l[tt] * __builtin_amdgcn_exp2f(run_m[tt] - ref) + ol * __builtin_amdgcn_exp2f(om - ref);
+            run_m[tt] = mn;
+        }
+        const int f = rg * FR + 32 * w + 16 * tt + f16;
+        if (kg == 0 && f < B) {
+            const size_t o = (size_t)(f >> 7) * S * BR + (size_t)x * BR + (f & (BR - 1));
+            part_m[o] = run_m[tt];
+            part_l[o] = run_l[tt];
+        }
+    }
+}
+
 struct GsPlan { int DT, DP, RG, S, RGF, Bp, wide, big; };
 // big: the wide-batch forward (no gradient state): 8 waves x NRG x 16 rows per workgroup on one slot stream
 static int gs_big_rows(int D) { return D > 256 ? 128 : 256; }       // cfl_bank_wide32_kernel: 8 waves x 32 rows, 4 waves beyond D = 256

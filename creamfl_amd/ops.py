@@ -721,7 +721,7 @@ def conw_logprob(vec, global_other, row0=0, rows=None):
     out = torch.empty(rows, dtype=torch.float32, device=V.device)
     if (not _CONW_NOIMG and lib.cfl_conw_img_supported(rows, M, D) and V.data_ptr() % 16 == 0 and G.data_ptr() % 16 == 0
             and not (_BANK_EXACT or lib.cfl_get_exact_gemm())):
-        # the bank pass of rows A3/A4 on the (cached) pre-split image of G: the bank moves through a CU once per 256 rows
+        # the bank pass of rows A3/A4 on the (cached) pre-split image of G: the bank moves through a CU once per 256 rows (128 beyond D = 256)
         img = bank_image(G)
         ws = _ws(lib.cfl_conw_img_ws_bytes(rows, M, D), V.device)
         _lib.check(lib.cfl_conw_logprob_img(_ptr(V), img.data_ptr(), _ptr(G), M, D, row0, rows, _ptr(out), _ptr(ws), _stream(V)),

@@ -348,7 +348,8 @@ int cfl_conw_combine(const float* const* Vptrs_host, const float* L, int C, int 
 /* Round 4: the same log-probabilities on the bank pass of rows A3/A4 (cfl_bank_image_build of G): the 8 waves of a workgroup
  * hold 256 rows of V in registers and stream the bank image once per 256 rows (32 x 32 x 16 MFMAs), online log-sum-exp per row, then one small launch
  * merges the splits and takes the positives as exact fp32 dot products.  Round 6: 256 < D <= 512 on the 4-wave form (one wave per
- * SIMD, 128 rows of V per workgroup).  rows >= 512, D <= 512, D % 4 == 0, 16-byte aligned
+ * SIMD, 128 rows of V per workgroup), 512 < D <= 768 on 16-row steps (16 x 16 x 32 MFMAs, per-lane running log-sum-exp).
+ * rows >= 512, D <= 768, D % 4 == 0, 16-byte aligned
  * operands; otherwise CFL_ELIMIT (cfl_conw_logprob takes every shape).  Same reference lines (MMFL.py:304-307).
  */
 int cfl_conw_img_supported(int rows, int M, int D);

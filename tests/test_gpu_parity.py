@@ -489,7 +489,9 @@ def test_a5_conw_row_shards(dev, m, d, row0, rows):
 @pytest.mark.parametrize('m,d,row0,rows', [(4096, 256, 0, 4096), (3000, 200, 1024, 1500), (2600, 128, 0, 2600),
                                            (1554, 36, 16, 1000), (5000, 256, 4096, 904),
                                            # round 6: 256 < D <= 512 on the 4-wave form (128 rows per workgroup, one wave per SIMD)
-                                           (4096, 512, 0, 4096), (3000, 384, 1024, 1500), (2200, 300, 7, 1111), (5000, 512, 4096, 904)])
+                                           (4096, 512, 0, 4096), (3000, 384, 1024, 1500), (2200, 300, 7, 1111), (5000, 512, 4096, 904),
+                                           # D <= 768: 16-row steps on the 16 x 16 x 32 MFMA, per-lane running log-sum-exp
+                                           (4096, 768, 0, 4096), (3000, 640, 1024, 1500), (2203, 516, 7, 1111), (5000, 768, 4096, 904)])
 def test_a5_conw_bank_pass_equals_tile_gemm(dev, m, d, row0, rows, monkeypatch):
     """Round 4: the con_w log-probabilities on the bank pass of rows A3 / A4 (pre-split image of G, 256 rows of V per workgroup
     in registers, online log-sum-exp, exact fp32 positives) against the fp64 oracle (MMFL.py:304-307) and against the tile GEMM of
@@ -523,7 +525,7 @@ def test_a5_conw_small_shards_stay_on_the_tile_gemm(dev):
     from creamfl_amd import _lib, ops
     lib = _lib.load()
     assert lib.cfl_conw_img_supported(511, 5000, 256) == 0 and lib.cfl_conw_img_supported(512, 5000, 256) == 1
-    assert lib.cfl_conw_img_supported(4096, 4096, 768) == 0 and lib.cfl_conw_img_supported(4096, 4096, 254) == 0
+    assert lib.cfl_conw_img_supported(4096, 4096, 772) == 0 and lib.cfl_conw_img_supported(4096, 4096, 254) == 0 and lib.cfl_conw_img_supported(4096, 4096, 768) == 1
     assert lib.cfl_conw_img_supported(4096, 4096, 512) == 1 and lib.cfl_conw_img_supported(4096, 4096, 260) == 1
     gen = torch.Generator().manual_seed(5)
     G = _unit(gen, 1000, 64)

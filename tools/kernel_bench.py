@@ -434,7 +434,8 @@ def main():
     if 'a5' in cases:
         out += [case_a5(args.conw_m, 256)]
     if 'a5wide' in cases:            # D = 512 (configs[1]): the 4-wave wide bank kernel vs the 128 x 128 tile GEMM of bank.hip; 768 (configs[4]): tile GEMM
-        out += [case_a5(args.conw_m, 512), case_a5(args.conw_m, 512, noimg=True), case_a5(args.conw_m, 384), case_a5(args.conw_m, 768)]
+        out += [case_a5(args.conw_m, 512), case_a5(args.conw_m, 512, noimg=True), case_a5(args.conw_m, 384), case_a5(args.conw_m, 768),
+                case_a5(args.conw_m, 768, noimg=True)]
     if 'a2' in cases:
         out += [case_a2(256, 49, 2048, 1024, 512), case_a2(256, 49, 2048, 1024, 512, torch.bfloat16), case_a2(128, 49, 512, 256, 256)]
     if 'a6' in cases:
