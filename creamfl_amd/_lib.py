@@ -51,6 +51,7 @@ SIGNATURES = {
     'cfl_daln_ws_bytes': (c_size_t, [c_int, c_int]),
     'cfl_daln_fwd': (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint, _P, _P, _P, _P, _P]),
     'cfl_daln_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint, _P, _P, _P, _P, c_int, _P, _P]),
+    'cfl_preln_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     'cfl_bias_gelu_ws_bytes': (c_size_t, [c_longlong, c_int]),
     'cfl_bias_gelu_fwd': (c_int, [_P, _P, c_int, c_longlong, c_int, _P, _P]),
     'cfl_bias_gelu_bwd': (c_int, [_P, _P, c_int, _P, c_longlong, c_int, _P, _P, c_int, _P, _P]),

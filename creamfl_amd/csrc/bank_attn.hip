@@ -415,9 +415,16 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
         int rc;
         // <DT, slot streams, waves, column split, staging (0 = LDS-DMA)>: D <= 256: 2 feature groups x 4 slot streams;
         // D = 512 / 768: 4 column-split pairs on one stream; always 8 waves, two per SIMD
+        // A/B (profiles/r6_a3_dma_ab.jsonl): CFL_BANK_DMA_ASM=1 issues the slots' LDS-DMA from inline assembly, which takes the compiler's
+        // s_waitcnt vmcnt(0) out of the middle of the iteration (it sits in front of the first transposing read of the gradient block with
+        // the builtin).  A tie on three leases (D = 256: 32.8-33.4 vs 33.5 us; D = 512: 97.0 vs 98.8; D = 768: 74.8 vs 73.8): that wait is
+        // not what the waves wait for.  The builtin form stays the default.
+        static const bool dma_builtin = getenv("CFL_BANK_DMA_ASM") == nullptr;
 #define CFL_STREAM(DT_, NGG_, NDS_)                                                                                       \
-    (want_grad ? launch_stream<DT_, NGG_, 8, NDS_, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)                  \
-               : launch_stream<DT_, NGG_, 8, NDS_, 0, false>(F, image_other, B, M, D, sc2, p, w, stream))
+    (dma_builtin ? (want_grad ? launch_stream<DT_, NGG_, 8, NDS_, 0, true>(F, image_other, B, M, D, sc2, p, w, stream)   \
+                              : launch_stream<DT_, NGG_, 8, NDS_, 0, false>(F, image_other, B, M, D, sc2, p, w, stream)) \
+                 : (want_grad ? launch_stream<DT_, NGG_, 8, NDS_, -1, true>(F, image_other, B, M, D, sc2, p, w, stream)  \
+                              : launch_stream<DT_, NGG_, 8, NDS_, -1, false>(F, image_other, B, M, D, sc2, p, w, stream)))
         rc = p.DT == 24 ? CFL_STREAM(24, 1, 2) : p.DT == 16 ? CFL_STREAM(16, 1, 2) : p.DT == 8 ? CFL_STREAM(8, 4, 1) : CFL_STREAM(4, 4, 1);
 #undef CFL_STREAM
         if (rc) return rc;

@@ -180,11 +180,27 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
     // buffer, lane-linear -- the image is stored in LDS order for exactly this): no staging registers, no ds_write (the
     // 64 KB per iteration a workgroup pushes through ds_write_b128 occupy the LDS write path for ~800 cycles of the ~3800 an
     // iteration takes), issued at the top of an iteration and complete at its closing barrier.
-    constexpr bool DMA = (LA == 0);
+    // LA = -1 (round 6): the same LDS-DMA issued from INLINE ASSEMBLY.  The compiler orders every LDS read it cannot tell apart from
+    // the transfer's target behind every LDS-DMA it knows of: with the builtin it put s_waitcnt vmcnt(0) in front of the first
+    // TRANSPOSING read of the gradient block (and, at D > 256, in front of the logit-exchange barrier) -- the next slot had to land in
+    // the MIDDLE of the iteration that issued it, not at its closing barrier.  What the compiler does not see it does not wait for;
+    // the wait is the explicit vmcnt(0) in front of the closing barrier.  M0 (the LDS base of a transfer) is saved and restored.
+    constexpr bool DMA = (LA <= 0), ASMDMA = (LA < 0);
     constexpr int NSET = DMA ? 1 : LA;
     u32x4v stage[NSET][DMA ? 1 : NPT];
+    const unsigned sbuf_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sbuf;
     auto dma_slot = [&](int it, int b) {
         const char* src = slot_src(it);
+        if (ASMDMA) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(sbuf_a + b * SM::SLOT + sw * 1024);
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src + j * STRIDE), "s"(dst + j * STRIDE) : "memory");
+            }
+            return;
+        }
         char* dst = sbuf + b * SM::SLOT + sw * 1024;          // this wave's 1 KB of every STRIDE-byte stripe (lane l: + 16 l)
 #pragma unroll
         for (int j = 0; j < NPT; ++j)
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
 #pragma unroll
         for (int j = 0; j < NPT; ++j) *reinterpret_cast<u32x4v*>(sbuf + j * STRIDE + toff) = stage[0][j];
     }
+    if (ASMDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // piece addresses: a few per-lane bases + compile-time multiples of 256 (the swizzle permutes within 256-byte windows);
     // a column-split wave starts dh KSW x 64 / dh NDTW x 32 bytes into the row (whole windows)
@@ -280,7 +297,11 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
         }
         if (NDS > 1) {                                           // the pair's partial logits meet (all waves take the barrier)
             xs[w * 64 + lane] = sa;
-            __syncthreads();
+            // a bare barrier behind this wave's own LDS write (round 6): __syncthreads() is a fence the compiler drains vmcnt to 0
+            // for, i.e. the LDS-DMA of the NEXT slot, issued at the top of this iteration, had to land here -- in the middle of the
+            // iteration -- instead of at its closing barrier; nobody reads that buffer before the closing barrier
+            if (ASMDMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else __syncthreads();
 #pragma unroll
             for (int o = 1; o < NDS; ++o) sa += xs[(w - dh + (dh + o) % NDS) * 64 + lane];
         }
@@ -342,6 +363,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
 #pragma unroll
             for (int j = 0; j < NPT; ++j) *reinterpret_cast<u32x4v*>(nb + j * STRIDE + toff) = wr[j];
         }
+        if (ASMDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // also the landing point of this iteration's LDS-DMA (vmcnt)
     };
     for (int it = 0; it < niter; it += NSET) {

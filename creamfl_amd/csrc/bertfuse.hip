@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void cfl_daln_bwd_kernel(const U2* __restrict_
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int T,
                                                            int H, u32 thr16, float scale, u32 seed, int rows_per_block,
                                                            U2* __restrict__ ds_out, U2* __restrict__ dy_out, float* __restrict__ partials,
-                                                           const u32* __restrict__ tick) {
+                                                           const u32* __restrict__ tick, const U2* __restrict__ ds_add) {
     __shared__ float red[4][NJ * 256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     seed = tick_seed(seed, tick);
@@ -189,12 +189,13 @@ __global__ __launch_bounds__(256) void cfl_daln_bwd_kernel(const U2* __restrict_
         for (int j = 0; j < NJ; ++j) {
             const int col = j * 256 + lane * 4;
             if (col < H) {
-                float d[4], dy[4];
+                float d[4], dy[4], da[4] = {0.f, 0.f, 0.f, 0.f};
                 bool k[4];
                 keep4(seed, base + col, thr16, k);
+                if (ds_add) unpack4(ds_add[(base + col) >> 2], da);      // pre-LN: the gradient that reaches s directly (the residual stream)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    d[t] = rs * (dz[j][t] * gam[j][t] - c1 - xh[j][t] * c2);
+                    d[t] = rs * (dz[j][t] * gam[j][t] - c1 - xh[j][t] * c2) + da[t];
                     dy[t] = k[t] ? d[t] * scale : 0.f;
                     dgam[j][t] = fmaf(dz[j][t], xh[j][t], dgam[j][t]);
                     dbet[j][t] += dz[j][t];
@@ -376,10 +377,35 @@ int cfl_daln_bwd(const void* s, const void* dz_a, const void* dz_b, const float*
     const int rpb = daln_rows_per_block(T), nblk = cfl_cdiv(T, rpb);
     float* partials = (float*)ws;
 #define DALN_BWD(NJ) CFL_LAUNCH(K_BERT_DALN, (cfl_daln_bwd_kernel<NJ>), dim3(nblk), dim3(256), 0, stream, (const U2*)s, (const U2*)dz_a, \
-                                (const U2*)dz_b, gamma, mean, rstd, T, H, thr, sc, seed, rpb, (U2*)ds, (U2*)dy, partials, g_dropout_tick)
+                                (const U2*)dz_b, gamma, mean, rstd, T, H, thr, sc, seed, rpb, (U2*)ds, (U2*)dy, partials, g_dropout_tick, \
+                                (const U2*)nullptr)
     const int nj = cfl_cdiv(H, 256);
     if (nj <= 1) DALN_BWD(1); else if (nj <= 2) DALN_BWD(2); else if (nj <= 3) DALN_BWD(3); else if (nj <= 4) DALN_BWD(4); else DALN_BWD(8);
 #undef DALN_BWD
+    CFL_LAUNCH(K_BERT_DALN, cfl_colsum_final_kernel, dim3(cfl_cdiv(3 * H, 16)), dim3(256), 0, stream, partials, nblk, 3 * H,
+               dgamma_dbeta, 2 * H, dbias, dbias_bf16);
+    return 0;
+}
+
+// Pre-LN blocks (the ViT trunk of configs[4]): s = g + bias + residual is the NEXT residual and z = LayerNorm(s) feeds the next GEMM, so
+// two different tensors leave the forward (cfl_daln_fwd with p = 0 writes both) and the gradient of s is
+//     ds = LayerNorm'(dz) + ds_direct        (ds_direct: what reaches s over the residual stream; NULL = none)
+// = d/d g = d/d residual; dbias = its column sums.
+int cfl_preln_bwd(const void* s, const void* dz, const void* ds_direct, const float* gamma, const float* mean, const float* rstd, int T,
+                  int H, void* ds, float* dgamma_dbeta, void* dbias, int dbias_bf16, void* ws, void* stream_) {
+    if (!s || !dz || !gamma || !mean || !rstd || !ds || !dgamma_dbeta || !ws || T <= 0 || H <= 0) return CFL_EINVAL;
+    if (H % 4 != 0 || H > 2048) return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const u32 thr = thr_of(0.f);
+    const float sc = scale_of(thr);
+    const int rpb = daln_rows_per_block(T), nblk = cfl_cdiv(T, rpb);
+    float* partials = (float*)ws;
+#define PRELN_BWD(NJ) CFL_LAUNCH(K_BERT_DALN, (cfl_daln_bwd_kernel<NJ>), dim3(nblk), dim3(256), 0, stream, (const U2*)s, (const U2*)dz, \
+                                 (const U2*)nullptr, gamma, mean, rstd, T, H, thr, sc, 0u, rpb, (U2*)ds, (U2*)nullptr, partials,         \
+                                 (const u32*)nullptr, (const U2*)ds_direct)
+    const int nj = cfl_cdiv(H, 256);
+    if (nj <= 1) PRELN_BWD(1); else if (nj <= 2) PRELN_BWD(2); else if (nj <= 3) PRELN_BWD(3); else if (nj <= 4) PRELN_BWD(4); else PRELN_BWD(8);
+#undef PRELN_BWD
     CFL_LAUNCH(K_BERT_DALN, cfl_colsum_final_kernel, dim3(cfl_cdiv(3 * H, 16)), dim3(256), 0, stream, partials, nblk, 3 * H,
                dgamma_dbeta, 2 * H, dbias, dbias_bf16);
     return 0;

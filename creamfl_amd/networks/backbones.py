@@ -250,6 +250,9 @@ _RESNETS = {
 }
 
 
+_VIT_NO_FUSE = bool(os.environ.get('CFL_NO_VIT_FUSE'))       # A/B: the ViT blocks on aten LayerNorm / GELU / adds
+
+
 class _ViTBlock(nn.Module):
     def __init__(self, dim, heads, mlp_dim):
         super().__init__()
@@ -266,6 +269,21 @@ class _ViTBlock(nn.Module):
         a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D)
         x = x + self.out_proj(a)
         return x + self.mlp(self.ln_2(x))
+
+    def forward_fused(self, x, h, next_ln):
+        """The same block on the glue kernels of the BERT tower (csrc/bertfuse.hip; round 6).  x: the residual stream (bf16), h =
+        ln_1(x), already formed by the previous block's tail; returns (x', next_ln(x')).  Each residual add + bias + the LayerNorm that
+        reads the sum is ONE pass per direction (`ops.preln_add_layernorm`: the backward also sums the two gradients of the residual
+        stream and yields the bias / LayerNorm parameter gradients), bias + GELU another (`ops.bert_bias_gelu`); the GEMMs stay on
+        hipBLASLt, the attention on the library's SDPA.  The residual stream is held in bf16 (eager autocast: fp32)."""
+        from .. import ops
+        B, L, D = x.shape
+        q, k, v = self.in_proj(h).view(B, L, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D)
+        x1, h2 = ops.preln_add_layernorm(F.linear(a, self.out_proj.weight), self.out_proj.bias, x, self.ln_2.weight, self.ln_2.bias,
+                                         self.ln_2.eps)
+        u = ops.bert_bias_gelu(F.linear(h2, self.mlp[0].weight), self.mlp[0].bias)
+        return ops.preln_add_layernorm(F.linear(u, self.mlp[2].weight), self.mlp[2].bias, x1, next_ln.weight, next_ln.bias, next_ln.eps)
 
 
 class ViTTrunk(nn.Module):
@@ -311,9 +329,22 @@ class ViTTrunk(nn.Module):
             pos = F.interpolate(pos.reshape(1, g, g, d).permute(0, 3, 1, 2), size=(h, w), mode='bilinear',
                                 align_corners=False).permute(0, 2, 3, 1).reshape(1, h * w, d)
         t = t + pos
-        for blk in self.layers:
-            t = blk(t)
-        t = self.ln(t)
+        blk0 = self.layers[0]
+        i8 = blk0.mlp[0].weight.shape[0] >> 3                   # (cfl_bias_gelu_bwd's column plan: >= 256 16-byte groups, or a divisor of 256)
+        if (not _VIT_NO_FUSE and _bert_fusable(t, blk0.out_proj.weight, max_out=2048) and _bert_fusable(t, blk0.mlp[0].weight)
+                and (i8 >= 256 or 256 % i8 == 0)
+                and isinstance(blk0.mlp[1], nn.GELU) and getattr(blk0.mlp[1], 'approximate', 'none') == 'none'):
+            # pre-LN chain on the fused glue: block i's tail forms block i + 1's ln_1 (the last one: the trunk's final LayerNorm)
+            t = t.to(torch.bfloat16)
+            hN = blk0.ln_1(t).to(torch.bfloat16)
+            for i, blk in enumerate(self.layers):
+                nxt = self.layers[i + 1].ln_1 if i + 1 < len(self.layers) else self.ln
+                t, hN = blk.forward_fused(t, hN, nxt)
+            t = hN
+        else:
+            for blk in self.layers:
+                t = blk(t)
+            t = self.ln(t)
         return t.transpose(1, 2).reshape(n, d, h, w)             # a view: memory stays [N, P, D]
 
     def forward(self, x):

@@ -2031,6 +2031,59 @@ class _DalnFn(torch.autograd.Function):
         return (dy if dy is not None else ds), dbias, ds, dgb[0], dgb[1], None, None, None
 
 
+class _PreLnFn(torch.autograd.Function):
+    """(s, z) = (g + bias + residual, LayerNorm(s)): the tail of a pre-LN sub-layer fused with the LayerNorm of the next one."""
+    @staticmethod
+    def forward(ctx, g, bias, residual, gamma, beta, eps):
+        lib = _lib.load()
+        H = g.shape[-1]
+        T = g.numel() // H
+        need = any(ctx.needs_input_grad[:5])
+        z = torch.empty_like(g)
+        s = torch.empty_like(g)
+        stats = torch.empty(2, T, dtype=torch.float32, device=g.device)
+        _lib.check(lib.cfl_daln_fwd(_ptr(g), _ptr(bias), int(bias is not None and bias.dtype == torch.bfloat16), _ptr(residual),
+                                    _ptr(gamma), _ptr(beta), T, H, eps, 0.0, 0, _ptr(z), _ptr(s), _ptr(stats), _ptr(stats[1]),
+                                    _stream(g)), 'cfl_daln_fwd')
+        if need:
+            ctx.save_for_backward(s, gamma, stats)
+        ctx.hyper = (T, H, None if bias is None else (bias.dtype, bias.shape))
+        ctx.set_materialize_grads(False)
+        return s, z
+
+    @staticmethod
+    def backward(ctx, ds_direct, dz):
+        lib = _lib.load()
+        s, gamma, stats = ctx.saved_tensors
+        T, H, bias_meta = ctx.hyper
+        if dz is None and ds_direct is None:
+            return (None,) * 6
+        if dz is None:                                     # (the LayerNorm output unused: only the residual stream carries a gradient)
+            dz = torch.zeros_like(s)
+        dz = _bf16c(dz, 'dz')
+        ds_direct = _bf16c(ds_direct, 'ds') if ds_direct is not None else None
+        ds = torch.empty_like(s)
+        dgb = torch.empty(2, H, dtype=torch.float32, device=s.device)
+        dbias = torch.empty(bias_meta[1], dtype=bias_meta[0], device=s.device) if (bias_meta and ctx.needs_input_grad[1]) else None
+        ws = _ws(lib.cfl_daln_ws_bytes(T, H), s.device)
+        _lib.check(lib.cfl_preln_bwd(_ptr(s), _ptr(dz), _ptr(ds_direct), _ptr(gamma), _ptr(stats), _ptr(stats[1]), T, H, _ptr(ds),
+                                     _ptr(dgb), _ptr(dbias), int(dbias is not None and dbias.dtype == torch.bfloat16), _ptr(ws),
+                                     _stream(s)), 'cfl_preln_bwd')
+        return ds, dbias, ds, dgb[0], dgb[1], None
+
+
+def preln_add_layernorm(g, bias, residual, gamma, beta, eps=1e-6):
+    """Tail of a pre-LN sub-layer (ViT block: x + out_proj(attn), x + mlp(...)) fused with the LayerNorm that reads the sum
+    (csrc/bertfuse.hip): returns (s, z) = (g + bias + residual in bf16, LayerNorm(s)); g is the bias-free GEMM output."""
+    g = _bf16c(g, 'g')
+    residual = _bf16c(residual, 'residual')
+    if residual.shape != g.shape:
+        raise RuntimeError(f'shape mismatch {tuple(g.shape)} vs {tuple(residual.shape)}')
+    if bias is not None and not bias.is_contiguous():
+        bias = bias.contiguous()
+    return _PreLnFn.apply(g, bias, residual, _f32(gamma, 'gamma'), _f32(beta, 'beta'), float(eps))
+
+
 def bert_dropout_add_layernorm(g, bias, residual, gamma, beta, p=0.0, eps=1e-12, seed=None):
     """LayerNorm(dropout(g + bias) + residual) for the BertSelfOutput / BertOutput sub-layers (csrc/bertfuse.hip).
     g: bias-free GEMM output, bf16 [..., H].  Returns TWO tensors on the same buffer: feed the first to the next

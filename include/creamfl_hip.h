@@ -174,6 +174,11 @@ int cfl_daln_fwd(const void* g, const void* bias, int bias_bf16, const void* res
 int cfl_daln_bwd(const void* s, const void* dz_a, const void* dz_b, const float* gamma, const float* mean, const float* rstd,
                  int T, int H, float p, unsigned seed, void* ds, void* dy, float* dgamma_dbeta, void* dbias, int dbias_bf16,
                  void* ws, void* stream);
+/* Pre-LN blocks (the build-defined ViT trunk of BASELINE.json configs[4]; the reference ships no ViT -- same element-wise glue as the
+ * BertLayer lines above): s = g + bias + residual is the next residual, z = LayerNorm(s) the next GEMM's input (cfl_daln_fwd, p = 0,
+ * writes both); preln_bwd: ds = LayerNorm'(dz) + ds_direct (ds_direct NULL = none) = d/d g = d/d residual, dgamma_dbeta[2H], dbias. */
+int cfl_preln_bwd(const void* s, const void* dz, const void* ds_direct, const float* gamma, const float* mean, const float* rstd, int T,
+                  int H, void* ds, float* dgamma_dbeta, void* dbias, int dbias_bf16, void* ws, void* stream);
 size_t cfl_bias_gelu_ws_bytes(long long T, int I);
 int cfl_bias_gelu_fwd(const void* g, const void* bias, int bias_bf16, long long T, int I, void* h, void* stream);
 int cfl_bias_gelu_bwd(const void* g, const void* bias, int bias_bf16, const void* dh, long long T, int I, void* du, void* dbias,

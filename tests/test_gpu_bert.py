@@ -253,3 +253,68 @@ def test_pcme_takes_the_packed_tower_only_with_host_lengths(dev):
         e0 = model._text_tower(b[1], None, bare)['embedding'].float()
     assert float((e1 - e0).abs().max()) <= 3e-2
     assert 'pack' in model._bert_inputs(b[1], None, lens.cpu())                            # host tensor: no copy needed
+
+
+@pytest.mark.parametrize('t,h,bias_bf16,direct', [(7, 256, False, True), (50176, 768, True, True), (197, 192, True, False), (33, 1024, False, True),
+                                                  (9, 260, True, True)])
+def test_preln_add_layernorm_matches_eager(dev, t, h, bias_bf16, direct):
+    """Round 6, the pre-LN tail of a ViT sub-layer (ops.preln_add_layernorm): (s, z) = (g + bias + residual, LayerNorm(s)) against the
+    fp32 composition on the same bf16-valued inputs; s takes a gradient of its own (the residual stream) unless `direct` is off."""
+    from creamfl_amd import ops
+    gen = torch.Generator().manual_seed(t + h)
+    g = torch.randn(t, h, generator=gen).to(torch.bfloat16).to(dev).requires_grad_(True)
+    res = torch.randn(t, h, generator=gen).to(torch.bfloat16).to(dev).requires_grad_(True)
+    bias = (0.3 * torch.randn(h, generator=gen)).to(torch.bfloat16 if bias_bf16 else torch.float32).to(dev).requires_grad_(True)
+    gamma = (1.0 + 0.2 * torch.randn(h, generator=gen)).to(dev).requires_grad_(True)
+    beta = (0.2 * torch.randn(h, generator=gen)).to(dev).requires_grad_(True)
+    wz = torch.randn(t, h, generator=gen).to(torch.bfloat16).to(dev)
+    ws = torch.randn(t, h, generator=gen).to(torch.bfloat16).to(dev)
+    s, z = ops.preln_add_layernorm(g, bias, res, gamma, beta, 1e-6)
+    loss = (z.float() * wz.float()).sum() + ((s.float() * ws.float()).sum() if direct else 0.0)
+    loss.backward()
+    got = [x.grad.float().clone() for x in (g, res, bias, gamma, beta)]
+    r = [x.detach().float().requires_grad_(True) for x in (g, res, bias, gamma, beta)]
+    s0 = (r[0] + r[2] + r[1])
+    s0q = s0 + (s0.detach().to(torch.bfloat16).float() - s0.detach())          # the kernel's single bf16 rounding of the sum (straight through)
+    z0 = F.layer_norm(s0q, (h,), r[3], r[4], 1e-6)
+    ((z0 * wz.float()).sum() + ((s0q * ws.float()).sum() if direct else 0.0)).backward()
+    np.testing.assert_allclose(s.detach().float().cpu().numpy(), s0q.detach().cpu().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(z.detach().float().cpu().numpy(), z0.detach().cpu().numpy(), rtol=2e-2, atol=2e-2)
+    assert torch.equal(g.grad, res.grad)
+    for name, a, b in zip(('g', 'res', 'bias', 'gamma', 'beta'), got, [x.grad for x in r]):
+        sc = float(b.abs().max()) + 1e-6
+        err = float((a - b).abs().max())
+        assert err <= 2e-2 * sc, (name, err, sc)             # bf16 gradients / fp32 column sums of bf16-rounded rows
+
+
+def test_vit_fused_chain_matches_the_aten_blocks(dev, monkeypatch):
+    """Round 6 (configs[4]): the ViT trunk on the fused pre-LN glue (each block's tail forms the next block's ln_1; bias + GELU fused)
+    against the same trunk on aten LayerNorm / GELU / adds under bf16 autocast: features and every parameter gradient."""
+    from creamfl_amd import _lib
+    from creamfl_amd.networks import backbones
+    torch.manual_seed(1)
+    vit = backbones.ViTTrunk(dim=192, depth=3, heads=3, mlp_dim=512, patch=16, img=64).to(dev).train()
+    x = torch.randn(5, 3, 64, 64, device=dev).contiguous(memory_format=torch.channels_last)
+    wout = torch.randn(5, 192, 4, 4, device=dev)
+
+    def run(fused):
+        monkeypatch.setattr(backbones, '_VIT_NO_FUSE', not fused)
+        vit.zero_grad(set_to_none=True)
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = vit(x).float()
+        (out * wout).sum().backward()
+        launches = {k: v[0] for k, v in _lib.prof_query().items()}
+        _lib.prof_enable(False)
+        return out.detach(), {n: p.grad.detach().float().clone() for n, p in vit.named_parameters()}, launches
+    o1, g1, l1 = run(True)
+    o0, g0, l0 = run(False)
+    assert l1.get('cfl_bert_daln_kernel', 0) >= 2 * 2 * 3 and l0.get('cfl_bert_daln_kernel', 0) == 0, (l1, l0)
+    np.testing.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=5e-2, atol=5e-2)
+    assert set(g1) == set(g0)
+    for n in g0:
+        sc = float(g0[n].abs().max()) + 1e-6
+        err = float((g1[n] - g0[n]).abs().max())
+        cos = float(torch.nn.functional.cosine_similarity(g1[n].flatten(), g0[n].flatten(), dim=0))
+        assert err <= 0.1 * sc + 1e-4 and cos >= 0.99, (n, err, sc, cos)

@@ -45,6 +45,7 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench as _bench                                       # the FLOP counter of the bench line (module hooks + attention)
     fwd = _bench.forward_flops(eng, images, b[1], b[2], b[3])
+    fwd = fwd['total'] if isinstance(fwd, dict) else fwd            # (by tower since round 5)
     vit = eng.model.img_enc.cnn                                   # + the ViT's QK^T / PV, which forward_flops does not see
     if hasattr(vit, 'layers'):
         Lp = (images.shape[2] // vit.patch) * (images.shape[3] // vit.patch)
@@ -86,7 +87,8 @@ def main():
                       'server_step_ms': round(ms, 2), 'pairs_per_s': round(args.batch / ms * 1e3, 1),
                       'loss': round(float(loss), 4), 'params_M': round(n_params / 1e6, 1),
                       'mfu': round(3.0 * fwd / (ms * 1e-3) / 2.5e15, 4), 'model_tflop_per_step': round(3.0 * fwd / 1e12, 2),
-                      'client_contrast_step_us_wall': round(cus, 1), 'bank_image_builds': builds}))
+                      'client_contrast_step_us_wall': round(cus, 1), 'bank_image_builds': builds,
+                      'vit_glue': 'aten' if os.environ.get('CFL_NO_VIT_FUSE') else 'fused (csrc/bertfuse.hip pre-LN chain)'}))
 
 
 if __name__ == '__main__':
