@@ -35,6 +35,7 @@ enum CflKernel {
     K_GRU_FWD, K_GRU_BWD, K_GRU_CELL0,
     K_CONV3_WGRAD, K_CONV3_WGRAD_REDUCE, K_CONV1_WGRAD, K_CONV1_WGRAD_REDUCE,
     K_CONV3_X3, K_CONV3_X3_WGRAD, K_CONV3_X3_WGRAD_REDUCE, K_CONV3_X3_WIMAGE,
+    K_PAIR_BWD_REDUCE,
     K_NUM
 };
 

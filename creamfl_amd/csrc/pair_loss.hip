@@ -26,7 +26,7 @@
 namespace {
 
 struct PairWs {
-    float *ni, *nt, *dd, *rowsum, *colsum, *rowpart, *colpart, *part, *it, *tt, *img_i, *img_t;
+    float *ni, *nt, *dd, *rowsum, *colsum, *rowpart, *colpart, *part, *it, *tt, *img_i, *img_t, *bpart;
 };
 static PairWs pair_ws(void* ws, int N, int D) {
     const int NT = cfl_cdiv(N, 64);
@@ -39,7 +39,8 @@ static PairWs pair_ws(void* ws, int N, int D) {
     w.part = p; p += (size_t)4 * NT * NT;
     p = (float*)cfl_align256((size_t)(uintptr_t)p);          // 16-byte alignment for vector access
     w.it = p; p += (size_t)D * N; w.tt = p; p += (size_t)D * N;
-    w.img_i = p; p += (size_t)N * D; w.img_t = p;          // image mode only (N % 32 == 0, D % 32 == 0)
+    w.img_i = p; p += (size_t)N * D; w.img_t = p; p += (size_t)N * D;   // image mode only (N % 32 == 0, D % 32 == 0)
+    w.bpart = p;                                           // big-tile backward only: [2][KSPLIT][N][D] split-K partials
     return w;
 }
 
@@ -378,6 +379,95 @@ __global__ __launch_bounds__(256) void cfl_pair_bwd_img_kernel(const float* __re
         }
 }
 
+// IMAGE MODE backward, 256 x 256 tiles + split-K (round 6).  The kernel above is bound by the L2 -> LDS path, not by HBM or the matrix
+// pipe: 256 workgroups x 128 stages x 32 KB = 1 GB per launch through it in 137 us = 7.6 TB/s of the 8-9 that path sustains, for
+// 41 us of MFMA work.  A 256 x 256 tile moves half the bytes per flop (64 KB per stage for four times the MFMAs): N D / 256^2 tiles
+// per GEMM are too few to fill the chip, so the contraction (K = N) is split KS ways -- (N / 256) (D / 256) x KS x 2 workgroups, one
+// per CU, one wave per SIMD with 256 accumulator registers -- and the fp32 partials [2][KS][N][D] are summed in fixed order by
+// cfl_pair_bwd_reduce_kernel, which also applies the epilogue  g (sums . X - acc).  Two 64 KB stages (the 4-stage ring does not fit
+// and a stage is 3072 MFMA cycles long: one stage ahead covers its load).
+__global__ __launch_bounds__(256, 1) void cfl_pair_bwd_img_big_kernel(const float* __restrict__ coef, const float* __restrict__ img_it,
+                                                                     const float* __restrict__ img_tt, int N, int D, int ksplit,
+                                                                     float* __restrict__ part) {
+    constexpr int TM = 4, TN = 4, BM = 256, BN = 256, STAGE = (BM + BN) * 32;      // floats per stage (64 KB)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ntc = D / BN, ntr = N / BM;
+    int ti, tj;
+    tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
+    const int row0 = ti * BM, col0 = tj * BN;
+    const int ks = blockIdx.y;
+    const bool second = blockIdx.z != 0;
+    const Opnd Ao{second ? coef + (long long)N * N : coef, N, N, N, 1};
+    const Opnd Bo{second ? img_it : img_tt, N, D, N, 1};
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int nk = N / 32 / ksplit, kt0 = ks * nk;
+    auto issue = [&](int kt) {
+        float* st = lds + (kt & 1) * STAGE;
+        glds_stage<BM>(Ao, row0, (kt0 + kt) * 32, st);
+        glds_stage<BN>(Bo, col0, (kt0 + kt) * 32, st + BM * 32);
+    };
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue(kt + 1);
+        const char* sa = reinterpret_cast<const char*>(lds + (kt & 1) * STAGE);
+        x3::compute<TM, TN>(sa, sa + BM * 128, acc, lane, wr, wc);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    float* out = part + ((long long)(second ? 1 : 0) * ksplit + ks) * N * D;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int j = col0 + acc_col<TN>(wc, n, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = row0 + acc_row<TM>(wr, m, r, lane);
+                out[(long long)i * D + j] = acc[m][n][r];
+            }
+        }
+}
+
+// dI / dT = g (sums . X - sum over the KS split partials, ks ascending): one thread per 16 bytes of [2][N][D]
+__global__ __launch_bounds__(256) void cfl_pair_bwd_reduce_kernel(const float* __restrict__ I, const float* __restrict__ T,
+                                                                  const float* __restrict__ part, int N, int D, int ksplit,
+                                                                  const float* __restrict__ rowsum, const float* __restrict__ colsum,
+                                                                  const float* __restrict__ gout, float* __restrict__ dI,
+                                                                  float* __restrict__ dT) {
+    const long long nd4 = (long long)N * D / 4;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= 2 * nd4) return;
+    const int z = e >= nd4;
+    const long long o = (e - (z ? nd4 : 0)) * 4;
+    const int i = (int)(o / D);
+    const float* X = z ? T : I;
+    const float* sums = z ? colsum : rowsum;
+    float* out = z ? dT : dI;
+    const float* p = part + (long long)z * ksplit * N * D + o;
+    f32x4 s = *reinterpret_cast<const f32x4*>(p);
+    for (int k = 1; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(p + (long long)k * N * D);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(X + o);
+    const float g = gout[0], sm = sums[i];
+    *reinterpret_cast<f32x4*>(out + o) = (x * sm - s) * g;
+}
+
+// split factor of the big-tile backward: 0 = not taken (shape, or switched off for an A/B: CFL_PAIR_BWD_BIG=0)
+static inline int pair_bwd_big_ksplit(int N, int D) {
+    static const bool off = [] { const char* e = getenv("CFL_PAIR_BWD_BIG"); return e && e[0] == '0'; }();
+    if (off || N % 256 != 0 || D % 256 != 0) return 0;
+    const long long tiles = (long long)(N / 256) * (D / 256) * 2;
+    int ks = 1;
+    while (ks < 8 && tiles * ks < 224 && (N / 32) % (2 * ks) == 0) ks *= 2;
+    return tiles * ks >= 128 ? ks : 0;                       // (too few workgroups even split 8 ways: the 128 x 128 kernel)
+}
+
 // image mode: 3 x bf16-split precision, shapes the split images tile without padding, and enough 128 x 128 tiles to fill the
 // chip (below N = 2048 the smaller tiles of the register-staged path give more workgroups)
 static inline bool pair_image_mode(int N, int D) {
@@ -393,7 +483,9 @@ size_t cfl_pair_loss_ws_bytes(int N, int D) {
     if (N <= 0) return 256;
     const size_t NT = (size_t)cfl_cdiv(N, 64);
     // 2 N D: It, Tt (image mode: their split images); + 2 N D: the untransposed feature images of image mode
-    return cfl_align256((5 * (size_t)N + 2 * NT * N + 4 * NT * NT + 4 * (size_t)N * (D > 0 ? D : 1)) * sizeof(float)) + 512;
+    // + 2 KS N D: the split-K partials of the big-tile backward (image mode, N % 256 == 0, D % 256 == 0; KS <= 8)
+    const size_t bp = (N >= 2048 && N % 256 == 0 && D % 256 == 0) ? (size_t)16 * N * D : 0;
+    return cfl_align256((5 * (size_t)N + 2 * NT * N + 4 * NT * NT + 4 * (size_t)N * (D > 0 ? D : 1) + bp) * sizeof(float)) + 512;
 }
 
 int cfl_pair_loss_fwd(const float* I, const float* T, int N, int D, const float* a_dev, const float* b_dev, float eps,
@@ -439,6 +531,16 @@ int cfl_pair_loss_bwd(const float* I, const float* T, const float* coef, int N, 
     hipStream_t stream = (hipStream_t)stream_;
     PairWs w = pair_ws(ws, N, D);
     if (pair_image_mode(N, D)) {          // coef / It / Tt hold split images (cfl_pair_loss_fwd took the same branch)
+        if (const int ks = pair_bwd_big_ksplit(N, D)) {
+            constexpr int LDSB2 = 2 * 512 * 128;
+            CFL_SET_LDS(cfl_pair_bwd_img_big_kernel, LDSB2);
+            CFL_LAUNCH(K_PAIR_BWD, cfl_pair_bwd_img_big_kernel, dim3((N / 256) * (D / 256), ks, 2), dim3(256), LDSB2, stream, coef, w.it, w.tt,
+                       N, D, ks, w.bpart);
+            const long long n4 = (long long)N * D / 2;
+            CFL_LAUNCH(K_PAIR_BWD_REDUCE, cfl_pair_bwd_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, I, T, w.bpart, N, D, ks,
+                       w.rowsum, w.colsum, gout_dev, dI, dT);
+            return 0;
+        }
         constexpr int NS = 4, LDSB = NS * 256 * 128;
         CFL_SET_LDS((cfl_pair_bwd_img_kernel<NS>), LDSB);
         CFL_LAUNCH(K_PAIR_BWD, (cfl_pair_bwd_img_kernel<NS>), dim3(cfl_cdiv(N, 128) * cfl_cdiv(D, 128), 1, 2), dim3(256), LDSB, stream,

@@ -23,6 +23,7 @@ static const char* const g_kernel_names[K_NUM] = {
     "cfl_gru_fwd_kernel", "cfl_gru_bwd_kernel", "cfl_gru_cell0_kernel",
     "cfl_conv3x3_wgrad_kernel", "cfl_conv3x3_wgrad_reduce_kernel", "cfl_conv1x1_wgrad_kernel", "cfl_conv1x1_wgrad_reduce_kernel",
     "cfl_conv3x3_x3_kernel", "cfl_conv3x3_x3_wgrad_kernel", "cfl_conv3x3_x3_wgrad_reduce_kernel", "cfl_conv3x3_wimage_kernel",
+    "cfl_pair_bwd_reduce_kernel",
 };
 
 namespace {

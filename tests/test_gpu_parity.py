@@ -82,7 +82,10 @@ def test_a1_pair_loss_golden(dev, fname):
 
 @pytest.mark.parametrize('n,d,matched', [(1, 8, False), (7, 5, False), (64, 64, True), (65, 130, False),
                                          (129, 257, True), (256, 512, True), (300, 768, False),
-                                         (2048, 512, True), (2049, 96, False), (2080, 96, True), (2112, 32, False)])
+                                         (2048, 512, True), (2049, 96, False), (2080, 96, True), (2112, 32, False),
+                                         # round 6: N % 256 == 0 and D % 256 == 0 take the 256 x 256-tile split-K backward (2048 x 512: 8 splits of 8
+                                         # stages; 2304 x 256: 9 row tiles, 8 splits of 9 stages); 2304 x 96 stays on the 128 x 128 ring
+                                         (2304, 256, False), (2304, 96, True)])
 def test_a1_pair_loss_shapes(dev, n, d, matched):
     """ragged / odd sizes, both tile variants (64x64 below 2048 rows, 128x128 from 2048), unaligned D; from N = 2048 with
     N % 32 == 0 and D % 32 == 0 the IMAGE mode (pre-split operand images, coefficients written in split form, ring-buffered
