@@ -425,6 +425,8 @@ int cfl_client_contrast_img_fwd(const float* F, const void* image_other, const f
                               : launch_stream<DT_, NGG_, 8, NDS_, 0, false>(F, image_other, B, M, D, sc2, p, w, stream)) \
                  : (want_grad ? launch_stream<DT_, NGG_, 8, NDS_, -1, true>(F, image_other, B, M, D, sc2, p, w, stream)  \
                               : launch_stream<DT_, NGG_, 8, NDS_, -1, false>(F, image_other, B, M, D, sc2, p, w, stream)))
+        // (measured and dropped, round 6: D > 256 with ONE wave per SIMD holding its 16 rows' whole F and O -- no column-split pair, no
+        // logit exchange, one barrier per slot: D = 512 117 us vs 97, D = 768 spills, 222 vs 72: profiles/r6_a3_1wave_ab.jsonl)
         rc = p.DT == 24 ? CFL_STREAM(24, 1, 2) : p.DT == 16 ? CFL_STREAM(16, 1, 2) : p.DT == 8 ? CFL_STREAM(8, 4, 1) : CFL_STREAM(4, 4, 1);
 #undef CFL_STREAM
         if (rc) return rc;

@@ -629,6 +629,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cfl_bank_wide32_kernel(const 
     }
 }
 
+// (Measured and dropped, round 6: D <= 256 with 64 rows of V per wave -- two 32-row B tiles per A fragment read, four waves, one per
+// SIMD, half the LDS bytes per MFMA of the 8-wave form, per-lane running log-sum-exp, pinned issue order: 3.47-3.50 ms against 3.30-3.31
+// ms at M = 50 000, D = 256 on the same lease (profiles/r6_a5_wide64_ab.jsonl).  The LDS read path is not what holds the 8-wave form at
+// 0.47 of the roof.)
+
 // ---- D = 768 (round 6): 16-row steps on v_mfma_f32_16x16x32_bf16 ----------------------------------------------------------------
 // 384 registers of pre-split V per wave (32 rows) and 2 x 96 KB of step buffers rule out the 32 x 32 form above.  Here a step is ONE
 // 16-row slot (48 KB): three slot buffers (144 KB), the LDS-DMA two steps ahead with a counted vmcnt wait; a wave's 32 rows of V are
