@@ -251,6 +251,9 @@ def parse_args(argv=None):
     import bench_clients
     bench_clients.add_arguments(ap)
     ap.add_argument('--no-recall', action='store_true')
+    ap.add_argument('--no-hot-kernels', action='store_true',
+                    help='config 1, one rank: skip the `extra.hot_kernels` record (con_w at M = 50 000 and the pair loss at N = 4096, '
+                         'timed after the step\'s timed region)')
     ap.add_argument('--no-client-steps', action='store_true',
                     help='config 1, one rank: skip the `extra.client_steps` record (the clients\' contrast steps of configs[2], measured by a '
                          'child process AFTER the timed region)')
@@ -572,6 +575,9 @@ def main():
         extra = None
         if world == 1 and args.config == 1 and not args.no_client_steps:
             extra = {'client_steps': client_steps(args)}
+        if world == 1 and args.config == 1 and not args.no_hot_kernels:
+            extra = dict(extra or {})
+            extra['hot_kernels'] = hot_kernels(dev)
         # model-FLOPs utilisation of the step: forward + backward = 3 x forward model FLOPs per step and GPU
         mfma_peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else F32_MFMA_PEAK_TFLOPS
         mfu = None
@@ -659,6 +665,59 @@ def _host_memory_limit_gb():
     except (OSError, ValueError):
         pass
     return None
+
+
+def hot_kernels(dev):
+    """`extra.hot_kernels` of the default line: the two hot-path kernels of BASELINE.json's north_star that the configs[1] step does not
+    run at their full size -- con_w (row A5: log-probabilities of ONE client's [M, D] representations against the global ones, M = 50 000,
+    the public set of configs[2]) at D = 256 / 512 and the pair loss (row A1) forward + backward at the global batch of configs[3],
+    N = 4096, d = 512 -- timed with events on the current stream AFTER the step's timed region (nothing of it can touch `value`).
+    FLOPs are the algorithmic 2 M^2 D (con_w) and 3 x 2 N^2 D (pair loss); the roof is the 3 x bf16-split rate of the dense bf16 MFMA
+    peak (every fp32 product = three bf16 MFMAs)."""
+    import torch.nn.functional as F
+    try:
+        from creamfl_amd import ops
+        roof = BF16_MFMA_PEAK_TFLOPS / 3.0
+        g = torch.Generator(device=dev).manual_seed(7)
+        unit = lambda n, d: F.normalize(torch.randn(n, d, generator=g, device=dev), dim=-1)
+
+        def timed(fn, iters, warm=2):
+            for _ in range(warm):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters
+        out = {'how': 'torch events around 4 (con_w) / 10 (pair loss) calls after 2 warm-ups, on the current stream, after the timed region'}
+        M = 50000
+        for D in (256, 512):
+            G = unit(M, D)
+            V = F.normalize(G + 0.5 * unit(M, D), dim=-1)
+            ms = timed(lambda: ops.conw_logprob(V, G), 4)
+            tf = 2.0 * M * M * D / (ms * 1e-3) / 1e12
+            out['conw_logprob_M50000_D%d' % D] = {'ms_per_client': round(ms, 3), 'algorithmic_tflops': round(tf, 1),
+                                                  'of_3xbf16_roof': round(tf / roof, 3)}
+            del G, V
+        N, D = 4096, 512
+        I = unit(N, D).requires_grad_(True)
+        T = F.normalize(I.detach() + 0.5 * unit(N, D), dim=-1).requires_grad_(True)
+        a = torch.tensor([15.0], device=dev, requires_grad=True)
+        b = torch.tensor([15.0], device=dev, requires_grad=True)
+
+        def step():
+            loss, _ = ops.pair_loss(I, T, a, b)
+            loss.backward()
+        ms = timed(step, 10)
+        tf = 3 * 2.0 * N * N * D / (ms * 1e-3) / 1e12
+        out['pair_loss_fwd_bwd_N4096_D512'] = {'us_per_call': round(ms * 1e3, 1), 'algorithmic_tflops': round(tf, 1),
+                                               'of_3xbf16_roof': round(tf / roof, 3), 'pairs_per_s': round(N / (ms * 1e-3))}
+        return out
+    except Exception as e:                                   # never let an extra record take the line down
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
 
 
 def client_steps(args):
