@@ -104,6 +104,7 @@ SIGNATURES = {
     'cfl_conv3x3_x3_wimage': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_conv3x3_x3_wimage_rot': (c_int, [_P, c_int, c_int, _P, _P]),
     'cfl_conv3x3_x3_fwd_img': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'cfl_conv3x3_x3_fwd_img_s2': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     'cfl_conv3x3_x3_wgrad_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_x3_wgrad_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'cfl_conv3x3_x3_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -307,13 +307,20 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3s_kernel(const float* __res
 //     one barrier.
 // DBG (measurements only, results are wrong): 1 no weight staging in the loop, 2 no per-tap barrier, 3 no MFMAs, 4 no fragment reads,
 // 6 no slab staging in the loop
-template <int TM, int TN, int DBG = 0>
+// S = 2 (round 6): the same kernel for stride 2 (padding 1, even H and W: the three down-sampling convolutions of ResNet-18).  Output
+// position p = (n Ho + ho) Wo + wo reads around input position c(p) = 2 (p div Wo) W + 2 (p mod Wo), which grows monotonically with p
+// (by 2 inside a row, by W + 2 at a row or image wrap), so a tile of BM output positions still reads ONE contiguous range of input
+// positions, c(row0) - (W + 1) ... c(row0 + BM - 1) + (W + 1), at most 4 BM + 3 W + 3 rows of the slab (W <= 63); a lane's nine row addresses
+// (the only place the mapping lives) are computed once, the loop is unchanged.  H, W here are the INPUT extents.
+template <int TM, int TN, int DBG = 0, int S = 1>
 __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __restrict__ x, const char* __restrict__ wimg, float* __restrict__ y,
                                                                int N, int H, int W, int Ci, int Co) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, NJ = (BM + 128) / 32, NB = BN / 32, PITCH = 144;
+    constexpr int BM = 64 * TM, BN = 64 * TN, NJ = (S == 2 ? 4 * BM + 256 : BM + 128) / 32, NB = BN / 32, PITCH = 144;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     char* slab = reinterpret_cast<char*>(lds_f);
-    const long long M = (long long)N * H * W;
+    const int Ho = S == 2 ? H / 2 : H, Wo = S == 2 ? W / 2 : W;
+    const long long M = (long long)N * Ho * Wo;                  // output positions
+    const long long Min = (long long)N * H * W;                  // input positions
     const int ntc = Co / BN, ntr = (int)((M + BM - 1) / BM);
     int ti, tj;
     tile_swizzle(xcd_remap(blockIdx.x, gridDim.x), ntr, ntc, ti, tj);
@@ -322,7 +329,11 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
     const int kq = t & 7, i32 = lane & 31, hh = lane >> 5;
     const int halo = W + 1;
-    const int nj = (BM + 2 * halo + 31) / 32;                 // 32-row groups of the slab actually used (<= NJ)
+    // centre input position of an output position (S = 1: itself)
+    auto centre = [&](long long p) -> long long { return S == 2 ? 2 * (p / Wo) * W + 2 * (p % Wo) : p; };
+    const long long last = (row0 + BM - 1 < M ? row0 + BM - 1 : M - 1);
+    const long long cbase = centre(row0) - halo;              // input position of slab row 0
+    const int nj = S == 2 ? (int)((centre(last) + halo - cbase + 1 + 31) / 32) : (BM + 2 * halo + 31) / 32;   // 32-row groups used (<= NJ)
     const int zrow = nj * 32;                                 // a row of zeros behind the slab
     char* const bst = slab + (nj * 32 + 1) * PITCH;           // two weight stages of BN rows behind it (16-byte aligned: 144 = 9 x 16)
 
@@ -333,15 +344,17 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
         const int rl = (wr * TM + m) * 32 + i32;
         const long long r = row0 + rl;
         int h = -4, ww = -4;                                  // (rows behind the tensor: every tap invalid)
+        int srow = rl + halo;                                 // slab row of the centre tap
         if (r < M) {
-            const int hw = (int)(r % ((long long)H * W));
-            h = hw / W; ww = hw % W;
+            const int hw = (int)(r % ((long long)Ho * Wo));
+            h = S * (hw / Wo); ww = S * (hw % Wo);                // the centre's input coordinates
+            if (S == 2) srow = (int)(centre(r) - cbase);
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap % 3;
             const bool ok = (unsigned)(h + kh - 1) < (unsigned)H && (unsigned)(ww + kw - 1) < (unsigned)W;
-            aoff[m][tap] = (ok ? rl + halo + (kh - 1) * W + (kw - 1) : zrow) * PITCH + hh * 16;
+            aoff[m][tap] = (ok ? srow + (kh - 1) * W + (kw - 1) : zrow) * PITCH + hh * 16;
         }
     }
     int boff[TN][4];                                          // weight fragments: hi kk = 0, 1, lo kk = 0, 1
@@ -360,8 +373,8 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (j < nj) {
-                const long long P = row0 - halo + j * 32 + (t >> 3);
-                const bool ok = P >= 0 && P < M;
+                const long long P = cbase + j * 32 + (t >> 3);
+                const bool ok = P >= 0 && P < Min;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(x + (ok ? P : 0) * Ci + c * 32 + 4 * kq);
                 sreg[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -907,6 +920,27 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
     }
 #undef CFL_X3CONVP
 #undef CFL_X3CONVQ
+    return 0;
+}
+
+// stride 2 / padding 1 (even H, W <= 62): y [N, H / 2, W / 2, Co]; the weight image is the stride-1 one (cfl_conv3x3_x3_wimage)
+extern "C" int cfl_conv3x3_x3_fwd_img_s2(const float* x, const void* wimg, int N, int H, int W, int Ci, int Co, float* y, void* stream_) {
+    if (!x || !wimg || !y) return CFL_EINVAL;
+    if (!x3conv_ok(N, H, W, Ci, Co) || W > 63 || (H & 1) || (W & 1) || (((uintptr_t)x | (uintptr_t)wimg | (uintptr_t)y) & 15))
+        return CFL_ELIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long M = (long long)N * (H / 2) * (W / 2);
+#define CFL_X3CONVS2(TN_)                                                                                                      \
+    do {                                                                                                                       \
+        constexpr int BM_ = 128, BN_ = 64 * TN_, LDS_ = (4 * BM_ + 256 + 1) * 144 + 2 * BN_ * 128;                             \
+        const int grid = (int)((M + BM_ - 1) / BM_) * (Co / BN_);                                                              \
+        CFL_SET_LDS((cfl_conv3x3_x3p_kernel<2, TN_, 5, 2>), LDS_);                                                              \
+        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3p_kernel<2, TN_, 5, 2>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, H, \
+                   W, Ci, Co);                                                                                                 \
+    } while (0)
+    if (Co % 128 == 0) CFL_X3CONVS2(2);
+    else CFL_X3CONVS2(1);
+#undef CFL_X3CONVS2
     return 0;
 }
 

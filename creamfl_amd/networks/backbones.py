@@ -105,7 +105,7 @@ class TrunkConv(nn.Conv2d):
                     and ops.conv3x3_x3_supported(x, self.weight, self.stride[0], self.padding[0]):
                 # forward-only passes of an fp32 channels_last encoder (the clients' old model, representation extraction) on the
                 # 3 x bf16-split kernel as well (csrc/conv3x3_x3.hip)
-                return ops.conv3x3_x3_forward(x, self.weight)
+                return ops.conv3x3_x3_forward(x, self.weight, stride=self.stride[0])
             if ops.conv_gate_worthwhile(x, self.weight, self.stride[0], self.padding[0]):
                 # every other case (the fp32 NCHW client encoders; forward-only passes: representation extraction, evaluation):
                 # the library's kernels, but answered from the shipped find-db per call where it holds the problem instead of a

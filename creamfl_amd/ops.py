@@ -1520,17 +1520,20 @@ def _conv_wgrad(args):
 # the weight gradient: conv3x3_x3_wgrad below.  `--client_conv_x3` (creamfl_amd/flags.py) / CFL_X3CONV=1 switch it on.
 X3CONV = [_os.environ.get('CFL_X3CONV', '0') == '1']
 X3CONV_TAKEN = [0]
+X3CONV_S2 = [_os.environ.get('CFL_NO_X3CONV_S2', '0') != '1']       # the stride-2 forward form (A/B: CFL_NO_X3CONV_S2=1 -> library)
 
 
 def conv3x3_x3_supported(x, w, stride, padding):
     if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and w.dim() == 4):
         return False
-    if not (w.shape[2] == 3 and w.shape[3] == 3 and stride == 1 and padding == 1 and w.shape[1] == x.shape[1]):
+    if not (w.shape[2] == 3 and w.shape[3] == 3 and stride in (1, 2) and padding == 1 and w.shape[1] == x.shape[1]):
         return False
     cl = torch.channels_last
     if not (x.is_contiguous(memory_format=cl) and w.is_contiguous(memory_format=cl)):
         return False
     N, Ci, H, W = x.shape
+    if stride == 2 and (not X3CONV_S2[0] or H % 2 or W % 2 or W > 62):     # (forward only: the down-sampling convolutions)
+        return False
     return bool(_lib.load().cfl_conv3x3_x3_supported(N, H, W, Ci, w.shape[0]))
 
 
@@ -1561,7 +1564,7 @@ def _x3_weight_image(w, rot=False):
     return img
 
 
-def conv3x3_x3_forward(x, w, variant=0, rotated=False):
+def conv3x3_x3_forward(x, w, variant=0, rotated=False, stride=1):
     """conv2d(x, w, stride 1, padding 1) for fp32 channels_last x [N, Ci, H, W] and w [Co, Ci, 3, 3] (csrc/conv3x3_x3.hip); no
     autograd (the Functions that own the convolutions call it for their forward and, on the rotated weight, their data gradient).
     variant 0 / >= 200: version 3 (the weight split once into an image of the kernel's LDS stage; maps up to 63 wide); 21 .. 142: the
@@ -1574,6 +1577,13 @@ def conv3x3_x3_forward(x, w, variant=0, rotated=False):
         Cout = w.shape[1]
     else:
         Cout = w.shape[0]
+    if stride == 2:                                        # forward of a down-sampling convolution (even H, W; the stride-1 weight image)
+        assert not rotated and H % 2 == 0 and W % 2 == 0
+        y = torch.empty((N, Cout, H // 2, W // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        img = _x3_weight_image(w)
+        _lib.check(lib.cfl_conv3x3_x3_fwd_img_s2(_ptr(x), _ptr(img), N, H, W, Cin, Cout, _ptr(y), _stream(x)), 'cfl_conv3x3_x3_fwd_img_s2')
+        X3CONV_TAKEN[0] += 1
+        return y
     y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if (variant == 0 or variant >= 200) and W <= 63:
         img = _x3_weight_image(w, rot=rotated)
@@ -1637,7 +1647,7 @@ def _conv_dgrad(args):
 
 def _conv_fwd(x, w, stride, padding):
     if X3CONV[0] and conv3x3_x3_supported(x, w, stride, padding):
-        return conv3x3_x3_forward(x, w)
+        return conv3x3_x3_forward(x, w, stride=stride)
     kh = w.shape[2]
     out_shape = (x.shape[0], w.shape[0], (x.shape[2] + 2 * padding - kh) // stride + 1, (x.shape[3] + 2 * padding - w.shape[3]) // stride + 1)
     return _miopen(_fdb_covered('F', x, w, out_shape, stride, padding), torch.nn.functional.conv2d, x, w, None, stride, padding)

@@ -230,6 +230,9 @@ size_t cfl_conv3x3_x3_wimage_bytes(int Ci, int Co);
 int cfl_conv3x3_x3_wimage(const float* w, int Ci, int Co, void* img, void* stream);
 int cfl_conv3x3_x3_wimage_rot(const float* w, int Ci, int Co, void* img, void* stream);   /* image of w_rot (Co x 9 Ci -> Ci x 9 Co) in one pass */
 int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, int H, int W, int Ci, int Co, float* y, int variant, void* stream);
+/* Round 6, stride 2 / padding 1 (the three down-sampling 3x3 convolutions of the clients' ResNet-18, resnet_client.py:33-66 with stride 2):
+ * forward only, even H and W <= 62, y [N, H/2, W/2, Co]; the same weight image; data / weight gradients stay on the library. */
+int cfl_conv3x3_x3_fwd_img_s2(const float* x, const void* wimg, int N, int H, int W, int Ci, int Co, float* y, void* stream);
 /* The weight gradient of the same convolutions (csrc/wgrad3x3_x3.hip; the reference: autograd through cuDNN's fp32 backward-filter,
  * src/algorithms/ClientTrainer.py:420 loss.backward()): dw[co,kh,kw,ci] = sum over (n,h,w) dy[n,h,w,co] x[n,h+kh-1,w+kw-1,ci], fp32 in
  * and out, products as three bf16 MFMAs on operands split while they are staged.  H = W in {7, 14, 28, 56}, Ci % 64 == 0,

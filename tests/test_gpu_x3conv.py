@@ -53,10 +53,30 @@ def test_x3conv_forward_matches_the_definition(dev, n, h, w, ci, co, variant):
     sc = float(ref.abs().max())
     assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 * sc
     assert torch.equal(y, ops.conv3x3_x3_forward(xd, wd, variant))                 # deterministic
-    assert not ops.conv3x3_x3_supported(xd, wd, 2, 1)
+    assert not ops.conv3x3_x3_supported(xd, wd, 3, 1)
+    assert ops.conv3x3_x3_supported(xd, wd, 2, 1) == (h % 2 == 0 and w % 2 == 0 and w <= 62)      # (forward only: round 6)
     if h * w > 1:                                                                  # (a 1 x 1 map is contiguous in both formats)
         assert not ops.conv3x3_x3_supported(xd.contiguous(), wd, 1, 1)
     assert not ops.conv3x3_x3_supported(xd.bfloat16(), wd.bfloat16(), 1, 1)
+
+
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 56, 56, 64, 128), (3, 28, 28, 128, 256), (5, 14, 14, 256, 512), (1, 2, 2, 32, 64), (4, 6, 10, 32, 64),
+                                         (7, 62, 62, 32, 64), (37, 14, 14, 64, 64), (128, 8, 4, 32, 192), (3, 62, 2, 64, 128)])
+def test_x3conv_stride2_forward_matches_the_definition(dev, n, h, w, ci, co):
+    """Round 6: y = conv2d(x, w, stride 2, padding 1) on the same kernel (a tile of output positions still reads one contiguous range of
+    input positions; only a lane's nine row addresses change) against fp64: the three down-sampling convolutions of ResNet-18 and the
+    corners -- a 2 x 2 map, the widest map, tiles that cut rows and images, row / image wraps inside a tile."""
+    from creamfl_amd import ops
+    x, wt = _case(n, h, w, ci, co, 3 * n + h + ci)
+    x = x * 0.8 + 0.25                                                             # (a mean: a padding mistake moves sums far beyond the tolerance)
+    xd, wd = x.to(dev).contiguous(memory_format=CL), wt.to(dev).contiguous(memory_format=CL)
+    assert ops.conv3x3_x3_supported(xd, wd, 2, 1)
+    y = ops.conv3x3_x3_forward(xd, wd, stride=2)
+    assert y.shape == (n, co, h // 2, w // 2) and y.is_contiguous(memory_format=CL)
+    ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
+    sc = float(ref.abs().max())
+    assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 * sc
+    assert torch.equal(y, ops.conv3x3_x3_forward(xd, wd, stride=2))
 
 
 @pytest.mark.parametrize('n,h,ci,co', [(2, 7, 64, 64), (9, 7, 512, 512), (5, 14, 64, 128), (16, 14, 256, 256), (3, 28, 128, 128),
