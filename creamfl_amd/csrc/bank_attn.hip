@@ -480,8 +480,13 @@ int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int 
         else if (rbv && rbv[0] == 's') CFL_WIDE32(16, 4, 4, 1);
         else if (rbv && rbv[0] == '4') CFL_WIDE32(16, 4, 4);
         else CFL_WIDE32(16, 4, 4, 2);
-    } else if (p.DT == 8) CFL_WIDE32(8, 8, 4);
-    else CFL_WIDE32(4, 8, 4);
+    } else if (p.DT == 8) {
+        // M = 50 000, D = 256, one lease (profiles/r6_a5_wide32_branch_ab.jsonl): with the per-burst liveness branch of rounds 4-5 3.25-3.28
+        // ms ('b'), without it 3.22-3.23 ('n'), without it and the issue order pinned per burst (eight reads, twelve MFMAs) 3.17-3.18
+        if (rbv && rbv[0] == 'b') CFL_WIDE32(8, 8, 4, 3);
+        else if (rbv && rbv[0] == 'n') CFL_WIDE32(8, 8, 4, 0);
+        else CFL_WIDE32(8, 8, 4, 1);
+    } else CFL_WIDE32(4, 8, 4);
 #undef CFL_WIDE32
     CFL_LAUNCH(K_LSE_FINAL, cfl_conw_finish_kernel, dim3(cfl_cdiv(rows, 64)), dim3(256), 0, stream, w.part_m, w.part_l, p.S, F,
                G + (size_t)row0 * D, rows, D, out);

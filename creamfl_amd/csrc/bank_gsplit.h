@@ -565,13 +565,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cfl_bank_wide32_kernel(const 
                     al[e] = *reinterpret_cast<const bf16x8*>(sb + SG * DP * 2 + off);
                 }
                 if (k0 == 0 && pend_ok) soft(pend, pend_row0);   // the previous step's soft-max, inside this burst's LDS latency
-                if (wave_live) {
+                // (no branch on wave_live, round 6: behind a branch per burst the compiler issued the fragment reads of bursts 1 .. 3 one
+                // pair at a time, each waited for at lgkmcnt(0) right in front of its MFMA triple; a dead wave -- last row group only --
+                // multiplies its clamped rows and stores nothing)
+                if (SCHED == 3 ? wave_live : true) {             // (SCHED = 3: the branch of rounds 4-5, kept for the A/B)
 #pragma unroll
                     for (int e = 0; e < RB; ++e) {
                         sa = MFMA32(ah[e], fh[k0 + e], sa);
                         sbb = MFMA32(al[e], fh[k0 + e], sbb);
                         sc = MFMA32(ah[e], fl[k0 + e], sc);
                     }
+                }
+                if (SCHED == 1) {                                // pinned: the burst's eight reads, then its twelve MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * RB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * RB, 0);
                 }
             }
         } else {
