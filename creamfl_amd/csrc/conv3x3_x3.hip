@@ -435,13 +435,13 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
         for (int tap = 0; tap < 9; ++tap) {
             const int par = (c + tap) & 1;                    // 9 taps per chunk: the stage parity alternates across chunks too
             const char* sb = bst + par * (BN * 128);
-            if (DBG != 1 && DBG != 5) {
+            if (DBG != 1 && DBG != 5 && DBG != 7) {
                 if (tap < 8) load_b(c, tap + 1);
                 else if (next_chunk) load_b(c + 1, 0);
             }
             if (DBG != 6 && tap == 1 && next_chunk) load_slab(c + 1);      // (first touch of these bytes: an HBM round trip, ~7 taps away)
             __builtin_amdgcn_sched_barrier(0);                // (the loads stay in front of the tap's MFMAs: their latency hides there)
-            if (DBG == 5) {
+            if (DBG == 5 || DBG == 7) {
                 x3::bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -457,11 +457,22 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (tap < 8) dma_b(c, tap + 1, bst + (par ^ 1) * (BN * 128));
-                else if (next_chunk) dma_b(c + 1, 0, bst + (par ^ 1) * (BN * 128));
-                __builtin_amdgcn_sched_barrier(0);
+                if (DBG == 5) {                                   // (DBG = 5: the order of the round's earlier sessions, kept for the A/B)
+                    if (tap < 8) dma_b(c, tap + 1, bst + (par ^ 1) * (BN * 128));
+                    else if (next_chunk) dma_b(c + 1, 0, bst + (par ^ 1) * (BN * 128));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
+                    if (kk == 1 && DBG == 7) {
+                        // the next tap's weight tile is requested BEHIND the first half's MFMAs (round 6): with the LDS-DMA between the
+                        // reads and the first MFMA the compiler waited for lgkmcnt(0) -- all sixteen fragment reads -- where the first
+                        // twelve MFMAs need eight of them (an LDS-DMA in flight makes its wait-count bookkeeping give up partial waits)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (tap < 8) dma_b(c, tap + 1, bst + (par ^ 1) * (BN * 128));
+                        else if (next_chunk) dma_b(c + 1, 0, bst + (par ^ 1) * (BN * 128));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(256) void cfl_conv3x3_x3p_kernel(const float* __res
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (DBG != 1 && DBG != 5 && (tap < 8 || next_chunk)) store_b(bst + (par ^ 1) * (BN * 128));
+            if (DBG != 1 && DBG != 5 && DBG != 7 && (tap < 8 || next_chunk)) store_b(bst + (par ^ 1) * (BN * 128));
             if (tap == 8 && next_chunk) {
                 __syncthreads();                              // every wave is done with this chunk's slab
                 if (DBG != 6) store_slab();
@@ -878,7 +889,13 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
         // measured at the four BasicBlock shapes of ResNet-18, batch 128 (profiles/r6_x3conv_probe_v3.jsonl): 128 positions x 128
         // channels where the channel count allows, x 64 otherwise; 64- and 256-position tiles lose 5-30 %
         // ... and the weight tiles by LDS-DMA (5xx): 3-5 % at three of the four shapes (profiles/r6_x3conv_decomposition.jsonl)
-        variant = bn128 ? 522 : 521;
+        // ... and requested behind the first half's MFMAs (8xx: the compiler then waits for the fragments it needs instead of
+        // lgkmcnt(0)): 2-4 % at three shapes (profiles/r6_x3conv_late_dma.jsonl); 64-channel tiles where 128-channel ones leave CUs idle
+        // (7 x 7 x 512 at batch 128: 196 tiles; 821 89.8 us, 522 99.5, 822 115).  CFL_X3_DMA_EARLY=1: the selection before (A/B).
+        static const bool early = getenv("CFL_X3_DMA_EARLY") != nullptr;
+        const long long t128 = ((M + 127) / 128) * (Co / 128);
+        if (early) variant = bn128 ? 522 : 521;
+        else variant = (bn128 && t128 >= 256) ? 822 : 821;
     }
 #define CFL_X3CONVP(TM_, TN_, DBG_)                                                                                              \
     do {                                                                                                                       \
@@ -913,6 +930,9 @@ extern "C" int cfl_conv3x3_x3_fwd_img(const float* x, const void* wimg, int N, i
         case 3222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 3); break;
         case 4222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 4); break;
         case 6222: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 6); break;
+        case 822: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 7); break;       // ... requested behind the first half's MFMAs
+        case 842: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(4, 2, 7); break;
+        case 821: CFL_X3CONVP(2, 1, 7); break;
         case 522: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(2, 2, 5); break;       // weight tiles by LDS-DMA
         case 542: if (!bn128) return CFL_ELIMIT; CFL_X3CONVP(4, 2, 5); break;
         case 521: CFL_X3CONVP(2, 1, 5); break;
@@ -934,8 +954,8 @@ extern "C" int cfl_conv3x3_x3_fwd_img_s2(const float* x, const void* wimg, int N
     do {                                                                                                                       \
         constexpr int BM_ = 128, BN_ = 64 * TN_, LDS_ = (4 * BM_ + 256 + 1) * 144 + 2 * BN_ * 128;                             \
         const int grid = (int)((M + BM_ - 1) / BM_) * (Co / BN_);                                                              \
-        CFL_SET_LDS((cfl_conv3x3_x3p_kernel<2, TN_, 5, 2>), LDS_);                                                              \
-        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3p_kernel<2, TN_, 5, 2>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, H, \
+        CFL_SET_LDS((cfl_conv3x3_x3p_kernel<2, TN_, 7, 2>), LDS_);                                                              \
+        CFL_LAUNCH(K_CONV3_X3, (cfl_conv3x3_x3p_kernel<2, TN_, 7, 2>), dim3(grid), dim3(256), LDS_, stream, x, (const char*)wimg, y, N, H, \
                    W, Ci, Co);                                                                                                 \
     } while (0)
     if (Co % 128 == 0) CFL_X3CONVS2(2);

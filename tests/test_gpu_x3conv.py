@@ -39,7 +39,9 @@ def _case(n, h, w, ci, co, seed):
                                                  (16, 7, 7, 512, 512, 522), (3, 56, 56, 64, 64, 521), (1, 1, 1, 32, 128, 522),
                                                  (3, 14, 14, 64, 128, 722), (2, 28, 28, 128, 128, 742), (5, 9, 13, 32, 64, 721),
                                                  (16, 7, 7, 512, 512, 722), (3, 56, 56, 64, 64, 721), (1, 1, 1, 32, 128, 722),
-                                                 (2, 5, 3, 96, 192, 721), (37, 14, 14, 256, 256, 722)])
+                                                 (2, 5, 3, 96, 192, 721), (37, 14, 14, 256, 256, 722),
+                                                 (3, 14, 14, 64, 128, 822), (2, 28, 28, 128, 128, 842), (5, 9, 13, 32, 64, 821),
+                                                 (16, 7, 7, 512, 512, 822), (3, 56, 56, 64, 64, 821), (1, 1, 1, 32, 128, 822)])
 def test_x3conv_forward_matches_the_definition(dev, n, h, w, ci, co, variant):
     """y = conv2d(x, w, 1, 1) against fp64 on the same fp32 inputs: 1e-5 of the output's scale (a 3 x bf16-split product is ~1e-6
     relative; the library's fp32 Winograd kernels are ~1e-3 of scale); ragged position counts, every tile variant, single pixels."""

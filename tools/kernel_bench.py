@@ -348,7 +348,7 @@ def case_x3conv(H, C, N=128, dbg=False):
     sc = float(ref.abs().max())
     out['library_fwd_relerr_vs_fp64'] = float((ylib.double() - ref).abs().max()) / sc
     M = N * H * H
-    VS = (522, 542, 521, 722, 742, 721, 0) + ((222, 1222, 2222, 3222, 4222, 6222) if dbg else ())
+    VS = (522, 521, 822, 821, 842, 522, 521, 822, 821, 0) + ((222, 1222, 2222, 3222, 4222, 6222) if dbg else ())
     for v in VS:
         if v % 10 == 2 and C % 128:
             continue
@@ -357,7 +357,7 @@ def case_x3conv(H, C, N=128, dbg=False):
             out[f'x3_v{v}_relerr_vs_fp64'] = float((y[:2].double() - ref).abs().max()) / sc
         us, prof = timed(lambda: ops.conv3x3_x3_forward(x, w, v), iters=20)
         k = prof.get('cfl_conv3x3_x3_kernel', us)                   # (version 3: without the weight-image launch, ~3 us)
-        out[f'x3_v{v}_fwd_us'] = k
+        out.setdefault(f'x3_v{v}_fwd_us', []).append(k)                  # (a variant listed twice is timed twice: A/B/A/B on one lease)
         out[f'x3_v{v}_TFLOPs_fp32_equivalent'] = round(flop / k / 1e6)
     wg = w.clone().requires_grad_(True)                                      # (a trainable weight: its image is rebuilt per call)
     us, prof = timed(lambda: ops.conv3x3_x3_forward(dy, wg, rotated=True), iters=20)
@@ -387,8 +387,8 @@ def case_x3conv(H, C, N=128, dbg=False):
             finally:
                 lib.cfl_conv3x3_x3_wgrad_splits(old)
             out[f'x3_wgrad_splits{sp}_us'] = [prof.get('cfl_conv3x3_x3_wgrad_kernel'), prof.get('cfl_conv3x3_x3_wgrad_reduce_kernel')]
-    best = min(out[f'x3_v{v}_fwd_us'] for v in VS if v < 1000 and f'x3_v{v}_fwd_us' in out)
-    out['best_variant'] = min((out[f'x3_v{v}_fwd_us'], v) for v in VS if v < 1000 and f'x3_v{v}_fwd_us' in out)[1]
+    best = min(min(out[f'x3_v{v}_fwd_us']) for v in VS if v < 1000 and f'x3_v{v}_fwd_us' in out)
+    out['best_variant'] = min((min(out[f'x3_v{v}_fwd_us']), v) for v in VS if v < 1000 and f'x3_v{v}_fwd_us' in out)[1]
     out['speedup_fwd'] = round(out['library_fwd_us'] / best, 2)
     out['speedup_dgrad'] = round(out['library_dgrad_us'] / out['x3_dgrad_us_incl_weight_rotation'], 2)
     return out
