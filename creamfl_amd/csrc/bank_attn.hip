@@ -475,7 +475,8 @@ int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int 
     } else if (p.DT == 16) {
         // measured at M = 50 000 (profiles/r6_a5_conw_lines.jsonl): bursts of 2 / 4 / 8 contraction steps 7.26 / 6.59 / 7.00 ms; with
         // the issue order pinned (sched_group_barrier) 's' -1.3 %, 't' -2.6 % against the plain burst of 4 on the same lease
-        if (rbv && rbv[0] == '8') CFL_WIDE32(16, 4, 8);
+        if (rbv && rbv[0] == 'a') CFL_WIDE32(16, 4, 4, 2, true);         // LDS-DMA from inline assembly
+        else if (rbv && rbv[0] == '8') CFL_WIDE32(16, 4, 8);
         else if (rbv && rbv[0] == '2') CFL_WIDE32(16, 4, 2);
         else if (rbv && rbv[0] == 's') CFL_WIDE32(16, 4, 4, 1);
         else if (rbv && rbv[0] == '4') CFL_WIDE32(16, 4, 4);
@@ -483,9 +484,12 @@ int cfl_conw_logprob_img(const float* V, const void* image, const float* G, int 
     } else if (p.DT == 8) {
         // M = 50 000, D = 256, one lease (profiles/r6_a5_wide32_branch_ab.jsonl): with the per-burst liveness branch of rounds 4-5 3.25-3.28
         // ms ('b'), without it 3.22-3.23 ('n'), without it and the issue order pinned per burst (eight reads, twelve MFMAs) 3.17-3.18
+        // ... and with the LDS-DMA issued from inline assembly (the compiler's waits for the fragment reads become partial): 3.16-3.17 ms
+        // against 3.21-3.24 on one lease (profiles/r6_a5_asm_dma_ab.jsonl; D = 512: a tie, the builtin stays there).  'd': builtin DMA.
         if (rbv && rbv[0] == 'b') CFL_WIDE32(8, 8, 4, 3);
         else if (rbv && rbv[0] == 'n') CFL_WIDE32(8, 8, 4, 0);
-        else CFL_WIDE32(8, 8, 4, 1);
+        else if (rbv && rbv[0] == 'd') CFL_WIDE32(8, 8, 4, 1);
+        else CFL_WIDE32(8, 8, 4, 1, true);
     } else CFL_WIDE32(4, 8, 4);
 #undef CFL_WIDE32
     CFL_LAUNCH(K_LSE_FINAL, cfl_conw_finish_kernel, dim3(cfl_cdiv(rows, 64)), dim3(256), 0, stream, w.part_m, w.part_l, p.S, F,

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void cfl_bank_stream_kernel(
 // rows (391 x 102 MB = 40 GB L2 -> LDS per client where the tile GEMM moves 78 GB), and what hides the fragment-read latency is
 // the next burst's reads issued ahead of this burst's MFMAs inside the one wave (the registers are there) instead of a second
 // wave.  D = 768 does not fit either way (384 registers of V, 2 x 96 KB of step buffers): it stays on the tile GEMM of bank.hip.
-template <int DT, int NW, int RB = 4, int SCHED = 0>
+template <int DT, int NW, int RB = 4, int SCHED = 0, bool ADMA = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void cfl_bank_wide32_kernel(const float* __restrict__ F, const char* __restrict__ img, int B,
                                                                         int M, int D, float sc2, int S, int RG,
                                                                         float* __restrict__ part_m, float* __restrict__ part_l) {
@@ -482,14 +482,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cfl_bank_wide32_kernel(const 
     const int limit = min(M, (c0 + nmine) * SG);                         // first bank row that is not this split's
     const bool wave_live = rg * FR + 32 * w < B;
     const char* sbase = img + (size_t)c0 * SLOT + (w * 64 + lane) * 16;
+    // ADMA (round 6): the LDS-DMA issued from inline assembly.  While a transfer the compiler KNOWS of is in flight its wait-count
+    // bookkeeping gives up partial LDS waits: every wait for a fragment read becomes lgkmcnt(0), i.e. also for the reads issued last.
+    // What it does not see it does not account for; the explicit vmcnt(0) in front of the step's barrier is the synchronisation.
+    const unsigned lds_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     auto dma_step = [&](int it) {
         const char* src = sbase + (size_t)it * STEP;
         char* dst = lds + (it & 1) * STEP + w * 1024;
+        const unsigned dst_a = __builtin_amdgcn_readfirstlane(lds_a + (it & 1) * STEP + w * 1024);
         const int valid = (2 * it + 1 < nmine) ? STEP : SLOT;
 #pragma unroll
         for (int j = 0; j < NPT; ++j)
-            if (j * STRIPE < valid)
-                __builtin_amdgcn_global_load_lds((glb_vptr)(src + j * STRIPE), (lds_vptr)(dst + j * STRIPE), 16, 0, 0);
+            if (j * STRIPE < valid) {
+                if (ADMA) {
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src + j * STRIPE), "s"(dst_a + j * STRIPE) : "memory");
+                } else {
+                    __builtin_amdgcn_global_load_lds((glb_vptr)(src + j * STRIPE), (lds_vptr)(dst + j * STRIPE), 16, 0, 0);
+                }
+            }
     };
     if (nstep > 0) dma_step(0);
     bf16x8 fh[KS], fl[KS];                                       // B operand: feature row r32, k = 16 ks + 8 kh .. + 7, pre-scaled
